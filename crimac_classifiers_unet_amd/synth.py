@@ -1,0 +1,139 @@
+"""Deterministic synthetic echograms, labels and name-keyed weights.
+
+There is no network on the build or GPU boxes, so benchmarks and parity tests run on
+synthetic data: linear sv = 10^U(-7.5, 0) per pixel, passed through the
+reference's dB transform (crimac_unet/batch/data_transforms/db_with_limits.py:20-24:
+10*log10(x + 1e-10) clamped to [-75, 0]); labels drawn from {0, 1, 2, -100}.
+
+Weights come from a generator keyed on the ``state_dict`` key *name* (crc32 of the name +
+seed -> numpy PCG64), so the same tensors are regenerated bit-identically in the build
+container (where golden fixtures are captured from the imported reference) and on the GPU box
+(where the reference cannot travel), independent of the torch version.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+LABEL_IGNORE_VAL = -100  # crimac_unet/constants.py:25
+
+
+def unet_state_shapes(n_classes=3, in_channels=4, depth=5, start_filts=64):
+    """Key -> shape of ``UNet_Baseline.state_dict()`` (crimac_unet/models/unet.py:200-289).
+
+    Key order follows module registration order in the reference: down_convs, up_convs, conv_final.
+    """
+    shapes = OrderedDict()
+
+    def bn(prefix, c):
+        shapes[prefix + ".weight"] = (c,)
+        shapes[prefix + ".bias"] = (c,)
+        shapes[prefix + ".running_mean"] = (c,)
+        shapes[prefix + ".running_var"] = (c,)
+        shapes[prefix + ".num_batches_tracked"] = ()
+
+    outs = in_channels
+    for i in range(depth):
+        ins = in_channels if i == 0 else outs
+        outs = start_filts * (2 ** i)
+        p = f"down_convs.{i}.main."
+        shapes[p + "0.weight"] = (outs, ins, 3, 3)
+        shapes[p + "0.bias"] = (outs,)
+        bn(p + "1", outs)
+        shapes[p + "3.weight"] = (outs, outs, 3, 3)
+        shapes[p + "3.bias"] = (outs,)
+        bn(p + "4", outs)
+    for i in range(depth - 1):
+        ins = outs
+        outs = ins // 2
+        p = f"up_convs.{i}."
+        shapes[p + "upconv.weight"] = (ins, outs, 2, 2)
+        shapes[p + "upconv.bias"] = (outs,)
+        shapes[p + "conv1.weight"] = (outs, 2 * outs, 3, 3)
+        shapes[p + "conv1.bias"] = (outs,)
+        shapes[p + "conv2.weight"] = (outs, outs, 3, 3)
+        shapes[p + "conv2.bias"] = (outs,)
+        bn(p + "bn1", outs)
+        bn(p + "bn2", outs)
+    shapes["conv_final.weight"] = (n_classes, outs, 1, 1)
+    shapes["conv_final.bias"] = (n_classes,)
+    return shapes
+
+
+def _is_bn_key(key: str) -> bool:
+    parts = key.split(".")
+    if parts[0] == "down_convs":
+        return parts[3] in ("1", "4")
+    if parts[0] == "up_convs":
+        return parts[2].startswith("bn")
+    return False
+
+
+def synth_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
+    """Deterministic values for one ``state_dict`` entry.
+
+    Convolution weights/biases: U(-1/sqrt(fan_in), +1/sqrt(fan_in)) -- the scale torch's default
+    init gives (the reference never calls reset_params).  BatchNorm affine
+    and running statistics are made non-trivial so eval-mode folding is actually exercised.
+    """
+    rng = np.random.Generator(np.random.PCG64((zlib.crc32(key.encode()) + 7919 * seed) & 0xFFFFFFFF))
+    leaf = key.split(".")[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros((), dtype=np.int64)
+    if _is_bn_key(key):
+        if leaf == "weight":
+            return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        if leaf == "bias":
+            return rng.uniform(-0.2, 0.2, size=shape).astype(np.float32)
+        if leaf == "running_mean":
+            return rng.normal(0.0, 0.1, size=shape).astype(np.float32)
+        if leaf == "running_var":
+            return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        raise KeyError(key)
+    # convolution / transposed convolution
+    if leaf == "weight":
+        if "upconv" in key:  # ConvTranspose2d weight [Cin, Cout, 2, 2]: torch fan_in = Cout*k*k
+            fan_in = shape[1] * shape[2] * shape[3]
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+        bound = 1.0 / np.sqrt(fan_in)
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+    if leaf == "bias":
+        # bound of the owning conv is not known from the bias shape alone; use 1/sqrt(9*C)
+        bound = 1.0 / np.sqrt(9.0 * max(int(shape[0]), 1))
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+    raise KeyError(key)
+
+
+def synth_state_dict(n_classes=3, in_channels=4, depth=5, start_filts=64, seed=0):
+    """Full deterministic ``state_dict`` (torch CPU tensors) for ``UNet_Baseline``."""
+    sd = OrderedDict()
+    for k, shp in unet_state_shapes(n_classes, in_channels, depth, start_filts).items():
+        sd[k] = torch.from_numpy(np.ascontiguousarray(synth_tensor(k, shp, seed)))
+    return sd
+
+
+def db_with_limits(x: np.ndarray) -> np.ndarray:
+    """dB transform of the reference (db_with_limits.py:20-24): 10*log10(x+1e-10) in [-75, 0]."""
+    out = 10.0 * np.log10(x + 1e-10)
+    out[out > 0] = 0
+    out[out < -75] = -75
+    return out
+
+
+def synth_echogram_batch(batch, channels=4, height=256, width=256, seed=1):
+    """[B,C,H,W] float32 model input in dB (linear sv = 10^U(-7.5,0) through db_with_limits)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u = rng.uniform(-7.5, 0.0, size=(batch, channels, height, width))
+    return db_with_limits(np.power(10.0, u)).astype(np.float32)
+
+
+def synth_labels(batch, height=256, width=256, seed=2, p=(0.90, 0.04, 0.04, 0.02)):
+    """[B,H,W] int16 labels ~ Categorical{0,1,2,-100} with probabilities ``p`` (iid per pixel)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vals = np.array([0, 1, 2, LABEL_IGNORE_VAL], dtype=np.int16)
+    idx = rng.choice(4, size=(batch, height, width), p=np.asarray(p))
+    return vals[idx]
