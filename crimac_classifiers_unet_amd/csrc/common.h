@@ -1,0 +1,106 @@
+// Shared device/host helpers for the CDNA4 (gfx950) U-Net kernels.
+// All kernels assume wave64 and are written for MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/crimac_unet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void crimac_set_error(const char* fmt, ...);
+#define CRIMAC_REQUIRE(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      crimac_set_error(__VA_ARGS__);              \
+      return CRIMAC_ERR_INVALID;                  \
+    }                                             \
+  } while (0)
+#define CRIMAC_LAUNCH_CHECK()                                              \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      crimac_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,      \
+                       hipGetErrorString(e_));                             \
+      return CRIMAC_ERR_LAUNCH;                                            \
+    }                                                                      \
+  } while (0)
+
+// ---- bf16 helpers (device) -------------------------------------------------------------------
+// Round-to-nearest-even via the hardware cast (v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float bfbits2f(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+__device__ __forceinline__ unsigned short f2bfbits(float x) {
+  bf16_t b = (bf16_t)x;
+  return *reinterpret_cast<unsigned short*>(&b);
+}
+// hi/lo split of an fp32 value into two bf16: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|.
+__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+  hi = f2bfbits(x);
+  lo = f2bfbits(x - bfbits2f(hi));
+}
+
+// Activation element traits: T = bf16_t (16-bit storage) or float (fp32 storage).
+template <typename T> struct ActT;
+template <> struct ActT<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;  // elements per 16-byte access
+};
+template <> struct ActT<float> {
+  static constexpr int kBytes = 4;
+  static constexpr int kVec = 4;
+};
+
+// Load/store 8 consecutive channels as fp32 regardless of storage type.
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  u16x8 r = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = bfbits2f(r[i]);
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  u16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = f2bfbits(v[i]);
+  *reinterpret_cast<u16x8*>(p) = r;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,940 @@
+// HBM-bound kernels of the U-Net hot path for CDNA4 (gfx950): BatchNorm statistics / apply /
+// backward, ReLU, 2x2 max-pool and its backward, layout conversion, weight packing, SGD.
+// All tensor accesses are 16-byte vectors over the contiguous NHWC channel axis; per-channel
+// reductions keep partial sums in registers, combine them in LDS and issue one global atomic per
+// channel per workgroup.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---- error text -------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void crimac_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* crimac_last_error(void) { return g_err; }
+extern "C" int crimac_version(void) { return 1; }
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// ---- layout: NCHW fp32 -> NHWC (channel padded) -----------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int C, long HW,
+                                    long npix, long ld) {
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix;
+       p += (long)gridDim.x * blockDim.x) {
+    const long b = p / HW, hw = p % HW;
+    const float* src = in + b * C * HW + hw;
+    T* dst = out + p * ld;
+    for (int c0 = 0; c0 < ld; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (c0 + j) < C ? src[(long)(c0 + j) * HW] : 0.f;
+      store8(dst + c0, v);
+    }
+  }
+}
+
+// ---- weight packing -----------------------------------------------------------------------------
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int Ci_pad,
+                                    const float* __restrict__ scale, unsigned short* fwd_hi,
+                                    unsigned short* fwd_lo, unsigned short* dg_hi,
+                                    unsigned short* dg_lo) {
+  const long n_fwd = 9L * Co * Ci_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_fwd;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci_pad);
+    const long r = i / Ci_pad;
+    const int co = (int)(r % Co), t = (int)(r / Co);
+    float v = 0.f;
+    if (ci < Ci) {
+      v = w[((long)co * Ci + ci) * 9 + t];
+      if (scale) v *= scale[co];
+    }
+    unsigned short hi, lo;
+    split_bf16(v, hi, lo);
+    fwd_hi[i] = hi;
+    if (fwd_lo) fwd_lo[i] = lo;
+  }
+  if (dg_hi) {
+    const long n_dg = 9L * Ci * Co;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_dg;
+         i += (long)gridDim.x * blockDim.x) {
+      const int co = (int)(i % Co);
+      const long r = i / Co;
+      const int ci = (int)(r % Ci), t = (int)(r / Ci);
+      const float v = w[((long)co * Ci + ci) * 9 + (8 - t)];
+      unsigned short hi, lo;
+      split_bf16(v, hi, lo);
+      dg_hi[i] = hi;
+      if (dg_lo) dg_lo[i] = lo;
+    }
+  }
+}
+
+__global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, unsigned short* fwd_hi,
+                                   unsigned short* fwd_lo, unsigned short* dg_hi,
+                                   unsigned short* dg_lo) {
+  // w[ci][co][a][b]; fwd[(ab*Co + co)][ci]; dgrad[ab][ci][co]
+  const long n = 4L * Ci * Co;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    {
+      const int ci = (int)(i % Ci);
+      const long r = i / Ci;
+      const int co = (int)(r % Co), ab = (int)(r / Co);
+      unsigned short hi, lo;
+      split_bf16(w[((long)ci * Co + co) * 4 + ab], hi, lo);
+      fwd_hi[i] = hi;
+      if (fwd_lo) fwd_lo[i] = lo;
+    }
+    if (dg_hi) {
+      const int co = (int)(i % Co);
+      const long r = i / Co;
+      const int ci = (int)(r % Ci), ab = (int)(r / Ci);
+      unsigned short hi, lo;
+      split_bf16(w[((long)ci * Co + co) * 4 + ab], hi, lo);
+      dg_hi[i] = hi;
+      if (dg_lo) dg_lo[i] = lo;
+    }
+  }
+}
+
+__global__ void unpack_wgrad_conv_kernel(const float* __restrict__ dw, int Co, int Ci, int Ci_pad,
+                                         float* __restrict__ grad) {
+  const long n = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % 9);
+    const long r = i / 9;
+    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    grad[i] = dw[((long)t * Co + co) * Ci_pad + ci];
+  }
+}
+
+__global__ void unpack_wgrad_upconv_kernel(const float* __restrict__ dw, int Ci, int Co,
+                                           float* __restrict__ grad) {
+  const long n = (long)Ci * Co * 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ab = (int)(i % 4);
+    const long r = i / 4;
+    const int co = (int)(r % Co), ci = (int)(r / Co);
+    grad[i] = dw[((long)ab * Ci + ci) * Co + co];
+  }
+}
+
+// ---- per-channel reductions over an [M][C] (pixel-major) matrix ---------------------------------
+// Thread -> (8-channel chunk, row lane).  OP produces up to two quantities per element.
+template <typename T, typename ACC, int NQ, typename OP>
+__device__ __forceinline__ void colreduce(long M, int C, OP op, ACC* out0, ACC* out1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);   // [NQ][C]
+  const int cpr = C / 8;
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;     // rows per iteration
+  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+  if (rl < rpi && cpr <= 256) {
+    for (long m = (long)blockIdx.x * rpi + rl; m < M; m += (long)gridDim.x * rpi) {
+      float q0[8], q1[8];
+      op(m, chunk * 8, q0, q1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0[j] += q0[j]; if (NQ > 1) s1[j] += q1[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&lds[chunk * 8 + j], s0[j]);
+      if (NQ > 1) atomicAdd(&lds[C + chunk * 8 + j], s1[j]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(&out0[c], (ACC)lds[c]);
+    if (NQ > 1) atomicAdd(&out1[c], (ACC)lds[C + c]);
+  }
+}
+
+template <typename T, typename ACC, int NQ>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ y, long ld, long M, int C,
+                                                       ACC* sum, ACC* sumsq) {
+  colreduce<T, ACC, NQ>(M, C,
+                        [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
+                          load8(y + m * ld + c0, q0);
+#pragma unroll
+                          for (int j = 0; j < 8; ++j) q1[j] = q0[j] * q0[j];
+                        },
+                        sum, sumsq);
+}
+
+__global__ void bn_finalize_kernel(const double* sum, const double* sumsq, long M, int C,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* rmean, float* rvar, long long* nbt, float* mean_o,
+                                   float* invstd_o, float* scale_o, float* shift_o) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  const double mean = sum[c] / (double)M;
+  double var = sumsq[c] / (double)M - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] - (float)mean * sc;
+  if (rmean) {
+    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+// ---- BN apply (+ReLU) (+2x2 max-pool) -------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, long y_ld,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int relu,
+                                                     T* __restrict__ out, long out_ld, long M, int C) {
+  const int cpr = C / 8;
+  const long total = M * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long m = i / cpr;
+    const int c0 = (int)(i % cpr) * 8;
+    float v[8];
+    load8(y + m * y_ld + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (scale) v[j] = v[j] * scale[c0 + j] + shift[c0 + j];
+      if (relu) v[j] = fmaxf(v[j], 0.f);
+    }
+    store8(out + m * out_ld + c0, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ y, long y_ld,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu,
+                                                          T* __restrict__ out, long out_ld,
+                                                          T* __restrict__ pool, long pool_ld, int B,
+                                                          int H, int W, int C) {
+  const int cpr = C / 8;
+  const int Hp = H / 2, Wp = W / 2;
+  const long total = (long)B * Hp * Wp * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cpr) * 8;
+    long r = i / cpr;
+    const int xp = (int)(r % Wp);
+    r /= Wp;
+    const int yp = (int)(r % Hp);
+    const long b = r / Hp;
+    float sc[8], sh[8], mx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = scale ? scale[c0 + j] : 1.f;
+      sh[j] = scale ? shift[c0 + j] : 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const long pix = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
+      float v[8];
+      load8(y + pix * y_ld + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = v[j] * sc[j] + sh[j];
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+        mx[j] = d == 0 ? v[j] : fmaxf(mx[j], v[j]);
+      }
+      if (out) store8(out + pix * out_ld + c0, v);
+    }
+    store8(pool + ((b * Hp + yp) * (long)Wp + xp) * pool_ld + c0, mx);
+  }
+}
+
+// ---- backward of max-pool + skip add ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ dp, long dp_ld,
+                                                         const T* __restrict__ a, long a_ld,
+                                                         const T* __restrict__ ds, long ds_ld,
+                                                         T* __restrict__ da, long da_ld, int B, int H,
+                                                         int W, int C) {
+  const int cpr = C / 8;
+  const int Hp = H / 2, Wp = W / 2;
+  const long total = (long)B * Hp * Wp * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cpr) * 8;
+    long r = i / cpr;
+    const int xp = (int)(r % Wp);
+    r /= Wp;
+    const int yp = (int)(r % Hp);
+    const long b = r / Hp;
+    float g[8], av[4][8];
+    load8(dp + ((b * Hp + yp) * (long)Wp + xp) * dp_ld + c0, g);
+    long pix[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      pix[d] = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
+      load8(a + pix[d] * a_ld + c0, av[d]);
+    }
+    int arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int best = 0;
+      float bv = av[0][j];
+#pragma unroll
+      for (int d = 1; d < 4; ++d)
+        if (av[d][j] > bv) { bv = av[d][j]; best = d; }   // first maximum wins (aten max_pool2d)
+      arg[j] = best;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float o[8];
+      if (ds) load8(ds + pix[d] * ds_ld + c0, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f);
+      store8(da + pix[d] * da_ld + c0, o);
+    }
+  }
+}
+
+// ---- BatchNorm + ReLU backward ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, long da_ld,
+                                                            const T* __restrict__ y, long y_ld,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, long M,
+                                                            int C, double* sum_dz, double* sum_dzx) {
+  colreduce<T, double, 2>(M, C,
+                          [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
+                            float g[8], yv[8];
+                            load8(da + m * da_ld + c0, g);
+                            load8(y + m * y_ld + c0, yv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                              const float act = yv[j] * scale[c0 + j] + shift[c0 + j];
+                              const float dz = act > 0.f ? g[j] : 0.f;
+                              q0[j] = dz;
+                              q1[j] = dz * (yv[j] - mean[c0 + j]) * invstd[c0 + j];
+                            }
+                          },
+                          sum_dz, sum_dzx);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const double* __restrict__ sum_dz,
+    const double* __restrict__ sum_dzx, long M, int C, T* __restrict__ dy, long dy_ld, float* dgamma,
+    float* dbeta, float* dbias) {
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dgamma[c] = (float)sum_dzx[c];
+      dbeta[c] = (float)sum_dz[c];
+    }
+  }
+  const double invM = 1.0 / (double)M;
+  if (dbias) {
+    colreduce<T, float, 1>(M, C,
+                           [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
+                             float g[8], yv[8], o[8];
+                             load8(da + m * da_ld + c0, g);
+                             load8(y + m * y_ld + c0, yv);
+#pragma unroll
+                             for (int j = 0; j < 8; ++j) {
+                               const int c = c0 + j;
+                               const float act = yv[j] * scale[c] + shift[c];
+                               const float dz = act > 0.f ? g[j] : 0.f;
+                               const float xh = (yv[j] - mean[c]) * invstd[c];
+                               o[j] = scale[c] * (dz - (float)(sum_dz[c] * invM) -
+                                                  xh * (float)(sum_dzx[c] * invM));
+                               q0[j] = o[j];
+                             }
+                             store8(dy + m * dy_ld + c0, o);
+                           },
+                           dbias, (float*)nullptr);
+  }
+}
+
+// ---- 1x1 head --------------------------------------------------------------------------------------------
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long x_ld, int Cin,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ logits, long npix, long HW,
+                                                       int softmax) {
+  const int lp = Cin / 8;               // lanes per pixel (power of two <= 64)
+  const int sub = threadIdx.x % lp;
+  float wr[NC][8];
+#pragma unroll
+  for (int o = 0; o < NC; ++o)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[o][j] = w[o * Cin + sub * 8 + j];
+  const long ppb = 256 / lp;            // pixels per block-iteration
+  for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
+    const long p = p0 + threadIdx.x / lp;
+    float acc[NC];
+#pragma unroll
+    for (int o = 0; o < NC; ++o) acc[o] = 0.f;
+    if (p < npix) {
+      float v[8];
+      load8(x + p * x_ld + sub * 8, v);
+#pragma unroll
+      for (int o = 0; o < NC; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[o] += v[j] * wr[o][j];
+    }
+    for (int off = lp >> 1; off > 0; off >>= 1)
+#pragma unroll
+      for (int o = 0; o < NC; ++o) acc[o] += __shfl_xor(acc[o], off, 64);
+    if (sub == 0 && p < npix) {
+      float z[NC];
+#pragma unroll
+      for (int o = 0; o < NC; ++o) z[o] = acc[o] + bias[o];
+      if (softmax) {
+        float mx = z[0];
+#pragma unroll
+        for (int o = 1; o < NC; ++o) mx = fmaxf(mx, z[o]);
+        float den = 0.f;
+#pragma unroll
+        for (int o = 0; o < NC; ++o) { z[o] = expf(z[o] - mx); den += z[o]; }
+#pragma unroll
+        for (int o = 0; o < NC; ++o) z[o] /= den;
+      }
+      const long b = p / HW, hw = p % HW;
+#pragma unroll
+      for (int o = 0; o < NC; ++o) logits[(b * NC + o) * HW + hw] = z[o];
+    }
+  }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl,
+                                                       const T* __restrict__ x, long x_ld, int Cin,
+                                                       const float* __restrict__ w, T* __restrict__ dx,
+                                                       long dx_ld, float* dw, float* db, long npix,
+                                                       long HW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);   // [NC][Cin] + [NC]
+  for (int i = threadIdx.x; i < NC * Cin + NC; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  const int lp = Cin / 8;
+  const int sub = threadIdx.x % lp;
+  float wr[NC][8], gw[NC][8], gb[NC];
+#pragma unroll
+  for (int o = 0; o < NC; ++o) {
+    gb[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wr[o][j] = w[o * Cin + sub * 8 + j]; gw[o][j] = 0.f; }
+  }
+  const long ppb = 256 / lp;
+  for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
+    const long p = p0 + threadIdx.x / lp;
+    if (p >= npix) continue;
+    const long b = p / HW, hw = p % HW;
+    float g[NC], v[8], o8[8];
+#pragma unroll
+    for (int o = 0; o < NC; ++o) g[o] = dl[(b * NC + o) * HW + hw];
+    load8(x + p * x_ld + sub * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < NC; ++o) { s += g[o] * wr[o][j]; gw[o][j] += g[o] * v[j]; }
+      o8[j] = s;
+    }
+    if (sub == 0)
+#pragma unroll
+      for (int o = 0; o < NC; ++o) gb[o] += g[o];
+    store8(dx + p * dx_ld + sub * 8, o8);
+  }
+#pragma unroll
+  for (int o = 0; o < NC; ++o) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&lds[o * Cin + sub * 8 + j], gw[o][j]);
+    if (sub == 0) atomicAdd(&lds[NC * Cin + o], gb[o]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NC * Cin; i += 256) atomicAdd(&dw[i], lds[i]);
+  if (threadIdx.x < NC) atomicAdd(&db[threadIdx.x], lds[NC * Cin + threadIdx.x]);
+}
+
+// ---- weighted cross entropy ---------------------------------------------------------------------------------
+__device__ __forceinline__ long load_label(const void* labels, int nbytes, long i) {
+  if (nbytes == 8) return ((const long long*)labels)[i];
+  if (nbytes == 4) return ((const int*)labels)[i];
+  return ((const short*)labels)[i];
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ logits,
+                                                      const void* __restrict__ labels, int lbytes,
+                                                      const float* __restrict__ cw, int ignore,
+                                                      long npix, long HW, double* sums) {
+  __shared__ double red[2][4];
+  double s0 = 0.0, s1 = 0.0;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix;
+       p += (long)gridDim.x * blockDim.x) {
+    const long y = load_label(labels, lbytes, p);
+    if (y == ignore) continue;
+    const long b = p / HW, hw = p % HW;
+    float z[NC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int o = 0; o < NC; ++o) { z[o] = logits[(b * NC + o) * HW + hw]; mx = fmaxf(mx, z[o]); }
+    float den = 0.f, zy = 0.f, wy = 0.f;
+#pragma unroll
+    for (int o = 0; o < NC; ++o) {
+      den += expf(z[o] - mx);
+      if (o == y) { zy = z[o]; wy = cw[o]; }
+    }
+    const float nll = (mx + logf(den)) - zy;
+    s0 += (double)(wy * nll);
+    s1 += (double)wy;
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = s0; red[1][wv] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&sums[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ logits,
+                                                      const void* __restrict__ labels, int lbytes,
+                                                      const float* __restrict__ cw, int ignore,
+                                                      long npix, long HW, const double* sums,
+                                                      float upstream, float* __restrict__ dl) {
+  const float inv = upstream / (float)sums[1];
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix;
+       p += (long)gridDim.x * blockDim.x) {
+    const long y = load_label(labels, lbytes, p);
+    const long b = p / HW, hw = p % HW;
+    float z[NC];
+    if (y == ignore) {
+#pragma unroll
+      for (int o = 0; o < NC; ++o) dl[(b * NC + o) * HW + hw] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int o = 0; o < NC; ++o) { z[o] = logits[(b * NC + o) * HW + hw]; mx = fmaxf(mx, z[o]); }
+    float den = 0.f, wy = 0.f;
+#pragma unroll
+    for (int o = 0; o < NC; ++o) {
+      z[o] = expf(z[o] - mx);
+      den += z[o];
+      if (o == y) wy = cw[o];
+    }
+    const float k = wy * inv;
+#pragma unroll
+    for (int o = 0; o < NC; ++o)
+      dl[(b * NC + o) * HW + hw] = k * (z[o] / den - (o == y ? 1.f : 0.f));
+  }
+}
+
+// ---- SGD with momentum over a flat parameter buffer -------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                  float* __restrict__ v, long n4, long n, float lr,
+                                                  float mom, float gscale, int zero_grad) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vv[j] = mom * vv[j] + gv[j] * gscale;
+      pv[j] -= lr * vv[j];
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // tail (n not a multiple of 4)
+  const long tail0 = n4 * 4;
+  const long t = tail0 + blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t < n) {
+    const float vv = mom * v[t] + g[t] * gscale;
+    v[t] = vv;
+    p[t] -= lr * vv;
+    if (zero_grad) g[t] = 0.f;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+//                                         C ABI
+// =================================================================================================
+#define ST ((hipStream_t)stream)
+#define PREC_OK(name) \
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, name ": bad precision %d", prec)
+
+extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, int C, int H, int W,
+                                   long ld, void* stream) {
+  PREC_OK("nchw_to_nhwc");
+  CRIMAC_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && ld >= C && ld % 8 == 0,
+                 "nchw_to_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
+  const long npix = (long)B * H * W;
+  const int grid = grid_for(npix, 256);
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST, in, (bf16_t*)out, C,
+                       (long)H * W, npix, ld);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, ST, in, (float*)out, C,
+                       (long)H * W, npix, ld);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, const float* scale,
+                                   void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo,
+                                   void* stream) {
+  CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0 && Ci_pad >= Ci, "pack_conv3x3: bad arguments");
+  CRIMAC_REQUIRE(!dg_hi || Ci_pad == Ci, "pack_conv3x3: dgrad planes need Ci_pad == Ci");
+  const int grid = grid_for(9L * Co * Ci_pad, 256);
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, ST, w, Co, Ci, Ci_pad, scale,
+                     (unsigned short*)fwd_hi, (unsigned short*)fwd_lo, (unsigned short*)dg_hi,
+                     (unsigned short*)dg_lo);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_pack_upconv2x2(const float* w, int Ci, int Co, void* fwd_hi, void* fwd_lo,
+                                     void* dg_hi, void* dg_lo, void* stream) {
+  CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0, "pack_upconv2x2: bad arguments");
+  const int grid = grid_for(4L * Co * Ci, 256);
+  hipLaunchKernelGGL(pack_upconv_kernel, dim3(grid), dim3(256), 0, ST, w, Ci, Co,
+                     (unsigned short*)fwd_hi, (unsigned short*)fwd_lo, (unsigned short*)dg_hi,
+                     (unsigned short*)dg_lo);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_unpack_wgrad_conv3x3(const float* dw, int Co, int Ci, int Ci_pad, float* grad,
+                                           void* stream) {
+  CRIMAC_REQUIRE(dw && grad && Co > 0 && Ci > 0 && Ci_pad >= Ci, "unpack_wgrad_conv3x3: bad arguments");
+  hipLaunchKernelGGL(unpack_wgrad_conv_kernel, dim3(grid_for(9L * Co * Ci, 256)), dim3(256), 0, ST, dw,
+                     Co, Ci, Ci_pad, grad);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_unpack_wgrad_upconv2x2(const float* dw, int Ci, int Co, float* grad,
+                                             void* stream) {
+  CRIMAC_REQUIRE(dw && grad && Co > 0 && Ci > 0, "unpack_wgrad_upconv2x2: bad arguments");
+  hipLaunchKernelGGL(unpack_wgrad_upconv_kernel, dim3(grid_for(4L * Co * Ci, 256)), dim3(256), 0, ST,
+                     dw, Ci, Co, grad);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+static int colreduce_grid(long M, int C) {
+  const int cpr = C / 8;
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
+  return grid_for(M, rpi * 16);
+}
+
+extern "C" int crimac_colstats(int prec, const void* y, long ld, long M, int C, double* sum,
+                               double* sumsq, void* stream) {
+  PREC_OK("colstats");
+  CRIMAC_REQUIRE(y && sum && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && ld >= C && ld % 8 == 0,
+                 "colstats: bad arguments (C=%d ld=%ld)", C, ld);
+  const int grid = colreduce_grid(M, C);
+  const size_t lds = 2 * C * sizeof(float);
+  if (prec == CRIMAC_PREC_BF16) {
+    if (sumsq)
+      hipLaunchKernelGGL((colstats_kernel<bf16_t, double, 2>), dim3(grid), dim3(256), lds, ST,
+                         (const bf16_t*)y, ld, M, C, sum, sumsq);
+    else
+      hipLaunchKernelGGL((colstats_kernel<bf16_t, double, 1>), dim3(grid), dim3(256), lds, ST,
+                         (const bf16_t*)y, ld, M, C, sum, sumsq);
+  } else {
+    if (sumsq)
+      hipLaunchKernelGGL((colstats_kernel<float, double, 2>), dim3(grid), dim3(256), lds, ST,
+                         (const float*)y, ld, M, C, sum, sumsq);
+    else
+      hipLaunchKernelGGL((colstats_kernel<float, double, 1>), dim3(grid), dim3(256), lds, ST,
+                         (const float*)y, ld, M, C, sum, sumsq);
+  }
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C, float* sum,
+                                 void* stream) {
+  PREC_OK("colsum_f32");
+  CRIMAC_REQUIRE(y && sum && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && ld >= C && ld % 8 == 0,
+                 "colsum_f32: bad arguments (C=%d ld=%ld)", C, ld);
+  const int grid = colreduce_grid(M, C);
+  const size_t lds = 2 * C * sizeof(float);
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL((colstats_kernel<bf16_t, float, 1>), dim3(grid), dim3(256), lds, ST,
+                       (const bf16_t*)y, ld, M, C, sum, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((colstats_kernel<float, float, 1>), dim3(grid), dim3(256), lds, ST,
+                       (const float*)y, ld, M, C, sum, (float*)nullptr);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_bn_finalize(const double* sum, const double* sumsq, long M, int C,
+                                  const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var,
+                                  long long* num_batches_tracked, float* mean, float* invstd,
+                                  float* scale, float* shift, void* stream) {
+  CRIMAC_REQUIRE(sum && sumsq && gamma && beta && mean && invstd && scale && shift && M > 0 && C > 0,
+                 "bn_finalize: bad arguments");
+  CRIMAC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, sum, sumsq, M, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd,
+                     scale, shift);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+template <typename T>
+static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, const float* shift,
+                              int relu, void* out, long out_ld, void* pool_out, long pool_ld, int B,
+                              int H, int W, int C, hipStream_t st) {
+  if (pool_out) {
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(bn_act_pool_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, st,
+                       (const T*)y, y_ld, scale, shift, relu, (T*)out, out_ld, (T*)pool_out, pool_ld, B,
+                       H, W, C);
+  } else {
+    const long M = (long)B * H * W;
+    hipLaunchKernelGGL(bn_act_kernel<T>, dim3(grid_for(M * (C / 8), 256)), dim3(256), 0, st,
+                       (const T*)y, y_ld, scale, shift, relu, (T*)out, out_ld, M, C);
+  }
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_bn_act_pool(int prec, const void* y, long y_ld, const float* scale,
+                                  const float* shift, int relu, void* out, long out_ld,
+                                  void* pool_out, long pool_ld, int B, int H, int W, int C,
+                                  void* stream) {
+  PREC_OK("bn_act_pool");
+  CRIMAC_REQUIRE(y && (out || pool_out) && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+                 "bn_act_pool: bad arguments");
+  CRIMAC_REQUIRE((scale == nullptr) == (shift == nullptr), "bn_act_pool: scale/shift must come together");
+  CRIMAC_REQUIRE(y_ld >= C && y_ld % 8 == 0 && (!out || (out_ld >= C && out_ld % 8 == 0)) &&
+                     (!pool_out || (pool_ld >= C && pool_ld % 8 == 0)),
+                 "bn_act_pool: bad pixel strides");
+  CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0), "bn_act_pool: pooling needs even H, W");
+  return prec == CRIMAC_PREC_BF16
+             ? bn_act_pool_launch<bf16_t>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld, B,
+                                          H, W, C, ST)
+             : bn_act_pool_launch<float>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld, B,
+                                         H, W, C, ST);
+}
+
+extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const void* a, long a_ld,
+                                 const void* ds, long ds_ld, void* da, long da_ld, int B, int H, int W,
+                                 int C, void* stream) {
+  PREC_OK("unpool_add");
+  CRIMAC_REQUIRE(dp && a && da && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 &&
+                     C % 8 == 0,
+                 "unpool_add: bad arguments");
+  CRIMAC_REQUIRE(dp_ld >= C && a_ld >= C && da_ld >= C && (!ds || ds_ld >= C) && dp_ld % 8 == 0 &&
+                     a_ld % 8 == 0 && da_ld % 8 == 0 && (!ds || ds_ld % 8 == 0),
+                 "unpool_add: bad pixel strides");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  const int grid = grid_for(total, 256);
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL(unpool_add_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST, (const bf16_t*)dp, dp_ld,
+                       (const bf16_t*)a, a_ld, (const bf16_t*)ds, ds_ld, (bf16_t*)da, da_ld, B, H, W, C);
+  else
+    hipLaunchKernelGGL(unpool_add_kernel<float>, dim3(grid), dim3(256), 0, ST, (const float*)dp, dp_ld,
+                       (const float*)a, a_ld, (const float*)ds, ds_ld, (float*)da, da_ld, B, H, W, C);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_bn_bwd_reduce(int prec, const void* da, long da_ld, const void* y, long y_ld,
+                                    const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, long M, int C, double* sum_dz,
+                                    double* sum_dz_xhat, void* stream) {
+  PREC_OK("bn_bwd_reduce");
+  CRIMAC_REQUIRE(da && y && scale && shift && mean && invstd && sum_dz && sum_dz_xhat && M > 0 &&
+                     C > 0 && C % 8 == 0 && C <= 2048 && da_ld >= C && y_ld >= C && da_ld % 8 == 0 &&
+                     y_ld % 8 == 0,
+                 "bn_bwd_reduce: bad arguments");
+  const int grid = colreduce_grid(M, C);
+  const size_t lds = 2 * C * sizeof(float);
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), lds, ST, (const bf16_t*)da,
+                       da_ld, (const bf16_t*)y, y_ld, scale, shift, mean, invstd, M, C, sum_dz,
+                       sum_dz_xhat);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, ST, (const float*)da,
+                       da_ld, (const float*)y, y_ld, scale, shift, mean, invstd, M, C, sum_dz,
+                       sum_dz_xhat);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, long y_ld,
+                                   const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const double* sum_dz,
+                                   const double* sum_dz_xhat, long M, int C, void* dy, long dy_ld,
+                                   float* dgamma, float* dbeta, float* dbias, void* stream) {
+  PREC_OK("bn_bwd_apply");
+  CRIMAC_REQUIRE(da && y && scale && shift && mean && invstd && sum_dz && sum_dz_xhat && dy && dgamma &&
+                     dbeta && dbias && M > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                 "bn_bwd_apply: bad arguments");
+  CRIMAC_REQUIRE(da_ld >= C && y_ld >= C && dy_ld >= C && da_ld % 8 == 0 && y_ld % 8 == 0 &&
+                     dy_ld % 8 == 0,
+                 "bn_bwd_apply: bad pixel strides");
+  const int grid = colreduce_grid(M, C);
+  const size_t lds = 2 * C * sizeof(float);
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, ST, (const bf16_t*)da,
+                       da_ld, (const bf16_t*)y, y_ld, scale, shift, mean, invstd, sum_dz, sum_dz_xhat, M,
+                       C, (bf16_t*)dy, dy_ld, dgamma, dbeta, dbias);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), lds, ST, (const float*)da,
+                       da_ld, (const float*)y, y_ld, scale, shift, mean, invstd, sum_dz, sum_dz_xhat, M,
+                       C, (float*)dy, dy_ld, dgamma, dbeta, dbias);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+template <typename T>
+static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, const float* b,
+                           float* logits, long npix, long HW, int ncls, int softmax, hipStream_t st) {
+  const int lp = Cin / 8;
+  const int grid = grid_for(npix, (256 / lp) * 8);
+#define HF(NC)                                                                                      \
+  hipLaunchKernelGGL((head_fwd_kernel<T, NC>), dim3(grid), dim3(256), 0, st, (const T*)x, x_ld, Cin, \
+                     w, b, logits, npix, HW, softmax)
+  if (ncls == 2) HF(2); else if (ncls == 3) HF(3); else HF(4);
+#undef HF
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+static bool head_cin_ok(int Cin) {
+  const int lp = Cin / 8;
+  return Cin > 0 && Cin % 8 == 0 && lp <= 64 && (lp & (lp - 1)) == 0;
+}
+
+extern "C" int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, const float* w,
+                               const float* b, float* logits, int B, int H, int W, int ncls,
+                               int softmax, void* stream) {
+  PREC_OK("head_fwd");
+  CRIMAC_REQUIRE(x && w && b && logits && B > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
+  CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "head_fwd: ncls=%d unsupported (2..4)", ncls);
+  CRIMAC_REQUIRE(head_cin_ok(Cin) && x_ld >= Cin && x_ld % 8 == 0,
+                 "head_fwd: Cin=%d must be 8*2^k <= 512", Cin);
+  const long HW = (long)H * W;
+  return prec == CRIMAC_PREC_BF16
+             ? head_fwd_launch<bf16_t>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, ST)
+             : head_fwd_launch<float>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, ST);
+}
+
+template <typename T>
+static int head_bwd_launch(const float* dl, const void* x, long x_ld, int Cin, const float* w, void* dx,
+                           long dx_ld, float* dw, float* db, long npix, long HW, int ncls,
+                           hipStream_t st) {
+  const int lp = Cin / 8;
+  int grid = grid_for(npix, (256 / lp) * 32);
+  if (grid > 1024) grid = 1024;
+  const size_t lds = (size_t)(ncls * Cin + ncls) * sizeof(float);
+#define HB(NC)                                                                                        \
+  hipLaunchKernelGGL((head_bwd_kernel<T, NC>), dim3(grid), dim3(256), lds, st, dl, (const T*)x, x_ld, \
+                     Cin, w, (T*)dx, dx_ld, dw, db, npix, HW)
+  if (ncls == 2) HB(2); else if (ncls == 3) HB(3); else HB(4);
+#undef HB
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_head_bwd(int prec, const float* dlogits, const void* x, long x_ld, int Cin,
+                               const float* w, void* dx, long dx_ld, float* dw, float* db, int B, int H,
+                               int W, int ncls, void* stream) {
+  PREC_OK("head_bwd");
+  CRIMAC_REQUIRE(dlogits && x && w && dx && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
+  CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "head_bwd: ncls=%d unsupported (2..4)", ncls);
+  CRIMAC_REQUIRE(head_cin_ok(Cin) && x_ld >= Cin && dx_ld >= Cin && x_ld % 8 == 0 && dx_ld % 8 == 0,
+                 "head_bwd: Cin=%d must be 8*2^k <= 512", Cin);
+  const long HW = (long)H * W;
+  return prec == CRIMAC_PREC_BF16
+             ? head_bwd_launch<bf16_t>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, ST)
+             : head_bwd_launch<float>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, ST);
+}
+
+extern "C" int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes,
+                              const float* class_w, int ncls, int ignore_index, int B, int H, int W,
+                              double* sums, void* stream) {
+  CRIMAC_REQUIRE(logits && labels && class_w && sums && B > 0 && H > 0 && W > 0, "wce_fwd: bad arguments");
+  CRIMAC_REQUIRE(label_bytes == 2 || label_bytes == 4 || label_bytes == 8, "wce_fwd: label_bytes=%d", label_bytes);
+  CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "wce_fwd: ncls=%d unsupported (2..4)", ncls);
+  const long HW = (long)H * W, npix = B * HW;
+  const int grid = grid_for(npix, 256 * 8);
+#define WF(NC)                                                                                     \
+  hipLaunchKernelGGL(wce_fwd_kernel<NC>, dim3(grid), dim3(256), 0, ST, logits, labels, label_bytes, \
+                     class_w, ignore_index, npix, HW, sums)
+  if (ncls == 2) WF(2); else if (ncls == 3) WF(3); else WF(4);
+#undef WF
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_wce_bwd(const float* logits, const void* labels, int label_bytes,
+                              const float* class_w, int ncls, int ignore_index, int B, int H, int W,
+                              const double* sums, float upstream, float* dlogits, void* stream) {
+  CRIMAC_REQUIRE(logits && labels && class_w && sums && dlogits && B > 0 && H > 0 && W > 0,
+                 "wce_bwd: bad arguments");
+  CRIMAC_REQUIRE(label_bytes == 2 || label_bytes == 4 || label_bytes == 8, "wce_bwd: label_bytes=%d", label_bytes);
+  CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "wce_bwd: ncls=%d unsupported (2..4)", ncls);
+  const long HW = (long)H * W, npix = B * HW;
+  const int grid = grid_for(npix, 256 * 4);
+#define WB(NC)                                                                                     \
+  hipLaunchKernelGGL(wce_bwd_kernel<NC>, dim3(grid), dim3(256), 0, ST, logits, labels, label_bytes, \
+                     class_w, ignore_index, npix, HW, sums, upstream, dlogits)
+  if (ncls == 2) WB(2); else if (ncls == 3) WB(3); else WB(4);
+#undef WB
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_sgd_momentum(float* p, float* g, float* v, long n, float lr, float momentum,
+                                   float grad_scale, int zero_grad, void* stream) {
+  CRIMAC_REQUIRE(p && g && v && n > 0, "sgd_momentum: bad arguments");
+  CRIMAC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                 "sgd_momentum: buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  const int grid = grid_for(n4 > 0 ? n4 : 1, 256 * 4);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
+                     zero_grad);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}

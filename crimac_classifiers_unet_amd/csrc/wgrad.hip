@@ -1,0 +1,240 @@
+// Weight-gradient contraction on MFMA for CDNA4 (gfx950), NHWC activations.
+//
+// Reference op: the weight half of aten::convolution_backward for nn.Conv2d 3x3 (unet.py:35-44)
+// and nn.ConvTranspose2d k2 s2 (unet.py:47-49) -- 64 % of the reference's CPU train step
+// (SURVEY.md §3.1).
+//
+//   dW[t][f][s] = sum over pixels p of  F[p][f] * S[shift_t(p)][s]
+//
+//   conv3x3 : F = dY (Cout), S = X (Cin),  9 taps, shift_t(y,x) = (y+ky-1, x+kx-1), zero outside
+//   upconv  : F = X coarse (Cin), S = dY fine (Cout), 4 taps, shift_ab(y,x) = (2y+a, 2x+b)
+//
+// The contraction index is the pixel, which is the *strided* index of an NHWC tensor, so both MFMA
+// operands are needed transposed.  The tiles are staged pixel-major in LDS exactly as they sit in
+// HBM (coalesced 16-byte loads) and read with ds_read_b64_tr_b16, gfx950's transposing LDS read:
+// no register or LDS transpose pass.
+//
+// Workgroup = 64 F-channels x 64 S-channels x ALL taps (the S halo tile is staged once and reused
+// by the 9 shifted reads), 4 waves as 2x2, each wave 32x32 per tap = 9 accumulators.  Pixel tiles
+// are TR x 16 spatial patches; the pixel range is split across workgroups and partial sums are
+// combined with fp32 atomics whose wave shape is two 128-byte row segments (full atomic rate).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+  const void* f; long f_ld; int CF;
+  const void* s; long s_ld; int CS;
+  int B, Hf, Wf;
+  float* dw;
+  int tiles_y, tiles_x;
+  long ntiles;
+  int tiles_per_block;
+};
+
+__device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 6; }
+
+__device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(p));
+}
+
+// MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
+template <typename TA, int MODE>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  constexpr bool X3 = sizeof(TA) == 4;
+  constexpr int TR = MODE == 0 ? 8 : 4;
+  constexpr int NTAPS = MODE == 0 ? 9 : 4;
+  constexpr int F_ROWS = TR * 16;
+  constexpr int S_ROWS = MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32;
+  constexpr int F_BYTES = F_ROWS * 128;
+  constexpr int S_BYTES = S_ROWS * 128;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sF_hi = smem;
+  unsigned char* sS_hi = smem + F_BYTES;
+  unsigned char* sF_lo = smem + F_BYTES + S_BYTES;
+  unsigned char* sS_lo = smem + 2 * F_BYTES + S_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wf = wave >> 1, ws = wave & 1;
+  const int cs_tiles = (p.CS + 63) / 64;
+  const int cf0 = (blockIdx.x / cs_tiles) * 64;
+  const int cs0 = (blockIdx.x % cs_tiles) * 64;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const TA* fp = reinterpret_cast<const TA*>(p.f);
+  const TA* sp = reinterpret_cast<const TA*>(p.s);
+  const int Hs = MODE == 0 ? p.Hf : 2 * p.Hf, Ws = MODE == 0 ? p.Wf : 2 * p.Wf;
+
+  // lane roles for the transposing reads
+  const int g = lane >> 4, li = lane & 15;
+  const int q = li >> 2, pp = li & 3;
+  const int kh = g >> 1, cgrp = g & 1;
+  const int f_chb = (wf * 32 + 16 * cgrp + 4 * pp) * 2;   // byte offset of this lane's 4 channels
+  const int s_chb = (ws * 32 + 16 * cgrp + 4 * pp) * 2;
+
+  auto stage_unit = [&](const TA* src, bool ok, unsigned char* hi_img, unsigned char* lo_img, int o) {
+    if constexpr (X3) {
+      u32x4 v0 = u32x4{0, 0, 0, 0}, v1 = u32x4{0, 0, 0, 0};
+      if (ok) {
+        v0 = *reinterpret_cast<const u32x4*>(src);
+        v1 = *reinterpret_cast<const u32x4*>(src + 4);
+      }
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float f0 = __uint_as_float(j < 2 ? v0[2 * j] : v1[2 * j - 4]);
+        const float f1 = __uint_as_float(j < 2 ? v0[2 * j + 1] : v1[2 * j - 3]);
+        unsigned short h0, l0, h1, l1;
+        split_bf16(f0, h0, l0);
+        split_bf16(f1, h1, l1);
+        hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+      *reinterpret_cast<u32x4*>(hi_img + o) = hi;
+      *reinterpret_cast<u32x4*>(lo_img + o) = lo;
+    } else {
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (ok) v = *reinterpret_cast<const u32x4*>(src);
+      *reinterpret_cast<u32x4*>(hi_img + o) = v;
+    }
+  };
+
+  const long t_begin = (long)blockIdx.y * p.tiles_per_block;
+  const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
+  for (long tile = t_begin; tile < t_end; ++tile) {
+    const int txi = (int)(tile % p.tiles_x);
+    const long tt = tile / p.tiles_x;
+    const int tyi = (int)(tt % p.tiles_y);
+    const long b = tt / p.tiles_y;
+    const int y0 = tyi * TR, x0 = txi * 16;
+
+    __syncthreads();   // previous tile's fragment reads are done
+    // ---- stage F tile: TR x 16 pixels x 64 channels ------------------------------------------
+    for (int uidx = tid; uidx < F_ROWS * 8; uidx += 256) {
+      const int row = uidx >> 3, u = uidx & 7;
+      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      const bool ok = y < p.Hf && x < p.Wf && (cf0 + u * 8) < p.CF;
+      const TA* src = fp + ((b * p.Hf + y) * (long)p.Wf + x) * p.f_ld + cf0 + u * 8;
+      stage_unit(src, ok, sF_hi, sF_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
+    }
+    // ---- stage S tile ---------------------------------------------------------------------------
+    for (int uidx = tid; uidx < S_ROWS * 8; uidx += 256) {
+      const int row = uidx >> 3, u = uidx & 7;
+      int y, x;
+      if constexpr (MODE == 0) {
+        y = y0 + row / 18 - 1;
+        x = x0 + row % 18 - 1;
+      } else {
+        const int fy = row >> 5, rem = row & 31;
+        y = 2 * y0 + fy;
+        x = 2 * (x0 + (rem & 15)) + (rem >> 4);
+      }
+      const bool ok = y >= 0 && y < Hs && x >= 0 && x < Ws && (cs0 + u * 8) < p.CS;
+      const TA* src = sp + ((b * Hs + y) * (long)Ws + x) * p.s_ld + cs0 + u * 8;
+      stage_unit(src, ok, sS_hi, sS_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
+    }
+    __syncthreads();
+
+    // ---- contraction over the tile's pixels: one k16 step per tile row --------------------------
+#pragma unroll 1
+    for (int py = 0; py < TR; ++py) {
+      bf16x8 a_hi, a_lo;
+      {
+        const int r0 = py * 16 + 8 * kh + q, r1 = r0 + 4;
+        const int o0 = r0 * 128 + (f_chb ^ swz_tr(r0)), o1 = r1 * 128 + (f_chb ^ swz_tr(r1));
+        bf16x4 x0v = lds_tr16(sF_hi + o0), x1v = lds_tr16(sF_hi + o1);
+        a_hi = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (X3) {
+          bf16x4 y0v = lds_tr16(sF_lo + o0), y1v = lds_tr16(sF_lo + o1);
+          a_lo = __builtin_shufflevector(y0v, y1v, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        int r0;
+        if constexpr (MODE == 0) {
+          r0 = (py + t / 3) * 18 + (t % 3) + 8 * kh + q;
+        } else {
+          r0 = (2 * py + (t >> 1)) * 32 + (t & 1) * 16 + 8 * kh + q;
+        }
+        const int r1 = r0 + 4;
+        const int o0 = r0 * 128 + (s_chb ^ swz_tr(r0)), o1 = r1 * 128 + (s_chb ^ swz_tr(r1));
+        bf16x4 x0v = lds_tr16(sS_hi + o0), x1v = lds_tr16(sS_hi + o1);
+        bf16x8 b_hi = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (X3) {
+          bf16x4 y0v = lds_tr16(sS_lo + o0), y1v = lds_tr16(sS_lo + o1);
+          bf16x8 b_lo = __builtin_shufflevector(y0v, y1v, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- combine partial sums: dw[t][cf][cs] += acc ---------------------------------------------
+  const int col = cs0 + ws * 32 + (lane & 31);
+  if (col < p.CS) {
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = cf0 + wf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.CF) atomicAdd(p.dw + ((long)t * p.CF + row) * p.CS + col, acc[t][r]);
+      }
+    }
+  }
+}
+
+template <typename TA, int MODE>
+int launch(WgradParams p, int target_blocks, hipStream_t st) {
+  constexpr bool X3 = sizeof(TA) == 4;
+  constexpr int TR = MODE == 0 ? 8 : 4;
+  constexpr int F_ROWS = TR * 16;
+  constexpr int S_ROWS = MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32;
+  p.tiles_y = cdiv(p.Hf, TR);
+  p.tiles_x = cdiv(p.Wf, 16);
+  p.ntiles = (long)p.B * p.tiles_y * p.tiles_x;
+  const int ch_tiles = cdiv(p.CF, 64) * cdiv(p.CS, 64);
+  int splits = target_blocks / ch_tiles;
+  if (splits < 1) splits = 1;
+  if (splits > p.ntiles) splits = (int)p.ntiles;
+  p.tiles_per_block = cdiv(p.ntiles, splits);
+  splits = cdiv(p.ntiles, p.tiles_per_block);
+  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (X3 ? 2 : 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<TA, MODE>), dim3(ch_tiles, splits), dim3(256), lds, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+}  // namespace
+
+extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
+                            long s_ld, int CS, int B, int Hf, int Wf, float* dw, int target_blocks,
+                            void* stream) {
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, "wgrad: bad precision %d", prec);
+  CRIMAC_REQUIRE(mode == 0 || mode == 1, "wgrad: bad mode %d", mode);
+  CRIMAC_REQUIRE(CF > 0 && CF % 8 == 0 && CS > 0 && CS % 8 == 0, "wgrad: channels must be multiples of 8");
+  CRIMAC_REQUIRE(f_ld >= CF && s_ld >= CS && f_ld % 8 == 0 && s_ld % 8 == 0, "wgrad: bad pixel strides");
+  CRIMAC_REQUIRE(B > 0 && Hf > 0 && Wf > 0 && f && s && dw, "wgrad: bad arguments");
+  WgradParams p;
+  p.f = f; p.f_ld = f_ld; p.CF = CF; p.s = s; p.s_ld = s_ld; p.CS = CS;
+  p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw;
+  if (target_blocks <= 0) target_blocks = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == CRIMAC_PREC_BF16)
+    return mode == 0 ? launch<bf16_t, 0>(p, target_blocks, st) : launch<bf16_t, 1>(p, target_blocks, st);
+  return mode == 0 ? launch<float, 0>(p, target_blocks, st) : launch<float, 1>(p, target_blocks, st);
+}

@@ -1,0 +1,533 @@
+"""Execution plan of the U-Net hot path on one MI355X.
+
+Drives the C-ABI kernels (include/crimac_unet_hip.h) for ``UNet_Baseline.forward``
+(reference crimac_unet/models/unet.py:327-343), its backward (``loss.backward()``,
+pipeline.py:177), the weighted cross entropy (pipeline.py:132-141) and the SGD-momentum update
+(pipeline.py:156, :178).
+
+Data layout in HBM
+  * activations NHWC, bf16 (``precision='bf16'``) or fp32 (``'f32x3'``); ``torch.cat((up, skip), 1)``
+    (unet.py:132) is never executed: the transposed conv and the encoder write into the two channel
+    halves of one ``[M, 2C]`` buffer (pixel stride ``ld = 2C``);
+  * parameters fp32 in ONE flat buffer (module parameters are views into it), gradients and momentum
+    likewise: one SGD launch, a few large all-reduce buckets;
+  * MFMA weight operands: bf16 hi(+lo) planes ``[tap][Cout][Cin]`` (forward) and ``[tap][Cin][Cout]``
+    (input gradient), re-packed from the fp32 masters after every update.
+PyTorch supplies memory and streams only; there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+from .hip import Act, call, ptr
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+CIN_PAD = 16          # first-layer input channels are zero-padded to one MFMA k-step
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class _ConvBlock:
+    """conv3x3 + BatchNorm2d (+ReLU): names of its tensors and its packed operands."""
+
+    def __init__(self, conv_key, bn_key, cin, cout, cin_pad=None):
+        self.conv_key, self.bn_key = conv_key, bn_key
+        self.cin, self.cout = cin, cout
+        self.cin_pad = cin_pad or cin
+        self.idx = None            # index among BN layers (stat scratch slot)
+
+
+class _UpConv:
+    def __init__(self, key, cin, cout):
+        self.key, self.cin, self.cout = key, cin, cout
+
+
+class UNetEngine:
+    def __init__(self, module, precision="bf16"):
+        if precision not in hip.PREC_NAMES:
+            raise ValueError(f"precision must be one of {list(hip.PREC_NAMES)}, got {precision!r}")
+        hip.load_library()       # fail loudly before anything else if the HIP library is missing
+        self.module = module
+        self.precision = precision
+        self.prec = hip.PREC_NAMES[precision]
+        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.depth = module.depth
+        self.sf = module.start_filts
+        self.in_channels = module.in_channels
+        self.n_classes = module.n_classes
+        if self.sf % 64 != 0:
+            raise ValueError("the MFMA tiles need start_filts to be a multiple of 64 "
+                             f"(got {self.sf}); the reference pipeline uses 64 (pipeline.py:394)")
+        if self.in_channels > CIN_PAD:
+            raise ValueError(f"in_channels={self.in_channels} > {CIN_PAD} is not supported")
+        if not 2 <= self.n_classes <= 4:
+            raise ValueError("n_classes must be in 2..4")
+        D, sf = self.depth, self.sf
+        self.enc, self.dec, self.ups = [], [], []
+        for i in range(D):
+            c = sf * 2 ** i
+            cin = self.in_channels if i == 0 else c // 2
+            p = f"down_convs.{i}.main."
+            self.enc.append((_ConvBlock(p + "0", p + "1", cin, c, CIN_PAD if i == 0 else None),
+                             _ConvBlock(p + "3", p + "4", c, c)))
+        for j in range(D - 1):
+            cprev = sf * 2 ** (D - 1 - j)
+            c = cprev // 2
+            p = f"up_convs.{j}."
+            self.ups.append(_UpConv(p + "upconv", cprev, c))
+            self.dec.append((_ConvBlock(p + "conv1", p + "bn1", 2 * c, c),
+                             _ConvBlock(p + "conv2", p + "bn2", c, c)))
+        self.blocks = [b for pair in self.enc for b in pair] + [b for pair in self.dec for b in pair]
+        for k, b in enumerate(self.blocks):
+            b.idx = k
+        self.device = None
+        self._bufs = {}
+        self._train_pack_dirty = True
+        self._eval_pack_dirty = True
+        self._versions = None
+        self.saved = None          # activations of the last train-mode forward
+        self.accumulate_grads = False   # True: backward() adds to the flat gradient (torch semantics
+        #                                 when .grad is not zeroed between backward calls)
+
+    # ------------------------------------------------------------------------------------------
+    # parameter storage
+    # ------------------------------------------------------------------------------------------
+    def bind(self):
+        """(Re)point every module parameter at a slice of the flat fp32 buffer on the module's GPU."""
+        params = list(self.module.named_parameters())
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise hip.HipLibraryError(
+                "UNet_Baseline (MI355X build) must live on a GPU: call .to('cuda'); "
+                "there is no CPU fallback for the hot path")
+        ok = self.device == dev and getattr(self, "flat_p", None) is not None
+        if ok:
+            base = self.flat_p.data_ptr()
+            for name, p in params:
+                off, n, _ = self.layout[name]
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if ok:
+            return
+        self.device = dev
+        self.layout, off = {}, 0
+        for name, p in params:
+            self.layout[name] = (off, p.numel(), tuple(p.shape))
+            off += _align(p.numel())
+        self.n_flat = off
+        flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for name, p in params:
+                o, n, shp = self.layout[name]
+                flat_p[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat_p[o:o + n].view(shp)
+                p.grad = self.flat_g[o:o + n].view(shp)
+        self.flat_p = flat_p
+        self.P = {name: p for name, p in params}
+        self.G = {name: self.flat_g[o:o + n].view(shp) for name, (o, n, shp) in self.layout.items()}
+        self.Bf = dict(self.module.named_buffers())
+        self._alloc_static()
+        self._train_pack_dirty = self._eval_pack_dirty = True
+        self._bufs = {}
+
+    def _alloc_static(self):
+        dev = self.device
+        i16 = torch.int16
+        self.pk = {}      # train-mode operand planes
+        self.pk_eval = {}  # eval-mode (BN folded) forward planes + folded bias
+        tot_dw = 0
+        self.dw_off = {}
+        for b in self.blocks:
+            n_f = 9 * b.cout * b.cin_pad
+            self.pk[b.conv_key] = {
+                "fwd_hi": torch.empty(n_f, dtype=i16, device=dev),
+                "fwd_lo": torch.empty(n_f, dtype=i16, device=dev),
+                "dg_hi": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if b.cin_pad == b.cin else None,
+                "dg_lo": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if b.cin_pad == b.cin else None,
+            }
+            self.pk_eval[b.conv_key] = {
+                "fwd_hi": torch.empty(n_f, dtype=i16, device=dev),
+                "fwd_lo": torch.empty(n_f, dtype=i16, device=dev),
+                "bias": torch.empty(b.cout, dtype=torch.float32, device=dev),
+            }
+            self.dw_off[b.conv_key] = tot_dw
+            tot_dw += _align(n_f)
+        for u in self.ups:
+            n = 4 * u.cin * u.cout
+            self.pk[u.key] = {k: torch.empty(n, dtype=i16, device=dev)
+                              for k in ("fwd_hi", "fwd_lo", "dg_hi", "dg_lo")}
+            self.dw_off[u.key] = tot_dw
+            tot_dw += _align(n)
+        self.dw_packed = torch.zeros(tot_dw, dtype=torch.float32, device=dev)
+        cmax = self.sf * 2 ** (self.depth - 1)
+        nb = len(self.blocks)
+        # fp64 scratch: [0:2] loss sums, then per BN layer 4 x cmax (sum, sumsq, sum_dz, sum_dz_xhat)
+        self.stat = torch.zeros(2 + nb * 4 * cmax, dtype=torch.float64, device=dev)
+        self.cmax = cmax
+        # fp32 per BN layer: mean, invstd, scale, shift
+        self.bnf = torch.zeros(nb * 4 * cmax, dtype=torch.float32, device=dev)
+        self.class_w = None
+
+    def _stat(self, b, k):
+        o = 2 + (b.idx * 4 + k) * self.cmax
+        return self.stat[o:o + b.cout]
+
+    def _bnf(self, b, k):
+        o = (b.idx * 4 + k) * self.cmax
+        return self.bnf[o:o + b.cout]
+
+    def _dw(self, key, n):
+        o = self.dw_off[key]
+        return self.dw_packed[o:o + n]
+
+    def mark_dirty(self):
+        self._train_pack_dirty = self._eval_pack_dirty = True
+
+    def _check_versions(self):
+        """Detect in-place edits made through torch (load_state_dict, manual init, optimizers)."""
+        v = sum(p._version for p in self.P.values()) + sum(b._version for b in self.Bf.values())
+        if v != self._versions:
+            self._versions = v
+            self.mark_dirty()
+
+    # ------------------------------------------------------------------------------------------
+    # operand packing
+    # ------------------------------------------------------------------------------------------
+    def _pack_train(self):
+        if not self._train_pack_dirty:
+            return
+        x3 = self.prec == hip.PREC_F32X3
+        for b in self.blocks:
+            pk = self.pk[b.conv_key]
+            call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin, b.cin_pad,
+                 None, ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]) if x3 else None, ptr(pk["dg_hi"]),
+                 ptr(pk["dg_lo"]) if (x3 and pk["dg_lo"] is not None) else None)
+        for u in self.ups:
+            pk = self.pk[u.key]
+            call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout,
+                 ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]) if x3 else None, ptr(pk["dg_hi"]),
+                 ptr(pk["dg_lo"]) if x3 else None)
+        self._train_pack_dirty = False
+
+    def _pack_eval(self):
+        """Fold eval-mode BatchNorm into the conv: W*s, (b-rm)*s+beta, s=g/sqrt(rv+eps)."""
+        if not self._eval_pack_dirty:
+            return
+        x3 = self.prec == hip.PREC_F32X3
+        with torch.no_grad():
+            for b in self.blocks:
+                g, be = self.P[b.bn_key + ".weight"], self.P[b.bn_key + ".bias"]
+                rm, rv = self.Bf[b.bn_key + ".running_mean"], self.Bf[b.bn_key + ".running_var"]
+                s = g * torch.rsqrt(rv + BN_EPS)
+                pk = self.pk_eval[b.conv_key]
+                pk["bias"].copy_((self.P[b.conv_key + ".bias"] - rm) * s + be)
+                call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin,
+                     b.cin_pad, ptr(s.contiguous()), ptr(pk["fwd_hi"]),
+                     ptr(pk["fwd_lo"]) if x3 else None, None, None)
+                # s must stay alive until the kernel ran: same stream, freed memory is stream-ordered
+        # up-conv planes are shared with the train pack (no BN behind them)
+        tp = self._train_pack_dirty
+        if tp:
+            for u in self.ups:
+                pk = self.pk[u.key]
+                call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout,
+                     ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]) if x3 else None, ptr(pk["dg_hi"]),
+                     ptr(pk["dg_lo"]) if x3 else None)
+        self._eval_pack_dirty = False
+
+    # ------------------------------------------------------------------------------------------
+    # buffers
+    # ------------------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype=None):
+        dtype = dtype or self.act_dtype
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def _geom(self, B, H, W):
+        D = self.depth
+        if H % (2 ** (D - 1)) or W % (2 ** (D - 1)):
+            raise ValueError(f"H, W must be divisible by {2 ** (D - 1)} (got {H}x{W})")
+        return [(H >> i, W >> i, B * (H >> i) * (W >> i)) for i in range(D)]
+
+    # ------------------------------------------------------------------------------------------
+    # kernels wrappers
+    # ------------------------------------------------------------------------------------------
+    def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None):
+        call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1,
+             ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"]),
+             ptr(bias), cout, out.p, out.ld, 1 if relu else 0, 0, 0,
+             flops=2.0 * 9 * (cin_real or cin) * cout * B * H * W)
+
+    def _upconv_fwd(self, x: Act, u, out: Act, B, H, W):
+        pk = self.pk[u.key]
+        call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, u.cin, 4 * u.cout, 1, 1, 0, 1,
+             ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(self.P[u.key + ".bias"]), u.cout, out.p, out.ld,
+             0, 1, u.cout, flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+
+    def _upconv_dgrad(self, dy: Act, u, out: Act, B, H, W):
+        """dy on the fine grid [B,2H,2W,cout] -> dx on the coarse grid [B,H,W,cin]."""
+        pk = self.pk[u.key]
+        call("crimac_igemm_conv", self.prec, dy.p, dy.ld, B, 2 * H, 2 * W, H, W, u.cout, u.cin, 4, 2, 0,
+             2, ptr(pk["dg_hi"]), ptr(pk["dg_lo"]), None, 0, out.p, out.ld, 0, 0, 0,
+             flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+
+    def _bn_train(self, b, y: Act, M):
+        call("crimac_colstats", self.prec, y.p, y.ld, M, b.cout, ptr(self._stat(b, 0)),
+             ptr(self._stat(b, 1)))
+        call("crimac_bn_finalize", ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), M, b.cout,
+             ptr(self.P[b.bn_key + ".weight"]), ptr(self.P[b.bn_key + ".bias"]), BN_EPS, BN_MOMENTUM,
+             ptr(self.Bf[b.bn_key + ".running_mean"]), ptr(self.Bf[b.bn_key + ".running_var"]),
+             ptr(self.Bf[b.bn_key + ".num_batches_tracked"]), ptr(self._bnf(b, 0)),
+             ptr(self._bnf(b, 1)), ptr(self._bnf(b, 2)), ptr(self._bnf(b, 3)))
+
+    def _act(self, b, y: Act, out: Act, pool: Act, B, H, W, train=True):
+        call("crimac_bn_act_pool", self.prec, y.p, y.ld,
+             ptr(self._bnf(b, 2)) if train else None, ptr(self._bnf(b, 3)) if train else None,
+             1 if train else 0, out.p if out is not None else None, out.ld if out is not None else 0,
+             pool.p if pool is not None else None, pool.ld if pool is not None else 0, B, H, W, b.cout)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _input(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input [B,{self.in_channels},H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise hip.HipLibraryError("input is not on a GPU: the HIP path has no CPU fallback")
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        xin = self._buf("x_nhwc", (B * H * W, CIN_PAD))
+        call("crimac_nchw_to_nhwc", self.prec, ptr(x), ptr(xin), B, self.in_channels, H, W, CIN_PAD)
+        return xin, B, H, W
+
+    def forward(self, x, training, softmax=False):
+        """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs."""
+        self.bind()
+        self._check_versions()
+        xin, B, H, W = self._input(x)
+        geo = self._geom(B, H, W)
+        D = self.depth
+        if training:
+            self._pack_train()
+            self.stat.zero_()
+        else:
+            self._pack_eval()
+        cur = Act(xin, CIN_PAD)
+        saved = {"B": B, "H": H, "W": W, "x0": cur}
+        for i in range(D):
+            h, w, M = geo[i]
+            c = self.sf * 2 ** i
+            b1, b2 = self.enc[i]
+            a1 = Act(self._buf(f"e{i}.a1", (M, c)), c)
+            if i < D - 1:
+                cat = self._buf(f"cat{i}", (M, 2 * c))
+                a2 = Act(cat, c, off=c, ld=2 * c)
+                pool = Act(self._buf(f"e{i}.pool", (geo[i + 1][2], c)), c)
+            else:
+                a2 = Act(self._buf(f"e{i}.a2", (M, c)), c)
+                pool = None
+            if training:
+                y1 = Act(self._buf(f"e{i}.y1", (M, c)), c)
+                y2 = Act(self._buf(f"e{i}.y2", (M, c)), c)
+                self._conv3x3(cur, self.pk[b1.conv_key], self.P[b1.conv_key + ".bias"], y1, B, h, w,
+                              b1.cin_pad, c, relu=False, cin_real=b1.cin)
+                self._bn_train(b1, y1, M)
+                self._act(b1, y1, a1, None, B, h, w)
+                self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
+                              relu=False)
+                self._bn_train(b2, y2, M)
+                self._act(b2, y2, a2, pool, B, h, w)
+                saved[f"e{i}"] = (cur, y1, a1, y2, a2)
+            else:
+                pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
+                self._conv3x3(cur, pe1, pe1["bias"], a1, B, h, w, b1.cin_pad, c, relu=True, cin_real=b1.cin)
+                self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
+                if pool is not None:
+                    self._act(b2, a2, None, pool, B, h, w, train=False)
+            cur = pool if pool is not None else a2
+        for j in range(D - 1):
+            L = D - 2 - j
+            h, w, M = geo[L]
+            c = self.sf * 2 ** L
+            u = self.ups[j]
+            b1, b2 = self.dec[j]
+            cat = self._buf(f"cat{L}", (M, 2 * c))
+            up = Act(cat, c, off=0, ld=2 * c)
+            catA = Act(cat, 2 * c)
+            hp, wp, _ = geo[L + 1]
+            self._upconv_fwd(cur, u, up, B, hp, wp)
+            a1 = Act(self._buf(f"d{j}.a1", (M, c)), c)
+            a2 = Act(self._buf(f"d{j}.a2", (M, c)), c)
+            if training:
+                y1 = Act(self._buf(f"d{j}.y1", (M, c)), c)
+                y2 = Act(self._buf(f"d{j}.y2", (M, c)), c)
+                self._conv3x3(catA, self.pk[b1.conv_key], self.P[b1.conv_key + ".bias"], y1, B, h, w,
+                              2 * c, c, relu=False)
+                self._bn_train(b1, y1, M)
+                self._act(b1, y1, a1, None, B, h, w)
+                self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
+                              relu=False)
+                self._bn_train(b2, y2, M)
+                self._act(b2, y2, a2, None, B, h, w)
+                saved[f"d{j}"] = (cur, catA, y1, a1, y2, a2)
+            else:
+                pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
+                self._conv3x3(catA, pe1, pe1["bias"], a1, B, h, w, 2 * c, c, relu=True)
+                self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
+            cur = a2
+        logits = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=self.device)
+        call("crimac_head_fwd", self.prec, cur.p, cur.ld, self.sf, ptr(self.P["conv_final.weight"]),
+             ptr(self.P["conv_final.bias"]), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0)
+        saved["head_in"] = cur
+        self.saved = saved if training else None
+        return logits
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------
+    def _block_bwd(self, tag, b, da: Act, y: Act, x_in: Act, B, h, w, M, dx_out: Act, cs=None):
+        """Backward of conv3x3+BN+ReLU given da (grad of the block output)."""
+        call("crimac_bn_bwd_reduce", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
+             ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
+             ptr(self._stat(b, 2)), ptr(self._stat(b, 3)))
+        dy = Act(self._buf(f"{tag}.dy", (M, b.cout)), b.cout)
+        call("crimac_bn_bwd_apply", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
+             ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), ptr(self._stat(b, 2)),
+             ptr(self._stat(b, 3)), M, b.cout, dy.p, dy.ld, ptr(self.G[b.bn_key + ".weight"]),
+             ptr(self.G[b.bn_key + ".bias"]), ptr(self.G[b.conv_key + ".bias"]))
+        n = 9 * b.cout * b.cin_pad
+        dw = self._dw(b.conv_key, n)
+        call("crimac_wgrad", self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w,
+             ptr(dw), self.wgrad_target_blocks, flops=2.0 * 9 * b.cin * b.cout * B * h * w)
+        call("crimac_unpack_wgrad_conv3x3", ptr(dw), b.cout, b.cin, b.cin_pad,
+             ptr(self.G[b.conv_key + ".weight"]))
+        if dx_out is not None:
+            self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                          dgrad=True)
+
+    wgrad_target_blocks = 1024
+
+    def backward(self, dlogits):
+        """Gradients of every parameter into the flat gradient buffer (overwrites it)."""
+        s = self.saved
+        if s is None:
+            raise RuntimeError("backward() needs a preceding train-mode forward()")
+        B, H, W = s["B"], s["H"], s["W"]
+        geo = self._geom(B, H, W)
+        D = self.depth
+        self.flat_g.zero_()
+        self.dw_packed.zero_()
+        dlogits = dlogits.contiguous().float()
+        head_in = s["head_in"]
+        h, w, M = geo[0]
+        d_cur = Act(self._buf("g.head", (M, self.sf)), self.sf)
+        call("crimac_head_bwd", self.prec, ptr(dlogits), head_in.p, head_in.ld, self.sf,
+             ptr(self.P["conv_final.weight"]), d_cur.p, d_cur.ld, ptr(self.G["conv_final.weight"]),
+             ptr(self.G["conv_final.bias"]), B, H, W, self.n_classes)
+        skip_grad = {}
+        for j in reversed(range(D - 1)):
+            L = D - 2 - j
+            h, w, M = geo[L]
+            c = self.sf * 2 ** L
+            u = self.ups[j]
+            b1, b2 = self.dec[j]
+            x_prev, catA, y1, a1, y2, a2 = s[f"d{j}"]
+            da1 = Act(self._buf(f"g.d{j}.a1", (M, c)), c)
+            self._block_bwd(f"g.d{j}.2", b2, d_cur, y2, a1, B, h, w, M, da1)
+            dcat = Act(self._buf(f"g.d{j}.cat", (M, 2 * c)), 2 * c)
+            self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat)
+            dup = dcat.slice(0, c)
+            skip_grad[L] = dcat.slice(c, c)
+            # transposed conv backward (unet.py:130)
+            call("crimac_colsum_f32", self.prec, dup.p, dup.ld, M, c, ptr(self.G[u.key + ".bias"]))
+            hp, wp, Mp = geo[L + 1]
+            n = 4 * u.cin * u.cout
+            dw = self._dw(u.key, n)
+            call("crimac_wgrad", self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp,
+                 wp, ptr(dw), self.wgrad_target_blocks, flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
+            call("crimac_unpack_wgrad_upconv2x2", ptr(dw), u.cin, u.cout, ptr(self.G[u.key + ".weight"]))
+            d_prev = Act(self._buf(f"g.d{j}.xprev", (Mp, u.cin)), u.cin)
+            self._upconv_dgrad(dup, u, d_prev, B, hp, wp)
+            d_cur = d_prev
+        d_pool = None
+        for i in reversed(range(D)):
+            h, w, M = geo[i]
+            c = self.sf * 2 ** i
+            b1, b2 = self.enc[i]
+            x_in, y1, a1, y2, a2 = s[f"e{i}"]
+            if i == D - 1:
+                da2 = d_cur
+            else:
+                da2 = Act(self._buf(f"g.e{i}.a2", (M, c)), c)
+                ds = skip_grad[i]
+                call("crimac_unpool_add", self.prec, d_pool.p, d_pool.ld, a2.p, a2.ld, ds.p, ds.ld,
+                     da2.p, da2.ld, B, h, w, c)
+            da1 = Act(self._buf(f"g.e{i}.a1", (M, c)), c)
+            self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1)
+            if i > 0:
+                d_pool = Act(self._buf(f"g.e{i}.xin", (M, b1.cin)), b1.cin)
+                self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool)
+            else:
+                self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, None)
+
+    # ------------------------------------------------------------------------------------------
+    # loss and optimiser
+    # ------------------------------------------------------------------------------------------
+    def _labels(self, labels):
+        if not labels.is_cuda:
+            raise hip.HipLibraryError("labels are not on a GPU")
+        if labels.dtype not in (torch.int16, torch.int32, torch.int64):
+            labels = labels.long()
+        return labels.contiguous()
+
+    def ce_forward(self, logits, labels, class_w, ignore_index=-100, sums=None):
+        """Accumulate (sum w*nll, sum w) into ``sums`` (fp64[2], zeroed by the caller or here)."""
+        labels = self._labels(labels)
+        B, nc, H, W = logits.shape
+        if tuple(labels.shape) != (B, H, W):
+            raise ValueError(f"labels {tuple(labels.shape)} do not match logits {tuple(logits.shape)}")
+        if sums is None:
+            sums = torch.zeros(2, dtype=torch.float64, device=logits.device)
+        call("crimac_wce_fwd", ptr(logits), ptr(labels), labels.element_size(), ptr(class_w), nc,
+             ignore_index, B, H, W, ptr(sums))
+        return sums, labels
+
+    def ce_backward(self, logits, labels, class_w, sums, upstream=1.0, ignore_index=-100):
+        B, nc, H, W = logits.shape
+        dl = self._buf("g.dlogits", (B, nc, H, W), torch.float32)
+        call("crimac_wce_bwd", ptr(logits), ptr(labels), labels.element_size(), ptr(class_w), nc,
+             ignore_index, B, H, W, ptr(sums), float(upstream), ptr(dl))
+        return dl
+
+    def sgd_step(self, lr, momentum, grad_scale=1.0, zero_grad=False):
+        call("crimac_sgd_momentum", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
+             float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0)
+        self.mark_dirty()
+
+    def train_step(self, x, labels, class_w, lr, momentum, grad_sync=None, ignore_index=-100):
+        """Fused step: forward + weighted CE + backward (+ gradient exchange) + SGD.
+
+        Mirrors the loop body of SegPipe.train_model (pipeline.py:163-178) without autograd and
+        without a host sync; returns the loss as a 0-d device tensor.
+        ``grad_sync(flat_grad) -> scale`` may all-reduce the flat gradient in place.
+        """
+        logits = self.forward(x, training=True)
+        sums = self.stat[0:2]
+        sums, labels = self.ce_forward(logits, labels, class_w, ignore_index, sums=sums)
+        dl = self.ce_backward(logits, labels, class_w, sums, 1.0, ignore_index)
+        self.backward(dl)
+        scale = 1.0
+        if grad_sync is not None:
+            scale = grad_sync(self.flat_g)
+        self.sgd_step(lr, momentum, grad_scale=scale)
+        return (sums[0] / sums[1]).float()

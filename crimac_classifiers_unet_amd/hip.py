@@ -1,0 +1,133 @@
+"""ctypes binding of libcrimac_unet_hip.so (the C ABI declared in include/crimac_unet_hip.h).
+
+PyTorch is used only for device memory and streams: tensors are passed as raw ``data_ptr()``s plus
+the current ``torch.cuda`` stream handle.  There is NO CPU fallback: if the library is missing or a
+tensor is not on a GPU, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+PREC_BF16 = 0
+PREC_F32X3 = 1
+PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3}
+
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes, exactly the prototypes of include/crimac_unet_hip.h
+SIGNATURES = {
+    "crimac_igemm_conv": [_i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i,
+                          _vp, _l, _i, _i, _i, _vp],
+    "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
+    "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "crimac_pack_upconv2x2": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "crimac_unpack_wgrad_conv3x3": [_vp, _i, _i, _i, _vp, _vp],
+    "crimac_unpack_wgrad_upconv2x2": [_vp, _i, _i, _vp, _vp],
+    "crimac_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _l, _vp],
+    "crimac_colstats": [_i, _vp, _l, _l, _i, _vp, _vp, _vp],
+    "crimac_colsum_f32": [_i, _vp, _l, _l, _i, _vp, _vp],
+    "crimac_bn_finalize": [_vp, _vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "crimac_bn_act_pool": [_i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
+    "crimac_unpool_add": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
+    "crimac_bn_bwd_reduce": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp],
+    "crimac_bn_bwd_apply": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp,
+                            _vp, _vp, _vp],
+    "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp],
+    "crimac_wce_fwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "crimac_wce_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp],
+    "crimac_sgd_momentum": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            f"{path} is missing: build it with `python -m crimac_classifiers_unet_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the U-Net hot path.")
+    lib = C.CDLL(path)
+    lib.crimac_version.restype = C.c_int
+    lib.crimac_version.argtypes = []
+    lib.crimac_last_error.restype = C.c_char_p
+    lib.crimac_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        msg = load_library().crimac_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{name} failed ({rc}): {msg}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, offset_elems: int = 0):
+    """Raw device pointer of a tensor (+ element offset); None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("tensor is not on a GPU: the HIP path has no CPU fallback")
+    return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+class Act:
+    """A channel slice of an NHWC activation buffer: base tensor + channel offset + pixel stride."""
+
+    __slots__ = ("t", "off", "ld", "C")
+
+    def __init__(self, t, C_, off=0, ld=None):
+        self.t = t
+        self.off = off
+        self.ld = ld if ld is not None else t.shape[-1]
+        self.C = C_
+
+    @property
+    def p(self):
+        return ptr(self.t, self.off)
+
+    def slice(self, off, C_):
+        return Act(self.t, C_, self.off + off, self.ld)
+
+
+# When set to a list (bench.py), every call that passes ``flops=`` is bracketed by HIP events on
+# the current stream and (name, flops, start, end) is appended.
+PROFILE = None
+
+
+def call(name: str, *args, flops=None):
+    lib = load_library()
+    if PROFILE is not None and flops is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        _check(getattr(lib, name)(*args, _stream()), name)
+        e.record()
+        PROFILE.append((name, flops, s, e))
+        return
+    _check(getattr(lib, name)(*args, _stream()), name)

@@ -1,0 +1,101 @@
+"""One-process-per-GPU data parallelism over RCCL / xGMI (the reference has no distributed code).
+
+Training: every rank runs the same step on its own mini-batch shard; the only
+exchange is the gradient all-reduce over the FLAT fp32 gradient buffer (31.04 M floats = 124 MB),
+issued as a few large buckets (xGMI is point-to-point; large messages keep every link busy) and
+averaged by folding 1/world into the SGD kernel's ``grad_scale``.  BatchNorm statistics stay
+per-rank (torch DDP default; SyncBN is out of scope this round -- DESIGN.md).
+
+Inference: patches are independent; patch ``p`` of a chunk goes to rank ``p % world`` and the
+per-rank softmax slabs are all-gathered.
+
+Backend: ``nccl`` (= RCCL on ROCm) when the tensors are on a GPU, ``gloo`` on CPU (used only by the
+CPU tests of this host logic).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), \
+        int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    world, rank, local = env_world()
+    if world == 1:
+        return world, rank, local
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def bucket_bounds(n, bucket_elems):
+    """[(start, end)] covering [0, n) in buckets of at most ``bucket_elems`` elements."""
+    if bucket_elems <= 0:
+        raise ValueError("bucket_elems must be positive")
+    return [(s, min(s + bucket_elems, n)) for s in range(0, n, bucket_elems)]
+
+
+class GradSync:
+    """Bucketed all-reduce (sum) of a flat gradient buffer; returns the 1/world averaging scale."""
+
+    def __init__(self, bucket_mb=32.0, group=None):
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.group = group
+
+    def __call__(self, flat_grad):
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1.0
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return 1.0
+        works = [dist.all_reduce(flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for s, e in bucket_bounds(flat_grad.numel(), self.bucket_elems)]
+        for w in works:
+            w.wait()
+        return 1.0 / world
+
+
+def shard_indices(n_items, rank, world):
+    """Indices of the items (patches) rank ``rank`` owns: round-robin ``p % world == rank``."""
+    return list(range(rank, n_items, world))
+
+
+def gather_shards(local, n_items, group=None):
+    """All-gather per-rank result slabs back into item order.
+
+    ``local``: [n_local, ...] results for ``shard_indices(n_items, rank, world)``; every rank gets
+    the full [n_items, ...] tensor.  Ranks with one item fewer are padded for the collective.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_max = (n_items + world - 1) // world
+    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        out[idx] = parts[r][: len(idx)]
+    return out
+
+
+def all_reduce_scalars(t, group=None):
+    """Sum a small tensor (loss numerator/denominator) over ranks in place."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

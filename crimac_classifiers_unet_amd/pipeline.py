@@ -1,0 +1,296 @@
+"""``SegPipe`` / ``SegPipeUNet`` for MI355X: the reference's training / prediction pipeline surface.
+
+Mirrors crimac_unet/pipeline_train_predict/pipeline.py (class SegPipe :39-376, SegPipeUNet :379-410,
+get_in_channels :413-425): same constructor keywords (so ``SegPipeUNet(**yaml_config)`` works with
+the reference's ``pipeline_config.yaml`` keys unchanged), same public attributes and methods, same
+batch dictionaries (``{'data','labels','center_coordinates'}`` from the reference ``Dataset``) and
+the same ``state_dict`` checkpoints (``best.pt`` / ``last.pt``).
+
+The compute behind ``train_model`` / ``predict_batch`` is the HIP engine; with ``torch.distributed``
+initialised (one process per GPU) ``train_model`` all-reduces gradients over RCCL.
+New optional keywords (all defaulted, so the baseline yaml still works): ``precision``
+('bf16' | 'f32x3'), ``loss_flush`` (how often queued train losses are handed to the logger).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import parallel
+from .train_ops import ExponentialLR, SGDMomentum, WeightedCrossEntropy
+from .unet import UNet_Baseline
+
+# crimac_unet/constants.py:20-33
+BACKGROUND, SANDEEL, OTHER = 0, 1, 2
+LABEL_IGNORE_VAL = -100
+LABEL_BOUNDARY_VAL = -100
+LABEL_OVERLAP_VAL = -70
+LABEL_SEABED_MASK_VAL = -50
+LABEL_REFINE_BOUNDARY_VAL = -30
+LABEL_UNUSED_SPECIES = -10
+
+CE_CLASS_WEIGHTS = (10.0, 300.0, 250.0)     # pipeline.py:135
+
+
+def _tqdm(it, **kw):
+    try:
+        from tqdm import tqdm
+        return tqdm(it, **kw)
+    except Exception:  # pragma: no cover
+        return it
+
+
+class SegPipe:
+    """Segmentation training-prediction pipeline (reference pipeline.py:39-376)."""
+
+    def __init__(self, checkpoint_dir, data_mode, frequencies, patch_size, loss_type, lr, lr_reduction,
+                 lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
+                 save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
+                 precision="bf16", loss_flush=50, **kwargs):
+        assert not (save_model_params and (checkpoint_dir is None))
+        self.model = None
+        self.model_is_loaded = False
+
+        self.data_mode = data_mode
+        self.frequencies = frequencies
+        if self.frequencies == "all":
+            self.frequencies = [18, 38, 120, 200]
+        if self.data_mode == "zarr":
+            self.frequencies = sorted([freq for freq in self.frequencies])
+        self.window_size = patch_size
+
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.loss_type = loss_type
+        self.lr, self.lr_reduction, self.momentum, self.lr_step = lr, lr_reduction, momentum, lr_step
+        self.iterations, self.test_iter, self.log_step = iterations, test_iter, log_step
+        self.batch_size, self.num_workers = batch_size, num_workers
+        self.save_model_params = save_model_params
+        self.checkpoint_dir = checkpoint_dir
+
+        self.meta_channels = meta_channels
+        self.late_meta_inject = late_meta_inject
+        self.use_metadata = len(self.meta_channels) > 0
+
+        self.model_name = experiment_name
+        self.eval_mode = eval_mode
+        self.best_F1_val = -np.inf
+
+        self.precision = precision
+        self.loss_flush = max(int(loss_flush), 1)
+
+    # ------------------------------------------------------------------------------------------
+    def load_model_params(self, checkpoint_path=None):
+        """Load a ``state_dict`` checkpoint (reference pipeline.py:109-130)."""
+        if self.model_is_loaded:
+            return
+        assert self.model is not None
+        if checkpoint_path is None:
+            checkpoint_path = Path(self.checkpoint_dir, "best.pt")
+        with torch.no_grad():
+            self.model.to(self.device)
+            self.model.load_state_dict(torch.load(checkpoint_path, map_location=self.device))
+            self.model.eval()
+        print("loaded model", checkpoint_path)
+        self.model_is_loaded = True
+
+    def get_criterion(self):
+        """Weighted CE, weight [10, 300, 250] (reference pipeline.py:132-141)."""
+        if self.loss_type == "CE":
+            return WeightedCrossEntropy(CE_CLASS_WEIGHTS).to(self.device)
+        raise ValueError("`loss_type` not recognized")
+
+    # ------------------------------------------------------------------------------------------
+    def train_model(self, dataloader_train, dataloader_test, logger=None):
+        """Training loop of the reference (pipeline.py:144-203) on the fused HIP step.
+
+        Each iteration = forward + weighted CE + backward (+ RCCL gradient all-reduce) + SGD.
+        The reference logs ``loss.item()`` every step (a host sync, :181); here losses stay on
+        the device and are flushed to ``logger`` every ``loss_flush`` steps with their original
+        ``global_step``.
+        """
+        assert not Path(self.checkpoint_dir).is_dir() if self.checkpoint_dir is not None else True, f"""
+            Attempting to train a model that already exists: {str(self.checkpoint_dir)}
+            Use a different model name or delete the saved model params file
+        """
+        self.model.to(self.device)
+        optimizer = SGDMomentum(self.model, lr=self.lr, momentum=self.momentum)
+        scheduler = ExponentialLR(optimizer, gamma=self.lr_reduction)
+        criterion = self.get_criterion()
+        engine = self.model.engine
+        grad_sync = parallel.GradSync()
+        is_rank0 = parallel.env_world()[1] == 0
+        pending = []
+
+        def flush():
+            if logger is not None and pending:
+                vals = torch.stack([v for _, v in pending]).cpu().tolist()
+                for (step, _), v in zip(pending, vals):
+                    logger.add_scalar(tag="train/loss", scalar_value=v, global_step=step)
+            pending.clear()
+
+        for i, batch in _tqdm(enumerate(dataloader_train), desc="Training model",
+                              total=len(dataloader_train), disable=not is_rank0):
+            inputs_train = batch["data"].float().to(self.device, non_blocking=True)
+            labels_train = batch["labels"].to(self.device, non_blocking=True)
+            self.model.train()
+            loss = engine.train_step(inputs_train, labels_train, criterion.weight,
+                                     optimizer.param_groups[0]["lr"], self.momentum,
+                                     grad_sync=grad_sync)
+            pending.append((i + 1, loss))
+            if len(pending) >= self.loss_flush:
+                flush()
+
+            if (i + 1) % self.log_step == 0:
+                flush()
+                self.validate_model_training(dataloader_test, criterion, logger, i)
+
+            if (i + 1) % self.lr_step == 0:
+                scheduler.step()
+                if logger is not None:
+                    for group_idx, group in enumerate(optimizer.param_groups):
+                        logger.add_scalar(tag=f"learning_rate_{group_idx}", scalar_value=group["lr"],
+                                          global_step=i + 1)
+        flush()
+        print("Training complete")
+        self.model_is_loaded = True
+
+        if self.save_model_params and is_rank0:
+            Path(self.checkpoint_dir).mkdir(parents=True, exist_ok=True)
+            checkpoint_path = Path(self.checkpoint_dir) / "last.pt"
+            torch.save(self.model.state_dict(), checkpoint_path)
+            print("Trained model parameters saved to file:", str(checkpoint_path))
+
+    # ------------------------------------------------------------------------------------------
+    def predict_batch(self, batch, return_softmax=False):
+        """Eval-mode forward of one batch dict (reference pipeline.py:205-219); result stays on GPU."""
+        self.model.eval()
+        with torch.no_grad():
+            inputs = batch["data"].float().to(self.device)
+            if self.late_meta_inject:
+                raise NotImplementedError("late metadata injection is not on the accelerated path")
+            if return_softmax:
+                return self.model.predict_softmax(inputs)
+            return self.model(inputs)
+
+    def set_label_ignore_val(self, labels):
+        """Reference pipeline.py:222-239 (in place, like the reference)."""
+        labels[labels == LABEL_OVERLAP_VAL] = LABEL_IGNORE_VAL
+        labels[labels == LABEL_REFINE_BOUNDARY_VAL] = LABEL_IGNORE_VAL
+        labels[labels == LABEL_BOUNDARY_VAL] = LABEL_IGNORE_VAL
+        labels[labels == LABEL_UNUSED_SPECIES] = LABEL_IGNORE_VAL
+        labels[labels == LABEL_SEABED_MASK_VAL] = 0
+        return labels
+
+    def get_predictions_dataloader(self, dataloader, criterion=None, disable_tqdm=False):
+        """Sandeel-probability vector + labels over a dataloader (reference pipeline.py:242-282)."""
+        preds, labels = [], []
+        sum_loss = None
+        self.model.eval()
+        with torch.no_grad():
+            for ii, batch_test in _tqdm(enumerate(dataloader), desc="Evaluating model",
+                                        total=len(dataloader), disable=disable_tqdm):
+                outputs_test = self.predict_batch(batch_test, return_softmax=False)
+                if criterion is not None:
+                    labels_input = batch_test["labels"].long().to(self.device)
+                    labels_input = self.set_label_ignore_val(labels_input)
+                    loss_test = criterion(outputs_test, labels_input)
+                    sum_loss = loss_test if sum_loss is None else sum_loss + loss_test
+                preds_softmax = torch.softmax(outputs_test, dim=1)      # 3-class epilogue: plumbing
+                preds += [preds_softmax[:, SANDEEL].to(torch.float16)]
+                labels += [batch_test["labels"].numpy().ravel()]
+        preds = torch.cat([p.reshape(-1) for p in preds]).cpu().numpy().astype(np.float16)
+        labels = np.hstack(labels).astype(np.int8)
+        mean_loss = (float(sum_loss) if sum_loss is not None else 0.0) / len(dataloader)
+        return labels, preds, mean_loss
+
+    def compute_evaluation_metrics(self, labels, preds):
+        """PR curve and F1 (reference pipeline.py:284-295)."""
+        from sklearn.metrics import precision_recall_curve
+        precision, recall, thresholds = precision_recall_curve(labels, preds, pos_label=SANDEEL)
+        numerator = 2 * recall * precision
+        denom = recall + precision
+        f1_scores = np.divide(numerator, denom, out=np.zeros_like(denom), where=(denom != 0))
+        return {"precision": precision, "recall": recall, "thresholds": thresholds, "F1": f1_scores}
+
+    def select_valid_predictions(self, labels, preds):
+        labels = self.set_label_ignore_val(labels)
+        idx = np.where(labels != LABEL_IGNORE_VAL)
+        return labels[idx], preds[idx]
+
+    def validate_model_training(self, dataloader_test, criterion, logger, iteration_no):
+        """Reference pipeline.py:305-341."""
+        labels, preds, loss_test = self.get_predictions_dataloader(dataloader_test, criterion=criterion)
+        preds[labels == LABEL_SEABED_MASK_VAL] = 0
+        labels, preds = self.select_valid_predictions(labels=labels, preds=preds)
+        metrics = self.compute_evaluation_metrics(labels=labels, preds=preds)
+        F1 = metrics["F1"]
+        argmax_F1 = np.argmax(F1)
+        iter_step = iteration_no + 1
+        if logger is not None:
+            logger.add_scalar(tag="test/F1_score", scalar_value=F1[argmax_F1], global_step=iter_step)
+            logger.add_scalar(tag="test/precision", scalar_value=metrics["precision"][argmax_F1],
+                              global_step=iter_step)
+            logger.add_scalar(tag="test/recall", scalar_value=metrics["recall"][argmax_F1],
+                              global_step=iter_step)
+            logger.add_scalar(tag="test/loss", scalar_value=loss_test, global_step=iter_step)
+            if hasattr(logger, "add_pr_curve"):
+                logger.add_pr_curve(tag="test/pr_curve", labels=labels, predictions=preds,
+                                    global_step=iter_step)
+        if F1[argmax_F1] > self.best_F1_val:
+            self.best_F1_val = F1[argmax_F1]
+            if self.checkpoint_dir is not None and parallel.env_world()[1] == 0:
+                Path(self.checkpoint_dir).mkdir(parents=True, exist_ok=True)
+                torch.save(self.model.state_dict(), Path(self.checkpoint_dir) / "best.pt")
+        return metrics
+
+    def validate_model_testing(self, dataloader, save_path_metrics, save_path_plot):
+        """Reference pipeline.py:343-376."""
+        if not self.model_is_loaded:
+            self.load_model_params()
+        labels, preds, _ = self.get_predictions_dataloader(dataloader, disable_tqdm=False)
+        preds[labels == LABEL_SEABED_MASK_VAL] = 0
+        labels, preds = self.select_valid_predictions(labels=labels, preds=preds)
+        metrics = self.compute_evaluation_metrics(labels=labels, preds=preds)
+        if save_path_metrics is not None:
+            import pandas as pd
+            metrics["thresholds"] = np.array(list(metrics["thresholds"]) + [np.nan])
+            pd.DataFrame(metrics).to_csv(save_path_metrics)
+        if save_path_plot is not None:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            fig, ax = plt.subplots(1, figsize=(8, 8))
+            ax.tick_params(labelsize=6)
+            ax.set_xlabel("Recall", fontsize=8)
+            ax.set_ylabel("Precision", fontsize=8)
+            ax.set_xticks([0, 0.2, 0.4, 0.6, 0.8, 1.0])
+            ax.scatter(metrics["recall"], metrics["precision"], s=2)
+            ax.set_xlim(-0.06, 1.06)
+            ax.set_ylim(-0.06, 1.06)
+            plt.savefig(save_path_plot)
+        F1 = metrics["F1"]
+        print(f"F1 score: {F1[np.argmax(F1)]}")
+        return metrics
+
+
+class SegPipeUNet(SegPipe):
+    """``SegPipe`` with the U-Net of the reference (pipeline.py:379-410)."""
+
+    def __init__(self, checkpoint_dir=None, **kwargs):
+        super().__init__(checkpoint_dir, **kwargs)
+        if self.late_meta_inject:
+            raise NotImplementedError("UNet_LateMetInject is not on the accelerated path")
+        self.model = UNet_Baseline(n_classes=3, in_channels=4 + get_in_channels(self.meta_channels),
+                                   late_meta_inject=False, depth=5, start_filts=64,
+                                   up_mode="transpose", merge_mode="concat", precision=self.precision)
+
+
+def get_in_channels(meta_channels):
+    """Extra input channels contributed by metadata (reference pipeline.py:413-425)."""
+    if len(meta_channels) != 0:
+        weights = {"portion_year": 1, "portion_day": 2, "depth_rel": 1, "depth_abs_surface": 1,
+                   "depth_abs_seabed": 1, "time_diff": 1}
+        return int(np.sum([meta_channels[kw] * weights[kw] for kw in weights.keys()]))
+    return 0

@@ -1,0 +1,160 @@
+"""``UNet_Baseline`` for MI355X: the reference's module surface over hand-written HIP kernels.
+
+Drop-in for ``crimac_unet/models/unet.py`` (``UNet_Baseline`` :304-343, ``UNet.__init__`` :200-289):
+same constructor signature, same ``state_dict`` keys / shapes / dtypes (so reference ``.pt``
+checkpoints load and vice versa, pipeline.py:109-130), same ``forward(x[B,C,H,W] fp32) -> logits
+[B,n_classes,H,W] fp32`` in train and eval mode, same default parameter initialisation (the torch
+layer objects are kept as parameter containers, constructed in the reference's order, so a given
+seed yields the same initial weights).
+
+What differs is only *who computes*: ``forward``/``backward`` run the CDNA4 kernels of
+libcrimac_unet_hip.so through :class:`~crimac_classifiers_unet_amd.engine.UNetEngine`.  No torch
+conv/BN/pool/CE kernel is ever dispatched and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .engine import UNetEngine
+
+
+class _EncoderStage(nn.Module):
+    """Parameter container with the reference's key names ``main.{0,1,3,4}`` (unet.py:76-83)."""
+
+    def __init__(self, cin, cout, pooling):
+        super().__init__()
+        self.pooling = pooling
+        self.main = nn.Sequential(
+            nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(),
+            nn.Conv2d(cout, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU())
+        if pooling:
+            self.pool = nn.MaxPool2d(2, 2)     # parameter-free; keeps the module tree identical
+
+
+class _DecoderStage(nn.Module):
+    """Parameter container with the reference's key names upconv/conv1/conv2/bn1/bn2 (unet.py:112-122)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.upconv = nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2)
+        self.conv1 = nn.Conv2d(2 * cout, cout, 3, padding=1)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.bn2 = nn.BatchNorm2d(cout)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward and backward are HIP kernel chains."""
+
+    @staticmethod
+    def forward(ctx, x, engine, *params):
+        ctx.engine = engine
+        ctx.nparams = len(params)
+        return engine.forward(x, training=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.engine
+        # keep whatever an un-zeroed .grad held (torch accumulates across backward calls)
+        carry = {}
+        for name, p in eng.P.items():
+            g = p.grad
+            if g is not None and g.data_ptr() != eng.G[name].data_ptr():
+                carry[name] = g
+        prev = eng.flat_g.clone() if eng.accumulate_grads else None
+        eng.backward(dlogits)
+        if prev is not None:
+            eng.flat_g.add_(prev)
+        for name, p in eng.P.items():
+            if name in carry:
+                eng.G[name].add_(carry[name])
+            p.grad = eng.G[name]     # .grad aliases the flat buffer (zero_grad(set_to_none) undoes it)
+        # gradients were written straight into the flat buffer; return None so autograd does not
+        # add them a second time
+        return (None, None) + (None,) * ctx.nparams
+
+
+class UNet_Baseline(nn.Module):
+    """U-Net of the reference pipeline (pipeline.py:390-398) on MI355X.
+
+    Extra keyword (defaults keep the reference call sites working unchanged):
+      precision: 'bf16'  -- bf16 activations / MFMA, fp32 accumulate (throughput mode)
+                 'f32x3' -- fp32 activations, split-bf16 MFMA (parity mode, <=1e-3 on logits)
+    """
+
+    def __init__(self, n_classes, in_channels, meta_in_channels=0, late_meta_inject=False, depth=5,
+                 start_filts=64, up_mode="transpose", merge_mode="concat", precision="bf16"):
+        super().__init__()
+        if up_mode not in ("transpose", "upsample"):
+            raise ValueError('"{}" is not a valid mode for upsampling. Only "transpose" and '
+                             '"upsample" are allowed.'.format(up_mode))
+        if merge_mode not in ("concat", "add"):
+            raise ValueError('"{}" is not a valid mode for merging up and down paths. Only "concat" '
+                             'and "add" are allowed.'.format(merge_mode))
+        if up_mode != "transpose" or merge_mode != "concat":
+            # the reference pipeline always passes transpose/concat (pipeline.py:396-397)
+            raise NotImplementedError("the MI355X hot path implements up_mode='transpose', "
+                                      "merge_mode='concat' (the only combination the pipeline uses)")
+        if late_meta_inject:
+            raise NotImplementedError("late metadata injection (UNet_LateMetInject) is not on the "
+                                      "accelerated path")
+        self.n_classes, self.in_channels = n_classes, in_channels
+        self.meta_in_channels = meta_in_channels
+        self.depth, self.start_filts = depth, start_filts
+        self.up_mode, self.merge_mode = up_mode, merge_mode
+
+        enc, outs = [], in_channels
+        for i in range(depth):
+            ins, outs = (in_channels if i == 0 else outs), start_filts * 2 ** i
+            enc.append(_EncoderStage(ins, outs, pooling=i < depth - 1))
+        dec = []
+        for _ in range(depth - 1):
+            ins, outs = outs, outs // 2
+            dec.append(_DecoderStage(ins, outs))
+        self.down_convs = nn.Sequential(*enc)
+        self.up_convs = nn.Sequential(*dec)
+        self.conv_final = nn.Conv2d(outs, n_classes, kernel_size=1)
+        self._precision = precision
+        self._engine = None
+
+    # -- engine plumbing -----------------------------------------------------------------------
+    @property
+    def engine(self) -> UNetEngine:
+        if self._engine is None:
+            object.__setattr__(self, "_engine", UNetEngine(self, self._precision))
+        return self._engine
+
+    @property
+    def precision(self):
+        return self._precision
+
+    def set_precision(self, precision):
+        if precision != self._precision:
+            self._precision = precision
+            object.__setattr__(self, "_engine", None)
+        return self
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        if self._engine is not None:
+            self._engine.mark_dirty()
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        if self._engine is not None:
+            self._engine.mark_dirty()
+        return out
+
+    # -- the hot path --------------------------------------------------------------------------
+    def forward(self, x):
+        eng = self.engine
+        if self.training and torch.is_grad_enabled():
+            eng.bind()
+            return _UNetFunction.apply(x, eng, *eng.P.values())
+        return eng.forward(x, training=self.training)
+
+    def predict_softmax(self, x):
+        """Eval forward with F.softmax(dim=1) fused into the 1x1 head (pipeline.py:205-219)."""
+        return self.engine.forward(x, training=False, softmax=True)

@@ -1,0 +1,148 @@
+/*
+ * crimac_unet_hip.h -- C ABI of the MI355X (gfx950) U-Net hot-path library
+ *                      (libcrimac_unet_hip.so, built from crimac_classifiers_unet_amd/csrc/).
+ *
+ * The reference (CRIMAC-classifiers-unet) is pure Python and has NO FFI/plugin layer: its hot path
+ * dispatches stock torch.nn modules to ATen.  The entry points below are what a
+ * binding for that path binds instead of the ATen kernels; each one cites the reference call site
+ * whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would
+ * add.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer owned by the caller (workspaces included); the library
+ *     allocates nothing and keeps no mutable global state; one process per GPU, re-entrant per stream
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is asynchronous
+ *   - return value: 0 (CRIMAC_OK) or a negative code; crimac_last_error() gives the thread-local text
+ *   - activations are NHWC; `ld` arguments are the pixel stride in ELEMENTS (>= channels), so a
+ *     tensor may live in a channel slice of a wider buffer (this is how torch.cat((up, skip), 1),
+ *     unet.py:132, is made free)
+ *   - `prec` selects the storage/compute type of activations:
+ *       CRIMAC_PREC_BF16  : bf16 activations, bf16 MFMA, fp32 accumulate (throughput mode)
+ *       CRIMAC_PREC_F32X3 : fp32 activations, split-bf16 (hi*hi + hi*lo + lo*hi) MFMA, fp32
+ *                           accumulate (parity mode: meets 1e-3 relative on logits)
+ *     parameters, gradients of parameters, statistics and the loss are always fp32 / fp64
+ */
+#ifndef CRIMAC_UNET_HIP_H_
+#define CRIMAC_UNET_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRIMAC_OK 0
+#define CRIMAC_ERR_INVALID (-22) /* bad argument (EINVAL) */
+#define CRIMAC_ERR_LAUNCH (-5)   /* kernel launch failed (EIO) */
+
+#define CRIMAC_PREC_BF16 0
+#define CRIMAC_PREC_F32X3 1
+
+/* Library identity / error text. */
+int crimac_version(void);
+const char* crimac_last_error(void);
+
+/* ---- dense contractions (MFMA) ------------------------------------------------------------- */
+
+/* Implicit-GEMM convolution: nn.Conv2d 3x3 pad 1 forward (unet.py:35-44, used at :77,:80,:114-119),
+ * its input gradient (aten::convolution_backward, pipeline.py:177), nn.ConvTranspose2d k2 s2
+ * forward (unet.py:47-49, :130) and its input gradient.
+ *   rows m=(b,oy,ox) on [B][Ho][Wo]; tap t reads input pixel (oy*stride + t/tw - pad,
+ *   ox*stride + t%tw - pad) of [B][Hi][Wi] (zero outside); w_hi/w_lo: bf16 [ntaps][N][Cin]
+ *   (w_lo only for F32X3); bias fp32 indexed n % bias_mod (NULL = none); relu != 0 clamps at 0;
+ *   out_mode 0: out[m*out_ld + n]; out_mode 1 (transposed conv): n=(a*2+b)*cout_up+o is scattered
+ *   to pixel (2oy+a, 2ox+b) of [B][2Ho][2Wo], channel o.  Cin % 16 == 0, N % 64 == 0. */
+int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int Wi, int Ho, int Wo,
+                      int Cin, int N, int ntaps, int tw, int pad, int stride, const void* w_hi,
+                      const void* w_lo, const float* bias, int bias_mod, void* out, long out_ld,
+                      int relu, int out_mode, int cout_up, void* stream);
+
+/* Weight gradient (aten::convolution_backward weight half, pipeline.py:177):
+ *   dw[t][f][s] += sum_pixels F[p][f] * S[shift_t(p)][s]   (fp32 atomics; caller zeroes dw)
+ *   mode 0 (conv3x3): F=dY [B][Hf][Wf][CF=Cout], S=X same grid [CS=Cin], 9 taps
+ *   mode 1 (upconv):  F=X  [B][Hf][Wf][CF=Cin],  S=dY [B][2Hf][2Wf][CS=Cout], 4 taps (a,b)
+ *   target_blocks: workgroups to aim for when splitting the pixel range (<=0: default). */
+int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld,
+                 int CS, int B, int Hf, int Wf, float* dw, int target_blocks, void* stream);
+
+/* ---- weight layout (fp32 master weights <-> bf16 MFMA operand planes) ------------------------ */
+
+/* Conv2d weight [Co][Ci][3][3] -> fwd planes [9][Co][Ci_pad] (scaled per Co by `scale` if given:
+ * eval-mode BatchNorm folding) and dgrad planes [9][Ci][Co] (flipped taps).
+ * lo planes / dgrad planes may be NULL. */
+int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, const float* scale,
+                        void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo, void* stream);
+/* ConvTranspose2d weight [Ci][Co][2][2] -> fwd planes [(a,b,o)][Ci], dgrad planes [(a,b)][Ci][Co]. */
+int crimac_pack_upconv2x2(const float* w, int Ci, int Co, void* fwd_hi, void* fwd_lo, void* dg_hi,
+                          void* dg_lo, void* stream);
+/* dw [9][Co][Ci_pad] -> grad [Co][Ci][3][3];  dw [4][Ci][Co] -> grad [Ci][Co][2][2]. */
+int crimac_unpack_wgrad_conv3x3(const float* dw, int Co, int Ci, int Ci_pad, float* grad, void* stream);
+int crimac_unpack_wgrad_upconv2x2(const float* dw, int Ci, int Co, float* grad, void* stream);
+
+/* ---- layout ---------------------------------------------------------------------------------- */
+
+/* Model input [B][C][H][W] fp32 (pipeline.py:163, :208 `.float().to(device)`) -> NHWC activations
+ * with channels zero-padded to ld. */
+int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, int C, int H, int W, long ld,
+                        void* stream);
+
+/* ---- BatchNorm2d / ReLU / MaxPool2d (unet.py:78-86, :121-122, :135-136) ---------------------- */
+
+/* Per-channel sum (and sum of squares if sumsq != NULL) over M pixels, accumulated into fp64. */
+int crimac_colstats(int prec, const void* y, long ld, long M, int C, double* sum, double* sumsq,
+                    void* stream);
+/* Per-channel sum accumulated into fp32 (bias gradients). */
+int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C, float* sum, void* stream);
+/* Train-mode statistics -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale; running stats
+ * updated with `momentum` (unbiased variance), num_batches_tracked += 1. */
+int crimac_bn_finalize(const double* sum, const double* sumsq, long M, int C, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, float* mean,
+                       float* invstd, float* scale, float* shift, void* stream);
+/* out = [relu](y*scale+shift) (scale NULL = identity); optional 2x2/2 max-pool of the result.
+ * out and pool_out are each optional. */
+int crimac_bn_act_pool(int prec, const void* y, long y_ld, const float* scale, const float* shift,
+                       int relu, void* out, long out_ld, void* pool_out, long pool_ld, int B, int H,
+                       int W, int C, void* stream);
+/* Backward of [pool ->] (skip add): da = ds + unpool(dp) with first-max tie rule of
+ * aten::max_pool2d; `a` is the forward activation that was pooled.  ds may be NULL. */
+int crimac_unpool_add(int prec, const void* dp, long dp_ld, const void* a, long a_ld, const void* ds,
+                      long ds_ld, void* da, long da_ld, int B, int H, int W, int C, void* stream);
+/* BatchNorm+ReLU backward, pass 1: sum_dz, sum_dz_xhat (fp64, caller zeroes) with
+ * dz = da * (y*scale+shift > 0), xhat = (y-mean)*invstd. */
+int crimac_bn_bwd_reduce(int prec, const void* da, long da_ld, const void* y, long y_ld,
+                         const float* scale, const float* shift, const float* mean,
+                         const float* invstd, long M, int C, double* sum_dz, double* sum_dz_xhat,
+                         void* stream);
+/* pass 2: dy = scale*(dz - sum_dz/M - xhat*sum_dz_xhat/M); dgamma = sum_dz_xhat, dbeta = sum_dz;
+ * dbias (conv bias in front of the BN, may be NULL) += sum over pixels of dy (caller zeroes). */
+int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, long y_ld,
+                        const float* scale, const float* shift, const float* mean,
+                        const float* invstd, const double* sum_dz, const double* sum_dz_xhat, long M,
+                        int C, void* dy, long dy_ld, float* dgamma, float* dbeta, float* dbias,
+                        void* stream);
+
+/* ---- 1x1 head, loss, optimiser --------------------------------------------------------------- */
+
+/* conv_final 1x1 (unet.py:59-60, :342): logits [B][ncls][H][W] fp32 (NCHW, as the reference
+ * returns them); softmax != 0 applies F.softmax(dim=1) (pipeline.py:218). ncls in 2..4. */
+int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, const float* w, const float* b,
+                    float* logits, int B, int H, int W, int ncls, int softmax, void* stream);
+int crimac_head_bwd(int prec, const float* dlogits, const void* x, long x_ld, int Cin, const float* w,
+                    void* dx, long dx_ld, float* dw, float* db, int B, int H, int W, int ncls,
+                    void* stream);
+/* nn.CrossEntropyLoss(weight) (pipeline.py:132-141): sums[0] += sum w[y]*nll, sums[1] += sum w[y]
+ * over pixels with y != ignore_index.  labels: int16/int32/int64 selected by label_bytes. */
+int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes, const float* class_w,
+                   int ncls, int ignore_index, int B, int H, int W, double* sums, void* stream);
+/* dlogits = upstream * w[y]/sums[1] * (softmax - onehot); 0 where ignored. */
+int crimac_wce_bwd(const float* logits, const void* labels, int label_bytes, const float* class_w,
+                   int ncls, int ignore_index, int B, int H, int W, const double* sums,
+                   float upstream, float* dlogits, void* stream);
+/* optim.SGD(lr, momentum) (pipeline.py:156, :178) over a flat buffer:
+ * g' = g*grad_scale; v = momentum*v + g'; p -= lr*v; g = 0 if zero_grad. */
+int crimac_sgd_momentum(float* p, float* g, float* v, long n, float lr, float momentum,
+                        float grad_scale, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRIMAC_UNET_HIP_H_ */

@@ -1,0 +1,357 @@
+"""GPU parity tests, one kernel at a time, through the C ABI (include/crimac_unet_hip.h).
+
+Each HIP kernel is compared with the torch CPU fp32 op the reference dispatches for the same step
+(the oracle of a single op is that op itself, run on the host).  Tolerances:
+  * 'f32x3' (parity mode): 1e-4 of max|ref| -- split-bf16 products carry ~2^-16 relative error;
+  * 'bf16'  (throughput mode): inputs are pre-rounded to bf16 on the host, so what is left is the
+    bf16 rounding of the OUTPUT (2^-9 relative) and accumulation order: 1e-2 of max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from crimac_classifiers_unet_amd import hip
+from crimac_classifiers_unet_amd.hip import call, ptr
+
+pytestmark = pytest.mark.gpu
+
+PRECS = ["f32x3", "bf16"]
+TOL = {"f32x3": 1e-4, "bf16": 1e-2}
+
+
+def _dt(prec):
+    return torch.bfloat16 if prec == "bf16" else torch.float32
+
+
+def _round(x, prec):
+    """Host-side rounding of kernel INPUTS to the activation storage type."""
+    return x.to(torch.bfloat16).float() if prec == "bf16" else x
+
+
+def to_nhwc(x, prec, ld=None):
+    """[B,C,H,W] fp32 (cpu) -> device [B*H*W, ld] activation matrix."""
+    B, C, H, W = x.shape
+    ld = ld or C
+    out = torch.zeros(B * H * W, ld, dtype=_dt(prec), device="cuda")
+    out[:, :C] = x.permute(0, 2, 3, 1).reshape(-1, C).to(_dt(prec)).cuda()
+    return out
+
+
+def from_nhwc(t, B, H, W, C=None):
+    C = C or t.shape[1]
+    return t[:, :C].float().cpu().reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def pack_conv(w, prec, cin_pad=None, scale=None, dgrad=True):
+    Co, Ci = w.shape[:2]
+    cin_pad = cin_pad or Ci
+    wd = w.float().cuda().contiguous()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.empty(9 * Co * cin_pad, **i16), torch.empty(9 * Co * cin_pad, **i16)
+    dh = torch.empty(9 * Ci * Co, **i16) if dgrad and cin_pad == Ci else None
+    dl = torch.empty(9 * Ci * Co, **i16) if dgrad and cin_pad == Ci else None
+    sc = scale.float().cuda() if scale is not None else None
+    call("crimac_pack_conv3x3", ptr(wd), Co, Ci, cin_pad, ptr(sc), ptr(fh), ptr(fl), ptr(dh), ptr(dl))
+    torch.cuda.synchronize()
+    return fh, fl, dh, dl
+
+
+def conv3x3(prec, x_nhwc, ld, B, H, W, Cin, Cout, w_hi, w_lo, bias, relu=False):
+    out = torch.empty(B * H * W, Cout, dtype=_dt(prec), device="cuda")
+    call("crimac_igemm_conv", hip.PREC_NAMES[prec], ptr(x_nhwc), ld, B, H, W, H, W, Cin, Cout, 9, 3, 1, 1,
+         ptr(w_hi), ptr(w_lo), ptr(bias), Cout, ptr(out), Cout, 1 if relu else 0, 0, 0)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (3, 8, 8, 256, 64),
+                                   (2, 16, 16, 4, 64), (1, 24, 40, 64, 192)])
+def test_conv3x3_forward(prec, shape):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(1)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    cin_pad = 16 if Ci < 16 else Ci
+    fh, fl, _, _ = pack_conv(w, prec, cin_pad, dgrad=False)
+    wr = _round(w, prec)
+    ref = F.conv2d(x, wr, b, padding=1)
+    xin = to_nhwc(x, prec, ld=cin_pad)
+    out = conv3x3(prec, xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, b.cuda())
+    assert relerr(from_nhwc(out, B, H, W), ref) < TOL[prec]
+    # fused bias+ReLU epilogue (eval-mode folded path)
+    out = conv3x3(prec, xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, b.cuda(), relu=True)
+    assert relerr(from_nhwc(out, B, H, W), torch.relu(ref)) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_conv3x3_bn_fold_scale_and_strided_io(prec):
+    """BatchNorm folding scale in the packer; input/output living in channel slices (ld > C)."""
+    B, H, W, Ci, Co = 2, 16, 16, 64, 64
+    g = torch.Generator().manual_seed(2)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 24
+    s = torch.rand(Co, generator=g) + 0.5
+    fh, fl, _, _ = pack_conv(w, prec, scale=s, dgrad=False)
+    ref = F.conv2d(x, _round(w * s[:, None, None, None], prec), None, padding=1)
+    big_in = torch.zeros(B * H * W, 2 * Ci, dtype=_dt(prec), device="cuda")
+    big_in[:, Ci:] = to_nhwc(x, prec)
+    big_out = torch.full((B * H * W, 3 * Co), 7.0, dtype=_dt(prec), device="cuda")
+    call("crimac_igemm_conv", hip.PREC_NAMES[prec], ptr(big_in, Ci), 2 * Ci, B, H, W, H, W, Ci, Co, 9, 3,
+         1, 1, ptr(fh), ptr(fl), None, 0, ptr(big_out, Co), 3 * Co, 0, 0, 0)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(big_out[:, Co:2 * Co].contiguous(), B, H, W), ref) < TOL[prec]
+    assert float((big_out[:, :Co].float() - 7).abs().max()) == 0 and \
+        float((big_out[:, 2 * Co:].float() - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 16, 128, 256)])
+def test_conv3x3_dgrad(prec, shape):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+    _, _, dh, dl = pack_conv(w, prec)
+    ref = torch.nn.grad.conv2d_input((B, Ci, H, W), _round(w, prec), dy, padding=1)
+    out = torch.empty(B * H * W, Ci, dtype=_dt(prec), device="cuda")
+    dyn = to_nhwc(dy, prec)       # keep every device operand alive in a variable until the sync
+    call("crimac_igemm_conv", hip.PREC_NAMES[prec], ptr(dyn), Co, B, H, W, H, W, Co, Ci, 9,
+         3, 1, 1, ptr(dh), ptr(dl), None, 0, ptr(out), Ci, 0, 0, 0)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out, B, H, W), ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 4, 8, 256, 128)])
+def test_upconv2x2_forward_dgrad_wgrad(prec, shape):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(4)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g)
+    i16 = dict(dtype=torch.int16, device="cuda")
+    n = 4 * Ci * Co
+    fh, fl, dh, dl = (torch.empty(n, **i16) for _ in range(4))
+    wd, bd, xn = w.cuda(), b.cuda(), to_nhwc(x, prec)
+    call("crimac_pack_upconv2x2", ptr(wd), Ci, Co, ptr(fh), ptr(fl), ptr(dh), ptr(dl))
+    wr = _round(w, prec)
+    ref = F.conv_transpose2d(x, wr, b, stride=2)
+    # forward writes into the first half of a [M, 2*Co] "concat" buffer
+    cat = torch.zeros(B * 4 * H * W, 2 * Co, dtype=_dt(prec), device="cuda")
+    P = hip.PREC_NAMES[prec]
+    call("crimac_igemm_conv", P, ptr(xn), Ci, B, H, W, H, W, Ci, 4 * Co, 1, 1, 0, 1,
+         ptr(fh), ptr(fl), ptr(bd), Co, ptr(cat), 2 * Co, 0, 1, Co)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(cat[:, :Co].contiguous(), B, 2 * H, 2 * W), ref) < TOL[prec]
+    assert float(cat[:, Co:].float().abs().max()) == 0
+    # input gradient
+    dy = _round(torch.randn(B, Co, 2 * H, 2 * W, generator=g), prec)
+    xg = x.clone().requires_grad_(True)
+    wg = wr.clone().requires_grad_(True)
+    F.conv_transpose2d(xg, wg, None, stride=2).backward(dy)
+    dyn = to_nhwc(dy, prec)
+    dx = torch.empty(B * H * W, Ci, dtype=_dt(prec), device="cuda")
+    call("crimac_igemm_conv", P, ptr(dyn), Co, B, 2 * H, 2 * W, H, W, Co, Ci, 4, 2, 0, 2, ptr(dh), ptr(dl),
+         None, 0, ptr(dx), Ci, 0, 0, 0)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(dx, B, H, W), xg.grad) < TOL[prec]
+    # weight gradient
+    dwp = torch.zeros(4 * Ci * Co, dtype=torch.float32, device="cuda")
+    call("crimac_wgrad", P, 1, ptr(xn), Ci, Ci, ptr(dyn), Co, Co, B, H, W, ptr(dwp), 64)
+    grad = torch.empty(Ci, Co, 2, 2, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_upconv2x2", ptr(dwp), Ci, Co, ptr(grad))
+    torch.cuda.synchronize()
+    assert relerr(grad.cpu(), wg.grad) < (2e-3 if prec == "bf16" else 1e-4)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 8, 32, 128, 64), (2, 16, 16, 4, 64),
+                                   (1, 12, 20, 64, 128)])
+def test_conv3x3_wgrad(prec, shape):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(5)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+    ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), dy, padding=1)
+    cin_pad = 16 if Ci < 16 else Ci
+    dwp = torch.zeros(9 * Co * cin_pad, dtype=torch.float32, device="cuda")
+    dyn, xn = to_nhwc(dy, prec), to_nhwc(x, prec, ld=cin_pad)
+    call("crimac_wgrad", hip.PREC_NAMES[prec], 0, ptr(dyn), Co, Co,
+         ptr(xn), cin_pad, cin_pad, B, H, W, ptr(dwp), 8)
+    grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, cin_pad, ptr(grad))
+    torch.cuda.synchronize()
+    # inputs are exact in both modes; the contraction accumulates in fp32
+    assert relerr(grad.cpu(), ref) < (1e-4 if prec == "f32x3" else 1e-4)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("C", [64, 256, 1024])
+def test_batchnorm_train_forward_backward_pool(prec, C):
+    B, H, W = 2, 8, 8
+    M = B * H * W
+    g = torch.Generator().manual_seed(6)
+    y = _round(torch.randn(B, C, H, W, generator=g) * 2 + 0.5, prec)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    P = hip.PREC_NAMES[prec]
+    d = "cuda"
+    yn = to_nhwc(y, prec)
+    s = torch.zeros(2, C, dtype=torch.float64, device=d)
+    call("crimac_colstats", P, ptr(yn), C, M, C, ptr(s[0]), ptr(s[1]))
+    rm_d, rv_d, gamma_d, beta_d = rm.to(d), rv.to(d), gamma.to(d), beta.to(d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    st = torch.zeros(4, C, dtype=torch.float32, device=d)   # mean, invstd, scale, shift
+    call("crimac_bn_finalize", ptr(s[0]), ptr(s[1]), M, C, ptr(gamma_d), ptr(beta_d), 1e-5, 0.1,
+         ptr(rm_d), ptr(rv_d), ptr(nbt), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]))
+    a = torch.empty(M, C, dtype=_dt(prec), device=d)
+    pool = torch.empty(M // 4, C, dtype=_dt(prec), device=d)
+    call("crimac_bn_act_pool", P, ptr(yn), C, ptr(st[2]), ptr(st[3]), 1, ptr(a), C, ptr(pool), C, B, H, W, C)
+    torch.cuda.synchronize()
+    # reference
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    z = F.batch_norm(yr, rm_r, rv_r, gr, br, training=True, momentum=0.1, eps=1e-5)
+    ar = torch.relu(z)
+    pr = F.max_pool2d(ar, 2, 2)
+    tol = TOL[prec]
+    assert relerr(from_nhwc(a, B, H, W), ar) < tol
+    assert relerr(from_nhwc(pool, B, H // 2, W // 2), pr) < tol
+    assert relerr(rm_d.cpu(), rm_r) < 1e-5 and relerr(rv_d.cpu(), rv_r) < 1e-5 and int(nbt) == 1
+    # backward: da = ds + unpool(dp)
+    dp = _round(torch.randn(B, C, H // 2, W // 2, generator=g), prec)
+    ds = _round(torch.randn(B, C, H, W, generator=g), prec)
+    (pr * dp).sum().backward(retain_graph=True)
+    (ar * ds).sum().backward()
+    da = torch.empty(M, C, dtype=_dt(prec), device=d)
+    dpn, dsn = to_nhwc(dp, prec), to_nhwc(ds, prec)
+    call("crimac_unpool_add", P, ptr(dpn), C, ptr(a), C, ptr(dsn), C, ptr(da), C,
+         B, H, W, C)
+    s2 = torch.zeros(2, C, dtype=torch.float64, device=d)
+    call("crimac_bn_bwd_reduce", P, ptr(da), C, ptr(yn), C, ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]), M,
+         C, ptr(s2[0]), ptr(s2[1]))
+    dy = torch.empty(M, C, dtype=_dt(prec), device=d)
+    dg, db, dbias = (torch.zeros(C, dtype=torch.float32, device=d) for _ in range(3))
+    call("crimac_bn_bwd_apply", P, ptr(da), C, ptr(yn), C, ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]),
+         ptr(s2[0]), ptr(s2[1]), M, C, ptr(dy), C, ptr(dg), ptr(db), ptr(dbias))
+    torch.cuda.synchronize()
+    if prec == "bf16":
+        # bf16-rounded activations tie inside 2x2 windows far more often than fp32 ones; a tie routes
+        # the pooled gradient to another pixel, so compare in L2 instead of max-norm
+        d_out, d_ref = from_nhwc(dy, B, H, W).double(), yr.grad.double()
+        assert float((d_out - d_ref).norm() / d_ref.norm()) < 0.1
+    else:
+        assert relerr(from_nhwc(dy, B, H, W), yr.grad) < 2e-4
+    assert relerr(dg.cpu(), gr.grad) < (2e-2 if prec == "bf16" else 2e-4)
+    assert relerr(db.cpu(), br.grad) < (2e-2 if prec == "bf16" else 2e-4)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_unpool_first_max_tie_rule(prec):
+    """Ties inside a 2x2 window: gradient goes to the FIRST maximum in scan order (aten max_pool2d)."""
+    B, C, H, W = 1, 8, 2, 2
+    a = torch.tensor([[1.0, 3.0], [3.0, 3.0]]).expand(B, C, H, W).contiguous()
+    ar = a.clone().requires_grad_(True)
+    F.max_pool2d(ar, 2, 2).sum().backward()
+    dp = torch.ones(B, C, 1, 1)
+    da = torch.empty(4, C, dtype=_dt(prec), device="cuda")
+    dpn, an = to_nhwc(dp, prec), to_nhwc(a, prec)
+    call("crimac_unpool_add", hip.PREC_NAMES[prec], ptr(dpn), C, ptr(an), C,
+         None, 0, ptr(da), C, B, H, W, C)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(da, B, H, W), ar.grad)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("ncls", [3, 2])
+def test_head_and_weighted_ce(prec, ncls):
+    B, H, W, C = 2, 16, 16, 64
+    g = torch.Generator().manual_seed(7)
+    x = _round(torch.randn(B, C, H, W, generator=g), prec)
+    w = torch.randn(ncls, C, 1, 1, generator=g) / 8
+    b = torch.randn(ncls, generator=g) * 0.1
+    labels = torch.randint(0, ncls, (B, H, W), generator=g)
+    labels[torch.rand(B, H, W, generator=g) < 0.1] = -100
+    cw = torch.tensor([10.0, 300.0, 250.0][:ncls])
+    P, d = hip.PREC_NAMES[prec], "cuda"
+    xn = to_nhwc(x, prec)
+    wd, bd, cwd = w.to(d), b.to(d), cw.to(d)
+    logits = torch.empty(B, ncls, H, W, dtype=torch.float32, device=d)
+    soft = torch.empty_like(logits)
+    call("crimac_head_fwd", P, ptr(xn), C, C, ptr(wd), ptr(bd), ptr(logits), B, H, W, ncls, 0)
+    call("crimac_head_fwd", P, ptr(xn), C, C, ptr(wd), ptr(bd), ptr(soft), B, H, W, ncls, 1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    zr = F.conv2d(xr, wr, br)
+    loss_r = F.cross_entropy(zr, labels, weight=cw, ignore_index=-100)
+    loss_r.backward()
+    torch.cuda.synchronize()
+    assert relerr(logits.cpu(), zr.detach()) < 1e-5
+    assert relerr(soft.cpu(), torch.softmax(zr.detach(), 1)) < 1e-5
+    for lab_dtype in (torch.int64, torch.int16, torch.int32):
+        lab = labels.to(lab_dtype).to(d)
+        sums = torch.zeros(2, dtype=torch.float64, device=d)
+        call("crimac_wce_fwd", ptr(logits), ptr(lab), lab.element_size(), ptr(cwd), ncls, -100, B, H, W,
+             ptr(sums))
+        assert abs(float(sums[0] / sums[1]) - float(loss_r)) < 1e-5 * abs(float(loss_r))
+    dl = torch.empty_like(logits)
+    call("crimac_wce_bwd", ptr(logits), ptr(lab), lab.element_size(), ptr(cwd), ncls, -100, B, H, W,
+         ptr(sums), 1.0, ptr(dl))
+    dx = torch.empty(B * H * W, C, dtype=_dt(prec), device=d)
+    dw = torch.zeros(ncls, C, dtype=torch.float32, device=d)
+    dbv = torch.zeros(ncls, dtype=torch.float32, device=d)
+    call("crimac_head_bwd", P, ptr(dl), ptr(xn), C, C, ptr(wd), ptr(dx), C, ptr(dw), ptr(dbv), B, H, W, ncls)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(dx, B, H, W), xr.grad) < (1e-2 if prec == "bf16" else 1e-4)
+    assert relerr(dw.cpu().reshape(ncls, C, 1, 1), wr.grad) < 1e-4
+    assert relerr(dbv.cpu(), br.grad) < 1e-4
+    # every pixel ignored -> 0/0 = NaN like torch
+    lab_all = torch.full((B, H, W), -100, dtype=torch.int64, device=d)
+    sums = torch.zeros(2, dtype=torch.float64, device=d)
+    call("crimac_wce_fwd", ptr(logits), ptr(lab_all), 8, ptr(cwd), ncls, -100, B, H, W, ptr(sums))
+    assert bool(torch.isnan(sums[0] / sums[1]))
+
+
+def test_sgd_momentum_matches_torch():
+    g = torch.Generator().manual_seed(8)
+    n = 1000 + 3
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.005, momentum=0.95)
+    p, v = p0.cuda(), torch.zeros(n, device="cuda")
+    for gr in grads:
+        pr.grad = gr.clone()
+        opt.step()
+        gd = gr.cuda()
+        call("crimac_sgd_momentum", ptr(p), ptr(gd), ptr(v), n, 0.005, 0.95, 1.0, 1)
+        torch.cuda.synchronize()
+        assert float(gd.abs().max()) == 0.0
+    assert relerr(p.cpu(), pr.detach()) < 1e-6
+
+
+def test_nchw_to_nhwc_padding():
+    x = torch.randn(2, 4, 8, 8)
+    for prec in PRECS:
+        out = torch.full((2 * 64, 16), 9.0, dtype=_dt(prec), device="cuda")
+        xd = x.cuda()
+        call("crimac_nchw_to_nhwc", hip.PREC_NAMES[prec], ptr(xd), ptr(out), 2, 4, 8, 8, 16)
+        torch.cuda.synchronize()
+        assert relerr(from_nhwc(out, 2, 8, 8, 4), _round(x, prec)) < 1e-6
+        assert float(out[:, 4:].float().abs().max()) == 0
+
+
+def test_bad_arguments_fail_loudly():
+    t = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(hip.HipLibraryError, match="Cin"):
+        call("crimac_igemm_conv", 0, ptr(t), 64, 1, 8, 8, 8, 8, 24, 64, 9, 3, 1, 1, ptr(t), None, None, 0,
+             ptr(t), 64, 0, 0, 0)
+    with pytest.raises(hip.HipLibraryError):
+        hip.ptr(torch.zeros(4))          # CPU tensor: no fallback
