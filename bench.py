@@ -11,7 +11,7 @@ over ranks and gradients are all-reduced over RCCL every step (configs[2], weak 
 The inference rate (eval forward + softmax, pipeline.py:205-219) is measured next to it and
 reported in the same JSON line as ``infer_patches_per_s``.
 
-``roofline``: the dominant kernel is the implicit-GEMM convolution (igemm_kernel): algorithmic
+``roofline``: the dominant kernel is the halo-staged implicit-GEMM 3x3 convolution (conv3x3_kernel): algorithmic
 FLOPs of its launches (2*taps*Cin*N*M each) / their HIP-event durations, measured
 inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
 ``cpu_baseline``: the CPU oracle (oracle/unet_oracle.py, kind "port") timed on this box's host
@@ -139,7 +139,7 @@ def main():
         fl, ms_ = sum(f for f, _ in sel), sum(m for _, m in sel)
         return (fl / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0), ms_, len(sel)
 
-    achieved, ms, n_launch = kernel_rate("crimac_igemm_conv")
+    achieved, ms, n_launch = kernel_rate("crimac_conv3x3")
     wg_achieved, wg_ms, wg_n = kernel_rate("crimac_wgrad")
     peak = MFMA_PEAK_TFLOPS[args.precision]
 
@@ -179,7 +179,7 @@ def main():
             "infer_patches_per_s": infer,
             "infer_tflops": infer * FWD_GFLOP_PER_PATCH / 1e3 if infer else None,
             "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv fwd+dgrad, all shapes)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
                          "launches": n_launch, "avg_launch_us": 1e3 * ms / max(n_launch, 1),

@@ -1,0 +1,388 @@
+// 3x3 convolution (stride 1, pad 1) as an im2col-free implicit GEMM on MFMA, CDNA4 (gfx950).
+//
+// Reference op: nn.Conv2d(k=3, padding=1, bias=True) forward (unet.py:35-44; call sites :77, :80,
+// :114-119) and its input gradient (aten::convolution_backward data half, pipeline.py:177 -- the
+// same kernel run on dY with flipped/transposed weights).
+//
+// Structure (one 256-thread workgroup = 4 waves as 2x2):
+//   * output tile = 8x16 spatial patch (128 pixels) x BN output channels; each wave 64 x BN/2 via
+//     v_mfma_f32_32x32x16_bf16;
+//   * the input HALO tile (10x18 pixels x BK channels) is staged ONCE per input-channel chunk into
+//     LDS and read 9 times at shifted rows (one per tap): ~6.4x less global->LDS traffic for the
+//     activation operand than gathering per tap, no im2col buffer anywhere;
+//   * the weight tile [BN x BK] of step (chunk, tap) streams through a 2-slot LDS ring, fetched to
+//     registers TWO steps ahead of its use, so HBM/L2 latency is covered by two steps of MFMAs; the
+//     next chunk's halo is fetched at tap 0 and committed to the other LDS buffer at tap 7;
+//   * one barrier per step; LDS images are XOR-swizzled so the 16-byte fragment reads are
+//     bank-conflict free (2 of 16 lanes 2-way on the shifted halo rows);
+//   * epilogue: bias (+ReLU) in registers, tile staged through LDS and written with coalesced
+//     16-byte stores; optionally the per-channel sum / sum of squares of the stored tile
+//     (BatchNorm batch statistics, unet.py:78,81,121-122) are reduced in LDS and added to fp64
+//     accumulators -- the BN statistics pass over the conv output is fused away.
+//
+// Precision: TA = bf16_t -> one MFMA per product; TA = float -> fp32 activations split into bf16
+// hi+lo while staging, weights pre-split, 3 MFMAs per product (see igemm.hip).
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+struct ConvParams {
+  const void* in;
+  long in_ld;
+  int B, H, W;
+  int Cin, N;
+  const unsigned short* w_hi;
+  const unsigned short* w_lo;
+  const float* bias;
+  void* out;
+  long out_ld;
+  int relu;
+  double* stat_sum;
+  double* stat_sumsq;
+  int stat_replicas;
+  int tiles_y, tiles_x;
+};
+
+constexpr int TR = 8, TC = 16, HP = TC + 2;       // tile rows/cols, halo pitch
+constexpr int HALO_ROWS = (TR + 2) * HP;           // 180
+
+template <int BK> struct Sw {
+  static constexpr int RB = BK * 2;
+  static constexpr int UPR = BK / 8;
+  static constexpr int RPL = 256 / RB;
+  __device__ static __forceinline__ int off(int row, int u) {
+    return row * RB + ((u ^ ((row / RPL) % UPR)) << 4);
+  }
+};
+
+template <typename TA, int BN, int BK>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
+  constexpr bool X3 = sizeof(TA) == 4;
+  constexpr int NPL = X3 ? 2 : 1;                       // operand planes (hi [, lo])
+  constexpr int UPR = BK / 8;
+  constexpr int NU_H = (HALO_ROWS * UPR + 255) / 256;   // halo units per thread
+  constexpr int NU_B = (BN * UPR + 255) / 256;
+  constexpr bool B_GUARD = (BN * UPR) % 256 != 0;
+  constexpr int NT = BN / 64;
+  constexpr int KS = BK / 16;
+  constexpr int A_BYTES = HALO_ROWS * BK * 2;           // one plane, one buffer
+  constexpr int B_BYTES = BN * BK * 2;
+  constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;  // epilogue staging row pitch (bytes)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [buffer][plane] images
+  auto sA = [&](int buf, int pl) { return smem + (buf * NPL + pl) * A_BYTES; };
+  auto sB = [&](int buf, int pl) { return smem + 2 * NPL * A_BYTES + (buf * NPL + pl) * B_BYTES; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  const int tilesN = p.N / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int tile_n = bid % tilesN;
+  int tile_m = bid / tilesN;
+  const int txi = tile_m % p.tiles_x;
+  tile_m /= p.tiles_x;
+  const int tyi = tile_m % p.tiles_y;
+  const int b = tile_m / p.tiles_y;
+  const int y0 = tyi * TR, x0 = txi * TC, n0 = tile_n * BN;
+
+  const TA* inp = reinterpret_cast<const TA*>(p.in);
+
+  // ---- halo staging coordinates (independent of the channel chunk) -----------------------------
+  long h_off[NU_H];
+  int h_lds[NU_H];
+  bool h_ok[NU_H];
+#pragma unroll
+  for (int i = 0; i < NU_H; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q / UPR, u = q % UPR;
+    const int y = y0 + row / HP - 1, x = x0 + row % HP - 1;
+    h_ok[i] = q < HALO_ROWS * UPR && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    h_off[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
+    h_lds[i] = q < HALO_ROWS * UPR ? Sw<BK>::off(row, u) : -1;
+  }
+
+  u32x4 rh[NU_H][NPL];      // halo prefetch registers (X3: 8 fp32 = 2 x 16 B)
+  u32x4 rb[2][NU_B][NPL];   // weight prefetch registers, two steps deep
+
+  auto load_halo = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NU_H; ++i) {
+      if (h_ok[i]) {
+        const TA* src = inp + h_off[i] + kc * BK;
+        rh[i][0] = *reinterpret_cast<const u32x4*>(src);
+        if constexpr (X3) rh[i][1] = *reinterpret_cast<const u32x4*>(src + 4);
+      } else {
+        rh[i][0] = u32x4{0, 0, 0, 0};
+        if constexpr (X3) rh[i][1] = u32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NU_H; ++i) {
+      if (h_lds[i] < 0) continue;
+      if constexpr (X3) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f0 = __uint_as_float(j < 2 ? rh[i][0][2 * j] : rh[i][1][2 * j - 4]);
+          const float f1 = __uint_as_float(j < 2 ? rh[i][0][2 * j + 1] : rh[i][1][2 * j - 3]);
+          unsigned short h0, l0, h1, l1;
+          split_bf16(f0, h0, l0);
+          split_bf16(f1, h1, l1);
+          hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+          lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        *reinterpret_cast<u32x4*>(sA(buf, 0) + h_lds[i]) = hi;
+        *reinterpret_cast<u32x4*>(sA(buf, 1) + h_lds[i]) = lo;
+      } else {
+        *reinterpret_cast<u32x4*>(sA(buf, 0) + h_lds[i]) = rh[i][0];
+      }
+    }
+  };
+  auto load_b = [&](auto set, int kc, int t) {
+#pragma unroll
+    for (int i = 0; i < NU_B; ++i) {
+      const int q = tid + 256 * i;
+      if (B_GUARD && q >= BN * UPR) continue;
+      const int row = q / UPR, u = q % UPR;
+      const long off = ((long)t * p.N + n0 + row) * p.Cin + kc * BK + u * 8;
+      rb[set][i][0] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
+      if constexpr (X3) rb[set][i][1] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+    }
+  };
+  auto store_b = [&](auto set, int buf) {
+#pragma unroll
+    for (int i = 0; i < NU_B; ++i) {
+      const int q = tid + 256 * i;
+      if (B_GUARD && q >= BN * UPR) continue;
+      const int o = Sw<BK>::off(q / UPR, q % UPR);
+      *reinterpret_cast<u32x4*>(sB(buf, 0) + o) = rb[set][i][0];
+      if constexpr (X3) *reinterpret_cast<u32x4*>(sB(buf, 1) + o) = rb[set][i][1];
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // this lane's two A rows (pixels) of the tile: m = wr*64 + i*32 + fr -> (py, px)
+  int a_row0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wr * 64 + i * 32 + fr;
+    a_row0[i] = (m >> 4) * HP + (m & 15);      // halo row of tap (0,0)
+  }
+
+  auto compute = [&](int abuf, int bbuf, int t) {
+    const int shift = (t / 3) * HP + (t % 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a_hi[2], a_lo[2], b_hi[NT], b_lo[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int o = Sw<BK>::off(a_row0[i] + shift, 2 * ks + fh);
+        a_hi[i] = *reinterpret_cast<const bf16x8*>(sA(abuf, 0) + o);
+        if constexpr (X3) a_lo[i] = *reinterpret_cast<const bf16x8*>(sA(abuf, 1) + o);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int o = Sw<BK>::off(wc * (BN / 2) + j * 32 + fr, 2 * ks + fh);
+        b_hi[j] = *reinterpret_cast<const bf16x8*>(sB(bbuf, 0) + o);
+        if constexpr (X3) b_lo[j] = *reinterpret_cast<const bf16x8*>(sB(bbuf, 1) + o);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int kchunks = p.Cin / BK;
+  const int nsteps = kchunks * 9;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: halo(0), B(0) in LDS; B(1) in flight -------------------------------------------
+  load_halo(0);
+  load_b(I0{}, 0, 0);
+  store_halo(0);
+  store_b(I0{}, 0);
+  if (nsteps > 1) load_b(I1{}, 0, 1);      // 9 taps per chunk: step 1 is (kc 0, tap 1)
+  __syncthreads();
+
+  int kc = 0, t = 0;       // coordinates of the current step s
+  // One step; PAR = s % 2 selects the register set / LDS slot statically.
+  auto step = [&](auto PAR, int s) {
+    constexpr int par = decltype(PAR)::value;
+    using SetCur = std::integral_constant<int, par>;        // set that will hold B(s+2)
+    using SetNext = std::integral_constant<int, 1 - par>;   // set holding B(s+1)
+    // coordinates of steps s+2
+    if (s + 2 < nsteps) {
+      int t2 = t + 2, kc2 = kc;
+      if (t2 >= 9) { t2 -= 9; kc2 += 1; }
+      load_b(SetCur{}, kc2, t2);
+    }
+    const bool halo_next = kc + 1 < kchunks;
+    if (t == 0 && halo_next) load_halo(kc + 1);
+    compute(kc & 1, par, t);
+    if (s + 1 < nsteps) store_b(SetNext{}, 1 - par);
+    if (t == 7 && halo_next) store_halo((kc + 1) & 1);
+    __syncthreads();
+    if (++t == 9) { t = 0; ++kc; }
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    step(I0{}, s);
+    step(I1{}, s + 1);
+  }
+  if (s < nsteps) step(I0{}, s);
+
+  // ---- epilogue -----------------------------------------------------------------------------------
+  unsigned char* stage = smem;                                   // [128][STAGE_PITCH]
+  float* sstat = reinterpret_cast<float*>(smem + 128 * STAGE_PITCH);   // [2][BN]
+  const bool do_stats = p.stat_sum != nullptr;
+  const bool full_tile = (y0 + TR <= p.H) && (x0 + TC <= p.W);
+  if (do_stats)
+    for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
+  float cs1[NT], cs2[NT];       // per-lane column partial sums (BatchNorm statistics)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = wc * (BN / 2) + j * 32 + fr;
+    const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+    cs1[j] = 0.f;
+    cs2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float v = acc[i][j][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const TA q = (TA)v;
+        *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = q;
+        // statistics of the value as STORED, rows outside the image excluded
+        const float vs = (float)q;
+        const bool ok = full_tile || ((y0 + (row >> 4) < p.H) && (x0 + (row & 15) < p.W));
+        cs1[j] += ok ? vs : 0.f;
+        cs2[j] += ok ? vs * vs : 0.f;
+      }
+  }
+  __syncthreads();
+  if (do_stats) {
+    // rows live in registers and in the two lane halves: one shuffle, then one LDS add per column
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float t1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
+      const float t2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (fh == 0) {
+        const int col = wc * (BN / 2) + j * 32 + fr;
+        atomicAdd(&sstat[col], t1);
+        atomicAdd(&sstat[BN + col], t2);
+      }
+    }
+  }
+  {
+    constexpr int CPR = BN / 8;            // 8-channel chunks per row
+    constexpr int RPP = 256 / CPR;         // rows per pass
+    const int c8 = tid % CPR, r0 = tid / CPR;
+    TA* outp = reinterpret_cast<TA*>(p.out);
+#pragma unroll
+    for (int rr = 0; rr < 128 / RPP; ++rr) {
+      const int row = r0 + rr * RPP;
+      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      if (full_tile || (y < p.H && x < p.W)) {
+        const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
+        TA* dst = outp + (((long)b * p.H + y) * p.W + x) * p.out_ld + n0 + c8 * 8;
+        if constexpr (X3) {
+          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
+          *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+        } else {
+          *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sp);
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    // thousands of workgroups add to the same N channels: spread them over replicas (the atomic
+    // unit serialises same-address adds), bn_finalize sums the replicas
+    const long rep = (long)(blockIdx.x % (unsigned)p.stat_replicas) * p.N;
+    for (int c = tid; c < BN; c += 256) {
+      atomicAdd(&p.stat_sum[rep + n0 + c], (double)sstat[c]);
+      atomicAdd(&p.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
+    }
+  }
+}
+
+template <typename TA, int BN, int BK>
+int launch(ConvParams p, hipStream_t st) {
+  constexpr bool X3 = sizeof(TA) == 4;
+  p.tiles_y = cdiv(p.H, TR);
+  p.tiles_x = cdiv(p.W, TC);
+  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x * (p.N / BN);
+  size_t lds = (size_t)2 * (X3 ? 2 : 1) * (HALO_ROWS * BK * 2 + BN * BK * 2);
+  const size_t stage = (size_t)128 * (BN * sizeof(TA) + 16) + 2 * BN * sizeof(float);
+  if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, BN, BK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_kernel<TA, BN, BK>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+}  // namespace
+
+extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                              const void* w_hi, const void* w_lo, const float* bias, void* out,
+                              long out_ld, int relu, double* stat_sum, double* stat_sumsq,
+                              int stat_replicas, void* stream) {
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, "conv3x3: bad precision %d", prec);
+  CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
+  CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
+  CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0,
+                 "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
+  CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && in && w_hi && out, "conv3x3: bad arguments");
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "conv3x3: f32x3 needs the low weight plane");
+  CRIMAC_REQUIRE((stat_sum == nullptr) == (stat_sumsq == nullptr), "conv3x3: stat pointers come together");
+  CRIMAC_REQUIRE(!stat_sum || stat_replicas >= 1, "conv3x3: stat_replicas must be >= 1");
+  ConvParams p;
+  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
+  p.w_hi = (const unsigned short*)w_hi; p.w_lo = (const unsigned short*)w_lo; p.bias = bias;
+  p.out = out; p.out_ld = out_ld; p.relu = relu; p.stat_sum = stat_sum; p.stat_sumsq = stat_sumsq;
+  p.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
+  hipStream_t st = (hipStream_t)stream;
+  const bool n128 = N % 128 == 0;
+  if (prec == CRIMAC_PREC_BF16) {
+    if (Cin % 64 == 0) return n128 ? launch<bf16_t, 128, 64>(p, st) : launch<bf16_t, 64, 64>(p, st);
+    if (Cin % 32 == 0) return n128 ? launch<bf16_t, 128, 32>(p, st) : launch<bf16_t, 64, 32>(p, st);
+    return n128 ? launch<bf16_t, 128, 16>(p, st) : launch<bf16_t, 64, 16>(p, st);
+  }
+  // split-bf16 keeps two planes per operand: use the 32-deep chunk so two workgroups fit a CU
+  if (Cin % 32 == 0) return n128 ? launch<float, 128, 32>(p, st) : launch<float, 64, 32>(p, st);
+  return n128 ? launch<float, 128, 16>(p, st) : launch<float, 64, 16>(p, st);
+}

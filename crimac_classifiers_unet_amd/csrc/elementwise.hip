@@ -151,7 +151,19 @@ __device__ __forceinline__ void colreduce(long M, int C, OP op, ACC* out0, ACC* 
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
   if (rl < rpi && cpr <= 256) {
-    for (long m = (long)blockIdx.x * rpi + rl; m < M; m += (long)gridDim.x * rpi) {
+    const long stride = (long)gridDim.x * rpi;
+    long m = (long)blockIdx.x * rpi + rl;
+    for (; m + stride < M; m += 2 * stride) {      // two independent rows in flight
+      float q0[8], q1[8], r0[8], r1[8];
+      op(m, chunk * 8, q0, q1);
+      op(m + stride, chunk * 8, r0, r1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s0[j] += q0[j] + r0[j];
+        if (NQ > 1) s1[j] += q1[j] + r1[j];
+      }
+    }
+    if (m < M) {
       float q0[8], q1[8];
       op(m, chunk * 8, q0, q1);
 #pragma unroll
@@ -182,15 +194,26 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ y, 
                         sum, sumsq);
 }
 
-__global__ void bn_finalize_kernel(const double* sum, const double* sumsq, long M, int C,
-                                   const float* gamma, const float* beta, float eps, float momentum,
-                                   float* rmean, float* rvar, long long* nbt, float* mean_o,
-                                   float* invstd_o, float* scale_o, float* shift_o) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  const double mean = sum[c] / (double)M;
-  double var = sumsq[c] / (double)M - mean * mean;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const double* sum, const double* sumsq, int nrep, long M, int C, const float* gamma,
+    const float* beta, float eps, float momentum, float* rmean, float* rvar, long long* nbt,
+    float* mean_o, float* invstd_o, float* scale_o, float* shift_o) {
+  // 16 channels per workgroup, 16 threads per channel striding over the replicas
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = rl; r < nrep; r += 16) { s1 += sum[(long)r * C + c]; s2 += sumsq[(long)r * C + c]; }
+  red[0][cl][rl] = s1;
+  red[1][cl][rl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s1 = 0.0; s2 = 0.0;
+  for (int r = 0; r < 16; ++r) { s1 += red[0][cl][r]; s2 += red[1][cl][r]; }
+  const double mean = s1 / (double)M;
+  double var = s2 / (double)M - mean * mean;
   if (var < 0) var = 0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -211,20 +234,35 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
                                                      T* __restrict__ out, long out_ld, long M, int C) {
+  // thread -> fixed 8-channel chunk (its scale/shift live in registers), rows strided over the grid
   const int cpr = C / 8;
-  const long total = M * cpr;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const long m = i / cpr;
-    const int c0 = (int)(i % cpr) * 8;
-    float v[8];
-    load8(y + m * y_ld + c0, v);
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  if (rl >= rpi) return;
+  const int c0 = chunk * 8;
+  float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (scale) v[j] = v[j] * scale[c0 + j] + shift[c0 + j];
-      if (relu) v[j] = fmaxf(v[j], 0.f);
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale ? scale[c0 + j] : 1.f;
+    sh[j] = scale ? shift[c0 + j] : 0.f;
+  }
+  const long stride = (long)gridDim.x * rpi;
+  constexpr int U = 4;
+  for (long m = (long)blockIdx.x * rpi + rl; m < M; m += U * stride) {
+    float v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (m + u * stride < M) load8(y + (m + u * stride) * y_ld + c0, v[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (m + u * stride >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[u][j] = v[u][j] * sc[j] + sh[j];
+        if (relu) v[u][j] = fmaxf(v[u][j], 0.f);
+      }
+      store8(out + (m + u * stride) * out_ld + c0, v[u]);
     }
-    store8(out + m * out_ld + c0, v);
   }
 }
 
@@ -325,6 +363,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, long M,
                                                             int C, double* sum_dz, double* sum_dzx) {
+  const int c0t = (threadIdx.x % (C / 8)) * 8;     // this thread's channel chunk (see colreduce)
+  float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[c0t + j]; sh[j] = shift[c0t + j]; mu[j] = mean[c0t + j]; is[j] = invstd[c0t + j];
+  }
   colreduce<T, double, 2>(M, C,
                           [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
                             float g[8], yv[8];
@@ -332,10 +376,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                             load8(y + m * y_ld + c0, yv);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
-                              const float act = yv[j] * scale[c0 + j] + shift[c0 + j];
+                              const float act = yv[j] * sc[j] + sh[j];
                               const float dz = act > 0.f ? g[j] : 0.f;
                               q0[j] = dz;
-                              q1[j] = dz * (yv[j] - mean[c0 + j]) * invstd[c0 + j];
+                              q1[j] = dz * (yv[j] - mu[j]) * is[j];
                             }
                           },
                           sum_dz, sum_dzx);
@@ -355,26 +399,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
   }
   const double invM = 1.0 / (double)M;
-  if (dbias) {
-    colreduce<T, float, 1>(M, C,
-                           [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
-                             float g[8], yv[8], o[8];
-                             load8(da + m * da_ld + c0, g);
-                             load8(y + m * y_ld + c0, yv);
+  const int c0t = (threadIdx.x % (C / 8)) * 8;
+  float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
-                             for (int j = 0; j < 8; ++j) {
-                               const int c = c0 + j;
-                               const float act = yv[j] * scale[c] + shift[c];
-                               const float dz = act > 0.f ? g[j] : 0.f;
-                               const float xh = (yv[j] - mean[c]) * invstd[c];
-                               o[j] = scale[c] * (dz - (float)(sum_dz[c] * invM) -
-                                                  xh * (float)(sum_dzx[c] * invM));
-                               q0[j] = o[j];
-                             }
-                             store8(dy + m * dy_ld + c0, o);
-                           },
-                           dbias, (float*)nullptr);
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[c0t + j]; sh[j] = shift[c0t + j]; mu[j] = mean[c0t + j]; is[j] = invstd[c0t + j];
+    k1[j] = (float)(sum_dz[c0t + j] * invM);
+    k2[j] = (float)(sum_dzx[c0t + j] * invM);
   }
+  colreduce<T, float, 1>(M, C,
+                         [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
+                           float g[8], yv[8], o[8];
+                           load8(da + m * da_ld + c0, g);
+                           load8(y + m * y_ld + c0, yv);
+#pragma unroll
+                           for (int j = 0; j < 8; ++j) {
+                             const float act = yv[j] * sc[j] + sh[j];
+                             const float dz = act > 0.f ? g[j] : 0.f;
+                             const float xh = (yv[j] - mu[j]) * is[j];
+                             o[j] = sc[j] * (dz - k1[j] - xh * k2[j]);
+                             q0[j] = o[j];
+                           }
+                           store8(dy + m * dy_ld + c0, o);
+                         },
+                         dbias, (float*)nullptr);
 }
 
 // ---- 1x1 head --------------------------------------------------------------------------------------------
@@ -704,20 +752,23 @@ extern "C" int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C
   return CRIMAC_OK;
 }
 
-extern "C" int crimac_bn_finalize(const double* sum, const double* sumsq, long M, int C,
+extern "C" int crimac_bn_finalize(const double* sum, const double* sumsq, int replicas, long M, int C,
                                   const float* gamma, const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var,
                                   long long* num_batches_tracked, float* mean, float* invstd,
                                   float* scale, float* shift, void* stream) {
-  CRIMAC_REQUIRE(sum && sumsq && gamma && beta && mean && invstd && scale && shift && M > 0 && C > 0,
+  CRIMAC_REQUIRE(sum && sumsq && gamma && beta && mean && invstd && scale && shift && M > 0 && C > 0 &&
+                     replicas >= 1,
                  "bn_finalize: bad arguments");
   CRIMAC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, sum, sumsq, M, C, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, ST, sum, sumsq, replicas, M, C, gamma,
                      beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd,
                      scale, shift);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
+
+static int colreduce_grid(long M, int C);
 
 template <typename T>
 static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, const float* shift,
@@ -730,7 +781,7 @@ static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, cons
                        H, W, C);
   } else {
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL(bn_act_kernel<T>, dim3(grid_for(M * (C / 8), 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(bn_act_kernel<T>, dim3(colreduce_grid(M, C)), dim3(256), 0, st,
                        (const T*)y, y_ld, scale, shift, relu, (T*)out, out_ld, M, C);
   }
   CRIMAC_LAUNCH_CHECK();
@@ -742,7 +793,7 @@ extern "C" int crimac_bn_act_pool(int prec, const void* y, long y_ld, const floa
                                   void* pool_out, long pool_ld, int B, int H, int W, int C,
                                   void* stream) {
   PREC_OK("bn_act_pool");
-  CRIMAC_REQUIRE(y && (out || pool_out) && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+  CRIMAC_REQUIRE(y && (out || pool_out) && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
                  "bn_act_pool: bad arguments");
   CRIMAC_REQUIRE((scale == nullptr) == (shift == nullptr), "bn_act_pool: scale/shift must come together");
   CRIMAC_REQUIRE(y_ld >= C && y_ld % 8 == 0 && (!out || (out_ld >= C && out_ld % 8 == 0)) &&

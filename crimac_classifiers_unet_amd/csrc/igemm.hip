@@ -221,38 +221,58 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias (+ReLU), store --------------------------------------------------------
-  TA* outp = reinterpret_cast<TA*>(p.out);
+  // ---- epilogue: bias (+ReLU) in registers, tile staged through LDS, coalesced 16-byte stores -----
+  constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;
+  unsigned char* stage = smem;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wc * (BN / 2) + j * 32 + fr;
-    const float bv = p.bias ? p.bias[n % p.bias_mod] : 0.f;
+    const int col = wc * (BN / 2) + j * 32 + fr;
+    const float bv = p.bias ? p.bias[(n0 + col) % p.bias_mod] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float v = acc[i][j][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = (TA)v;
+      }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = BN / 8;
+    constexpr int RPP = 256 / CPR;
+    const int c8 = tid % CPR, r0 = tid / CPR;
+    const int n = n0 + c8 * 8;
     int up_o = 0, up_a = 0, up_b = 0;
     if constexpr (OUT_MODE == 1) {
-      const int ab = n / p.cout_up;
+      const int ab = n / p.cout_up;          // 8 consecutive columns never straddle an (a,b) group
       up_o = n % p.cout_up;
       up_a = ab >> 1;
       up_b = ab & 1;
     }
+    TA* outp = reinterpret_cast<TA*>(p.out);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        long o;
-        if constexpr (OUT_MODE == 1) {
-          const int ox = (int)(m % p.Wo);
-          const long t = m / p.Wo;
-          const int oy = (int)(t % p.Ho);
-          const long b = t / p.Ho;
-          o = ((b * (2L * p.Ho) + 2 * oy + up_a) * (2L * p.Wo) + 2 * ox + up_b) * p.out_ld + up_o;
-        } else {
-          o = m * p.out_ld + n;
-        }
-        outp[o] = (TA)v;
+    for (int rr = 0; rr < BM / RPP; ++rr) {
+      const int row = r0 + rr * RPP;
+      const long m = m0 + row;
+      if (m >= p.M) continue;
+      long o;
+      if constexpr (OUT_MODE == 1) {
+        const int ox = (int)(m % p.Wo);
+        const long t = m / p.Wo;
+        const int oy = (int)(t % p.Ho);
+        const long bb = t / p.Ho;
+        o = ((bb * (2L * p.Ho) + 2 * oy + up_a) * (2L * p.Wo) + 2 * ox + up_b) * p.out_ld + up_o;
+      } else {
+        o = m * p.out_ld + n;
+      }
+      const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
+      if constexpr (X3) {
+        *reinterpret_cast<f32x4*>(outp + o) = *reinterpret_cast<const f32x4*>(sp);
+        *reinterpret_cast<f32x4*>(outp + o + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+      } else {
+        *reinterpret_cast<u32x4*>(outp + o) = *reinterpret_cast<const u32x4*>(sp);
       }
     }
   }
@@ -262,7 +282,9 @@ template <typename TA, int BN, int BK, int OUT_MODE>
 int launch(const IgemmParams& p, hipStream_t st) {
   constexpr bool X3 = sizeof(TA) == 4;
   const int tilesM = cdiv(p.M, BM), tilesN = p.N / BN;
-  const size_t lds = (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1);
+  size_t lds = (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1);
+  const size_t stage = (size_t)BM * (BN * sizeof(TA) + 16);
+  if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<TA, BN, BK, OUT_MODE>),
@@ -304,6 +326,8 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   CRIMAC_REQUIRE(out_mode == 0 || (out_mode == 1 && cout_up > 0 && N == 4 * cout_up),
                  "igemm: bad output mode / cout_up");
   CRIMAC_REQUIRE(out_mode == 1 ? out_ld >= cout_up : out_ld >= N, "igemm: out_ld too small");
+  CRIMAC_REQUIRE(out_ld % 8 == 0 && (out_mode == 0 || cout_up % 8 == 0),
+                 "igemm: out_ld (and cout_up) must be multiples of 8 for the 16-byte stores");
   IgemmParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo;
   p.Cin = Cin; p.N = N; p.ntaps = ntaps; p.tw = tw; p.pad = pad; p.stride = stride;

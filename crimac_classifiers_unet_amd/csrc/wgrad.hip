@@ -39,6 +39,13 @@ __device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
 }
 
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
+//
+// bf16 path: tiles go global -> LDS directly (global_load_lds_dwordx4, no registers), double
+// buffered: the loads of tile t+1 are in flight while tile t is contracted; one barrier per tile.
+// The LDS image of such a load is lane-linear (1 KiB = 8 pixel rows per wave-instruction), so the
+// tr-read swizzle is applied on the per-lane SOURCE address.  Pixels outside the image are zeroed
+// with plain LDS stores by the lane that would have loaded them.
+// fp32 (split-bf16) path: register staging with the hi/lo split, single buffer.
 template <typename TA, int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr bool X3 = sizeof(TA) == 4;
@@ -46,14 +53,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int NTAPS = MODE == 0 ? 9 : 4;
   constexpr int F_ROWS = TR * 16;
   constexpr int S_ROWS = MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32;
+  constexpr int S_ROWS_PAD = (S_ROWS + 7) / 8 * 8;
   constexpr int F_BYTES = F_ROWS * 128;
-  constexpr int S_BYTES = S_ROWS * 128;
+  constexpr int S_BYTES = S_ROWS_PAD * 128;
+  constexpr int BUF_BYTES = F_BYTES + S_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sF_hi = smem;
-  unsigned char* sS_hi = smem + F_BYTES;
-  unsigned char* sF_lo = smem + F_BYTES + S_BYTES;
-  unsigned char* sS_lo = smem + 2 * F_BYTES + S_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wf = wave >> 1, ws = wave & 1;
@@ -78,70 +83,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int f_chb = (wf * 32 + 16 * cgrp + 4 * pp) * 2;   // byte offset of this lane's 4 channels
   const int s_chb = (ws * 32 + 16 * cgrp + 4 * pp) * 2;
 
-  auto stage_unit = [&](const TA* src, bool ok, unsigned char* hi_img, unsigned char* lo_img, int o) {
-    if constexpr (X3) {
-      u32x4 v0 = u32x4{0, 0, 0, 0}, v1 = u32x4{0, 0, 0, 0};
-      if (ok) {
-        v0 = *reinterpret_cast<const u32x4*>(src);
-        v1 = *reinterpret_cast<const u32x4*>(src + 4);
-      }
-      u32x4 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float f0 = __uint_as_float(j < 2 ? v0[2 * j] : v1[2 * j - 4]);
-        const float f1 = __uint_as_float(j < 2 ? v0[2 * j + 1] : v1[2 * j - 3]);
-        unsigned short h0, l0, h1, l1;
-        split_bf16(f0, h0, l0);
-        split_bf16(f1, h1, l1);
-        hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-      }
-      *reinterpret_cast<u32x4*>(hi_img + o) = hi;
-      *reinterpret_cast<u32x4*>(lo_img + o) = lo;
-    } else {
-      u32x4 v = u32x4{0, 0, 0, 0};
-      if (ok) v = *reinterpret_cast<const u32x4*>(src);
-      *reinterpret_cast<u32x4*>(hi_img + o) = v;
-    }
-  };
-
-  const long t_begin = (long)blockIdx.y * p.tiles_per_block;
-  const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
-  for (long tile = t_begin; tile < t_end; ++tile) {
-    const int txi = (int)(tile % p.tiles_x);
-    const long tt = tile / p.tiles_x;
-    const int tyi = (int)(tt % p.tiles_y);
-    const long b = tt / p.tiles_y;
-    const int y0 = tyi * TR, x0 = txi * 16;
-
-    __syncthreads();   // previous tile's fragment reads are done
-    // ---- stage F tile: TR x 16 pixels x 64 channels ------------------------------------------
-    for (int uidx = tid; uidx < F_ROWS * 8; uidx += 256) {
-      const int row = uidx >> 3, u = uidx & 7;
-      const int y = y0 + (row >> 4), x = x0 + (row & 15);
-      const bool ok = y < p.Hf && x < p.Wf && (cf0 + u * 8) < p.CF;
-      const TA* src = fp + ((b * p.Hf + y) * (long)p.Wf + x) * p.f_ld + cf0 + u * 8;
-      stage_unit(src, ok, sF_hi, sF_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
-    }
-    // ---- stage S tile ---------------------------------------------------------------------------
-    for (int uidx = tid; uidx < S_ROWS * 8; uidx += 256) {
-      const int row = uidx >> 3, u = uidx & 7;
-      int y, x;
-      if constexpr (MODE == 0) {
-        y = y0 + row / 18 - 1;
-        x = x0 + row % 18 - 1;
-      } else {
-        const int fy = row >> 5, rem = row & 31;
-        y = 2 * y0 + fy;
-        x = 2 * (x0 + (rem & 15)) + (rem >> 4);
-      }
-      const bool ok = y >= 0 && y < Hs && x >= 0 && x < Ws && (cs0 + u * 8) < p.CS;
-      const TA* src = sp + ((b * Hs + y) * (long)Ws + x) * p.s_ld + cs0 + u * 8;
-      stage_unit(src, ok, sS_hi, sS_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
-    }
-    __syncthreads();
-
-    // ---- contraction over the tile's pixels: one k16 step per tile row --------------------------
+  // contraction over one staged tile: one k16 step per tile row
+  auto contract = [&](const unsigned char* sF_hi, const unsigned char* sF_lo,
+                      const unsigned char* sS_hi, const unsigned char* sS_lo) {
 #pragma unroll 1
     for (int py = 0; py < TR; ++py) {
       bf16x8 a_hi, a_lo;
@@ -176,6 +120,125 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
       }
     }
+  };
+
+  // pixel of S image row `row` for the tile at (y0, x0)
+  auto s_pixel = [&](int row, int y0, int x0, int& y, int& x) {
+    if constexpr (MODE == 0) {
+      y = y0 + row / 18 - 1;
+      x = x0 + row % 18 - 1;
+    } else {
+      const int fy = row >> 5, rem = row & 31;
+      y = 2 * y0 + fy;
+      x = 2 * (x0 + (rem & 15)) + (rem >> 4);
+    }
+  };
+  auto tile_origin = [&](long tile, long& b, int& y0, int& x0) {
+    const int txi = (int)(tile % p.tiles_x);
+    const long tt = tile / p.tiles_x;
+    const int tyi = (int)(tt % p.tiles_y);
+    b = tt / p.tiles_y;
+    y0 = tyi * TR;
+    x0 = txi * 16;
+  };
+
+  const long t_begin = (long)blockIdx.y * p.tiles_per_block;
+  const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
+
+  if constexpr (!X3) {
+    // ---- bf16: direct-to-LDS double buffering ----------------------------------------------------
+    auto issue_tile = [&](long tile, int buf) {
+      long b; int y0, x0;
+      tile_origin(tile, b, y0, x0);
+      unsigned char* base = smem + buf * BUF_BYTES;
+      const int sub = lane >> 3, c = lane & 7;
+      for (int k = wave; k < F_ROWS / 8; k += 4) {
+        const int row = 8 * k + sub;
+        const int u = c ^ (4 * ((row >> 1) & 1));
+        const int y = y0 + (row >> 4), x = x0 + (row & 15);
+        const bool ok = y < p.Hf && x < p.Wf && (cf0 + u * 8) < p.CF;
+        if (ok) {
+          const bf16_t* src = fp + ((b * p.Hf + y) * (long)p.Wf + x) * p.f_ld + cf0 + u * 8;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(base + k * 1024),
+                                           16, 0, 0);
+        } else {
+          *reinterpret_cast<u32x4*>(base + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+        }
+      }
+      unsigned char* sbase = base + F_BYTES;
+      for (int k = wave; k < S_ROWS_PAD / 8; k += 4) {
+        const int row = 8 * k + sub;
+        const int u = c ^ (4 * ((row >> 1) & 1));
+        int y, x;
+        s_pixel(row, y0, x0, y, x);
+        const bool in_img = row < S_ROWS && y >= 0 && y < Hs && x >= 0 && x < Ws && (cs0 + u * 8) < p.CS;
+        if (in_img) {
+          const bf16_t* src = sp + ((b * Hs + y) * (long)Ws + x) * p.s_ld + cs0 + u * 8;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(sbase + k * 1024),
+                                           16, 0, 0);
+        } else {
+          *reinterpret_cast<u32x4*>(sbase + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+        }
+      }
+    };
+    if (t_begin < t_end) issue_tile(t_begin, 0);
+    for (long tile = t_begin; tile < t_end; ++tile) {
+      const int cur = (int)((tile - t_begin) & 1);
+      __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
+      if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+      const unsigned char* base = smem + cur * BUF_BYTES;
+      contract(base, nullptr, base + F_BYTES, nullptr);
+    }
+  } else {
+    // ---- fp32 activations: register staging with hi/lo split ---------------------------------------
+    unsigned char* sF_hi = smem;
+    unsigned char* sS_hi = smem + F_BYTES;
+    unsigned char* sF_lo = smem + F_BYTES + S_BYTES;
+    unsigned char* sS_lo = smem + 2 * F_BYTES + S_BYTES;
+    auto stage_unit = [&](const TA* src, bool ok, unsigned char* hi_img, unsigned char* lo_img, int o) {
+      u32x4 v0 = u32x4{0, 0, 0, 0}, v1 = u32x4{0, 0, 0, 0};
+      if (ok) {
+        v0 = *reinterpret_cast<const u32x4*>(src);
+        v1 = *reinterpret_cast<const u32x4*>(src + 4);
+      }
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float f0 = __uint_as_float(j < 2 ? v0[2 * j] : v1[2 * j - 4]);
+        const float f1 = __uint_as_float(j < 2 ? v0[2 * j + 1] : v1[2 * j - 3]);
+        unsigned short h0, l0, h1, l1;
+        split_bf16(f0, h0, l0);
+        split_bf16(f1, h1, l1);
+        hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+      *reinterpret_cast<u32x4*>(hi_img + o) = hi;
+      *reinterpret_cast<u32x4*>(lo_img + o) = lo;
+    };
+    for (long tile = t_begin; tile < t_end; ++tile) {
+      long b; int y0, x0;
+      tile_origin(tile, b, y0, x0);
+      __syncthreads();   // previous tile's fragment reads are done
+      for (int uidx = tid; uidx < F_ROWS * 8; uidx += 256) {
+        const int row = uidx >> 3, u = uidx & 7;
+        const int y = y0 + (row >> 4), x = x0 + (row & 15);
+        const bool ok = y < p.Hf && x < p.Wf && (cf0 + u * 8) < p.CF;
+        const TA* src = fp + ((b * p.Hf + y) * (long)p.Wf + x) * p.f_ld + cf0 + u * 8;
+        stage_unit(src, ok, sF_hi, sF_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
+      }
+      for (int uidx = tid; uidx < S_ROWS * 8; uidx += 256) {
+        const int row = uidx >> 3, u = uidx & 7;
+        int y, x;
+        s_pixel(row, y0, x0, y, x);
+        const bool ok = y >= 0 && y < Hs && x >= 0 && x < Ws && (cs0 + u * 8) < p.CS;
+        const TA* src = sp + ((b * Hs + y) * (long)Ws + x) * p.s_ld + cs0 + u * 8;
+        stage_unit(src, ok, sS_hi, sS_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
+      }
+      __syncthreads();
+      contract(sF_hi, sF_lo, sS_hi, sS_lo);
+    }
   }
 
   // ---- combine partial sums: dw[t][cf][cs] += acc ---------------------------------------------
@@ -197,7 +260,7 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   constexpr bool X3 = sizeof(TA) == 4;
   constexpr int TR = MODE == 0 ? 8 : 4;
   constexpr int F_ROWS = TR * 16;
-  constexpr int S_ROWS = MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32;
+  constexpr int S_ROWS = ((MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32) + 7) / 8 * 8;   // padded to 8 rows
   p.tiles_y = cdiv(p.Hf, TR);
   p.tiles_x = cdiv(p.Wf, 16);
   p.ntiles = (long)p.B * p.tiles_y * p.tiles_x;

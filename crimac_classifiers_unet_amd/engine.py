@@ -17,6 +17,8 @@ PyTorch supplies memory and streams only; there is no CPU or eager fallback.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip
@@ -25,6 +27,7 @@ from .hip import Act, call, ptr
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 CIN_PAD = 16          # first-layer input channels are zero-padded to one MFMA k-step
+STAT_REPLICAS = 64    # conv epilogues spread their BatchNorm partial sums over this many accumulators
 
 
 def _align(n, a=64):
@@ -168,15 +171,22 @@ class UNetEngine:
         self.dw_packed = torch.zeros(tot_dw, dtype=torch.float32, device=dev)
         cmax = self.sf * 2 ** (self.depth - 1)
         nb = len(self.blocks)
-        # fp64 scratch: [0:2] loss sums, then per BN layer 4 x cmax (sum, sumsq, sum_dz, sum_dz_xhat)
-        self.stat = torch.zeros(2 + nb * 4 * cmax, dtype=torch.float64, device=dev)
+        # fp64 scratch: [0:2] loss sums, then per BN layer (2*R + 2) x cmax:
+        # sum[R][C], sumsq[R][C] (R replicas filled by the conv epilogues), sum_dz[C], sum_dz_xhat[C]
+        self.stat = torch.zeros(2 + nb * (2 * STAT_REPLICAS + 2) * cmax, dtype=torch.float64, device=dev)
         self.cmax = cmax
         # fp32 per BN layer: mean, invstd, scale, shift
         self.bnf = torch.zeros(nb * 4 * cmax, dtype=torch.float32, device=dev)
         self.class_w = None
 
     def _stat(self, b, k):
-        o = 2 + (b.idx * 4 + k) * self.cmax
+        """k: 0 sum[R][C], 1 sumsq[R][C], 2 sum_dz[C], 3 sum_dz_xhat[C] of BN layer b."""
+        R = STAT_REPLICAS
+        base = 2 + b.idx * (2 * R + 2) * self.cmax
+        if k < 2:
+            o = base + k * R * self.cmax
+            return self.stat[o:o + R * b.cout]
+        o = base + (2 * R + k - 2) * self.cmax
         return self.stat[o:o + b.cout]
 
     def _bnf(self, b, k):
@@ -262,11 +272,21 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     # kernels wrappers
     # ------------------------------------------------------------------------------------------
-    def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None):
-        call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1,
-             ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"]),
-             ptr(bias), cout, out.p, out.ld, 1 if relu else 0, 0, 0,
-             flops=2.0 * 9 * (cin_real or cin) * cout * B * H * W)
+    conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
+
+    def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
+                 stats=None):
+        flops = 2.0 * 9 * (cin_real or cin) * cout * B * H * W
+        w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
+        if self.conv_impl == "halo":
+            call("crimac_conv3x3", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
+                 out.p, out.ld, 1 if relu else 0, ptr(stats[0]) if stats else None,
+                 ptr(stats[1]) if stats else None, STAT_REPLICAS, flops=flops)
+            return
+        call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1, w_hi, w_lo,
+             ptr(bias), cout, out.p, out.ld, 1 if relu else 0, 0, 0, flops=flops)
+        if stats:
+            call("crimac_colstats", self.prec, out.p, out.ld, B * H * W, cout, ptr(stats[0]), ptr(stats[1]))
 
     def _upconv_fwd(self, x: Act, u, out: Act, B, H, W):
         pk = self.pk[u.key]
@@ -282,9 +302,8 @@ class UNetEngine:
              flops=2.0 * 4 * u.cin * u.cout * B * H * W)
 
     def _bn_train(self, b, y: Act, M):
-        call("crimac_colstats", self.prec, y.p, y.ld, M, b.cout, ptr(self._stat(b, 0)),
-             ptr(self._stat(b, 1)))
-        call("crimac_bn_finalize", ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), M, b.cout,
+        """Batch statistics were accumulated by the conv epilogue; finish them."""
+        call("crimac_bn_finalize", ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), STAT_REPLICAS, M, b.cout,
              ptr(self.P[b.bn_key + ".weight"]), ptr(self.P[b.bn_key + ".bias"]), BN_EPS, BN_MOMENTUM,
              ptr(self.Bf[b.bn_key + ".running_mean"]), ptr(self.Bf[b.bn_key + ".running_var"]),
              ptr(self.Bf[b.bn_key + ".num_batches_tracked"]), ptr(self._bnf(b, 0)),
@@ -340,11 +359,12 @@ class UNetEngine:
                 y1 = Act(self._buf(f"e{i}.y1", (M, c)), c)
                 y2 = Act(self._buf(f"e{i}.y2", (M, c)), c)
                 self._conv3x3(cur, self.pk[b1.conv_key], self.P[b1.conv_key + ".bias"], y1, B, h, w,
-                              b1.cin_pad, c, relu=False, cin_real=b1.cin)
+                              b1.cin_pad, c, relu=False, cin_real=b1.cin,
+                              stats=(self._stat(b1, 0), self._stat(b1, 1)))
                 self._bn_train(b1, y1, M)
                 self._act(b1, y1, a1, None, B, h, w)
                 self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
-                              relu=False)
+                              relu=False, stats=(self._stat(b2, 0), self._stat(b2, 1)))
                 self._bn_train(b2, y2, M)
                 self._act(b2, y2, a2, pool, B, h, w)
                 saved[f"e{i}"] = (cur, y1, a1, y2, a2)
@@ -372,11 +392,11 @@ class UNetEngine:
                 y1 = Act(self._buf(f"d{j}.y1", (M, c)), c)
                 y2 = Act(self._buf(f"d{j}.y2", (M, c)), c)
                 self._conv3x3(catA, self.pk[b1.conv_key], self.P[b1.conv_key + ".bias"], y1, B, h, w,
-                              2 * c, c, relu=False)
+                              2 * c, c, relu=False, stats=(self._stat(b1, 0), self._stat(b1, 1)))
                 self._bn_train(b1, y1, M)
                 self._act(b1, y1, a1, None, B, h, w)
                 self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
-                              relu=False)
+                              relu=False, stats=(self._stat(b2, 0), self._stat(b2, 1)))
                 self._bn_train(b2, y2, M)
                 self._act(b2, y2, a2, None, B, h, w)
                 saved[f"d{j}"] = (cur, catA, y1, a1, y2, a2)

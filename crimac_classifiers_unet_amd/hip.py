@@ -23,6 +23,7 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "crimac_igemm_conv": [_i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i,
                           _vp, _l, _i, _i, _i, _vp],
+    "crimac_conv3x3": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "crimac_pack_upconv2x2": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -31,7 +32,7 @@ SIGNATURES = {
     "crimac_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _l, _vp],
     "crimac_colstats": [_i, _vp, _l, _l, _i, _vp, _vp, _vp],
     "crimac_colsum_f32": [_i, _vp, _l, _l, _i, _vp, _vp],
-    "crimac_bn_finalize": [_vp, _vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "crimac_bn_finalize": [_vp, _vp, _i, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "crimac_bn_act_pool": [_i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
     "crimac_unpool_add": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
     "crimac_bn_bwd_reduce": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp],

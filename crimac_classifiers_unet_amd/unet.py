@@ -122,7 +122,11 @@ class UNet_Baseline(nn.Module):
     @property
     def engine(self) -> UNetEngine:
         if self._engine is None:
-            object.__setattr__(self, "_engine", UNetEngine(self, self._precision))
+            try:
+                eng = UNetEngine(self, self._precision)
+            except AttributeError as e:   # nn.Module.__getattr__ would swallow it as "no attribute engine"
+                raise RuntimeError(f"cannot create the HIP engine: {e}") from e
+            object.__setattr__(self, "_engine", eng)
         return self._engine
 
     @property

@@ -55,6 +55,17 @@ int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int W
                       const void* w_lo, const float* bias, int bias_mod, void* out, long out_ld,
                       int relu, int out_mode, int cout_up, void* stream);
 
+/* 3x3 convolution, stride 1, pad 1 (nn.Conv2d forward, unet.py:35-44; with the dgrad weight planes
+ * of crimac_pack_conv3x3 it is the input gradient): halo tile staged once per channel chunk in LDS,
+ * weights streamed two steps ahead, coalesced epilogue.  w_hi/w_lo: bf16 [9][N][Cin].
+ * stat_sum/stat_sumsq (both or neither): per-output-channel sum / sum of squares of the STORED
+ * output, added to fp64 accumulators [stat_replicas][N] (caller zeroes; workgroups spread over the
+ * replicas to avoid same-address atomic serialisation; crimac_bn_finalize sums them) -- BatchNorm
+ * batch statistics fused into the convolution (unet.py:78,81,121-122).  Cin % 16 == 0, N % 64 == 0. */
+int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                   const void* w_hi, const void* w_lo, const float* bias, void* out, long out_ld,
+                   int relu, double* stat_sum, double* stat_sumsq, int stat_replicas, void* stream);
+
 /* Weight gradient (aten::convolution_backward weight half, pipeline.py:177):
  *   dw[t][f][s] += sum_pixels F[p][f] * S[shift_t(p)][s]   (fp32 atomics; caller zeroes dw)
  *   mode 0 (conv3x3): F=dY [B][Hf][Wf][CF=Cout], S=X same grid [CS=Cin], 9 taps
@@ -92,8 +103,9 @@ int crimac_colstats(int prec, const void* y, long ld, long M, int C, double* sum
 /* Per-channel sum accumulated into fp32 (bias gradients). */
 int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C, float* sum, void* stream);
 /* Train-mode statistics -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale; running stats
- * updated with `momentum` (unbiased variance), num_batches_tracked += 1. */
-int crimac_bn_finalize(const double* sum, const double* sumsq, long M, int C, const float* gamma,
+ * updated with `momentum` (unbiased variance), num_batches_tracked += 1.
+ * sum/sumsq are [replicas][C] partial accumulators that are added up first. */
+int crimac_bn_finalize(const double* sum, const double* sumsq, int replicas, long M, int C, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, long long* num_batches_tracked, float* mean,
                        float* invstd, float* scale, float* shift, void* stream);

@@ -210,7 +210,7 @@ def test_batchnorm_train_forward_backward_pool(prec, C):
     rm_d, rv_d, gamma_d, beta_d = rm.to(d), rv.to(d), gamma.to(d), beta.to(d)
     nbt = torch.zeros((), dtype=torch.int64, device=d)
     st = torch.zeros(4, C, dtype=torch.float32, device=d)   # mean, invstd, scale, shift
-    call("crimac_bn_finalize", ptr(s[0]), ptr(s[1]), M, C, ptr(gamma_d), ptr(beta_d), 1e-5, 0.1,
+    call("crimac_bn_finalize", ptr(s[0]), ptr(s[1]), 1, M, C, ptr(gamma_d), ptr(beta_d), 1e-5, 0.1,
          ptr(rm_d), ptr(rv_d), ptr(nbt), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]))
     a = torch.empty(M, C, dtype=_dt(prec), device=d)
     pool = torch.empty(M // 4, C, dtype=_dt(prec), device=d)
@@ -355,3 +355,67 @@ def test_bad_arguments_fail_loudly():
              ptr(t), 64, 0, 0, 0)
     with pytest.raises(hip.HipLibraryError):
         hip.ptr(torch.zeros(4))          # CPU tensor: no fallback
+
+
+# ---- conv3x3.hip: halo-staged kernel (the one the engine uses) -------------------------------------
+def conv3x3_halo(prec, x_nhwc, in_ld, B, H, W, Cin, Cout, w_hi, w_lo, bias, relu=False, out=None,
+                 out_ld=None, out_off=0, stats=None):
+    if out is None:
+        out = torch.empty(B * H * W, Cout, dtype=_dt(prec), device="cuda")
+    out_ld = out_ld or Cout
+    call("crimac_conv3x3", hip.PREC_NAMES[prec], ptr(x_nhwc), in_ld, B, H, W, Cin, Cout, ptr(w_hi),
+         ptr(w_lo), ptr(bias), ptr(out, out_off), out_ld, 1 if relu else 0,
+         ptr(stats[0]) if stats is not None else None, ptr(stats[1]) if stats is not None else None,
+         stats.shape[1] if stats is not None else 1)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (3, 8, 16, 256, 64),
+                                   (2, 16, 16, 4, 64), (1, 24, 40, 64, 192), (2, 12, 20, 32, 128),
+                                   (1, 32, 32, 576, 128)])
+def test_conv3x3_halo_forward_stats(prec, shape):
+    """Forward incl. fused bias/ReLU and fused BatchNorm statistics; partial tiles (H%8, W%16 != 0);
+    odd number of (chunk, tap) steps (Cin = 64, 576) and even (Cin = 128)."""
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(11)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    cin_pad = 16 if Ci < 16 else Ci
+    fh, fl, _, _ = pack_conv(w, prec, cin_pad, dgrad=False)
+    ref = F.conv2d(x, _round(w, prec), b, padding=1)
+    xin, bd = to_nhwc(x, prec, ld=cin_pad), b.cuda()
+    stats = torch.zeros(2, 5, Co, dtype=torch.float64, device="cuda")      # 5 replicas
+    out = conv3x3_halo(prec, xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, bd, stats=stats)
+    assert relerr(from_nhwc(out, B, H, W), ref) < TOL[prec]
+    stored = out.double()
+    assert relerr(stats[0].sum(0).cpu(), stored.sum(0).cpu()) < 1e-5
+    assert relerr(stats[1].sum(0).cpu(), (stored * stored).sum(0).cpu()) < 1e-5
+    out = conv3x3_halo(prec, xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, bd, relu=True)
+    assert relerr(from_nhwc(out, B, H, W), torch.relu(ref)) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_conv3x3_halo_strided_io_and_dgrad(prec):
+    B, H, W, Ci, Co = 2, 16, 16, 64, 128
+    g = torch.Generator().manual_seed(12)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 24
+    fh, fl, dh, dl = pack_conv(w, prec)
+    ref = F.conv2d(x, _round(w, prec), None, padding=1)
+    big_in = torch.zeros(B * H * W, 2 * Ci, dtype=_dt(prec), device="cuda")
+    big_in[:, Ci:] = to_nhwc(x, prec)
+    big_out = torch.full((B * H * W, 3 * Co), 7.0, dtype=_dt(prec), device="cuda")
+    call("crimac_conv3x3", hip.PREC_NAMES[prec], ptr(big_in, Ci), 2 * Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl),
+         None, ptr(big_out, Co), 3 * Co, 0, None, None, 1)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(big_out[:, Co:2 * Co].contiguous(), B, H, W), ref) < TOL[prec]
+    assert float((big_out[:, :Co].float() - 7).abs().max()) == 0 and \
+        float((big_out[:, 2 * Co:].float() - 7).abs().max()) == 0
+    dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+    refg = torch.nn.grad.conv2d_input((B, Ci, H, W), _round(w, prec), dy, padding=1)
+    dyn = to_nhwc(dy, prec)
+    dx = conv3x3_halo(prec, dyn, Co, B, H, W, Co, Ci, dh, dl, None)
+    assert relerr(from_nhwc(dx, B, H, W), refg) < TOL[prec]

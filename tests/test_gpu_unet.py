@@ -117,7 +117,7 @@ def test_train_step_matches_reference_golden_f32x3(full_case):
         # tolerance is tied to the reference's own fp32-vs-fp64 noise floor for this tensor
         # (tools/make_golden.py): gradients of this net are chaotic in the forward rounding (ReLU /
         # max-pool decisions flip), and the split-bf16 forward perturbs ~10x more than fp32 rounding
-        tol = max(20 * noise, 5e-3)
+        tol = max(20 * noise, 2e-2)
         assert abs(float(g.double().norm()) - gn) <= tol * gn, (k, float(g.double().norm()), gn)
         if "grad/" + k in fix.files:
             r = l2rel(g, fix["grad/" + k])
