@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/crimac_unet_hip.h declares (no
+compute calls without a GPU), and host-side logic of the drop-in surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import crimac_classifiers_unet_amd as pkg
+from crimac_classifiers_unet_amd import build, hip, parallel, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "crimac_unet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crimac_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    build.build()
+    lib = ctypes.CDLL(build.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+    # and the binding table covers the header exactly (plus version / last_error)
+    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error"} == set(syms)
+    assert hip.load_library().crimac_version() >= 1
+
+
+def test_argument_validation_runs_without_gpu():
+    """Argument checks precede any HIP call, so they are testable on the CPU box."""
+    lib = hip.load_library()
+    rc = lib.crimac_conv3x3(0, None, 64, 1, 8, 8, 24, 64, None, None, None, None, 64, 0, None, None, 1, None)
+    assert rc < 0 and b"Cin" in lib.crimac_last_error()
+    rc = lib.crimac_sgd_momentum(None, None, None, 0, 0.1, 0.9, 1.0, 0, None)
+    assert rc < 0
+
+
+def test_module_surface_matches_reference_layout():
+    m = pkg.UNet_Baseline(n_classes=3, in_channels=4)
+    sd = m.state_dict()
+    shapes = synth.unet_state_shapes()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in sd)
+    assert sum(p.numel() for p in m.parameters()) == 31044227
+    m.load_state_dict(synth.synth_state_dict())          # reference-style checkpoint loads
+    with pytest.raises(ValueError):
+        pkg.UNet_Baseline(3, 4, up_mode="bogus")
+    with pytest.raises(ValueError):
+        pkg.UNet_Baseline(3, 4, merge_mode="bogus")
+    with pytest.raises(NotImplementedError):
+        pkg.UNet_Baseline(3, 4, merge_mode="add")
+
+
+def test_same_seed_gives_reference_style_init():
+    torch.manual_seed(10)
+    a = pkg.UNet_Baseline(3, 4).state_dict()
+    torch.manual_seed(10)
+    b = pkg.UNet_Baseline(3, 4).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    w = a["down_convs.1.main.0.weight"]
+    assert abs(float(w.abs().max()) - 1 / (64 * 9) ** 0.5) < 1e-3
+
+
+def test_segpipe_accepts_the_reference_yaml_keys():
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg["save_model_params"] = False
+    pipe = pkg.SegPipeUNet(experiment_name="cpu", **cfg)
+    assert pipe.frequencies == [18, 38, 120, 200] and pipe.window_size == [256, 256]
+    assert pipe.model.in_channels == 4 and pipe.model_name == "cpu"
+    crit = pipe.get_criterion()
+    assert crit.weight.tolist() == [10.0, 300.0, 250.0]
+    lab = torch.tensor([-100, -70, -50, -30, -10, 0, 1, 2])
+    assert pipe.set_label_ignore_val(lab.clone()).tolist() == [-100, -100, 0, -100, -100, 0, 1, 2]
+    with pytest.raises(AssertionError):
+        pkg.SegPipeUNet(checkpoint_dir=None, experiment_name="x", **{**cfg, "save_model_params": True})
+    with pytest.raises(ValueError):
+        pkg.SegPipeUNet(experiment_name="x", **{**cfg, "loss_type": "Focal"}).get_criterion()
+    assert pkg.get_in_channels([]) == 0
+    assert pkg.get_in_channels({"portion_year": True, "portion_day": True, "depth_rel": False,
+                                "depth_abs_surface": True, "depth_abs_seabed": False,
+                                "time_diff": False}) == 4
+
+
+def test_cpu_forward_fails_loudly_not_silently():
+    m = pkg.UNet_Baseline(3, 4)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 32, 32))
+    with pytest.raises(hip.HipLibraryError):
+        hip.ptr(torch.zeros(3))
+
+
+def test_metric_helpers_f1():
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg["save_model_params"] = False
+    pipe = pkg.SegPipeUNet(experiment_name="cpu", **cfg)
+    labels = np.array([1, 1, 0, 0, 2, -100], dtype=np.int8)
+    preds = np.array([0.9, 0.8, 0.1, 0.7, 0.2, 0.99], dtype=np.float16)
+    l, p = pipe.select_valid_predictions(labels.copy(), preds)
+    assert len(l) == 5
+    m = pipe.compute_evaluation_metrics(l, p)
+    assert abs(m["F1"].max() - 1.0) < 1e-6      # threshold 0.8 separates both sandeel pixels
+
+
+def test_bucket_and_shard_plans():
+    assert parallel.bucket_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert parallel.shard_indices(10, 1, 4) == [1, 5, 9]
+    allidx = sorted(i for r in range(8) for i in parallel.shard_indices(95, r, 8))
+    assert allidx == list(range(95))             # 95 patches of one 4096-ping chunk
