@@ -22,6 +22,8 @@
 //
 // Precision: TA = bf16_t -> one MFMA per product; TA = float -> fp32 activations split into bf16
 // hi+lo while staging, weights pre-split, 3 MFMAs per product (see igemm.hip).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -45,9 +47,14 @@ struct ConvParams {
   int tiles_y, tiles_x;
 };
 
-constexpr int TR = 8, TC = 16, HP = TC + 2;       // tile rows/cols, halo pitch
-constexpr int HALO_ROWS = (TR + 2) * HP;           // 180
+constexpr int TC = 16, HP = TC + 2;       // tile columns, halo pitch
 
+// XOR swizzle of the 16-byte units inside a row (RB bytes per row, RPL rows per 256-byte bank line).
+// Weight tile: key from the row index (a 16-lane read group covers 16 consecutive-ish rows).
+// Halo tile: key from the halo COLUMN hx (row = hy*18 + hx): a ds_read_b128 lane group of the A
+// fragment holds pixels {0-3,12-15} of one image row and {4-11} of the next, whose linear halo rows
+// collide mod 16 but whose columns do not -- conflict-free for every tap shift (HP even => the
+// bank-line half of a row is hx & 1 for BK = 64).
 template <int BK> struct Sw {
   static constexpr int RB = BK * 2;
   static constexpr int UPR = BK / 8;
@@ -55,10 +62,18 @@ template <int BK> struct Sw {
   __device__ static __forceinline__ int off(int row, int u) {
     return row * RB + ((u ^ ((row / RPL) % UPR)) << 4);
   }
+  __device__ static __forceinline__ int off_halo(int row, int hx, int u) {
+    return row * RB + ((u ^ ((hx / RPL) % UPR)) << 4);
+  }
 };
 
-template <typename TA, int BN, int BK>
+// TR = tile rows: 8 (128-pixel tile, wave 64 x BN/2, 2 workgroups per CU) or 16 (256-pixel tile,
+// wave 128 x BN/2: 25 % fewer LDS fragment bytes per MFMA, 1 workgroup per CU).
+template <typename TA, int BN, int BK, int TR>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
+  constexpr int HALO_ROWS = (TR + 2) * HP;
+  constexpr int BM = TR * TC;
+  constexpr int MT = BM / 64;                            // 32-row MFMA tiles per wave
   constexpr bool X3 = sizeof(TA) == 4;
   constexpr int NPL = X3 ? 2 : 1;                       // operand planes (hi [, lo])
   constexpr int UPR = BK / 8;
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     const int y = y0 + row / HP - 1, x = x0 + row % HP - 1;
     h_ok[i] = q < HALO_ROWS * UPR && y >= 0 && y < p.H && x >= 0 && x < p.W;
     h_off[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
-    h_lds[i] = q < HALO_ROWS * UPR ? Sw<BK>::off(row, u) : -1;
+    h_lds[i] = q < HALO_ROWS * UPR ? Sw<BK>::off_halo(row, row % HP, u) : -1;
   }
 
   u32x4 rh[NU_H][NPL];      // halo prefetch registers (X3: 8 fp32 = 2 x 16 B)
@@ -172,30 +187,32 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     }
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // this lane's two A rows (pixels) of the tile: m = wr*64 + i*32 + fr -> (py, px)
-  int a_row0[2];
+  int a_row0[MT], a_hx0[MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = wr * 64 + i * 32 + fr;
+  for (int i = 0; i < MT; ++i) {
+    const int m = wr * (BM / 2) + i * 32 + fr;
     a_row0[i] = (m >> 4) * HP + (m & 15);      // halo row of tap (0,0)
+    a_hx0[i] = m & 15;                          // its halo column
   }
 
   auto compute = [&](int abuf, int bbuf, int t) {
-    const int shift = (t / 3) * HP + (t % 3);
+    const int kx = t % 3;
+    const int shift = (t / 3) * HP + kx;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 a_hi[2], a_lo[2], b_hi[NT], b_lo[NT];
+      bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int o = Sw<BK>::off(a_row0[i] + shift, 2 * ks + fh);
+      for (int i = 0; i < MT; ++i) {
+        const int o = Sw<BK>::off_halo(a_row0[i] + shift, a_hx0[i] + kx, 2 * ks + fh);
         a_hi[i] = *reinterpret_cast<const bf16x8*>(sA(abuf, 0) + o);
         if constexpr (X3) a_lo[i] = *reinterpret_cast<const bf16x8*>(sA(abuf, 1) + o);
       }
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
         if constexpr (X3) b_lo[j] = *reinterpret_cast<const bf16x8*>(sB(bbuf, 1) + o);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           if constexpr (X3) {
@@ -259,8 +276,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   if (s < nsteps) step(I0{}, s);
 
   // ---- epilogue -----------------------------------------------------------------------------------
-  unsigned char* stage = smem;                                   // [128][STAGE_PITCH]
-  float* sstat = reinterpret_cast<float*>(smem + 128 * STAGE_PITCH);   // [2][BN]
+  unsigned char* stage = smem;                                   // [BM][STAGE_PITCH]
+  float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);    // [2][BN]
   const bool do_stats = p.stat_sum != nullptr;
   const bool full_tile = (y0 + TR <= p.H) && (x0 + TC <= p.W);
   if (do_stats)
@@ -273,10 +290,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     cs1[j] = 0.f;
     cs2[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int row = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         float v = acc[i][j][r] + bv;
         if (p.relu) v = fmaxf(v, 0.f);
         const TA q = (TA)v;
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     const int c8 = tid % CPR, r0 = tid / CPR;
     TA* outp = reinterpret_cast<TA*>(p.out);
 #pragma unroll
-    for (int rr = 0; rr < 128 / RPP; ++rr) {
+    for (int rr = 0; rr < BM / RPP; ++rr) {
       const int row = r0 + rr * RPP;
       const int y = y0 + (row >> 4), x = x0 + (row & 15);
       if (full_tile || (y < p.H && x < p.W)) {
@@ -335,22 +352,24 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   }
 }
 
-template <typename TA, int BN, int BK>
+template <typename TA, int BN, int BK, int TR>
 int launch(ConvParams p, hipStream_t st) {
   constexpr bool X3 = sizeof(TA) == 4;
+  constexpr int HALO_ROWS = (TR + 2) * HP;
+  constexpr int BM = TR * TC;
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x * (p.N / BN);
   size_t lds = (size_t)2 * (X3 ? 2 : 1) * (HALO_ROWS * BK * 2 + BN * BK * 2);
-  const size_t stage = (size_t)128 * (BN * sizeof(TA) + 16) + 2 * BN * sizeof(float);
+  const size_t stage = (size_t)BM * (BN * sizeof(TA) + 16) + 2 * BN * sizeof(float);
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, BN, BK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, BN, BK, TR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<TA, BN, BK>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_kernel<TA, BN, BK, TR>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -377,12 +396,23 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
   p.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
   hipStream_t st = (hipStream_t)stream;
   const bool n128 = N % 128 == 0;
+  // 256-pixel tiles when the image holds them and the layer is MFMA-bound
+  static const int force_tr = getenv("CRIMAC_CONV_TR") ? atoi(getenv("CRIMAC_CONV_TR")) : 0;
+  // measured (tools/bench_conv.py): the 256-pixel tile (1 workgroup/CU) loses 5-20 % to the
+  // 128-pixel tile (2 workgroups/CU) on every layer -- occupancy beats LDS traffic here
+  const bool big = force_tr == 16;
+  static const int force_bk = getenv("CRIMAC_CONV_BK") ? atoi(getenv("CRIMAC_CONV_BK")) : 0;
   if (prec == CRIMAC_PREC_BF16) {
-    if (Cin % 64 == 0) return n128 ? launch<bf16_t, 128, 64>(p, st) : launch<bf16_t, 64, 64>(p, st);
-    if (Cin % 32 == 0) return n128 ? launch<bf16_t, 128, 32>(p, st) : launch<bf16_t, 64, 32>(p, st);
-    return n128 ? launch<bf16_t, 128, 16>(p, st) : launch<bf16_t, 64, 16>(p, st);
+    // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
+    // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128
+    if (Cin % 64 == 0 && force_bk != 32 && (n128 || force_bk == 64)) {
+      if (big) return n128 ? launch<bf16_t, 128, 64, 16>(p, st) : launch<bf16_t, 64, 64, 16>(p, st);
+      return n128 ? launch<bf16_t, 128, 64, 8>(p, st) : launch<bf16_t, 64, 64, 8>(p, st);
+    }
+    if (Cin % 32 == 0) return n128 ? launch<bf16_t, 128, 32, 8>(p, st) : launch<bf16_t, 64, 32, 8>(p, st);
+    return n128 ? launch<bf16_t, 128, 16, 8>(p, st) : launch<bf16_t, 64, 16, 8>(p, st);
   }
   // split-bf16 keeps two planes per operand: use the 32-deep chunk so two workgroups fit a CU
-  if (Cin % 32 == 0) return n128 ? launch<float, 128, 32>(p, st) : launch<float, 64, 32>(p, st);
-  return n128 ? launch<float, 128, 16>(p, st) : launch<float, 64, 16>(p, st);
+  if (Cin % 32 == 0) return n128 ? launch<float, 128, 32, 8>(p, st) : launch<float, 64, 32, 8>(p, st);
+  return n128 ? launch<float, 128, 16, 8>(p, st) : launch<float, 64, 16, 8>(p, st);
 }

@@ -265,12 +265,21 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   p.tiles_x = cdiv(p.Wf, 16);
   p.ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   const int ch_tiles = cdiv(p.CF, 64) * cdiv(p.CS, 64);
+  const bool autosplit = target_blocks <= 0;
+  if (autosplit) target_blocks = 1024;
   int splits = target_blocks / ch_tiles;
+  if (autosplit) {
+    // every split adds one fp32-atomic pass over dW (chip-wide atomic rate ~1.3 TB/s): keep at
+    // least ~4096 contraction pixels per split so the atomics stay below the MFMA time
+    const long max_splits = ((long)p.B * p.Hf * p.Wf) / 4096;
+    if (splits > max_splits) splits = (int)max_splits;
+  }
   if (splits < 1) splits = 1;
   if (splits > p.ntiles) splits = (int)p.ntiles;
   p.tiles_per_block = cdiv(p.ntiles, splits);
   splits = cdiv(p.ntiles, p.tiles_per_block);
-  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (X3 ? 2 : 1);
+  // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of hi+lo planes
+  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, MODE>),
@@ -295,7 +304,6 @@ extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF
   WgradParams p;
   p.f = f; p.f_ld = f_ld; p.CF = CF; p.s = s; p.s_ld = s_ld; p.CS = CS;
   p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw;
-  if (target_blocks <= 0) target_blocks = 1024;
   hipStream_t st = (hipStream_t)stream;
   if (prec == CRIMAC_PREC_BF16)
     return mode == 0 ? launch<bf16_t, 0>(p, target_blocks, st) : launch<bf16_t, 1>(p, target_blocks, st);

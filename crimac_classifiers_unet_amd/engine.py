@@ -435,7 +435,7 @@ class UNetEngine:
             self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                           dgrad=True)
 
-    wgrad_target_blocks = 1024
+    wgrad_target_blocks = 0      # 0 = let the library pick the pixel-range split
 
     def backward(self, dlogits):
         """Gradients of every parameter into the flat gradient buffer (overwrites it)."""

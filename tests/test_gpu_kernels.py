@@ -164,7 +164,7 @@ def test_upconv2x2_forward_dgrad_wgrad(prec, shape):
     assert relerr(from_nhwc(dx, B, H, W), xg.grad) < TOL[prec]
     # weight gradient
     dwp = torch.zeros(4 * Ci * Co, dtype=torch.float32, device="cuda")
-    call("crimac_wgrad", P, 1, ptr(xn), Ci, Ci, ptr(dyn), Co, Co, B, H, W, ptr(dwp), 64)
+    call("crimac_wgrad", P, 1, ptr(xn), Ci, Ci, ptr(dyn), Co, Co, B, H, W, ptr(dwp), 2)   # multi-tile loops
     grad = torch.empty(Ci, Co, 2, 2, dtype=torch.float32, device="cuda")
     call("crimac_unpack_wgrad_upconv2x2", ptr(dwp), Ci, Co, ptr(grad))
     torch.cuda.synchronize()
@@ -172,9 +172,10 @@ def test_upconv2x2_forward_dgrad_wgrad(prec, shape):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("target_blocks", [1, 3, 64])     # 1: one workgroup loops over ALL pixel tiles
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 8, 32, 128, 64), (2, 16, 16, 4, 64),
-                                   (1, 12, 20, 64, 128)])
-def test_conv3x3_wgrad(prec, shape):
+                                   (1, 12, 20, 64, 128), (3, 24, 48, 64, 64)])
+def test_conv3x3_wgrad(prec, shape, target_blocks):
     B, H, W, Ci, Co = shape
     g = torch.Generator().manual_seed(5)
     x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
@@ -184,7 +185,7 @@ def test_conv3x3_wgrad(prec, shape):
     dwp = torch.zeros(9 * Co * cin_pad, dtype=torch.float32, device="cuda")
     dyn, xn = to_nhwc(dy, prec), to_nhwc(x, prec, ld=cin_pad)
     call("crimac_wgrad", hip.PREC_NAMES[prec], 0, ptr(dyn), Co, Co,
-         ptr(xn), cin_pad, cin_pad, B, H, W, ptr(dwp), 8)
+         ptr(xn), cin_pad, cin_pad, B, H, W, ptr(dwp), target_blocks)
     grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
     call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, cin_pad, ptr(grad))
     torch.cuda.synchronize()
