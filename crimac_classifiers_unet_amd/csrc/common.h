@@ -55,6 +55,38 @@ __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned
   lo = f2bfbits(x - bfbits2f(hi));
 }
 
+// Split 8 fp32 values (two 16-byte registers) into NPL bf16 planes of 8 values each:
+// x = p0 + p1 (+ p2) up to 2^-17 (2^-25) relative.  Each subtraction is exact in fp32.
+template <int NPL>
+__device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4 (&pl)[NPL]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float f[2] = {__uint_as_float(j < 2 ? r0[2 * j] : r1[2 * j - 4]),
+                  __uint_as_float(j < 2 ? r0[2 * j + 1] : r1[2 * j - 3])};
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const unsigned short b0 = f2bfbits(f[0]), b1 = f2bfbits(f[1]);
+      pl[k][j] = (unsigned)b0 | ((unsigned)b1 << 16);
+      f[0] -= bfbits2f(b0);
+      f[1] -= bfbits2f(b1);
+    }
+  }
+}
+
+// D += A * B with A, B given as NPL bf16 planes: all plane products of total order < NPL, smallest
+// terms first (NPL 1: 1 MFMA, 2: 3 MFMAs, 3: 6 MFMAs).
+template <int NPL>
+__device__ __forceinline__ void mfma_planes(const bf16x8 (&a)[NPL], const bf16x8 (&b)[NPL], f32x16& acc) {
+#pragma unroll
+  for (int s = NPL - 1; s >= 0; --s)
+#pragma unroll
+    for (int i = 0; i <= s; ++i)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[s - i], acc, 0, 0, 0);
+}
+
+// Number of operand planes of a precision mode.
+__host__ __device__ constexpr int planes_of(int prec) { return prec == 0 ? 1 : (prec == 1 ? 2 : 3); }
+
 // Activation element traits: T = bf16_t (16-bit storage) or float (fp32 storage).
 template <typename T> struct ActT;
 template <> struct ActT<bf16_t> {

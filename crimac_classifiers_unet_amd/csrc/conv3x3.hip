@@ -69,13 +69,13 @@ template <int BK> struct Sw {
 
 // TR = tile rows: 8 (128-pixel tile, wave 64 x BN/2, 2 workgroups per CU) or 16 (256-pixel tile,
 // wave 128 x BN/2: 25 % fewer LDS fragment bytes per MFMA, 1 workgroup per CU).
-template <typename TA, int BN, int BK, int TR>
+template <typename TA, int NPL, int BN, int BK, int TR>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   constexpr int HALO_ROWS = (TR + 2) * HP;
   constexpr int BM = TR * TC;
   constexpr int MT = BM / 64;                            // 32-row MFMA tiles per wave
-  constexpr bool X3 = sizeof(TA) == 4;
-  constexpr int NPL = X3 ? 2 : 1;                       // operand planes (hi [, lo])
+  constexpr bool X3 = sizeof(TA) == 4;                  // fp32 activations, split into NPL bf16 planes
+  static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
   constexpr int UPR = BK / 8;
   constexpr int NU_H = (HALO_ROWS * UPR + 255) / 256;   // halo units per thread
   constexpr int NU_B = (BN * UPR + 255) / 256;
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   const int y0 = tyi * TR, x0 = txi * TC, n0 = tile_n * BN;
 
   const TA* inp = reinterpret_cast<const TA*>(p.in);
+  const long w_plane = 9L * p.N * p.Cin;      // elements per weight plane
 
   // ---- halo staging coordinates (independent of the channel chunk) -----------------------------
   long h_off[NU_H];
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     h_lds[i] = q < HALO_ROWS * UPR ? Sw<BK>::off_halo(row, row % HP, u) : -1;
   }
 
-  u32x4 rh[NU_H][NPL];      // halo prefetch registers (X3: 8 fp32 = 2 x 16 B)
-  u32x4 rb[2][NU_B][NPL];   // weight prefetch registers, two steps deep
+  u32x4 rh[NU_H][X3 ? 2 : 1];   // halo prefetch registers (fp32: 8 values = 2 x 16 B)
+  u32x4 rb[2][NU_B][NPL];       // weight prefetch registers (NPL planes), two steps deep
 
   auto load_halo = [&](int kc) {
 #pragma unroll
@@ -147,19 +148,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     for (int i = 0; i < NU_H; ++i) {
       if (h_lds[i] < 0) continue;
       if constexpr (X3) {
-        u32x4 hi, lo;
+        u32x4 pl[NPL];
+        split8<NPL>(rh[i][0], rh[i][1], pl);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float f0 = __uint_as_float(j < 2 ? rh[i][0][2 * j] : rh[i][1][2 * j - 4]);
-          const float f1 = __uint_as_float(j < 2 ? rh[i][0][2 * j + 1] : rh[i][1][2 * j - 3]);
-          unsigned short h0, l0, h1, l1;
-          split_bf16(f0, h0, l0);
-          split_bf16(f1, h1, l1);
-          hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-          lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        *reinterpret_cast<u32x4*>(sA(buf, 0) + h_lds[i]) = hi;
-        *reinterpret_cast<u32x4*>(sA(buf, 1) + h_lds[i]) = lo;
+        for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(sA(buf, k) + h_lds[i]) = pl[k];
       } else {
         *reinterpret_cast<u32x4*>(sA(buf, 0) + h_lds[i]) = rh[i][0];
       }
@@ -173,7 +165,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
       const int row = q / UPR, u = q % UPR;
       const long off = ((long)t * p.N + n0 + row) * p.Cin + kc * BK + u * 8;
       rb[set][i][0] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
-      if constexpr (X3) rb[set][i][1] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+#pragma unroll
+      for (int k = 1; k < NPL; ++k)
+        rb[set][i][k] = *reinterpret_cast<const u32x4*>(p.w_lo + (long)(k - 1) * w_plane + off);
     }
   };
   auto store_b = [&](auto set, int buf) {
@@ -182,8 +176,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
       const int q = tid + 256 * i;
       if (B_GUARD && q >= BN * UPR) continue;
       const int o = Sw<BK>::off(q / UPR, q % UPR);
-      *reinterpret_cast<u32x4*>(sB(buf, 0) + o) = rb[set][i][0];
-      if constexpr (X3) *reinterpret_cast<u32x4*>(sB(buf, 1) + o) = rb[set][i][1];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(sB(buf, k) + o) = rb[set][i][k];
     }
   };
 
@@ -209,29 +203,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     const int shift = (t / 3) * HP + kx;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
+      bf16x8 af[MT][NPL], bfr[NT][NPL];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int o = Sw<BK>::off_halo(a_row0[i] + shift, a_hx0[i] + kx, 2 * ks + fh);
-        a_hi[i] = *reinterpret_cast<const bf16x8*>(sA(abuf, 0) + o);
-        if constexpr (X3) a_lo[i] = *reinterpret_cast<const bf16x8*>(sA(abuf, 1) + o);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) af[i][k] = *reinterpret_cast<const bf16x8*>(sA(abuf, k) + o);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int o = Sw<BK>::off(wc * (BN / 2) + j * 32 + fr, 2 * ks + fh);
-        b_hi[j] = *reinterpret_cast<const bf16x8*>(sB(bbuf, 0) + o);
-        if constexpr (X3) b_lo[j] = *reinterpret_cast<const bf16x8*>(sB(bbuf, 1) + o);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) bfr[j][k] = *reinterpret_cast<const bf16x8*>(sB(bbuf, k) + o);
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if constexpr (X3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; ++j) mfma_planes<NPL>(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -352,24 +340,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   }
 }
 
-template <typename TA, int BN, int BK, int TR>
+template <typename TA, int NPL, int BN, int BK, int TR>
 int launch(ConvParams p, hipStream_t st) {
-  constexpr bool X3 = sizeof(TA) == 4;
   constexpr int HALO_ROWS = (TR + 2) * HP;
   constexpr int BM = TR * TC;
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x * (p.N / BN);
-  size_t lds = (size_t)2 * (X3 ? 2 : 1) * (HALO_ROWS * BK * 2 + BN * BK * 2);
+  size_t lds = (size_t)2 * NPL * (HALO_ROWS * BK * 2 + BN * BK * 2);
   const size_t stage = (size_t)BM * (BN * sizeof(TA) + 16) + 2 * BN * sizeof(float);
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, BN, BK, TR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, NPL, BN, BK, TR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_kernel<TA, BN, BK, TR>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_kernel<TA, NPL, BN, BK, TR>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -380,13 +367,13 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
                               const void* w_hi, const void* w_lo, const float* bias, void* out,
                               long out_ld, int relu, double* stat_sum, double* stat_sumsq,
                               int stat_replicas, void* stream) {
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, "conv3x3: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
   CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0,
                  "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
   CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && in && w_hi && out, "conv3x3: bad arguments");
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "conv3x3: f32x3 needs the low weight plane");
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "conv3x3: split precisions need the low weight plane(s)");
   CRIMAC_REQUIRE((stat_sum == nullptr) == (stat_sumsq == nullptr), "conv3x3: stat pointers come together");
   CRIMAC_REQUIRE(!stat_sum || stat_replicas >= 1, "conv3x3: stat_replicas must be >= 1");
   ConvParams p;
@@ -406,13 +393,17 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
     // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
     // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128
     if (Cin % 64 == 0 && force_bk != 32 && (n128 || force_bk == 64)) {
-      if (big) return n128 ? launch<bf16_t, 128, 64, 16>(p, st) : launch<bf16_t, 64, 64, 16>(p, st);
-      return n128 ? launch<bf16_t, 128, 64, 8>(p, st) : launch<bf16_t, 64, 64, 8>(p, st);
+      if (big) return n128 ? launch<bf16_t, 1, 128, 64, 16>(p, st) : launch<bf16_t, 1, 64, 64, 16>(p, st);
+      return n128 ? launch<bf16_t, 1, 128, 64, 8>(p, st) : launch<bf16_t, 1, 64, 64, 8>(p, st);
     }
-    if (Cin % 32 == 0) return n128 ? launch<bf16_t, 128, 32, 8>(p, st) : launch<bf16_t, 64, 32, 8>(p, st);
-    return n128 ? launch<bf16_t, 128, 16, 8>(p, st) : launch<bf16_t, 64, 16, 8>(p, st);
+    if (Cin % 32 == 0) return n128 ? launch<bf16_t, 1, 128, 32, 8>(p, st) : launch<bf16_t, 1, 64, 32, 8>(p, st);
+    return n128 ? launch<bf16_t, 1, 128, 16, 8>(p, st) : launch<bf16_t, 1, 64, 16, 8>(p, st);
   }
-  // split-bf16 keeps two planes per operand: use the 32-deep chunk so two workgroups fit a CU
-  if (Cin % 32 == 0) return n128 ? launch<float, 128, 32, 8>(p, st) : launch<float, 64, 32, 8>(p, st);
-  return n128 ? launch<float, 128, 16, 8>(p, st) : launch<float, 64, 16, 8>(p, st);
+  // split-bf16 keeps 2-3 planes per operand: 32-deep chunks keep the LDS footprint in bounds
+  if (prec == CRIMAC_PREC_F32X3) {
+    if (Cin % 32 == 0) return n128 ? launch<float, 2, 128, 32, 8>(p, st) : launch<float, 2, 64, 32, 8>(p, st);
+    return n128 ? launch<float, 2, 128, 16, 8>(p, st) : launch<float, 2, 64, 16, 8>(p, st);
+  }
+  if (Cin % 32 == 0) return n128 ? launch<float, 3, 128, 32, 8>(p, st) : launch<float, 3, 64, 32, 8>(p, st);
+  return n128 ? launch<float, 3, 128, 16, 8>(p, st) : launch<float, 3, 64, 16, 8>(p, st);
 }

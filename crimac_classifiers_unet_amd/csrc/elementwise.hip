@@ -48,8 +48,20 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 }
 
 // ---- weight packing -----------------------------------------------------------------------------
+// value -> plane 0 in `hi`, planes 1..npl-1 in `lo` (plane stride `n`)
+__device__ __forceinline__ void put_planes(float v, int npl, unsigned short* hi, unsigned short* lo,
+                                           long i, long n) {
+  unsigned short b = f2bfbits(v);
+  hi[i] = b;
+  for (int k = 1; k < npl; ++k) {
+    v -= bfbits2f(b);
+    b = f2bfbits(v);
+    lo[(long)(k - 1) * n + i] = b;
+  }
+}
+
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int Ci_pad,
-                                    const float* __restrict__ scale, unsigned short* fwd_hi,
+                                    const float* __restrict__ scale, int npl, unsigned short* fwd_hi,
                                     unsigned short* fwd_lo, unsigned short* dg_hi,
                                     unsigned short* dg_lo) {
   const long n_fwd = 9L * Co * Ci_pad;
@@ -63,10 +75,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       v = w[((long)co * Ci + ci) * 9 + t];
       if (scale) v *= scale[co];
     }
-    unsigned short hi, lo;
-    split_bf16(v, hi, lo);
-    fwd_hi[i] = hi;
-    if (fwd_lo) fwd_lo[i] = lo;
+    put_planes(v, npl, fwd_hi, fwd_lo, i, n_fwd);
   }
   if (dg_hi) {
     const long n_dg = 9L * Ci * Co;
@@ -75,18 +84,14 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       const int co = (int)(i % Co);
       const long r = i / Co;
       const int ci = (int)(r % Ci), t = (int)(r / Ci);
-      const float v = w[((long)co * Ci + ci) * 9 + (8 - t)];
-      unsigned short hi, lo;
-      split_bf16(v, hi, lo);
-      dg_hi[i] = hi;
-      if (dg_lo) dg_lo[i] = lo;
+      put_planes(w[((long)co * Ci + ci) * 9 + (8 - t)], npl, dg_hi, dg_lo, i, n_dg);
     }
   }
 }
 
-__global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, unsigned short* fwd_hi,
-                                   unsigned short* fwd_lo, unsigned short* dg_hi,
-                                   unsigned short* dg_lo) {
+__global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, int npl,
+                                   unsigned short* fwd_hi, unsigned short* fwd_lo,
+                                   unsigned short* dg_hi, unsigned short* dg_lo) {
   // w[ci][co][a][b]; fwd[(ab*Co + co)][ci]; dgrad[ab][ci][co]
   const long n = 4L * Ci * Co;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
@@ -95,19 +100,13 @@ __global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, 
       const int ci = (int)(i % Ci);
       const long r = i / Ci;
       const int co = (int)(r % Co), ab = (int)(r / Co);
-      unsigned short hi, lo;
-      split_bf16(w[((long)ci * Co + co) * 4 + ab], hi, lo);
-      fwd_hi[i] = hi;
-      if (fwd_lo) fwd_lo[i] = lo;
+      put_planes(w[((long)ci * Co + co) * 4 + ab], npl, fwd_hi, fwd_lo, i, n);
     }
     if (dg_hi) {
       const int co = (int)(i % Co);
       const long r = i / Co;
       const int ci = (int)(r % Ci), ab = (int)(r / Ci);
-      unsigned short hi, lo;
-      split_bf16(w[((long)ci * Co + co) * 4 + ab], hi, lo);
-      dg_hi[i] = hi;
-      if (dg_lo) dg_lo[i] = lo;
+      put_planes(w[((long)ci * Co + co) * 4 + ab], npl, dg_hi, dg_lo, i, n);
     }
   }
 }
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 // =================================================================================================
 #define ST ((hipStream_t)stream)
 #define PREC_OK(name) \
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, name ": bad precision %d", prec)
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, name ": bad precision %d", prec)
 
 extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, int C, int H, int W,
                                    long ld, void* stream) {
@@ -662,23 +661,27 @@ extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, 
 }
 
 extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, const float* scale,
-                                   void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo,
+                                   int planes, void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo,
                                    void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0 && Ci_pad >= Ci, "pack_conv3x3: bad arguments");
+  CRIMAC_REQUIRE(planes >= 1 && planes <= 3 && (planes == 1 || fwd_lo) && (planes == 1 || !dg_hi || dg_lo),
+                 "pack_conv3x3: planes=%d needs the lo plane buffers", planes);
   CRIMAC_REQUIRE(!dg_hi || Ci_pad == Ci, "pack_conv3x3: dgrad planes need Ci_pad == Ci");
   const int grid = grid_for(9L * Co * Ci_pad, 256);
-  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, ST, w, Co, Ci, Ci_pad, scale,
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, ST, w, Co, Ci, Ci_pad, scale, planes,
                      (unsigned short*)fwd_hi, (unsigned short*)fwd_lo, (unsigned short*)dg_hi,
                      (unsigned short*)dg_lo);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
 
-extern "C" int crimac_pack_upconv2x2(const float* w, int Ci, int Co, void* fwd_hi, void* fwd_lo,
-                                     void* dg_hi, void* dg_lo, void* stream) {
+extern "C" int crimac_pack_upconv2x2(const float* w, int Ci, int Co, int planes, void* fwd_hi,
+                                     void* fwd_lo, void* dg_hi, void* dg_lo, void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0, "pack_upconv2x2: bad arguments");
+  CRIMAC_REQUIRE(planes >= 1 && planes <= 3 && (planes == 1 || fwd_lo) && (planes == 1 || !dg_hi || dg_lo),
+                 "pack_upconv2x2: planes=%d needs the lo plane buffers", planes);
   const int grid = grid_for(4L * Co * Ci, 256);
-  hipLaunchKernelGGL(pack_upconv_kernel, dim3(grid), dim3(256), 0, ST, w, Ci, Co,
+  hipLaunchKernelGGL(pack_upconv_kernel, dim3(grid), dim3(256), 0, ST, w, Ci, Co, planes,
                      (unsigned short*)fwd_hi, (unsigned short*)fwd_lo, (unsigned short*)dg_hi,
                      (unsigned short*)dg_lo);
   CRIMAC_LAUNCH_CHECK();

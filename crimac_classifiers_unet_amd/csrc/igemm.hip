@@ -54,9 +54,10 @@ template <int BK> struct Swz {
   }
 };
 
-template <typename TA, int BN, int BK, int OUT_MODE>
+template <typename TA, int NPL, int BN, int BK, int OUT_MODE>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
-  constexpr bool X3 = sizeof(TA) == 4;
+  constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
+  static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
   constexpr int UPR = BK / 8;
   constexpr int NU_A = (BM * UPR + 255) / 256;
   constexpr int NU_B = (BN * UPR + 255) / 256;
@@ -68,10 +69,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   static_assert((BM * UPR) % 256 == 0, "A tile must be a whole number of 256-thread passes");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA_hi = smem;
-  unsigned char* sB_hi = smem + A_BYTES;
-  unsigned char* sA_lo = smem + A_BYTES + B_BYTES;            // X3 only
-  unsigned char* sB_lo = smem + 2 * A_BYTES + B_BYTES;        // X3 only
+  auto sA = [&](int pl) { return smem + pl * A_BYTES; };
+  auto sB = [&](int pl) { return smem + NPL * A_BYTES + pl * B_BYTES; };
+  const long w_plane = (long)p.ntaps * p.N * p.Cin;      // elements per weight plane
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 
   u32x4 ra[NU_A][X3 ? 2 : 1];
-  u32x4 rb[NU_B][X3 ? 2 : 1];
+  u32x4 rb[NU_B][NPL];
   const int kchunks = p.Cin / BK;
   const int nsteps = kchunks * p.ntaps;
 
@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int row = q / UPR, u = q % UPR;
       const long off = ((long)t * p.N + n0 + row) * p.Cin + kc * BK + u * 8;
       rb[i][0] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
-      if constexpr (X3) rb[i][1] = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+#pragma unroll
+      for (int k = 1; k < NPL; ++k)
+        rb[i][k] = *reinterpret_cast<const u32x4*>(p.w_lo + (long)(k - 1) * w_plane + off);
     }
   };
 
@@ -149,22 +151,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     for (int i = 0; i < NU_A; ++i) {
       const int o = Swz<BK>::off(a_row[i], a_u[i]);
       if constexpr (X3) {
-        // 8 fp32 -> 8 bf16 hi + 8 bf16 lo
-        u32x4 hi, lo;
+        u32x4 pl[NPL];
+        split8<NPL>(ra[i][0], ra[i][1], pl);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float f0 = __uint_as_float(j < 2 ? ra[i][0][2 * j] : ra[i][1][2 * j - 4]);
-          const float f1 = __uint_as_float(j < 2 ? ra[i][0][2 * j + 1] : ra[i][1][2 * j - 3]);
-          unsigned short h0, l0, h1, l1;
-          split_bf16(f0, h0, l0);
-          split_bf16(f1, h1, l1);
-          hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-          lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        *reinterpret_cast<u32x4*>(sA_hi + o) = hi;
-        *reinterpret_cast<u32x4*>(sA_lo + o) = lo;
+        for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(sA(k) + o) = pl[k];
       } else {
-        *reinterpret_cast<u32x4*>(sA_hi + o) = ra[i][0];
+        *reinterpret_cast<u32x4*>(sA(0) + o) = ra[i][0];
       }
     }
 #pragma unroll
@@ -172,8 +164,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int q = tid + 256 * i;
       if (B_GUARD && q >= BN * UPR) continue;
       const int o = Swz<BK>::off(q / UPR, q % UPR);
-      *reinterpret_cast<u32x4*>(sB_hi + o) = rb[i][0];
-      if constexpr (X3) *reinterpret_cast<u32x4*>(sB_lo + o) = rb[i][1];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(sB(k) + o) = rb[i][k];
     }
   };
 
@@ -194,29 +186,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if (s + 1 < nsteps) load_step(s + 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 a_hi[2], a_lo[2], b_hi[NT], b_lo[NT];
+      bf16x8 af[2][NPL], bfr[NT][NPL];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int o = Swz<BK>::off(wr * 64 + i * 32 + fr, 2 * ks + fh);
-        a_hi[i] = *reinterpret_cast<const bf16x8*>(sA_hi + o);
-        if constexpr (X3) a_lo[i] = *reinterpret_cast<const bf16x8*>(sA_lo + o);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) af[i][k] = *reinterpret_cast<const bf16x8*>(sA(k) + o);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int o = Swz<BK>::off(wc * (BN / 2) + j * 32 + fr, 2 * ks + fh);
-        b_hi[j] = *reinterpret_cast<const bf16x8*>(sB_hi + o);
-        if constexpr (X3) b_lo[j] = *reinterpret_cast<const bf16x8*>(sB_lo + o);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) bfr[j][k] = *reinterpret_cast<const bf16x8*>(sB(k) + o);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if constexpr (X3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; ++j) mfma_planes<NPL>(af[i], bfr[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -278,33 +264,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 }
 
-template <typename TA, int BN, int BK, int OUT_MODE>
+template <typename TA, int NPL, int BN, int BK, int OUT_MODE>
 int launch(const IgemmParams& p, hipStream_t st) {
-  constexpr bool X3 = sizeof(TA) == 4;
   const int tilesM = cdiv(p.M, BM), tilesN = p.N / BN;
-  size_t lds = (size_t)(BM + BN) * BK * 2 * (X3 ? 2 : 1);
+  size_t lds = (size_t)(BM + BN) * BK * 2 * NPL;
   const size_t stage = (size_t)BM * (BN * sizeof(TA) + 16);
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<TA, BN, BK, OUT_MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<TA, NPL, BN, BK, OUT_MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<TA, BN, BK, OUT_MODE>), dim3(tilesM * tilesN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_kernel<TA, NPL, BN, BK, OUT_MODE>), dim3(tilesM * tilesN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
 
-template <typename TA, int OUT_MODE>
+template <typename TA, int NPL, int OUT_MODE>
 int dispatch(const IgemmParams& p, hipStream_t st) {
   const bool n128 = (p.N % 128) == 0;
-  if (p.Cin % 64 == 0) {
-    return n128 ? launch<TA, 128, 64, OUT_MODE>(p, st) : launch<TA, 64, 64, OUT_MODE>(p, st);
+  if (p.Cin % 64 == 0 && NPL < 3) {
+    return n128 ? launch<TA, NPL, 128, 64, OUT_MODE>(p, st) : launch<TA, NPL, 64, 64, OUT_MODE>(p, st);
   } else if (p.Cin % 32 == 0) {
-    return n128 ? launch<TA, 128, 32, OUT_MODE>(p, st) : launch<TA, 64, 32, OUT_MODE>(p, st);
+    return n128 ? launch<TA, NPL, 128, 32, OUT_MODE>(p, st) : launch<TA, NPL, 64, 32, OUT_MODE>(p, st);
   } else {
-    return n128 ? launch<TA, 128, 16, OUT_MODE>(p, st) : launch<TA, 64, 16, OUT_MODE>(p, st);
+    return n128 ? launch<TA, NPL, 128, 16, OUT_MODE>(p, st) : launch<TA, NPL, 64, 16, OUT_MODE>(p, st);
   }
 }
 
@@ -315,14 +300,14 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
                                  const void* w_hi, const void* w_lo, const float* bias, int bias_mod,
                                  void* out, long out_ld, int relu, int out_mode, int cout_up,
                                  void* stream) {
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, "igemm: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "igemm: bad precision %d", prec);
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "igemm: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "igemm: N=%d must be a positive multiple of 64", N);
   CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0, "igemm: in_ld=%ld must be >= Cin and a multiple of 8", in_ld);
   CRIMAC_REQUIRE(ntaps >= 1 && tw >= 1 && ntaps % tw == 0 && stride >= 1, "igemm: bad tap geometry");
   CRIMAC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "igemm: bad grid");
   CRIMAC_REQUIRE(in && w_hi && out, "igemm: null pointer");
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "igemm: f32x3 needs the low weight plane");
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "igemm: split precisions need the low weight plane(s)");
   CRIMAC_REQUIRE(out_mode == 0 || (out_mode == 1 && cout_up > 0 && N == 4 * cout_up),
                  "igemm: bad output mode / cout_up");
   CRIMAC_REQUIRE(out_mode == 1 ? out_ld >= cout_up : out_ld >= N, "igemm: out_ld too small");
@@ -337,6 +322,8 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   p.M = (long)B * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
   if (prec == CRIMAC_PREC_BF16)
-    return out_mode == 0 ? dispatch<bf16_t, 0>(p, st) : dispatch<bf16_t, 1>(p, st);
-  return out_mode == 0 ? dispatch<float, 0>(p, st) : dispatch<float, 1>(p, st);
+    return out_mode == 0 ? dispatch<bf16_t, 1, 0>(p, st) : dispatch<bf16_t, 1, 1>(p, st);
+  if (prec == CRIMAC_PREC_F32X3)
+    return out_mode == 0 ? dispatch<float, 2, 0>(p, st) : dispatch<float, 2, 1>(p, st);
+  return out_mode == 0 ? dispatch<float, 3, 0>(p, st) : dispatch<float, 3, 1>(p, st);
 }

@@ -46,9 +46,10 @@ __device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
 // tr-read swizzle is applied on the per-lane SOURCE address.  Pixels outside the image are zeroed
 // with plain LDS stores by the lane that would have loaded them.
 // fp32 (split-bf16) path: register staging with the hi/lo split, single buffer.
-template <typename TA, int MODE>
+template <typename TA, int NPL, int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
-  constexpr bool X3 = sizeof(TA) == 4;
+  constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
+  static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
   constexpr int TR = MODE == 0 ? 8 : 4;
   constexpr int NTAPS = MODE == 0 ? 9 : 4;
   constexpr int F_ROWS = TR * 16;
@@ -83,20 +84,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int f_chb = (wf * 32 + 16 * cgrp + 4 * pp) * 2;   // byte offset of this lane's 4 channels
   const int s_chb = (ws * 32 + 16 * cgrp + 4 * pp) * 2;
 
-  // contraction over one staged tile: one k16 step per tile row
-  auto contract = [&](const unsigned char* sF_hi, const unsigned char* sF_lo,
-                      const unsigned char* sS_hi, const unsigned char* sS_lo) {
+  // contraction over one staged tile: one k16 step per tile row.  Plane k of F at sF + k*F_BYTES,
+  // plane k of S at sS + k*S_BYTES.
+  auto contract = [&](const unsigned char* sF, const unsigned char* sS) {
 #pragma unroll 1
     for (int py = 0; py < TR; ++py) {
-      bf16x8 a_hi, a_lo;
+      bf16x8 af[NPL];
       {
         const int r0 = py * 16 + 8 * kh + q, r1 = r0 + 4;
         const int o0 = r0 * 128 + (f_chb ^ swz_tr(r0)), o1 = r1 * 128 + (f_chb ^ swz_tr(r1));
-        bf16x4 x0v = lds_tr16(sF_hi + o0), x1v = lds_tr16(sF_hi + o1);
-        a_hi = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
-        if constexpr (X3) {
-          bf16x4 y0v = lds_tr16(sF_lo + o0), y1v = lds_tr16(sF_lo + o1);
-          a_lo = __builtin_shufflevector(y0v, y1v, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          bf16x4 x0v = lds_tr16(sF + k * F_BYTES + o0), x1v = lds_tr16(sF + k * F_BYTES + o1);
+          af[k] = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
 #pragma unroll
@@ -109,15 +109,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         }
         const int r1 = r0 + 4;
         const int o0 = r0 * 128 + (s_chb ^ swz_tr(r0)), o1 = r1 * 128 + (s_chb ^ swz_tr(r1));
-        bf16x4 x0v = lds_tr16(sS_hi + o0), x1v = lds_tr16(sS_hi + o1);
-        bf16x8 b_hi = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
-        if constexpr (X3) {
-          bf16x4 y0v = lds_tr16(sS_lo + o0), y1v = lds_tr16(sS_lo + o1);
-          bf16x8 b_lo = __builtin_shufflevector(y0v, y1v, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
+        bf16x8 bfr[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          bf16x4 x0v = lds_tr16(sS + k * S_BYTES + o0), x1v = lds_tr16(sS + k * S_BYTES + o1);
+          bfr[k] = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+        mfma_planes<NPL>(af, bfr, acc[t]);
       }
     }
   };
@@ -189,33 +187,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
       if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
       const unsigned char* base = smem + cur * BUF_BYTES;
-      contract(base, nullptr, base + F_BYTES, nullptr);
+      contract(base, base + F_BYTES);
     }
   } else {
-    // ---- fp32 activations: register staging with hi/lo split ---------------------------------------
-    unsigned char* sF_hi = smem;
-    unsigned char* sS_hi = smem + F_BYTES;
-    unsigned char* sF_lo = smem + F_BYTES + S_BYTES;
-    unsigned char* sS_lo = smem + 2 * F_BYTES + S_BYTES;
-    auto stage_unit = [&](const TA* src, bool ok, unsigned char* hi_img, unsigned char* lo_img, int o) {
+    // ---- fp32 activations: register staging with the plane split ------------------------------------
+    unsigned char* sF = smem;                       // NPL planes of F
+    unsigned char* sS = smem + NPL * F_BYTES;       // NPL planes of S
+    auto stage_unit = [&](const TA* src, bool ok, unsigned char* img, int plane_bytes, int o) {
       u32x4 v0 = u32x4{0, 0, 0, 0}, v1 = u32x4{0, 0, 0, 0};
       if (ok) {
         v0 = *reinterpret_cast<const u32x4*>(src);
         v1 = *reinterpret_cast<const u32x4*>(src + 4);
       }
-      u32x4 hi, lo;
+      u32x4 pl[NPL];
+      split8<NPL>(v0, v1, pl);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float f0 = __uint_as_float(j < 2 ? v0[2 * j] : v1[2 * j - 4]);
-        const float f1 = __uint_as_float(j < 2 ? v0[2 * j + 1] : v1[2 * j - 3]);
-        unsigned short h0, l0, h1, l1;
-        split_bf16(f0, h0, l0);
-        split_bf16(f1, h1, l1);
-        hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-      }
-      *reinterpret_cast<u32x4*>(hi_img + o) = hi;
-      *reinterpret_cast<u32x4*>(lo_img + o) = lo;
+      for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(img + k * plane_bytes + o) = pl[k];
     };
     for (long tile = t_begin; tile < t_end; ++tile) {
       long b; int y0, x0;
@@ -226,7 +213,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         const int y = y0 + (row >> 4), x = x0 + (row & 15);
         const bool ok = y < p.Hf && x < p.Wf && (cf0 + u * 8) < p.CF;
         const TA* src = fp + ((b * p.Hf + y) * (long)p.Wf + x) * p.f_ld + cf0 + u * 8;
-        stage_unit(src, ok, sF_hi, sF_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
+        stage_unit(src, ok, sF, F_BYTES, row * 128 + ((u * 16) ^ swz_tr(row)));
       }
       for (int uidx = tid; uidx < S_ROWS * 8; uidx += 256) {
         const int row = uidx >> 3, u = uidx & 7;
@@ -234,10 +221,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         s_pixel(row, y0, x0, y, x);
         const bool ok = y >= 0 && y < Hs && x >= 0 && x < Ws && (cs0 + u * 8) < p.CS;
         const TA* src = sp + ((b * Hs + y) * (long)Ws + x) * p.s_ld + cs0 + u * 8;
-        stage_unit(src, ok, sS_hi, sS_lo, row * 128 + ((u * 16) ^ swz_tr(row)));
+        stage_unit(src, ok, sS, S_BYTES, row * 128 + ((u * 16) ^ swz_tr(row)));
       }
       __syncthreads();
-      contract(sF_hi, sF_lo, sS_hi, sS_lo);
+      contract(sF, sS);
     }
   }
 
@@ -255,9 +242,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   }
 }
 
-template <typename TA, int MODE>
+template <typename TA, int NPL, int MODE>
 int launch(WgradParams p, int target_blocks, hipStream_t st) {
-  constexpr bool X3 = sizeof(TA) == 4;
   constexpr int TR = MODE == 0 ? 8 : 4;
   constexpr int F_ROWS = TR * 16;
   constexpr int S_ROWS = ((MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32) + 7) / 8 * 8;   // padded to 8 rows
@@ -278,15 +264,15 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   if (splits > p.ntiles) splits = (int)p.ntiles;
   p.tiles_per_block = cdiv(p.ntiles, splits);
   splits = cdiv(p.ntiles, p.tiles_per_block);
-  // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of hi+lo planes
-  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * 2;
+  // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of NPL planes
+  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 : NPL);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, NPL, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<TA, MODE>), dim3(ch_tiles, splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE>), dim3(ch_tiles, splits), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -296,7 +282,7 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
 extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
                             long s_ld, int CS, int B, int Hf, int Wf, float* dw, int target_blocks,
                             void* stream) {
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_F32X3, "wgrad: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "wgrad: bad precision %d", prec);
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "wgrad: bad mode %d", mode);
   CRIMAC_REQUIRE(CF > 0 && CF % 8 == 0 && CS > 0 && CS % 8 == 0, "wgrad: channels must be multiples of 8");
   CRIMAC_REQUIRE(f_ld >= CF && s_ld >= CS && f_ld % 8 == 0 && s_ld % 8 == 0, "wgrad: bad pixel strides");
@@ -306,6 +292,8 @@ extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF
   p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw;
   hipStream_t st = (hipStream_t)stream;
   if (prec == CRIMAC_PREC_BF16)
-    return mode == 0 ? launch<bf16_t, 0>(p, target_blocks, st) : launch<bf16_t, 1>(p, target_blocks, st);
-  return mode == 0 ? launch<float, 0>(p, target_blocks, st) : launch<float, 1>(p, target_blocks, st);
+    return mode == 0 ? launch<bf16_t, 1, 0>(p, target_blocks, st) : launch<bf16_t, 1, 1>(p, target_blocks, st);
+  if (prec == CRIMAC_PREC_F32X3)
+    return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
+  return mode == 0 ? launch<float, 3, 0>(p, target_blocks, st) : launch<float, 3, 1>(p, target_blocks, st);
 }

@@ -58,6 +58,7 @@ class UNetEngine:
         self.precision = precision
         self.prec = hip.PREC_NAMES[precision]
         self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.planes = hip.PREC_PLANES[self.prec]
         self.depth = module.depth
         self.sf = module.start_filts
         self.in_channels = module.in_channels
@@ -149,23 +150,28 @@ class UNetEngine:
         self.dw_off = {}
         for b in self.blocks:
             n_f = 9 * b.cout * b.cin_pad
+            n_lo = max(self.planes - 1, 1)        # the lo buffer holds planes 1..planes-1
+            has_dg = b.cin_pad == b.cin
             self.pk[b.conv_key] = {
                 "fwd_hi": torch.empty(n_f, dtype=i16, device=dev),
-                "fwd_lo": torch.empty(n_f, dtype=i16, device=dev),
-                "dg_hi": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if b.cin_pad == b.cin else None,
-                "dg_lo": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if b.cin_pad == b.cin else None,
+                "fwd_lo": torch.empty(n_lo * n_f, dtype=i16, device=dev),
+                "dg_hi": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
+                "dg_lo": torch.empty(n_lo * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
             }
             self.pk_eval[b.conv_key] = {
                 "fwd_hi": torch.empty(n_f, dtype=i16, device=dev),
-                "fwd_lo": torch.empty(n_f, dtype=i16, device=dev),
+                "fwd_lo": torch.empty(n_lo * n_f, dtype=i16, device=dev),
                 "bias": torch.empty(b.cout, dtype=torch.float32, device=dev),
             }
             self.dw_off[b.conv_key] = tot_dw
             tot_dw += _align(n_f)
         for u in self.ups:
             n = 4 * u.cin * u.cout
-            self.pk[u.key] = {k: torch.empty(n, dtype=i16, device=dev)
-                              for k in ("fwd_hi", "fwd_lo", "dg_hi", "dg_lo")}
+            n_lo = max(self.planes - 1, 1)
+            self.pk[u.key] = {"fwd_hi": torch.empty(n, dtype=i16, device=dev),
+                              "fwd_lo": torch.empty(n_lo * n, dtype=i16, device=dev),
+                              "dg_hi": torch.empty(n, dtype=i16, device=dev),
+                              "dg_lo": torch.empty(n_lo * n, dtype=i16, device=dev)}
             self.dw_off[u.key] = tot_dw
             tot_dw += _align(n)
         self.dw_packed = torch.zeros(tot_dw, dtype=torch.float32, device=dev)
@@ -213,24 +219,24 @@ class UNetEngine:
     def _pack_train(self):
         if not self._train_pack_dirty:
             return
-        x3 = self.prec == hip.PREC_F32X3
         for b in self.blocks:
             pk = self.pk[b.conv_key]
             call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin, b.cin_pad,
-                 None, ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]) if x3 else None, ptr(pk["dg_hi"]),
-                 ptr(pk["dg_lo"]) if (x3 and pk["dg_lo"] is not None) else None)
+                 None, self.planes, ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(pk["dg_hi"]),
+                 ptr(pk["dg_lo"]))
+        self._pack_ups()
+        self._train_pack_dirty = False
+
+    def _pack_ups(self):
         for u in self.ups:
             pk = self.pk[u.key]
-            call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout,
-                 ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]) if x3 else None, ptr(pk["dg_hi"]),
-                 ptr(pk["dg_lo"]) if x3 else None)
-        self._train_pack_dirty = False
+            call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout, self.planes,
+                 ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(pk["dg_hi"]), ptr(pk["dg_lo"]))
 
     def _pack_eval(self):
         """Fold eval-mode BatchNorm into the conv: W*s, (b-rm)*s+beta, s=g/sqrt(rv+eps)."""
         if not self._eval_pack_dirty:
             return
-        x3 = self.prec == hip.PREC_F32X3
         with torch.no_grad():
             for b in self.blocks:
                 g, be = self.P[b.bn_key + ".weight"], self.P[b.bn_key + ".bias"]
@@ -239,17 +245,12 @@ class UNetEngine:
                 pk = self.pk_eval[b.conv_key]
                 pk["bias"].copy_((self.P[b.conv_key + ".bias"] - rm) * s + be)
                 call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin,
-                     b.cin_pad, ptr(s.contiguous()), ptr(pk["fwd_hi"]),
-                     ptr(pk["fwd_lo"]) if x3 else None, None, None)
+                     b.cin_pad, ptr(s.contiguous()), self.planes, ptr(pk["fwd_hi"]),
+                     ptr(pk["fwd_lo"]), None, None)
                 # s must stay alive until the kernel ran: same stream, freed memory is stream-ordered
         # up-conv planes are shared with the train pack (no BN behind them)
-        tp = self._train_pack_dirty
-        if tp:
-            for u in self.ups:
-                pk = self.pk[u.key]
-                call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout,
-                     ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]) if x3 else None, ptr(pk["dg_hi"]),
-                     ptr(pk["dg_lo"]) if x3 else None)
+        if self._train_pack_dirty:
+            self._pack_ups()
         self._eval_pack_dirty = False
 
     # ------------------------------------------------------------------------------------------

@@ -15,7 +15,9 @@ from . import build as _build
 
 PREC_BF16 = 0
 PREC_F32X3 = 1
-PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3}
+PREC_F32X6 = 2
+PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6}
+PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3}     # bf16 planes per MFMA operand
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -25,8 +27,8 @@ SIGNATURES = {
                           _vp, _l, _i, _i, _i, _vp],
     "crimac_conv3x3": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
-    "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "crimac_pack_upconv2x2": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "crimac_pack_upconv2x2": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_unpack_wgrad_conv3x3": [_vp, _i, _i, _i, _vp, _vp],
     "crimac_unpack_wgrad_upconv2x2": [_vp, _i, _i, _vp, _vp],
     "crimac_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _l, _vp],

@@ -80,7 +80,9 @@ class UNet_Baseline(nn.Module):
 
     Extra keyword (defaults keep the reference call sites working unchanged):
       precision: 'bf16'  -- bf16 activations / MFMA, fp32 accumulate (throughput mode)
-                 'f32x3' -- fp32 activations, split-bf16 MFMA (parity mode, <=1e-3 on logits)
+                 'f32x3' -- fp32 activations, 2-plane split-bf16 MFMA (~2^-16 per product)
+                 'f32x6' -- fp32 activations, 3-plane split, 6 MFMAs per product (fp32-equivalent:
+                            the parity mode, <=1e-3 on logits with bit-exact argmax masks)
     """
 
     def __init__(self, n_classes, in_channels, meta_in_channels=0, late_meta_inject=False, depth=5,

@@ -19,7 +19,11 @@
  *   - `prec` selects the storage/compute type of activations:
  *       CRIMAC_PREC_BF16  : bf16 activations, bf16 MFMA, fp32 accumulate (throughput mode)
  *       CRIMAC_PREC_F32X3 : fp32 activations, split-bf16 (hi*hi + hi*lo + lo*hi) MFMA, fp32
- *                           accumulate (parity mode: meets 1e-3 relative on logits)
+ *                           accumulate (~2^-16 per product: meets 1e-3 relative on logits)
+ *       CRIMAC_PREC_F32X6 : fp32 activations, 3-plane split, 6 MFMAs per product (~2^-24 per product,
+ *                           i.e. fp32-equivalent: the parity mode for bit-exact argmax masks)
+ *     weight operands: `w_hi` is plane 0; `w_lo` holds the remaining (planes-1) planes back to back
+ *     (unused for BF16)
  *     parameters, gradients of parameters, statistics and the loss are always fp32 / fp64
  */
 #ifndef CRIMAC_UNET_HIP_H_
@@ -35,6 +39,7 @@ extern "C" {
 
 #define CRIMAC_PREC_BF16 0
 #define CRIMAC_PREC_F32X3 1
+#define CRIMAC_PREC_F32X6 2
 
 /* Library identity / error text. */
 int crimac_version(void);
@@ -79,12 +84,13 @@ int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const voi
 
 /* Conv2d weight [Co][Ci][3][3] -> fwd planes [9][Co][Ci_pad] (scaled per Co by `scale` if given:
  * eval-mode BatchNorm folding) and dgrad planes [9][Ci][Co] (flipped taps).
- * lo planes / dgrad planes may be NULL. */
-int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, const float* scale,
+ * `planes` (1..3): number of bf16 planes the value is split into; *_lo receive planes 1..planes-1
+ * back to back (may be NULL when planes == 1); dgrad planes may be NULL. */
+int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, const float* scale, int planes,
                         void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo, void* stream);
 /* ConvTranspose2d weight [Ci][Co][2][2] -> fwd planes [(a,b,o)][Ci], dgrad planes [(a,b)][Ci][Co]. */
-int crimac_pack_upconv2x2(const float* w, int Ci, int Co, void* fwd_hi, void* fwd_lo, void* dg_hi,
-                          void* dg_lo, void* stream);
+int crimac_pack_upconv2x2(const float* w, int Ci, int Co, int planes, void* fwd_hi, void* fwd_lo,
+                          void* dg_hi, void* dg_lo, void* stream);
 /* dw [9][Co][Ci_pad] -> grad [Co][Ci][3][3];  dw [4][Ci][Co] -> grad [Ci][Co][2][2]. */
 int crimac_unpack_wgrad_conv3x3(const float* dw, int Co, int Ci, int Ci_pad, float* grad, void* stream);
 int crimac_unpack_wgrad_upconv2x2(const float* dw, int Ci, int Co, float* grad, void* stream);
