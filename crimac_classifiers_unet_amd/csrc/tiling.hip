@@ -1,0 +1,147 @@
+// Tiled whole-survey inference plumbing on the GPU (CDNA4 / gfx950), HBM-bound byte movers.
+//
+// Reference: save_survey_predictions_zarr's per-patch host work (save_predict.py:160-209):
+//   * DatasetGriddedReader.get_preload_data_labels -> new_get_crop_3d (dataset.py:192-205,
+//     utils/np.py:361-375): gather a 256x256 crop around each grid centre from the preloaded chunk,
+//     0 outside the chunk;
+//   * remove_nan_inf + db_with_limits (remove_nan_inf.py:23-34, db_with_limits.py:20-24, :36-38):
+//     non-finite -> 0, 10*log10(x + 1e-10) clamped to [-75, 0];
+//   * fill_out_array (save_predict.py:41-65) with the validity rules of the test-time label
+//     transforms (convert_label_indexing_unused_species, mask_label_seabed, mask_label_overlap,
+//     remove_nan_inf): scatter softmax channels [SANDEEL, OTHER] of each patch's valid interior into
+//     the chunk's [2, range, pings] output.
+//
+// The chunk stays resident in HBM in the reader's own (zarr) orientation [freq][ping][range] (range
+// contiguous); the gather transposes through LDS so both the reads (along range) and the NHWC writes
+// (along ping, 16 channels per pixel) are coalesced, and the dB transform, channel padding and
+// bf16/fp32 conversion are fused into it -- the patch lands directly in the first conv's input layout.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 32;   // tile side
+
+// data [C][Wd][H] fp32; centres [P][2] = (cy, cx_local) with cx_local relative to the chunk slice.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ data, int C, int Wd,
+                                                             int H, const int* __restrict__ centres,
+                                                             int ph, int pw, T* __restrict__ out,
+                                                             int ld) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);      // [C][TS (x)][TS + 1 (y)]
+  const int p = blockIdx.z;
+  const int ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+  const int cy = centres[2 * p], cx = centres[2 * p + 1];
+  const int y_base = cy - ((ph + 1) / 2) + 1 + ty0;        // data row of tile row 0 (np.py:40-46)
+  const int x_base = cx - ((pw + 1) / 2) + 1 + tx0;
+  const int tx = threadIdx.x & 31, tr = threadIdx.x >> 5;  // tr 0..7
+  // read phase: lanes run along range (contiguous in the chunk)
+  for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xi = tr + 8 * k;                 // tile column (ping)
+      const int x = x_base + xi, y = y_base + tx;
+      float v = 0.f;                             // boundary_val_data = 0 (dataset.py:195)
+      if (x >= 0 && x < Wd && y >= 0 && y < H && (ty0 + tx) < ph && (tx0 + xi) < pw)
+        v = data[((long)c * Wd + x) * H + y];
+      if (!isfinite(v)) v = 0.f;                 // remove_nan_inf
+      v = 10.f * log10f(v + 1e-10f);             // db_with_limits
+      v = fminf(fmaxf(v, -75.f), 0.f);
+      tile[(c * TS + xi) * (TS + 1) + tx] = v;
+    }
+  }
+  __syncthreads();
+  // write phase: lanes run along ping (contiguous pixels of the NHWC patch)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yi = tr + 8 * k;
+    const int py = ty0 + yi, px = tx0 + tx;
+    if (py >= ph || px >= pw) continue;
+    T* dst = out + (((long)p * ph + py) * pw + px) * ld;
+    for (int c0 = 0; c0 < ld; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (c0 + j) < C ? tile[((c0 + j) * TS + tx) * (TS + 1) + yi] : 0.f;
+      store8(dst + c0, v);
+    }
+  }
+}
+
+// probs [P][ncls][ph][pw] fp32; centres [P][2] global (cy, cx); out [2][H][n_chunk] fp32.
+__global__ __launch_bounds__(256) void scatter_patches_kernel(
+    const float* __restrict__ probs, int ncls, const int* __restrict__ centres, int P, int ph, int pw,
+    int overlap, int start_ping, int n_chunk, int H, const short* __restrict__ labels,
+    const unsigned char* __restrict__ seabed_mask, int mask_ping0, int mask_pings,
+    const float* __restrict__ data0, int data_ping0, int data_pings, int seabed_pad,
+    float* __restrict__ out) {
+  const int iw = pw - 2 * overlap, ih = ph - 2 * overlap;
+  const long per_patch = (long)ih * iw;
+  const long total = per_patch * P;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i / per_patch);
+    const int r = (int)(i % per_patch);
+    const int py = overlap + r / iw, px = overlap + r % iw;      // mask_label_overlap: rim excluded
+    const int cy = centres[2 * p], cx = centres[2 * p + 1];
+    const int y = cy - ph / 2 + 1 + py, x = cx - pw / 2 + 1 + px;   // patch_coord_to_data_coord
+    const int xl = x - start_ping;
+    if (y < 0 || y >= H || xl < 0 || xl >= n_chunk) continue;       // label crop out of range: -100
+    int lab = labels ? (int)labels[(long)xl * H + y] : 0;
+    if (lab < 0) continue;                                           // convert_label_indexing: -100
+    if (lab == 0 && seabed_mask) {                                   // mask_label_seabed (background only)
+      const int y_top = max(cy - ph / 2 + 1, 0);
+      const int xm = x - mask_ping0;
+      if (y - y_top >= seabed_pad && xm >= 0 && xm < mask_pings &&
+          seabed_mask[(long)xm * H + (y - seabed_pad)])
+        continue;
+    }
+    if (data0) {                                                     // remove_nan_inf: ch 0 non-finite
+      const int xd = x - data_ping0;
+      if (xd >= 0 && xd < data_pings && !isfinite(data0[(long)xd * H + y])) continue;
+    }
+    const long src = (((long)p * ncls + 1) * ph + py) * pw + px;     // channel SANDEEL = 1
+    out[((long)0 * H + y) * n_chunk + xl] = probs[src];
+    out[((long)1 * H + y) * n_chunk + xl] = probs[src + (long)ph * pw];   // channel OTHER = 2
+  }
+}
+
+}  // namespace
+
+extern "C" int crimac_gather_patches(int prec, const float* data, int C, int Wd, int H, const int* centres,
+                                     int P, int ph, int pw, void* out, long ld, void* stream) {
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "gather_patches: bad precision %d", prec);
+  CRIMAC_REQUIRE(data && centres && out && C > 0 && C <= 16 && Wd > 0 && H > 0 && P > 0 && ph > 0 && pw > 0,
+                 "gather_patches: bad arguments (C=%d must be <= 16)", C);
+  CRIMAC_REQUIRE(ld >= C && ld % 8 == 0 && ld <= 16, "gather_patches: ld=%ld must be 8 or 16 and >= C", ld);
+  CRIMAC_REQUIRE(P <= 65535, "gather_patches: at most 65535 patches per call");
+  dim3 grid((pw + TS - 1) / TS, (ph + TS - 1) / TS, P);
+  const size_t lds = (size_t)C * TS * (TS + 1) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL(gather_patches_kernel<bf16_t>, grid, dim3(256), lds, st, data, C, Wd, H, centres, ph,
+                       pw, (bf16_t*)out, (int)ld);
+  else
+    hipLaunchKernelGGL(gather_patches_kernel<float>, grid, dim3(256), lds, st, data, C, Wd, H, centres, ph,
+                       pw, (float*)out, (int)ld);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int P, int ph, int pw,
+                                      int overlap, int start_ping, int n_chunk, int H, const short* labels,
+                                      const unsigned char* seabed_mask, int mask_ping0, int mask_pings,
+                                      const float* data0, int data_ping0, int data_pings, int seabed_pad,
+                                      float* out, void* stream) {
+  CRIMAC_REQUIRE(probs && centres && out && P > 0 && ph > 0 && pw > 0 && n_chunk > 0 && H > 0,
+                 "scatter_patches: bad arguments");
+  CRIMAC_REQUIRE(ncls >= 3, "scatter_patches: needs the SANDEEL (1) and OTHER (2) channels, ncls=%d", ncls);
+  CRIMAC_REQUIRE(overlap >= 0 && 2 * overlap < ph && 2 * overlap < pw, "scatter_patches: bad overlap %d", overlap);
+  const long total = (long)P * (ph - 2 * overlap) * (pw - 2 * overlap);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scatter_patches_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, probs,
+                     ncls, centres, P, ph, pw, overlap, start_ping, n_chunk, H, labels, seabed_mask, mask_ping0,
+                     mask_pings, data0, data_ping0, data_pings, seabed_pad, out);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}

@@ -333,8 +333,16 @@ class UNetEngine:
     def forward(self, x, training, softmax=False):
         """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs."""
         self.bind()
-        self._check_versions()
         xin, B, H, W = self._input(x)
+        return self.forward_nhwc(xin, B, H, W, training, softmax)
+
+    def forward_nhwc(self, xin, B, H, W, training, softmax=False):
+        """Same, from an NHWC activation matrix [B*H*W, 16] already in the engine's storage type
+        (what ``crimac_gather_patches`` writes for the tiled-inference path)."""
+        self.bind()
+        self._check_versions()
+        if tuple(xin.shape) != (B * H * W, CIN_PAD) or xin.dtype != self.act_dtype or not xin.is_cuda:
+            raise ValueError(f"expected a [{B * H * W},{CIN_PAD}] {self.act_dtype} GPU tensor")
         geo = self._geom(B, H, W)
         D = self.depth
         if training:

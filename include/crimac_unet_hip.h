@@ -161,6 +161,30 @@ int crimac_wce_bwd(const float* logits, const void* labels, int label_bytes, con
 int crimac_sgd_momentum(float* p, float* g, float* v, long n, float lr, float momentum,
                         float grad_scale, int zero_grad, void* stream);
 
+/* ---- tiled whole-survey inference (save_predict.py:160-209) ------------------------------------ */
+
+/* DatasetGriddedReader.get_preload_data_labels + remove_nan_inf + db_with_limits (dataset.py:192-205,
+ * remove_nan_inf.py:23-34, db_with_limits.py:20-24): gather P crops of ph x pw pixels around
+ * centres[p] = (range idx, ping idx RELATIVE to the chunk slice) from data [C][Wd pings][H range] fp32
+ * (the reader's zarr orientation), 0 outside the slice, non-finite -> 0, 10*log10(x+1e-10) clamped
+ * to [-75, 0]; written as NHWC activations [P*ph*pw][ld] (channels >= C zero) -- the first conv's input. */
+int crimac_gather_patches(int prec, const float* data, int C, int Wd, int H, const int* centres, int P,
+                          int ph, int pw, void* out, long ld, void* stream);
+/* fill_out_array (save_predict.py:41-65) for P patches: probs [P][ncls][ph][pw] fp32 softmax;
+ * centres[p] = (range idx, GLOBAL ping idx); writes channels SANDEEL(1), OTHER(2) of every valid
+ * interior pixel into out [2][H][n_chunk] fp32 (ping = global ping - start_ping).  A pixel is valid
+ * unless: it lies in the `overlap` rim (mask_label_overlap.py:41-46); its raw label (labels
+ * [n_chunk][H] int16, NULL = all background) is negative (convert_label_indexing.py:24-47 -> -100);
+ * it is background below the seabed (mask_label_seabed.py:24-68: seabed_mask [mask_pings][H] uint8
+ * starting at global ping mask_ping0, shifted down by seabed_pad inside the patch slice); channel 0 of
+ * the chunk data (data0 [data_pings][H], global ping data_ping0) is non-finite there
+ * (remove_nan_inf.py:31); or it falls outside the chunk / the range axis. */
+int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int P, int ph, int pw,
+                           int overlap, int start_ping, int n_chunk, int H, const short* labels,
+                           const unsigned char* seabed_mask, int mask_ping0, int mask_pings,
+                           const float* data0, int data_ping0, int data_pings, int seabed_pad, float* out,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

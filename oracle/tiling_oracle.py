@@ -1,0 +1,166 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  CPU (numpy) restatement of the reference's tiled
+whole-survey inference plumbing around the U-Net.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
+
+Restated pieces (each cites the reference lines it follows; pinned against the reference's own
+functions run on a fake in-memory reader, fixture ``tests/golden/tiling.npz`` made by
+``tools/make_golden_tiling.py``):
+
+* chunk plan       -- utils/preload_data_split.py:22-30 (``get_data_split``)
+* patch-centre grid -- batch/samplers/gridded.py:22-54, :121-163 (``get_data_grid`` mode 'all')
+* crop geometry    -- utils/np.py:38-46 (``getGrid``), :347-375 (``new_get_crop_2d/3d``),
+                      batch/dataset.py:192-205 (``get_preload_data_labels``)
+* label masks that decide which output pixels are written -- label_transforms/
+  convert_label_indexing.py:24-47, mask_label_seabed.py:24-68, mask_label_overlap.py:23-48,
+  data_transforms/remove_nan_inf.py:23-34
+* data transform   -- data_transforms/remove_nan_inf.py:23-34, db_with_limits.py:20-24, :36-38
+* scatter          -- pipeline_train_predict/save_predict.py:41-65 (``fill_out_array``)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LABEL_IGNORE_VAL = -100
+LABEL_BOUNDARY_VAL = -100
+LABEL_OVERLAP_VAL = -70
+LABEL_SEABED_MASK_VAL = -50
+LABEL_UNUSED_SPECIES = -10
+SANDEEL, OTHER = 1, 2
+SEABED_PAD = 10          # mask_label_seabed.py:50-52
+SEABED_MARGIN = 50       # gridded.py:150-156
+
+
+def get_data_split(valid_pings_ranges, max_n_pings=1000):
+    """Equal-sized chunks of at most ``max_n_pings`` pings (preload_data_split.py:22-30)."""
+    splits = []
+    for start, end in valid_pings_ranges:
+        n_splits = int(np.ceil((end - start) / max_n_pings))
+        edges = np.linspace(start, end, n_splits + 1).astype(int)
+        splits.extend([[edges[i], edges[i + 1]] for i in range(n_splits)])
+    return np.array(splits)
+
+
+def get_data_grid(n_range, max_seabed, start_ping, end_ping, patch_size=(256, 256), patch_overlap=20):
+    """Patch centres (range idx, ping idx), ping index fastest (gridded.py:35-54, :150-159).
+
+    ``max_seabed`` is the deepest seabed index in [start_ping, end_ping); the range extent is capped
+    at ``max_seabed + 50``.
+    """
+    end_range = n_range
+    cap = max_seabed + SEABED_MARGIN
+    if cap < end_range:
+        end_range = cap
+    pw, ph = patch_size
+    ys = np.arange(0 - (patch_overlap + 1), end_range - (patch_overlap + 1), ph - 2 * patch_overlap) + ph // 2
+    xs = np.arange(start_ping - (patch_overlap + 1), end_ping - (patch_overlap + 1),
+                   pw - 2 * patch_overlap) + pw // 2
+    return np.array(np.meshgrid(ys, xs)).T.reshape(-1, 2)
+
+
+def patch_offsets(n):
+    """Offsets of the n patch pixels relative to the centre: -((n+1)//2)+1 .. n//2 (np.py:40-46)."""
+    return np.arange(-((n + 1) // 2) + 1, n // 2 + 1)
+
+
+def crop(arr, centre, size, boundary_val):
+    """``new_get_crop_2d/3d``: arr[..., H, W] sampled on the patch grid, ``boundary_val`` outside."""
+    ys = centre[0] + patch_offsets(size[0])[:, None] + np.zeros((1, size[1]), dtype=int)
+    xs = centre[1] + patch_offsets(size[1])[None, :] + np.zeros((size[0], 1), dtype=int)
+    n0, n1 = arr.shape[-2:]
+    oob = (ys < 0) | (xs < 0) | (ys >= n0) | (xs >= n1)
+    ys = np.where(oob, 0, ys)
+    xs = np.where(oob, 0, xs)
+    out = arr[..., ys, xs].copy()
+    out[..., oob] = boundary_val
+    return out
+
+
+def data_transform(data):
+    """remove_nan_inf + db_with_limits on a linear-sv crop (returns data, non-finite mask of ch 0)."""
+    nonfinite0 = ~np.isfinite(data[0])
+    data = np.where(np.isfinite(data), data, data.dtype.type(0))
+    db = 10 * np.log10(data + 1e-10)
+    db = np.clip(db, -75, 0).astype(data.dtype)
+    return db, nonfinite0
+
+
+def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfinite0):
+    """Labels of one patch after the test-time transforms, as far as they decide validity.
+
+    raw_labels: [n_range, chunk_pings] crop source (chunk-local ping axis, already offset);
+    seabed: per-ping seabed index vector indexable by the GLOBAL ping of each patch column.
+    Returns the label patch with values in {-100, -70, -50, -10, 0, 1, 2} (refine_label_boundary's
+    -30 never changes validity and is not modelled).
+    """
+    lab = crop(raw_labels, centre["local"], size, LABEL_BOUNDARY_VAL).astype(np.int64)
+    raw = lab.copy()
+    # convert_label_indexing_unused_species
+    new = np.full(raw.shape, LABEL_IGNORE_VAL, dtype=np.int64)
+    new[raw == 0] = 0
+    new[raw == 27] = SANDEEL
+    new[raw == 1] = OTHER
+    new[(raw > 0) & (raw != 1) & (raw != 27)] = LABEL_UNUSED_SPECIES
+    lab = new
+    # mask_label_seabed (reader pad semantics: the mask slice is shifted down by 10 INSIDE the slice)
+    cy, cx = centre["global"]
+    offs_y, offs_x = patch_offsets(size[0]), patch_offsets(size[1])
+    y_data = cy + offs_y
+    x_data = cx + offs_x
+    y_top = max(cy - size[0] // 2 + 1, 0)
+    below = np.zeros(lab.shape, dtype=bool)
+    for j, x in enumerate(x_data):
+        if x < 0 or x >= len(seabed):
+            continue
+        ok_rows = (y_data >= 0) & (y_data < n_range)
+        r = y_data - y_top
+        below[:, j] = ok_rows & (r >= SEABED_PAD) & ((y_data - SEABED_PAD) >= seabed[x])
+    lab[below & (lab == 0)] = LABEL_SEABED_MASK_VAL
+    # mask_label_overlap
+    if patch_overlap > 0:
+        out = np.full(lab.shape, LABEL_OVERLAP_VAL, dtype=np.int64)
+        o = patch_overlap
+        out[o:-o, o:-o] = lab[o:-o, o:-o]
+        out[lab == LABEL_BOUNDARY_VAL] = LABEL_BOUNDARY_VAL
+        lab = out
+    # remove_nan_inf
+    lab[nonfinite0] = LABEL_IGNORE_VAL
+    return lab
+
+
+def fill_out_array(out_array, preds, labels, centre, ping_start):
+    """save_predict.py:41-65: write softmax channels [SANDEEL, OTHER] at the valid pixels."""
+    valid = (labels != LABEL_OVERLAP_VAL) & (labels != LABEL_SEABED_MASK_VAL) & (labels != LABEL_BOUNDARY_VAL)
+    yl, xl = np.nonzero(valid)
+    if len(yl) == 0:
+        return out_array
+    y = yl + centre[0] - labels.shape[0] // 2 + 1
+    x = xl + centre[1] - labels.shape[1] // 2 + 1 - ping_start
+    out_array[:, y, x] = preds[[SANDEEL, OTHER]][:, yl, xl]
+    return out_array
+
+
+def predict_chunk(sv, raw_labels, seabed, start_ping, end_ping, predict_fn, patch_size=(256, 256),
+                  patch_overlap=20):
+    """One chunk of ``save_survey_predictions_zarr`` (save_predict.py:171-209) on in-memory arrays.
+
+    sv [C, n_pings_total, n_range] linear (zarr orientation), raw_labels [n_pings_total, n_range],
+    seabed [n_pings_total]; ``predict_fn(data[C,H,W] dB) -> softmax [3,H,W]``.
+    Returns out_array [2, n_range, end_ping - start_ping] float64 (zeros where nothing is written).
+    """
+    n_total, n_range = sv.shape[1], sv.shape[2]
+    grid = get_data_grid(n_range, int(seabed[start_ping:end_ping].max()), start_ping, end_ping, patch_size,
+                         patch_overlap)
+    lo = max(0, grid[0, 1] - patch_size[1] // 2)                   # dataset.py:175-177
+    hi = min(n_total, grid[-1, 1] + patch_size[1] // 2)
+    data = sv[:, lo:hi].swapaxes(1, 2)                             # [C, H, pings]
+    labels = raw_labels[start_ping:end_ping].T                     # [H, chunk pings]
+    out = np.zeros([2, n_range, end_ping - start_ping])
+    for c in grid:
+        d = crop(data, (c[0], c[1] - lo), patch_size, 0)
+        d, nonfinite0 = data_transform(d)          # stays in the reader's dtype (float32 on the preload path)
+        lab = patch_labels(labels, {"local": (c[0], c[1] - start_ping), "global": (c[0], c[1])},
+                           patch_size, seabed, n_range, patch_overlap, nonfinite0)
+        preds = predict_fn(d.astype(np.float32))
+        fill_out_array(out, preds, lab, c, start_ping)
+    return out, grid

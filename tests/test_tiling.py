@@ -1,0 +1,161 @@
+"""Tiled whole-survey inference (save_predict.py path).
+
+CPU: the numpy oracle and the product's host planners against golden vectors produced by the
+REFERENCE's own functions on the fake reader (tools/make_golden_tiling.py).
+GPU: gather / scatter kernels and the whole chunk loop against the oracle and the same fixture.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from crimac_classifiers_unet_amd import tiled_inference as ti  # noqa: E402
+from oracle import tiling_oracle as orc  # noqa: E402
+from tools.fake_reader import FakeZarrReader, linear_predictor, synth_survey  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fix(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiling.npz"))
+
+
+@pytest.fixture(scope="module")
+def survey():
+    return synth_survey()
+
+
+def test_oracle_matches_reference_golden(fix, survey):
+    sv, labels, seabed = survey
+    n_pings, n_range = int(fix["n_pings"]), int(fix["n_range"])
+    splits = orc.get_data_split([[0, n_pings]], int(fix["preload"]))
+    assert np.array_equal(splits, fix["splits"])
+    outs = []
+    for i, (s, e) in enumerate(splits):
+        out, grid = orc.predict_chunk(sv, labels, seabed, s, e, linear_predictor, (256, 256), int(fix["overlap"]))
+        if i == 0:
+            assert np.array_equal(grid, fix["grid0"])
+        if i == len(splits) - 1:
+            assert np.array_equal(grid, fix["grid_last"])
+        outs.append(out)
+    full = np.concatenate(outs, axis=2).astype(np.float16)
+    assert np.array_equal(full, fix["out_f16"])
+    # one patch exactly as the reference Dataset returned it
+    c = fix["patch_centre"]
+    s = [sp for sp in splits if sp[0] <= c[1] - 0 and True][0]
+    s0, e0 = [sp for sp in splits if sp[0] - 21 + 128 <= c[1] < sp[1] + 128][0]
+    grid = orc.get_data_grid(n_range, int(seabed[s0:e0].max()), s0, e0)
+    lo = max(0, grid[0, 1] - 128)
+    hi = min(n_pings, grid[-1, 1] + 128)
+    d = orc.crop(sv[:, lo:hi].swapaxes(1, 2), (c[0], c[1] - lo), (256, 256), 0)
+    d, nf = orc.data_transform(d)
+    assert np.abs(d - fix["patch_data"]).max() < 1e-5
+    lab = orc.patch_labels(labels[s0:e0].T, {"local": (c[0], c[1] - s0), "global": tuple(c)}, (256, 256),
+                           seabed, n_range, int(fix["overlap"]), nf)
+    ref = fix["patch_labels"].astype(np.int64)
+    same_validity = np.isin(lab, (-100, -70, -50)) == np.isin(ref, (-100, -70, -50))
+    assert same_validity.all()
+    assert np.array_equal(lab[ref != -30], ref[ref != -30])      # -30 (refine_label_boundary) not modelled
+
+
+def test_host_planners_match_oracle_and_reference(fix, survey):
+    _, _, seabed = survey
+    n_pings, n_range = int(fix["n_pings"]), int(fix["n_range"])
+    chunks = ti.plan_chunks(0, n_pings, int(fix["preload"]))
+    assert np.array_equal(np.array(chunks), fix["splits"])
+    s, e = chunks[0]
+    assert np.array_equal(ti.plan_grid(n_range, seabed[s:e].max(), s, e, (256, 256), 20), fix["grid0"])
+    s, e = chunks[-1]
+    assert np.array_equal(ti.plan_grid(n_range, seabed[s:e].max(), s, e, (256, 256), 20), fix["grid_last"])
+    # 8192 pings x 1024 range, seabed 900, preload 4096 -> 2 chunks x 95 patches
+    assert ti.plan_chunks(0, 8192, 4096) == [(0, 4096), (4096, 8192)]
+    g = ti.plan_grid(1024, 900, 0, 4096)
+    assert len(g) == 95 and tuple(g[0]) == (107, 107) and tuple(g[1]) == (107, 323) and g[:, 0].max() == 971
+    # resume in the middle, chunk sizes stay equal (np.linspace semantics)
+    assert ti.plan_chunks(1000, 8192, 4096) == [(1000, 4596), (4596, 8192)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32x6", "bf16"])
+def test_gather_patches_matches_oracle_crop_and_transform(survey, prec):
+    from crimac_classifiers_unet_amd import hip
+    from crimac_classifiers_unet_amd.hip import call, ptr
+    sv, labels, seabed = survey
+    lo, hi = 100, 700
+    data = torch.from_numpy(np.ascontiguousarray(sv[:, lo:hi])).cuda()
+    centres = np.array([[107, 107], [323, 539], [539, 683], [60, 101], [580, 650]], dtype=np.int32)   # some cross borders
+    local = centres.copy()
+    local[:, 1] -= lo
+    loc_d = torch.from_numpy(local).cuda()
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    out = torch.full((len(centres) * 256 * 256, 16), 3.0, dtype=dt, device="cuda")
+    call("crimac_gather_patches", hip.PREC_NAMES[prec], ptr(data), 4, hi - lo, sv.shape[2], ptr(loc_d),
+         len(centres), 256, 256, ptr(out), 16)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy().reshape(len(centres), 256, 256, 16)
+    for i, c in enumerate(local):
+        ref, _ = orc.data_transform(orc.crop(sv[:, lo:hi].swapaxes(1, 2), c, (256, 256), 0))
+        tol = 0.3 if prec == "bf16" else 2e-5          # bf16: 8 mantissa bits on values up to 75
+        assert np.abs(got[i, :, :, :4].transpose(2, 0, 1) - ref).max() < tol
+        assert np.abs(got[i, :, :, 4:]).max() == 0
+
+
+@pytest.mark.gpu
+def test_chunk_loop_with_linear_predictor_matches_reference_golden(fix, survey):
+    """gather -> (stand-in predictor) -> scatter over every chunk == the reference's out_array."""
+    import crimac_classifiers_unet_amd as pkg
+    sv, labels, seabed = survey
+    reader = FakeZarrReader(sv, labels, seabed)
+    n_pings, n_range = reader.shape
+    model = pkg.UNet_Baseline(3, 4, precision="f32x6").cuda().eval()
+    cp = ti.ChunkPredictor(model, n_range, (256, 256), int(fix["overlap"]), batch_size=4)
+
+    def predict_fn(x, P, H, W):          # x: NHWC [P*H*W,16] dB -> softmax [P,3,H,W] with the stand-in net
+        d = x.float().reshape(P, H, W, 16)[..., :4].permute(0, 3, 1, 2).cpu().numpy()
+        return torch.from_numpy(np.stack([linear_predictor(di) for di in d])).cuda().contiguous()
+
+    outs = []
+    for s, e in ti.plan_chunks(0, n_pings, int(fix["preload"])):
+        grid = ti.plan_grid(n_range, seabed[s:e].max(), s, e, (256, 256), int(fix["overlap"]))
+        lo, hi = max(0, grid[0, 1] - 128), min(n_pings, grid[-1, 1] + 128)
+        cp.load_chunk(reader.get_data_slice(lo, hi - lo), lo, reader.get_label_slice(s, e - s),
+                      reader.get_seabed_mask(s, e - s, 0, n_range), s, e)
+        outs.append(cp.predict(grid, predict_fn).cpu().numpy())
+    full = np.concatenate(outs, axis=2)
+    ref = fix["out_f16"].astype(np.float32)
+    assert np.array_equal(full != 0, ref != 0)                   # exactly the same pixels written
+    assert np.abs(full - ref).max() < 1e-3                       # fixture is float16-rounded
+
+
+@pytest.mark.gpu
+def test_predict_survey_with_unet_matches_oracle(survey):
+    """The full path (gather, U-Net f32x6, softmax, scatter) on one chunk vs oracle net + oracle tiling."""
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    from oracle import unet_oracle as uorc
+    sv, labels, seabed = survey
+    sv, labels, seabed = sv[:, :440, :300], labels[:440, :300], np.clip(seabed[:440], 0, 230)
+    reader = FakeZarrReader(sv, labels, seabed)
+    sd = synth.synth_state_dict(seed=0)
+
+    class Pipe:
+        frequencies = [18, 38, 120, 200]
+        device = torch.device("cuda")
+    pipe = Pipe()
+    pipe.model = pkg.UNet_Baseline(3, 4, precision="f32x6")
+    pipe.model.load_state_dict(sd)
+    chunks = list(ti.predict_survey(reader, pipe, (256, 256), 20, 3, 440))
+    assert len(chunks) == 1 and chunks[0][:2] == (0, 440)
+    got = chunks[0][2]
+    torch.set_num_threads(8)
+
+    def net(d):
+        return uorc.predict(sd, torch.from_numpy(d)[None], return_softmax=True)[0].numpy()
+    ref, grid = orc.predict_chunk(sv, labels, seabed, 0, 440, net)
+    assert len(grid) == 6
+    assert np.array_equal(got != 0, ref != 0)
+    assert np.abs(got - ref).max() < 1e-4

@@ -1,0 +1,83 @@
+"""In-memory stand-in for the reference's zarr reader (crimac_unet/data/data_reader.py:510-1120,
+not importable here: needs xarray/zarr).  Test/bench infrastructure: implements the five members the
+hot path's callers use: shape/data_format/time_vector/range_vector/name,
+get_data_slice, get_label_slice, get_seabed, get_seabed_mask -- with the real reader's semantics
+(data [freq, ping, range]; labels [ping, range]; seabed mask = 1 below the seabed, ``seabed_pad``
+shifting the mask down INSIDE the requested slice, data_reader.py:837-841)."""
+import numpy as np
+
+
+class _Val:
+    def __init__(self, v):
+        self.values = v
+
+    def max(self):
+        return _Val(np.max(self.values))
+
+
+class FakeZarrReader:
+    data_format = "zarr"
+
+    def __init__(self, sv, labels, seabed, name="fake_survey"):
+        self.sv = sv                    # [C, pings, range] linear sv, float32
+        self.labels = labels            # [pings, range] raw species labels
+        self.seabed = seabed            # [pings] seabed range index
+        self.shape = (sv.shape[1], sv.shape[2])
+        self.time_vector = np.arange(sv.shape[1])
+        self.range_vector = np.arange(sv.shape[2]) * 0.19
+        self.name = name
+        self.objects = []
+
+    def get_data_slice(self, idx_ping, n_pings, idx_range=None, n_range=None, frequencies=None,
+                       drop_na=False, return_numpy=True):
+        return self.sv[:, idx_ping:idx_ping + n_pings].copy()
+
+    def get_label_slice(self, idx_ping, n_pings, idx_range=None, n_range=None, drop_na=False,
+                        categories=None, return_numpy=True, correct_transducer_offset=False, mask=True):
+        return self.labels[idx_ping:idx_ping + n_pings].copy()
+
+    def get_seabed(self, idx_ping, n_pings=1, idx_range=None, n_range=None, return_numpy=True):
+        v = self.seabed[idx_ping:idx_ping + n_pings]
+        return v.copy() if return_numpy else _Val(v)
+
+    def get_seabed_mask(self, idx_ping, n_pings, idx_range=None, n_range=None, return_numpy=False,
+                        seabed_pad=0):
+        idx_range = 0 if idx_range is None else idx_range
+        hi = self.shape[1] if n_range is None else idx_range + n_range
+        r = np.arange(idx_range, min(hi, self.shape[1]))
+        m = (r[None, :] >= self.seabed[idx_ping:idx_ping + n_pings, None]).astype(np.float64)
+        if seabed_pad != 0:
+            out = np.zeros_like(m)
+            out[:, seabed_pad:] = m[:, :-seabed_pad]
+            return out
+        return m
+
+
+def synth_survey(n_pings=1200, n_range=600, channels=4, seed=7):
+    """Synthetic survey: linear sv 10^U(-7.5,0) with a few non-finite samples, undulating seabed,
+    species blobs (27 sandeel, 1 other, 12 unused species, -1 ignore)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sv = np.power(10.0, rng.uniform(-7.5, 0.0, size=(channels, n_pings, n_range))).astype(np.float32)
+    bad = rng.random((n_pings, n_range)) < 2e-4
+    sv[0][bad] = np.nan
+    sv[2][rng.random((n_pings, n_range)) < 1e-4] = np.inf
+    x = np.arange(n_pings)
+    seabed = (0.75 * n_range + 0.12 * n_range * np.sin(x / 97.0) + 0.03 * n_range * np.sin(x / 13.0)).astype(np.int64)
+    seabed = np.clip(seabed, 40, n_range - 5)
+    labels = np.zeros((n_pings, n_range), dtype=np.int64)
+    for val in (27, 1, 12, -1, 27, 1):
+        for _ in range(6):
+            px, py = rng.integers(0, n_pings - 40), rng.integers(0, n_range - 30)
+            labels[px:px + rng.integers(8, 40), py:py + rng.integers(6, 30)] = val
+    return sv, labels, seabed
+
+
+def linear_predictor(data):
+    """Deterministic stand-in for the network in tiling tests: softmax over 3 fixed linear maps of the
+    (dB) input channels.  data [C,H,W] -> [3,H,W] float32."""
+    a = np.array([[0.02, -0.01, 0.015, 0.005], [-0.015, 0.02, 0.0, 0.01], [0.005, 0.005, -0.02, 0.0]],
+                 dtype=np.float32)[:, : data.shape[0]]
+    z = np.tensordot(a, data.astype(np.float32), axes=(1, 0))
+    z = z - z.max(0, keepdims=True)
+    e = np.exp(z)
+    return (e / e.sum(0, keepdims=True)).astype(np.float32)
