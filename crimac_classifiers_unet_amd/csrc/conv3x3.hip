@@ -243,17 +243,27 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
     using SetCur = std::integral_constant<int, par>;        // set that will hold B(s+2)
     using SetNext = std::integral_constant<int, 1 - par>;   // set holding B(s+1)
     // coordinates of steps s+2
+#ifndef CRIMAC_EXP_NOLOAD
     if (s + 2 < nsteps) {
       int t2 = t + 2, kc2 = kc;
       if (t2 >= 9) { t2 -= 9; kc2 += 1; }
       load_b(SetCur{}, kc2, t2);
     }
+#endif
     const bool halo_next = kc + 1 < kchunks;
+#ifndef CRIMAC_EXP_NOLOAD
     if (t == 0 && halo_next) load_halo(kc + 1);
+#endif
+#ifndef CRIMAC_EXP_NOCOMPUTE
     compute(kc & 1, par, t);
+#endif
+#ifndef CRIMAC_EXP_NOSTORE
     if (s + 1 < nsteps) store_b(SetNext{}, 1 - par);
     if (t == 7 && halo_next) store_halo((kc + 1) & 1);
+#endif
+#ifndef CRIMAC_EXP_NOBARRIER
     __syncthreads();
+#endif
     if (++t == 9) { t = 0; ++kc; }
   };
   int s = 0;
@@ -363,6 +373,11 @@ int launch(ConvParams p, hipStream_t st) {
 
 }  // namespace
 
+// conv3x3_glds.hip: bf16 direct-to-LDS variant
+int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                             const void* w_hi, const float* bias, void* out, long out_ld, int relu,
+                             double* stat_sum, double* stat_sumsq, int stat_replicas, hipStream_t st);
+
 extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
                               const void* w_hi, const void* w_lo, const float* bias, void* out,
                               long out_ld, int relu, double* stat_sum, double* stat_sumsq,
@@ -389,6 +404,14 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
   // 128-pixel tile (2 workgroups/CU) on every layer -- occupancy beats LDS traffic here
   const bool big = force_tr == 16;
   static const int force_bk = getenv("CRIMAC_CONV_BK") ? atoi(getenv("CRIMAC_CONV_BK")) : 0;
+  // bf16 with 64-deep channel chunks: LDS-DMA streaming kernel (CRIMAC_CONV_GLDS=0 selects the
+  // register-staged kernel below, kept for A/B measurements and as the fp32-mode structure)
+  // Measured (tools/bench_conv.py, B=32): +8-18 % on every layer with N >= 128, -10 % on the N = 64
+  // layers (HBM-heavy, want more workgroups per CU) -> used for N % 128 == 0 only.
+  static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
+  if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && (use_glds == 2 || (use_glds == 1 && n128)))
+    return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, bias, out, out_ld, relu, stat_sum,
+                                    stat_sumsq, stat_replicas, st);
   if (prec == CRIMAC_PREC_BF16) {
     // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
     // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128

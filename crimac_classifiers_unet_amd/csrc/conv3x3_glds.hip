@@ -1,0 +1,326 @@
+// 3x3 convolution (stride 1, pad 1), bf16, direct-to-LDS streaming variant for CDNA4 (gfx950).
+//
+// Same contraction and epilogue as conv3x3.hip (reference: nn.Conv2d 3x3 forward and input gradient,
+// unet.py:35-44, pipeline.py:177), restructured after measuring the register-staged kernel
+// (tools/bench_conv.py ablations, 1024->1024 @16x16, B=32): the VGPR->LDS stores of the staged tiles
+// cost 36 % of its time, the loads 24 %, the MFMAs only ~45 %.  Here
+//   * every tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+//     ds_write; the XOR swizzles are applied on the per-lane SOURCE address (the LDS image of one
+//     wave-instruction is lane-linear: 8 rows x 128 B);
+//   * one workgroup per CU with 8 waves (4 along pixels x 2 along channels, 64 x BN/2 each) on a
+//     16x16-pixel x BN-channel tile: the weight tile of a step is shared by twice as many MFMAs as in
+//     the 128-pixel kernel, and a 3-slot weight ring keeps TWO steps of weights in flight;
+//   * counted `s_waitcnt vmcnt(N)` + raw `s_barrier`: only the tile needed next is waited for, the
+//     younger loads stay in flight across the barrier (never vmcnt(0) inside the loop);
+//   * halo rows outside the image never change for a workgroup: they are zeroed once, the loads of
+//     those lanes are masked off.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct ConvParams {
+  const void* in;
+  long in_ld;
+  int B, H, W;
+  int Cin, N;
+  const unsigned short* w_hi;
+  const float* bias;
+  void* out;
+  long out_ld;
+  int relu;
+  double* stat_sum;
+  double* stat_sumsq;
+  int stat_replicas;
+  int tiles_y, tiles_x;
+};
+
+constexpr int TR = 16, TC = 16, HP = TC + 2;
+constexpr int BM = TR * TC;                       // 256 pixels
+constexpr int HALO_ROWS = (TR + 2) * HP;          // 324
+constexpr int HALO_INSTR = (HALO_ROWS + 7) / 8;   // 41 wave-instructions of 8 rows
+constexpr int BK = 64, RB = BK * 2;               // 64 channels = 128 B per row
+constexpr int A_BYTES = HALO_INSTR * 1024;        // one halo buffer (padded to whole instructions)
+constexpr int NWAVES = 8;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+}
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p) {
+  constexpr int NT = BN / 64;                      // 32-col MFMA tiles per wave
+  constexpr int B_BYTES = BN * RB;                 // one weight slot
+  constexpr int B_INSTR = BN / 8;                  // wave-instructions per weight tile
+  constexpr int NB = B_INSTR / NWAVES;             // ... per wave (2 for BN 128, 1 for BN 64)
+  static_assert(B_INSTR % NWAVES == 0, "weight tile must split evenly over the waves");
+  constexpr int STAGE_PITCH = BN * 2 + 16;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto sA = [&](int buf) { return smem + buf * A_BYTES; };
+  auto sB = [&](int slot) { return smem + 2 * A_BYTES + slot * B_BYTES; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int sub = lane >> 3, c8 = lane & 7;        // LDS-DMA roles: row within the instruction, 16-B slot
+
+  const int tilesN = p.N / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  const int tile_n = bid % tilesN;
+  int tile_m = bid / tilesN;
+  const int txi = tile_m % p.tiles_x;
+  tile_m /= p.tiles_x;
+  const int tyi = tile_m % p.tiles_y;
+  const int b = tile_m / p.tiles_y;
+  const int y0 = tyi * TR, x0 = txi * TC, n0 = tile_n * BN;
+
+  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
+
+  // ---- this wave's halo wave-instructions: k = wave, wave+8, ... (<= 6) ---------------------------
+  constexpr int NH = (HALO_INSTR + NWAVES - 1) / NWAVES;     // 6
+  long h_src[NH];       // element offset of the lane's source unit (without the channel chunk), -1 = masked
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int k = wave + NWAVES * i;
+    const int row = 8 * k + sub;
+    h_src[i] = -1;
+    if (k < HALO_INSTR && row < HALO_ROWS) {
+      const int hy = row / HP, hx = row % HP;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      const int u = c8 ^ ((hx >> 1) & 7);                  // source-side swizzle (see conv3x3.hip Sw)
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+        h_src[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
+      else {
+        // outside the image for every channel chunk: zero both buffers once
+        *reinterpret_cast<u32x4*>(sA(0) + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(sA(1) + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+      }
+    }
+  }
+  auto issue_halo = [&](int kc, int buf) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int k = wave + NWAVES * i;
+      if (h_src[i] >= 0) glds16(inp + h_src[i] + kc * BK, sA(buf) + k * 1024);
+    }
+  };
+  // ---- weight tile of step (kc, t) -> ring slot ----------------------------------------------------
+  long b_src[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int k = wave + NWAVES * i;
+    const int row = 8 * k + sub;
+    const int u = c8 ^ ((row >> 1) & 7);
+    b_src[i] = (long)(n0 + row) * p.Cin + u * 8;
+  }
+  const long w_tap = (long)p.N * p.Cin;
+  auto issue_b = [&](int kc, int t, int slot) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int k = wave + NWAVES * i;
+      glds16(p.w_hi + t * w_tap + b_src[i] + kc * BK, sB(slot) + k * 1024);
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int a_row0[2], a_hx0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wr * 64 + i * 32 + fr;
+    a_row0[i] = (m >> 4) * HP + (m & 15);
+    a_hx0[i] = m & 15;
+  }
+
+  // fragment loads of k-step ks (A rows shifted by the tap, B rows plain)
+  auto load_frags = [&](const unsigned char* A, const unsigned char* Bs, int shift, int kx, int ks,
+                        bf16x8 (&af)[2], bf16x8 (&bfr)[NT]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = a_row0[i] + shift;
+      const int o = row * RB + (((2 * ks + fh) ^ (((a_hx0[i] + kx) >> 1) & 7)) << 4);
+      af[i] = *reinterpret_cast<const bf16x8*>(A + o);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wc * (BN / 2) + j * 32 + fr;
+      const int o = row * RB + (((2 * ks + fh) ^ ((row >> 1) & 7)) << 4);
+      bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + o);
+    }
+  };
+  // one step = 4 k-steps of 16; the fragments of k-step ks+1 are requested before the MFMAs of
+  // k-step ks issue, so the LDS latency is covered by matrix work of the same wave
+  auto compute = [&](const unsigned char* A, const unsigned char* Bs, int t) {
+    const int kx = t % 3;
+    const int shift = (t / 3) * HP + kx;
+    bf16x8 af[2][2], bfr[2][NT];
+    load_frags(A, Bs, shift, kx, 0, af[0], bfr[0]);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < BK / 16) load_frags(A, Bs, shift, kx, ks + 1, af[cur ^ 1], bfr[cur ^ 1]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  const int kchunks = p.Cin / BK;
+  const int nsteps = kchunks * 9;
+
+  // ---- prologue: halo(0), B(step 0), B(step 1) -----------------------------------------------------
+  issue_halo(0, 0);
+  issue_b(0, 0, 0);
+  issue_b(0, 1, 1);                 // nsteps >= 9
+  wait_vmcnt<NB>();                 // everything but B(step 1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fills
+  __builtin_amdgcn_s_barrier();
+
+  int kc = 0, t = 0, slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 2 < nsteps;
+#ifndef CRIMAC_EXP_NOLOAD
+    if (t == 0 && kc + 1 < kchunks) issue_halo(kc + 1, (kc + 1) & 1);
+    if (more) {
+      int t2 = t + 2, kc2 = kc;
+      if (t2 >= 9) { t2 -= 9; kc2 += 1; }
+      int slot2 = slot + 2;
+      if (slot2 >= 3) slot2 -= 3;
+      issue_b(kc2, t2, slot2);
+    }
+#endif
+#ifndef CRIMAC_EXP_NOCOMPUTE
+    compute(sA(kc & 1), sB(slot), t);
+#endif
+    // B(s+1) (and a halo issued this step) must have landed; B(s+2) stays in flight
+#ifndef CRIMAC_EXP_NOLOAD
+    if (more) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+#endif
+#ifndef CRIMAC_EXP_NOBARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    if (++t == 9) { t = 0; ++kc; }
+    if (++slot == 3) slot = 0;
+  }
+
+  // ---- epilogue (as conv3x3.hip): bias/ReLU, BN statistics, LDS-staged coalesced stores -------------
+  unsigned char* stage = smem;
+  float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);
+  const bool do_stats = p.stat_sum != nullptr;
+  const bool full_tile = (y0 + TR <= p.H) && (x0 + TC <= p.W);
+  if (do_stats)
+    for (int i = tid; i < 2 * BN; i += 512) sstat[i] = 0.f;
+  float cs1[NT], cs2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = wc * (BN / 2) + j * 32 + fr;
+    const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+    cs1[j] = 0.f;
+    cs2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float v = acc[i][j][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const bf16_t q = (bf16_t)v;
+        *reinterpret_cast<bf16_t*>(stage + row * STAGE_PITCH + col * 2) = q;
+        const float vs = (float)q;
+        const bool ok = full_tile || ((y0 + (row >> 4) < p.H) && (x0 + (row & 15) < p.W));
+        cs1[j] += ok ? vs : 0.f;
+        cs2[j] += ok ? vs * vs : 0.f;
+      }
+  }
+  __syncthreads();
+  if (do_stats) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float t1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
+      const float t2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (fh == 0) {
+        const int col = wc * (BN / 2) + j * 32 + fr;
+        atomicAdd(&sstat[col], t1);
+        atomicAdd(&sstat[BN + col], t2);
+      }
+    }
+  }
+  {
+    constexpr int CPR = BN / 8;
+    constexpr int RPP = 512 / CPR;
+    const int cc = tid % CPR, r0 = tid / CPR;
+    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+    for (int rr = 0; rr < BM / RPP; ++rr) {
+      const int row = r0 + rr * RPP;
+      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      if (full_tile || (y < p.H && x < p.W)) {
+        const bf16_t* sp = reinterpret_cast<const bf16_t*>(stage + row * STAGE_PITCH) + cc * 8;
+        bf16_t* dst = outp + (((long)b * p.H + y) * p.W + x) * p.out_ld + n0 + cc * 8;
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sp);
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    const long rep = (long)(blockIdx.x % (unsigned)p.stat_replicas) * p.N;
+    for (int c = tid; c < BN; c += 512) {
+      atomicAdd(&p.stat_sum[rep + n0 + c], (double)sstat[c]);
+      atomicAdd(&p.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
+    }
+  }
+}
+
+template <int BN>
+int launch(ConvParams p, hipStream_t st) {
+  p.tiles_y = cdiv(p.H, TR);
+  p.tiles_x = cdiv(p.W, TC);
+  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x * (p.N / BN);
+  const size_t lds = (size_t)2 * A_BYTES + 3 * BN * RB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_glds_kernel<BN>), dim3((unsigned)ntiles), dim3(512), lds, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+}  // namespace
+
+// bf16, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
+int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                             const void* w_hi, const float* bias, void* out, long out_ld, int relu,
+                             double* stat_sum, double* stat_sumsq, int stat_replicas, hipStream_t st) {
+  ConvParams p;
+  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
+  p.w_hi = (const unsigned short*)w_hi; p.bias = bias; p.out = out; p.out_ld = out_ld; p.relu = relu;
+  p.stat_sum = stat_sum; p.stat_sumsq = stat_sumsq; p.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
+  return N % 128 == 0 ? launch<128>(p, st) : launch<64>(p, st);
+}

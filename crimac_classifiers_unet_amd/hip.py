@@ -58,7 +58,7 @@ class HipLibraryError(RuntimeError):
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    return os.environ.get("CRIMAC_LIB", _build.LIB_PATH)       # override: kernel experiments only
 
 
 def load_library():
