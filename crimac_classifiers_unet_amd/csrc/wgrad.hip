@@ -63,9 +63,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wf = wave >> 1, ws = wave & 1;
+  // Workgroup -> (channel-tile pair q, pixel split).  Workgroups with equal id % 8 share an XCD (and
+  // its 4 MiB L2): give each XCD a contiguous block of channel-tile pairs (same F channels, a run of
+  // S channels) and let it walk the splits, so the F/S pixel ranges it streams are shared by all its
+  // workgroups instead of every XCD pulling every tensor through its own L2.
   const int cs_tiles = (p.CS + 63) / 64;
-  const int cf0 = (blockIdx.x / cs_tiles) * 64;
-  const int cs0 = (blockIdx.x % cs_tiles) * 64;
+  const int ch_tiles = ((p.CF + 63) / 64) * cs_tiles;
+  int qt, split;
+  if (ch_tiles % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, R = ch_tiles >> 3;
+    qt = xcd * R + j % R;
+    split = j / R;
+  } else {
+    qt = blockIdx.x % ch_tiles;
+    split = blockIdx.x / ch_tiles;
+  }
+  const int cf0 = (qt / cs_tiles) * 64;
+  const int cs0 = (qt % cs_tiles) * 64;
 
   f32x16 acc[NTAPS];
 #pragma unroll
@@ -140,54 +154,86 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     x0 = txi * 16;
   };
 
-  const long t_begin = (long)blockIdx.y * p.tiles_per_block;
+  const long t_begin = (long)split * p.tiles_per_block;
   const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
 
   if constexpr (!X3) {
     // ---- bf16: direct-to-LDS double buffering ----------------------------------------------------
+    // Per-lane geometry of this wave's wave-instructions is the same for every tile: precompute the
+    // pixel offsets relative to the tile origin once, so a tile costs one add + one bounds test per
+    // instruction instead of div/mod chains (the address VALU work was as long as the MFMA work).
+    constexpr int NF = F_ROWS / 8 / 4;                       // F wave-instructions per wave
+    constexpr int NS = (S_ROWS_PAD / 8 + 3) / 4;             // S wave-instructions per wave
+    const int sub = lane >> 3, c = lane & 7;
+    int f_rel[NF], f_yx[NF];          // element offset from the tile origin pixel; packed (ry << 8 | rx)
+    int s_rel[NS], s_yx[NS];          // S: offsets on the S grid (fine grid for MODE 1); -1 = never valid
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int row = 8 * (wave + 4 * i) + sub;
+      const int u = c ^ (4 * ((row >> 1) & 1));
+      const int ry = row >> 4, rx = row & 15;
+      f_rel[i] = (cf0 + u * 8) < p.CF ? (int)((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) : -1;
+      f_yx[i] = (ry << 8) | rx;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int k = wave + 4 * i;
+      const int row = 8 * k + sub;
+      const int u = c ^ (4 * ((row >> 1) & 1));
+      int ry, rx;                     // relative to (y0 - 1, x0 - 1) for MODE 0, to (2*y0, 2*x0) for MODE 1
+      if constexpr (MODE == 0) {
+        ry = row / 18;
+        rx = row % 18;
+      } else {
+        ry = row >> 5;
+        rx = 2 * (row & 15) + ((row & 31) >> 4);
+      }
+      const bool ok = k < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
+      s_rel[i] = ok ? (int)((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) : -1;
+      s_yx[i] = (ry << 8) | rx;
+    }
     auto issue_tile = [&](long tile, int buf) {
       long b; int y0, x0;
       tile_origin(tile, b, y0, x0);
       unsigned char* base = smem + buf * BUF_BYTES;
-      const int sub = lane >> 3, c = lane & 7;
-      for (int k = wave; k < F_ROWS / 8; k += 4) {
-        const int row = 8 * k + sub;
-        const int u = c ^ (4 * ((row >> 1) & 1));
-        const int y = y0 + (row >> 4), x = x0 + (row & 15);
-        const bool ok = y < p.Hf && x < p.Wf && (cf0 + u * 8) < p.CF;
-        if (ok) {
-          const bf16_t* src = fp + ((b * p.Hf + y) * (long)p.Wf + x) * p.f_ld + cf0 + u * 8;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(base + k * 1024),
-                                           16, 0, 0);
-        } else {
+      const bf16_t* fbase = fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int k = wave + 4 * i;
+        const bool ok = f_rel[i] >= 0 && (y0 + (f_yx[i] >> 8)) < p.Hf && (x0 + (f_yx[i] & 255)) < p.Wf;
+        if (ok)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fbase + f_rel[i]),
+                                           (__attribute__((address_space(3))) void*)(base + k * 1024), 16, 0, 0);
+        else
           *reinterpret_cast<u32x4*>(base + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
-        }
       }
       unsigned char* sbase = base + F_BYTES;
-      for (int k = wave; k < S_ROWS_PAD / 8; k += 4) {
-        const int row = 8 * k + sub;
-        const int u = c ^ (4 * ((row >> 1) & 1));
-        int y, x;
-        s_pixel(row, y0, x0, y, x);
-        const bool in_img = row < S_ROWS && y >= 0 && y < Hs && x >= 0 && x < Ws && (cs0 + u * 8) < p.CS;
-        if (in_img) {
-          const bf16_t* src = sp + ((b * Hs + y) * (long)Ws + x) * p.s_ld + cs0 + u * 8;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(sbase + k * 1024),
-                                           16, 0, 0);
-        } else {
+      const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0, sx0 = MODE == 0 ? x0 - 1 : 2 * x0;
+      const bf16_t* spbase = sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int k = wave + 4 * i;
+        if (k >= S_ROWS_PAD / 8) continue;
+        const int y = sy0 + (s_yx[i] >> 8), x = sx0 + (s_yx[i] & 255);
+        const bool ok = s_rel[i] >= 0 && y >= 0 && y < Hs && x >= 0 && x < Ws;
+        if (ok)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(spbase + s_rel[i]),
+                                           (__attribute__((address_space(3))) void*)(sbase + k * 1024), 16, 0, 0);
+        else
           *reinterpret_cast<u32x4*>(sbase + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
-        }
       }
     };
     if (t_begin < t_end) issue_tile(t_begin, 0);
     for (long tile = t_begin; tile < t_end; ++tile) {
       const int cur = (int)((tile - t_begin) & 1);
       __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
+#ifndef CRIMAC_EXP_NOLOAD
       if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+#endif
       const unsigned char* base = smem + cur * BUF_BYTES;
+#ifndef CRIMAC_EXP_NOCOMPUTE
       contract(base, base + F_BYTES);
+#endif
     }
   } else {
     // ---- fp32 activations: register staging with the plane split ------------------------------------
@@ -230,7 +276,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   // ---- combine partial sums: dw[t][cf][cs] += acc ---------------------------------------------
   const int col = cs0 + ws * 32 + (lane & 31);
+#ifdef CRIMAC_EXP_NOATOMIC
+  if (col < 0) {
+#else
   if (col < p.CS) {
+#endif
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
@@ -257,7 +307,9 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   if (autosplit) {
     // every split adds one fp32-atomic pass over dW (chip-wide atomic rate ~1.3 TB/s): keep at
     // least ~4096 contraction pixels per split so the atomics stay below the MFMA time
-    const long max_splits = ((long)p.B * p.Hf * p.Wf) / 4096;
+    long max_splits = ((long)p.B * p.Hf * p.Wf) / 4096;
+    // ... unless that leaves fewer than two workgroups per CU: then parallelism is worth more
+    while (max_splits * ch_tiles < 512 && max_splits * 2 <= ((long)p.B * p.Hf * p.Wf) / 1024) max_splits *= 2;
     if (splits > max_splits) splits = (int)max_splits;
   }
   if (splits < 1) splits = 1;
@@ -272,7 +324,7 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE>), dim3(ch_tiles, splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE>), dim3(ch_tiles * splits), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
