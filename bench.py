@@ -140,6 +140,17 @@ def main():
         return (fl / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0), ms_, len(sel)
 
     achieved, ms, n_launch = kernel_rate("crimac_conv3x3")
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    # (tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); bench.py
+    # itself cannot collect counters
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        sel = [v for k, v in pmc.items() if k.startswith("conv3x3")]
+        nl = sum(v["launches"] for v in sel)
+        traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
+    except Exception:
+        pass
     wg_achieved, wg_ms, wg_n = kernel_rate("crimac_wgrad")
     peak = MFMA_PEAK_TFLOPS[args.precision]
 
@@ -181,7 +192,9 @@ def main():
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": "HBM (L2-miss) bytes per launch, rocprofv3 PMC, profiles/r01_pmc_traffic.json",
+                         "algorithmic_flops_per_launch": (achieved * 1e12) * (ms * 1e-3) / max(n_launch, 1),
                          "launches": n_launch, "avg_launch_us": 1e3 * ms / max(n_launch, 1),
                          "share_of_step": ms / (1e3 * elapsed)},
             "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_kernel (weight gradient, all shapes)",

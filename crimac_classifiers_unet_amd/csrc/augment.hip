@@ -1,0 +1,110 @@
+// On-GPU training augmentation fused with the data transform (CDNA4 / gfx950), HBM-bound.
+//
+// Reference (numpy, in DataLoader workers): add_noise (batch/data_augmentation/add_noise.py:21-41) then
+// flip_x_axis (flip_x_axis.py:21-25), composed by define_data_augmentation (batch/transforms.py:39-46),
+// followed by remove_nan_inf + db_with_limits (remove_nan_inf.py:23-34, db_with_limits.py:20-24):
+//   with p = .5 per sample: 5 % of the (channel, pixel) values are multiplied by U(1,10) (half of
+//   them) or U(0,1) (the other half); with p = .5 per sample the ping axis of data and labels is
+//   flipped; non-finite -> 0 (label -> -100 where channel 0 is non-finite); 10*log10(x+1e-10) in [-75,0].
+// One pass: NCHW fp32 linear sv in -> NHWC activations (the first conv's input) + int16 labels out.
+// Randomness: Philox4x32-10 keyed on (seed, sample), counter = element index -- reproducible and
+// independent of the launch geometry; oracle/augment_oracle.py restates the same generator in numpy.
+#include "common.h"
+
+namespace {
+
+struct u4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ u4 philox4x32_10(u4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+    u4 n;
+    n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (unsigned)p1;
+    n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (unsigned)p0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void augment_db_kernel(
+    const float* __restrict__ data, const void* __restrict__ labels_in, int label_bytes,
+    T* __restrict__ out, short* __restrict__ labels_out, int B, int C, int H, int W, int ld,
+    unsigned seed_lo, unsigned seed_hi, int do_noise, int do_flip, float p_apply, float p_change) {
+  const long HW = (long)H * W, npix = (long)B * HW;
+  for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix;
+       pix += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(pix / HW);
+    const long hw = pix % HW;
+    const int y = (int)(hw / W), x = (int)(hw % W);
+    // per-sample decisions: counter (0,0,0,0xA5A5A5A5), key (seed_lo ^ b, seed_hi)
+    const u4 s = philox4x32_10(u4{0u, 0u, 0u, 0xA5A5A5A5u}, seed_lo ^ (unsigned)b, seed_hi);
+    const bool noisy = do_noise && u01(s.x) < p_apply;
+    const bool flip = do_flip && u01(s.y) < p_apply;
+    const int xo = flip ? W - 1 - x : x;
+    float v[16];
+    bool nonfinite0 = false;
+    for (int c = 0; c < C; ++c) {
+      float d = data[((long)b * C + c) * HW + hw];
+      if (noisy) {
+        const u4 r = philox4x32_10(u4{(unsigned)(c * HW + hw), (unsigned)((c * HW + hw) >> 32), 1u, 0u},
+                                   seed_lo ^ (unsigned)b, seed_hi);
+        if (u01(r.x) < p_change) d *= (u01(r.y) < 0.5f) ? (1.0f + 9.0f * u01(r.z)) : u01(r.w);
+      }
+      if (!isfinite(d)) { if (c == 0) nonfinite0 = true; d = 0.f; }
+      d = 10.f * log10f(d + 1e-10f);
+      v[c] = fminf(fmaxf(d, -75.f), 0.f);
+    }
+    for (int c = C; c < ld; ++c) v[c] = 0.f;
+    T* dst = out + (((long)b * H + y) * W + xo) * ld;
+    for (int c0 = 0; c0 < ld; c0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = v[c0 + j];
+      store8(dst + c0, t);
+    }
+    if (labels_out) {
+      long l = 0;
+      if (labels_in) {
+        if (label_bytes == 8) l = ((const long long*)labels_in)[pix];
+        else if (label_bytes == 4) l = ((const int*)labels_in)[pix];
+        else l = ((const short*)labels_in)[pix];
+      }
+      if (nonfinite0) l = -100;
+      labels_out[((long)b * H + y) * W + xo] = (short)l;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* labels_in, int label_bytes,
+                                      void* out, short* labels_out, int B, int C, int H, int W, long ld,
+                                      unsigned long long seed, int do_noise, int do_flip, void* stream) {
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "augment_db_nhwc: bad precision %d", prec);
+  CRIMAC_REQUIRE(data && out && B > 0 && C > 0 && C <= 16 && H > 0 && W > 0 && ld >= C && ld <= 16 && ld % 8 == 0,
+                 "augment_db_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
+  CRIMAC_REQUIRE(!labels_in || label_bytes == 2 || label_bytes == 4 || label_bytes == 8,
+                 "augment_db_nhwc: label_bytes=%d", label_bytes);
+  const long npix = (long)B * H * W;
+  long blocks = (npix + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (prec == CRIMAC_PREC_BF16)
+    hipLaunchKernelGGL(augment_db_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, data, labels_in,
+                       label_bytes, (bf16_t*)out, labels_out, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
+                       0.05f);
+  else
+    hipLaunchKernelGGL(augment_db_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, data, labels_in,
+                       label_bytes, (float*)out, labels_out, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
+                       0.05f);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}

@@ -308,6 +308,7 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
     // every split adds one fp32-atomic pass over dW (chip-wide atomic rate ~1.3 TB/s): keep at
     // least ~4096 contraction pixels per split so the atomics stay below the MFMA time
     long max_splits = ((long)p.B * p.Hf * p.Wf) / 4096;
+    if (max_splits < 1) max_splits = 1;
     // ... unless that leaves fewer than two workgroups per CU: then parallelism is worth more
     while (max_splits * ch_tiles < 512 && max_splits * 2 <= ((long)p.B * p.Hf * p.Wf) / 1024) max_splits *= 2;
     if (splits > max_splits) splits = (int)max_splits;

@@ -551,6 +551,9 @@ class UNetEngine:
         ``grad_sync(flat_grad) -> scale`` may all-reduce the flat gradient in place.
         """
         logits = self.forward(x, training=True)
+        return self._loss_backward_update(logits, labels, class_w, lr, momentum, grad_sync, ignore_index)
+
+    def _loss_backward_update(self, logits, labels, class_w, lr, momentum, grad_sync, ignore_index):
         sums = self.stat[0:2]
         sums, labels = self.ce_forward(logits, labels, class_w, ignore_index, sums=sums)
         dl = self.ce_backward(logits, labels, class_w, sums, 1.0, ignore_index)
@@ -560,3 +563,34 @@ class UNetEngine:
             scale = grad_sync(self.flat_g)
         self.sgd_step(lr, momentum, grad_scale=scale)
         return (sums[0] / sums[1]).float()
+
+    # ------------------------------------------------------------------------------------------
+    # on-GPU augmentation (BASELINE configs[4]; reference: batch/data_augmentation/*)
+    # ------------------------------------------------------------------------------------------
+    def augment_batch(self, data_linear, labels, seed, do_noise=True, do_flip=True):
+        """add_noise + flip_x_axis + remove_nan_inf + db_with_limits + NCHW->NHWC in one kernel.
+
+        data_linear [B,C,H,W] fp32 LINEAR sv on the GPU, labels [B,H,W] int16/32/64 (or None).
+        Returns (x_nhwc [B*H*W,16] in the engine's storage type, labels int16 [B,H,W])."""
+        self.bind()
+        if not data_linear.is_cuda:
+            raise hip.HipLibraryError("augment_batch: data is not on a GPU")
+        data_linear = data_linear.contiguous().float()
+        B, C, H, W = data_linear.shape
+        if C != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} channels, got {C}")
+        x = self._buf("x_nhwc", (B * H * W, CIN_PAD))
+        lab_out = self._buf("aug.labels", (B, H, W), torch.int16)
+        lab_in = None if labels is None else self._labels(labels)
+        call("crimac_augment_db_nhwc", self.prec, ptr(data_linear), ptr(lab_in),
+             lab_in.element_size() if lab_in is not None else 0, ptr(x), ptr(lab_out), B, C, H, W, CIN_PAD,
+             int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if do_noise else 0, 1 if do_flip else 0)
+        return x, lab_out
+
+    def train_step_augmented(self, data_linear, labels, class_w, lr, momentum, seed, grad_sync=None,
+                             do_noise=True, do_flip=True, ignore_index=-100):
+        """Training step on RAW linear-sv crops: augmentation and dB transform run on the GPU."""
+        B, _, H, W = data_linear.shape
+        x, lab = self.augment_batch(data_linear, labels, seed, do_noise, do_flip)
+        logits = self.forward_nhwc(x, B, H, W, training=True)
+        return self._loss_backward_update(logits, lab, class_w, lr, momentum, grad_sync, ignore_index)

@@ -48,7 +48,7 @@ class SegPipe:
     def __init__(self, checkpoint_dir, data_mode, frequencies, patch_size, loss_type, lr, lr_reduction,
                  lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
-                 precision="bf16", loss_flush=50, **kwargs):
+                 precision="bf16", loss_flush=50, gpu_augment=False, random_seed=0, **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -79,6 +79,11 @@ class SegPipe:
 
         self.precision = precision
         self.loss_flush = max(int(loss_flush), 1)
+        # gpu_augment: the train Dataset hands RAW linear-sv crops (augmentation_function=None,
+        # data_transform_function=None) and add_noise / flip_x_axis / remove_nan_inf / db_with_limits
+        # run fused on the GPU (BASELINE configs[4]); default keeps the reference's numpy workers
+        self.gpu_augment = bool(gpu_augment)
+        self.random_seed = int(random_seed)
 
     # ------------------------------------------------------------------------------------------
     def load_model_params(self, checkpoint_path=None):
@@ -135,9 +140,15 @@ class SegPipe:
             inputs_train = batch["data"].float().to(self.device, non_blocking=True)
             labels_train = batch["labels"].to(self.device, non_blocking=True)
             self.model.train()
-            loss = engine.train_step(inputs_train, labels_train, criterion.weight,
-                                     optimizer.param_groups[0]["lr"], self.momentum,
-                                     grad_sync=grad_sync)
+            if self.gpu_augment:
+                rank = parallel.env_world()[1]
+                loss = engine.train_step_augmented(
+                    inputs_train, labels_train, criterion.weight, optimizer.param_groups[0]["lr"],
+                    self.momentum, seed=(self.random_seed << 40) ^ (rank << 32) ^ i, grad_sync=grad_sync)
+            else:
+                loss = engine.train_step(inputs_train, labels_train, criterion.weight,
+                                         optimizer.param_groups[0]["lr"], self.momentum,
+                                         grad_sync=grad_sync)
             pending.append((i + 1, loss))
             if len(pending) >= self.loss_flush:
                 flush()
@@ -278,12 +289,13 @@ class SegPipe:
 class SegPipeUNet(SegPipe):
     """``SegPipe`` with the U-Net of the reference (pipeline.py:379-410)."""
 
-    def __init__(self, checkpoint_dir=None, **kwargs):
+    def __init__(self, checkpoint_dir=None, start_filts=64, depth=5, **kwargs):
         super().__init__(checkpoint_dir, **kwargs)
         if self.late_meta_inject:
             raise NotImplementedError("UNet_LateMetInject is not on the accelerated path")
+        # reference: depth 5, 64 filters (pipeline.py:390-398); start_filts=128 is BASELINE configs[4]
         self.model = UNet_Baseline(n_classes=3, in_channels=4 + get_in_channels(self.meta_channels),
-                                   late_meta_inject=False, depth=5, start_filts=64,
+                                   late_meta_inject=False, depth=depth, start_filts=start_filts,
                                    up_mode="transpose", merge_mode="concat", precision=self.precision)
 
 

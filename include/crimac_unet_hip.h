@@ -185,6 +185,18 @@ int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int
                            const float* data0, int data_ping0, int data_pings, int seabed_pad, float* out,
                            void* stream);
 
+/* ---- on-GPU training augmentation + data transform (BASELINE configs[4]) -------------------------- */
+
+/* add_noise + flip_x_axis (batch/data_augmentation/add_noise.py:21-41, flip_x_axis.py:21-25) fused
+ * with remove_nan_inf + db_with_limits and the NCHW->NHWC conversion: data [B][C][H][W] fp32 LINEAR sv,
+ * labels_in [B][H][W] int16/32/64 (or NULL) -> out NHWC [B*H*W][ld] dB activations, labels_out int16
+ * (NULL to skip; flipped with the data, -100 where channel 0 is non-finite).  Per sample with p=.5:
+ * 5 % of the values x U(1,10) or x U(0,1) (half each); per sample with p=.5: ping axis flipped.
+ * Randomness: Philox4x32-10 keyed on (seed, sample index), counter = element index. */
+int crimac_augment_db_nhwc(int prec, const float* data, const void* labels_in, int label_bytes, void* out,
+                           short* labels_out, int B, int C, int H, int W, long ld,
+                           unsigned long long seed, int do_noise, int do_flip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,67 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  numpy restatement of the on-GPU augmentation + data transform.
+
+Arithmetic follows the reference: add_noise (batch/data_augmentation/add_noise.py:21-41), flip_x_axis
+(flip_x_axis.py:21-25), remove_nan_inf (remove_nan_inf.py:23-34), db_with_limits
+(db_with_limits.py:20-24, :36-38).  The reference draws from numpy's global MT19937 in DataLoader
+workers; the GPU path draws from Philox4x32-10 keyed on (seed, sample) with the element index as
+counter, restated here bit for bit so the arithmetic can be compared exactly; the DISTRIBUTIONS
+(p=.5 per sample, 5 % of values, half U(1,10) / half U(0,1), p=.5 flip) are what the reference
+specifies and are checked statistically in tests/test_augment.py against the reference functions.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (Salmon et al. 2011); all arguments uint64 arrays holding 32-bit values."""
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) for v in (c0, c1, c2, c3))
+    k0 = np.uint64(k0) & MASK
+    k1 = np.uint64(k1) & MASK
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & MASK, p1 & MASK, \
+                         ((p0 >> np.uint64(32)) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0 = (k0 + np.uint64(W0)) & MASK
+        k1 = (k1 + np.uint64(W1)) & MASK
+    return c0, c1, c2, c3
+
+
+def u01(x):
+    return (np.asarray(x, dtype=np.uint64) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def augment_db(data, labels, seed, do_noise=True, do_flip=True):
+    """data [B,C,H,W] float32 linear sv, labels [B,H,W] -> (dB data [B,C,H,W] float32, labels int16,
+    noisy[B], flipped[B])."""
+    B, C, H, W = data.shape
+    out = np.empty_like(data, dtype=np.float32)
+    lab_out = np.empty(labels.shape, dtype=np.int16)
+    noisy_f, flip_f = np.zeros(B, bool), np.zeros(B, bool)
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    idx = np.arange(C * H * W, dtype=np.uint64)
+    for b in range(B):
+        s = philox4x32_10([0], [0], [0], [0xA5A5A5A5], lo ^ b, hi)
+        noisy = bool(do_noise and u01(s[0])[0] < 0.5)
+        flip = bool(do_flip and u01(s[1])[0] < 0.5)
+        d = data[b].astype(np.float32).copy()
+        if noisy:
+            r = philox4x32_10(idx & MASK, idx >> np.uint64(32), np.ones_like(idx), np.zeros_like(idx), lo ^ b, hi)
+            change = u01(r[0]) < np.float32(0.05)
+            inc = u01(r[1]) < np.float32(0.5)
+            f = np.where(inc, np.float32(1.0) + np.float32(9.0) * u01(r[2]), u01(r[3])).astype(np.float32)
+            d = (d.reshape(-1) * np.where(change, f, np.float32(1.0))).reshape(C, H, W).astype(np.float32)
+        nonfinite0 = ~np.isfinite(d[0])
+        d = np.where(np.isfinite(d), d, np.float32(0))
+        with np.errstate(divide="ignore"):
+            d = np.clip(np.float32(10) * np.log10(d + np.float32(1e-10)), -75, 0).astype(np.float32)
+        lab = labels[b].astype(np.int64).copy()
+        lab[nonfinite0] = -100
+        if flip:
+            d = d[:, :, ::-1]
+            lab = lab[:, ::-1]
+        out[b], lab_out[b] = d, lab.astype(np.int16)
+        noisy_f[b], flip_f[b] = noisy, flip
+    return out, lab_out, noisy_f, flip_f

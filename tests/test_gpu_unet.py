@@ -284,3 +284,61 @@ def test_cpu_module_fails_loudly():
     m = pkg.UNet_Baseline(3, 4)
     with pytest.raises(Exception, match="no CPU fallback"):
         m(torch.zeros(1, 4, 32, 32))
+
+
+def test_wide_net_start_filts_128_matches_oracle():
+    """BASELINE configs[4] architecture (2x channels): eval logits and a train-step loss vs the oracle."""
+    sd = synth.synth_state_dict(start_filts=128, seed=2)
+    x = torch.from_numpy(synth.synth_echogram_batch(1, 4, 32, 32, seed=4))
+    lab = torch.from_numpy(synth.synth_labels(1, 32, 32, seed=5))
+    m = pkg.UNet_Baseline(3, 4, start_filts=128, precision="f32x6")
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    assert rel(out, orc.predict(sd, x)) < 1e-5
+    ref_loss, _, ref_grads, _ = orc.loss_and_grads(sd, x, lab)
+    m.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    loss = crit(m(x.cuda()), lab.long().cuda())
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    assert l2rel(m.conv_final.weight.grad, ref_grads["conv_final.weight"]) < 1e-3
+
+
+def test_train_model_loop_with_logger_and_lr_schedule(tmp_path):
+    """SegPipe.train_model (pipeline.py:144-203) on an in-memory loader: loss logging with the original
+    global steps, LR schedule, validation + best.pt / last.pt checkpoints."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(precision="bf16", batch_size=2, iterations=6, log_step=3, lr_step=2, save_model_params=True,
+               loss_flush=4)
+    ckpt = tmp_path / "exp" / "ts"
+    pipe = pkg.SegPipeUNet(checkpoint_dir=ckpt, experiment_name="t", **cfg)
+    pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+    x = synth.synth_echogram_batch(2, 4, 64, 64, seed=1)
+    lab = synth.synth_labels(2, 64, 64, seed=2, p=(0.6, 0.2, 0.15, 0.05))
+    batch = {"data": torch.from_numpy(x), "labels": torch.from_numpy(lab),
+             "center_coordinates": torch.zeros(2, 2, dtype=torch.int64)}
+    train = [batch] * 6
+    test = [batch] * 2
+
+    class Logger:
+        def __init__(self):
+            self.scalars = []
+
+        def add_scalar(self, tag, scalar_value, global_step):
+            self.scalars.append((tag, float(scalar_value), int(global_step)))
+
+        def add_pr_curve(self, **kw):
+            self.scalars.append(("pr_curve", 0.0, int(kw["global_step"])))
+    lg = Logger()
+    pipe.train_model(train, test, lg)
+    losses = [(s, v) for t, v, s in lg.scalars if t == "train/loss"]
+    assert [s for s, _ in losses] == [1, 2, 3, 4, 5, 6] and losses[-1][1] < losses[0][1]
+    lrs = [v for t, v, s in lg.scalars if t == "learning_rate_0"]
+    assert np.allclose(lrs, [0.0025, 0.00125, 0.000625])
+    assert [s for t, v, s in lg.scalars if t == "test/F1_score"] == [3, 6]
+    assert (ckpt / "best.pt").exists() and (ckpt / "last.pt").exists()
+    sd = torch.load(ckpt / "last.pt", map_location="cpu")
+    assert list(sd.keys()) == list(synth.unet_state_shapes().keys())
