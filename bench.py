@@ -86,6 +86,7 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    local = local % max(torch.cuda.device_count(), 1)     # (rehearsals with several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist

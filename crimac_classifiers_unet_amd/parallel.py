@@ -32,11 +32,11 @@ def init_distributed(backend=None):
         return world, rank, local
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CRIMAC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 
