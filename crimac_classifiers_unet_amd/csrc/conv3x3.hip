@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -37,13 +38,7 @@ struct ConvParams {
   int Cin, N;
   const unsigned short* w_hi;
   const unsigned short* w_lo;
-  const float* bias;
-  void* out;
-  long out_ld;
-  int relu;
-  double* stat_sum;
-  double* stat_sumsq;
-  int stat_replicas;
+  EpiParams epi;
   int tiles_y, tiles_x;
 };
 
@@ -273,81 +268,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   }
   if (s < nsteps) step(I0{}, s);
 
-  // ---- epilogue -----------------------------------------------------------------------------------
-  unsigned char* stage = smem;                                   // [BM][STAGE_PITCH]
-  float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);    // [2][BN]
-  const bool do_stats = p.stat_sum != nullptr;
-  const bool full_tile = (y0 + TR <= p.H) && (x0 + TC <= p.W);
-  if (do_stats)
-    for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
-  float cs1[NT], cs2[NT];       // per-lane column partial sums (BatchNorm statistics)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = wc * (BN / 2) + j * 32 + fr;
-    const float bv = p.bias ? p.bias[n0 + col] : 0.f;
-    cs1[j] = 0.f;
-    cs2[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        float v = acc[i][j][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        const TA q = (TA)v;
-        *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = q;
-        // statistics of the value as STORED, rows outside the image excluded
-        const float vs = (float)q;
-        const bool ok = full_tile || ((y0 + (row >> 4) < p.H) && (x0 + (row & 15) < p.W));
-        cs1[j] += ok ? vs : 0.f;
-        cs2[j] += ok ? vs * vs : 0.f;
-      }
-  }
-  __syncthreads();
-  if (do_stats) {
-    // rows live in registers and in the two lane halves: one shuffle, then one LDS add per column
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float t1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
-      const float t2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (fh == 0) {
-        const int col = wc * (BN / 2) + j * 32 + fr;
-        atomicAdd(&sstat[col], t1);
-        atomicAdd(&sstat[BN + col], t2);
-      }
-    }
-  }
-  {
-    constexpr int CPR = BN / 8;            // 8-channel chunks per row
-    constexpr int RPP = 256 / CPR;         // rows per pass
-    const int c8 = tid % CPR, r0 = tid / CPR;
-    TA* outp = reinterpret_cast<TA*>(p.out);
-#pragma unroll
-    for (int rr = 0; rr < BM / RPP; ++rr) {
-      const int row = r0 + rr * RPP;
-      const int y = y0 + (row >> 4), x = x0 + (row & 15);
-      if (full_tile || (y < p.H && x < p.W)) {
-        const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
-        TA* dst = outp + (((long)b * p.H + y) * p.W + x) * p.out_ld + n0 + c8 * 8;
-        if constexpr (X3) {
-          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
-          *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
-        } else {
-          *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sp);
-        }
-      }
-    }
-  }
-  if (do_stats) {
-    __syncthreads();
-    // thousands of workgroups add to the same N channels: spread them over replicas (the atomic
-    // unit serialises same-address adds), bn_finalize sums the replicas
-    const long rep = (long)(blockIdx.x % (unsigned)p.stat_replicas) * p.N;
-    for (int c = tid; c < BN; c += 256) {
-      atomicAdd(&p.stat_sum[rep + n0 + c], (double)sstat[c]);
-      atomicAdd(&p.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
-    }
-  }
+  // ---- epilogue (conv_epilogue.h): bias/ReLU, fused reductions, LDS-staged coalesced stores -------
+  conv_epilogue<TA, BN, BM, 256, MT, NT>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
 }
 
 template <typename TA, int NPL, int BN, int BK, int TR>
@@ -375,13 +297,13 @@ int launch(ConvParams p, hipStream_t st) {
 
 // conv3x3_glds.hip: bf16 direct-to-LDS variant
 int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                             const void* w_hi, const float* bias, void* out, long out_ld, int relu,
-                             double* stat_sum, double* stat_sumsq, int stat_replicas, hipStream_t st);
+                             const void* w_hi, const EpiParams& epi, hipStream_t st);
 
 extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
                               const void* w_hi, const void* w_lo, const float* bias, void* out,
-                              long out_ld, int relu, double* stat_sum, double* stat_sumsq,
-                              int stat_replicas, void* stream) {
+                              long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
+                              int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
+                              long bnb_stride, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
@@ -389,29 +311,33 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
                  "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
   CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && in && w_hi && out, "conv3x3: bad arguments");
   CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "conv3x3: split precisions need the low weight plane(s)");
-  CRIMAC_REQUIRE((stat_sum == nullptr) == (stat_sumsq == nullptr), "conv3x3: stat pointers come together");
-  CRIMAC_REQUIRE(!stat_sum || stat_replicas >= 1, "conv3x3: stat_replicas must be >= 1");
+  CRIMAC_REQUIRE(stat_mode >= 0 && stat_mode <= 2, "conv3x3: stat_mode=%d", stat_mode);
+  CRIMAC_REQUIRE(stat_mode == 0 || (stat_sum && stat_sumsq && stat_replicas >= 1),
+                 "conv3x3: stat_mode %d needs both accumulators and replicas >= 1", stat_mode);
+  CRIMAC_REQUIRE(stat_mode != 2 || (bnb_y && bnb_vec && bnb_y_ld >= N && bnb_y_ld % 8 == 0 && bnb_stride >= N),
+                 "conv3x3: stat_mode 2 needs y, its pixel stride and the BatchNorm vectors");
   ConvParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
-  p.w_hi = (const unsigned short*)w_hi; p.w_lo = (const unsigned short*)w_lo; p.bias = bias;
-  p.out = out; p.out_ld = out_ld; p.relu = relu; p.stat_sum = stat_sum; p.stat_sumsq = stat_sumsq;
-  p.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
+  p.w_hi = (const unsigned short*)w_hi; p.w_lo = (const unsigned short*)w_lo;
+  EpiParams& e = p.epi;
+  e.bias = bias; e.out = out; e.out_ld = out_ld; e.relu = relu; e.H = H; e.W = W; e.N = N;
+  e.stat_mode = stat_mode; e.stat_sum = stat_mode ? stat_sum : nullptr; e.stat_sumsq = stat_sumsq;
+  e.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
+  e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
   hipStream_t st = (hipStream_t)stream;
   const bool n128 = N % 128 == 0;
-  // 256-pixel tiles when the image holds them and the layer is MFMA-bound
+  // measured (tools/bench_conv.py): the 256-pixel tile of THIS kernel (4 waves, 1 workgroup/CU) loses
+  // 5-20 % to the 128-pixel tile (2 workgroups/CU) on every layer -- occupancy beats LDS traffic here
   static const int force_tr = getenv("CRIMAC_CONV_TR") ? atoi(getenv("CRIMAC_CONV_TR")) : 0;
-  // measured (tools/bench_conv.py): the 256-pixel tile (1 workgroup/CU) loses 5-20 % to the
-  // 128-pixel tile (2 workgroups/CU) on every layer -- occupancy beats LDS traffic here
   const bool big = force_tr == 16;
   static const int force_bk = getenv("CRIMAC_CONV_BK") ? atoi(getenv("CRIMAC_CONV_BK")) : 0;
   // bf16 with 64-deep channel chunks: LDS-DMA streaming kernel (CRIMAC_CONV_GLDS=0 selects the
-  // register-staged kernel below, kept for A/B measurements and as the fp32-mode structure)
+  // register-staged kernel below, kept for A/B measurements and as the fp32-mode structure).
   // Measured (tools/bench_conv.py, B=32): +8-18 % on every layer with N >= 128, -10 % on the N = 64
   // layers (HBM-heavy, want more workgroups per CU) -> used for N % 128 == 0 only.
   static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
   if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && (use_glds == 2 || (use_glds == 1 && n128)))
-    return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, bias, out, out_ld, relu, stat_sum,
-                                    stat_sumsq, stat_replicas, st);
+    return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, e, st);
   if (prec == CRIMAC_PREC_BF16) {
     // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
     // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -26,13 +27,7 @@ struct ConvParams {
   int B, H, W;
   int Cin, N;
   const unsigned short* w_hi;
-  const float* bias;
-  void* out;
-  long out_ld;
-  int relu;
-  double* stat_sum;
-  double* stat_sumsq;
-  int stat_replicas;
+  EpiParams epi;
   int tiles_y, tiles_x;
 };
 
@@ -62,7 +57,6 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p) {
   constexpr int B_INSTR = BN / 8;                  // wave-instructions per weight tile
   constexpr int NB = B_INSTR / NWAVES;             // ... per wave (2 for BN 128, 1 for BN 64)
   static_assert(B_INSTR % NWAVES == 0, "weight tile must split evenly over the waves");
-  constexpr int STAGE_PITCH = BN * 2 + 16;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   auto sA = [&](int buf) { return smem + buf * A_BYTES; };
@@ -227,72 +221,8 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p) {
     if (++slot == 3) slot = 0;
   }
 
-  // ---- epilogue (as conv3x3.hip): bias/ReLU, BN statistics, LDS-staged coalesced stores -------------
-  unsigned char* stage = smem;
-  float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);
-  const bool do_stats = p.stat_sum != nullptr;
-  const bool full_tile = (y0 + TR <= p.H) && (x0 + TC <= p.W);
-  if (do_stats)
-    for (int i = tid; i < 2 * BN; i += 512) sstat[i] = 0.f;
-  float cs1[NT], cs2[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = wc * (BN / 2) + j * 32 + fr;
-    const float bv = p.bias ? p.bias[n0 + col] : 0.f;
-    cs1[j] = 0.f;
-    cs2[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        float v = acc[i][j][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        const bf16_t q = (bf16_t)v;
-        *reinterpret_cast<bf16_t*>(stage + row * STAGE_PITCH + col * 2) = q;
-        const float vs = (float)q;
-        const bool ok = full_tile || ((y0 + (row >> 4) < p.H) && (x0 + (row & 15) < p.W));
-        cs1[j] += ok ? vs : 0.f;
-        cs2[j] += ok ? vs * vs : 0.f;
-      }
-  }
-  __syncthreads();
-  if (do_stats) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float t1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
-      const float t2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (fh == 0) {
-        const int col = wc * (BN / 2) + j * 32 + fr;
-        atomicAdd(&sstat[col], t1);
-        atomicAdd(&sstat[BN + col], t2);
-      }
-    }
-  }
-  {
-    constexpr int CPR = BN / 8;
-    constexpr int RPP = 512 / CPR;
-    const int cc = tid % CPR, r0 = tid / CPR;
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-#pragma unroll
-    for (int rr = 0; rr < BM / RPP; ++rr) {
-      const int row = r0 + rr * RPP;
-      const int y = y0 + (row >> 4), x = x0 + (row & 15);
-      if (full_tile || (y < p.H && x < p.W)) {
-        const bf16_t* sp = reinterpret_cast<const bf16_t*>(stage + row * STAGE_PITCH) + cc * 8;
-        bf16_t* dst = outp + (((long)b * p.H + y) * p.W + x) * p.out_ld + n0 + cc * 8;
-        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sp);
-      }
-    }
-  }
-  if (do_stats) {
-    __syncthreads();
-    const long rep = (long)(blockIdx.x % (unsigned)p.stat_replicas) * p.N;
-    for (int c = tid; c < BN; c += 512) {
-      atomicAdd(&p.stat_sum[rep + n0 + c], (double)sstat[c]);
-      atomicAdd(&p.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
-    }
-  }
+  // ---- epilogue (conv_epilogue.h): bias/ReLU, fused reductions, LDS-staged coalesced stores -------
+  conv_epilogue<bf16_t, BN, BM, 512, 2, NT>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
 }
 
 template <int BN>
@@ -316,11 +246,10 @@ int launch(ConvParams p, hipStream_t st) {
 
 // bf16, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
 int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                             const void* w_hi, const float* bias, void* out, long out_ld, int relu,
-                             double* stat_sum, double* stat_sumsq, int stat_replicas, hipStream_t st) {
+                             const void* w_hi, const EpiParams& epi, hipStream_t st) {
   ConvParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
-  p.w_hi = (const unsigned short*)w_hi; p.bias = bias; p.out = out; p.out_ld = out_ld; p.relu = relu;
-  p.stat_sum = stat_sum; p.stat_sumsq = stat_sumsq; p.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
+  p.w_hi = (const unsigned short*)w_hi;
+  p.epi = epi;
   return N % 128 == 0 ? launch<128>(p, st) : launch<64>(p, st);
 }

@@ -1,0 +1,155 @@
+// Shared epilogue of the 3x3 convolution kernels (conv3x3.hip, conv3x3_glds.hip).
+//
+//   bias (+ReLU) in registers -> tile staged through LDS -> coalesced 16-byte stores, plus one of
+//   the fused per-channel reductions (fp64 atomics spread over `stat_replicas` accumulators):
+//     stat_mode 1: sum / sum of squares of the STORED output (BatchNorm batch statistics of the
+//                  layer the convolution feeds, unet.py:78,81,121-122);
+//     stat_mode 2: BatchNorm+ReLU BACKWARD sums of the layer the (input-gradient) convolution feeds:
+//                  with da = this output, y = that layer's saved conv output, dz = da * [y*scale+shift > 0],
+//                  xhat = (y-mean)*invstd:  stat_sum += sum dz, stat_sumsq += sum dz*xhat
+//                  -- the bn_bwd_reduce pass over (da, y) is fused away.
+#pragma once
+#include "common.h"
+
+struct EpiParams {
+  const float* bias;
+  void* out;
+  long out_ld;
+  int relu, H, W, N;
+  double* stat_sum;
+  double* stat_sumsq;
+  int stat_replicas;
+  int stat_mode;
+  const void* bnb_y;      // [pixels][bnb_y_ld], same pixel grid as the output
+  long bnb_y_ld;
+  const float* bnb_vec;   // rows: mean, invstd, scale, shift; row stride bnb_stride
+  long bnb_stride;
+};
+
+// acc[MT][NT]: wave (wr, wc) holds rows wr*MT*32 + i*32 + ..., cols wc*(BN/2) + j*32 + lane%32.
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MT][NT], const EpiParams& e,
+                                              unsigned char* smem, int b, int y0, int x0, int n0,
+                                              int tile_rows, int wr, int wc) {
+  constexpr int TCOLS = 16;
+  constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;
+  constexpr bool F32 = sizeof(TA) == 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int fr = lane & 31, fh = lane >> 5;
+  unsigned char* stage = smem;                                           // [BM][STAGE_PITCH]
+  float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);     // [2][BN]
+  const int mode = e.stat_sum ? e.stat_mode : 0;
+  const bool full_tile = (y0 + tile_rows <= e.H) && (x0 + TCOLS <= e.W);
+  if (mode)
+    for (int i = tid; i < 2 * BN; i += NTHREADS) sstat[i] = 0.f;
+  float cs1[NT], cs2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = wc * (BN / 2) + j * 32 + fr;
+    const float bv = e.bias ? e.bias[n0 + col] : 0.f;
+    cs1[j] = 0.f;
+    cs2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float v = acc[i][j][r] + bv;
+        if (e.relu) v = fmaxf(v, 0.f);
+        const TA q = (TA)v;
+        *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = q;
+        const float vs = (float)q;       // statistics of the value as STORED
+        const bool ok = full_tile || ((y0 + (row >> 4) < e.H) && (x0 + (row & 15) < e.W));
+        cs1[j] += ok ? vs : 0.f;
+        cs2[j] += ok ? vs * vs : 0.f;
+      }
+  }
+  __syncthreads();
+  if (mode == 1) {
+    // rows live in registers and in the two lane halves: one shuffle, then one LDS add per column
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float t1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
+      const float t2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (fh == 0) {
+        const int col = wc * (BN / 2) + j * 32 + fr;
+        atomicAdd(&sstat[col], t1);
+        atomicAdd(&sstat[BN + col], t2);
+      }
+    }
+  }
+  {
+    constexpr int CPR = BN / 8;                 // 8-channel chunks per row
+    constexpr int RPP = NTHREADS / CPR;         // rows per pass
+    const int c8 = tid % CPR, r0 = tid / CPR;
+    TA* outp = reinterpret_cast<TA*>(e.out);
+    float sc[8], sh[8], mu[8], is[8], d1[8], d2[8];
+    if (mode == 2) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = n0 + c8 * 8 + k;
+        mu[k] = e.bnb_vec[c];
+        is[k] = e.bnb_vec[e.bnb_stride + c];
+        sc[k] = e.bnb_vec[2 * e.bnb_stride + c];
+        sh[k] = e.bnb_vec[3 * e.bnb_stride + c];
+        d1[k] = 0.f;
+        d2[k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < BM / RPP; ++rr) {
+      const int row = r0 + rr * RPP;
+      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      if (full_tile || (y < e.H && x < e.W)) {
+        const long pix = ((long)b * e.H + y) * e.W + x;
+        const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
+        TA* dst = outp + pix * e.out_ld + n0 + c8 * 8;
+        if constexpr (F32) {
+          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
+          *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+        } else {
+          *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sp);
+        }
+        if (mode == 2) {
+          float g[8], yv[8];
+          load8(sp, g);
+          load8(reinterpret_cast<const TA*>(e.bnb_y) + pix * e.bnb_y_ld + n0 + c8 * 8, yv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float dz = (yv[k] * sc[k] + sh[k]) > 0.f ? g[k] : 0.f;
+            d1[k] += dz;
+            d2[k] += dz * (yv[k] - mu[k]) * is[k];
+          }
+        }
+      }
+    }
+    if (mode == 2) {
+      // threads of one chunk sit CPR lanes apart: fold inside the wave, then one LDS add per wave
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) {
+          d1[k] += __shfl_xor(d1[k], o, 64);
+          d2[k] += __shfl_xor(d2[k], o, 64);
+        }
+      }
+      if (lane < CPR) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          atomicAdd(&sstat[c8 * 8 + k], d1[k]);
+          atomicAdd(&sstat[BN + c8 * 8 + k], d2[k]);
+        }
+      }
+    }
+  }
+  if (mode) {
+    __syncthreads();
+    // thousands of workgroups add to the same N channels: spread them over replicas (the atomic
+    // unit serialises same-address adds); the consumer sums the replicas
+    const long rep = (long)(blockIdx.x % (unsigned)e.stat_replicas) * e.N;
+    for (int c = tid; c < BN; c += NTHREADS) {
+      atomicAdd(&e.stat_sum[rep + n0 + c], (double)sstat[c]);
+      atomicAdd(&e.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
+    }
+  }
+}

@@ -227,6 +227,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
   }
 }
 
+// dst[i] = sum over replicas of src[r*stride + i]  (fp64 and/or fp32 destination);
+// 16 channels per workgroup, 16 threads per channel striding over the replicas
+__global__ __launch_bounds__(256) void sum_replicas_kernel(const double* __restrict__ src, int nrep,
+                                                           long stride, int n, double* dst64, float* dst32) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
+  double s = 0.0;
+  if (i < n)
+    for (int r = rl; r < nrep; r += 16) s += src[(long)r * stride + i];
+  red[cl][rl] = s;
+  __syncthreads();
+  if (rl != 0 || i >= n) return;
+  s = 0.0;
+  for (int r = 0; r < 16; ++r) s += red[cl][r];
+  if (dst64) dst64[i] = s;
+  if (dst32) dst32[i] = (float)s;
+}
+
 // ---- BN apply (+ReLU) (+2x2 max-pool) -------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, long y_ld,
@@ -751,6 +770,16 @@ extern "C" int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C
   else
     hipLaunchKernelGGL((colstats_kernel<float, float, 1>), dim3(grid), dim3(256), lds, ST,
                        (const float*)y, ld, M, C, sum, (float*)nullptr);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_sum_replicas(const double* src, int replicas, long stride, int n, double* dst_f64,
+                                   float* dst_f32, void* stream) {
+  CRIMAC_REQUIRE(src && (dst_f64 || dst_f32) && replicas >= 1 && n > 0 && stride >= n,
+                 "sum_replicas: bad arguments");
+  hipLaunchKernelGGL(sum_replicas_kernel, dim3(cdiv(n, 16)), dim3(256), 0, ST, src, replicas, stride, n,
+                     dst_f64, dst_f32);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

@@ -181,6 +181,7 @@ class UNetEngine:
         # sum[R][C], sumsq[R][C] (R replicas filled by the conv epilogues), sum_dz[C], sum_dz_xhat[C]
         self.stat = torch.zeros(2 + nb * (2 * STAT_REPLICAS + 2) * cmax, dtype=torch.float64, device=dev)
         self.cmax = cmax
+        self.bias_scr = torch.zeros(2 * STAT_REPLICAS * 2 * cmax, dtype=torch.float64, device=dev)
         # fp32 per BN layer: mean, invstd, scale, shift
         self.bnf = torch.zeros(nb * 4 * cmax, dtype=torch.float32, device=dev)
         self.class_w = None
@@ -274,20 +275,41 @@ class UNetEngine:
     # kernels wrappers
     # ------------------------------------------------------------------------------------------
     conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
+    fuse_bn_bwd = os.environ.get("CRIMAC_FUSE_BNB", "1") != "0"   # BN-backward sums inside the dgrad conv
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
-                 stats=None):
+                 stats=None, bnb=None):
+        """3x3 conv (forward planes, or dgrad planes).  ``stats=(sum, sumsq)``: fused statistics of
+        the stored output (stat_mode 1).  ``bnb=(block, y)``: the output is the ``da`` of that
+        BatchNorm block -> its backward sums are fused in (stat_mode 2, into the block's replica
+        accumulators).  Returns True if the requested fusion ran inside the conv kernel."""
         flops = 2.0 * 9 * (cin_real or cin) * cout * B * H * W
         w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
         if self.conv_impl == "halo":
+            mode, s0, s1, by, by_ld, bvec = 0, None, None, None, 0, None
+            if stats is not None:
+                mode, s0, s1 = 1, ptr(stats[0]), ptr(stats[1])
+            elif bnb is not None and self.fuse_bn_bwd:
+                blk, y = bnb
+                self._stat_fwd_region(blk).zero_()
+                mode, s0, s1 = 2, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1))
+                by, by_ld, bvec = y.p, y.ld, ptr(self._bnf(blk, 0))
             call("crimac_conv3x3", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
-                 out.p, out.ld, 1 if relu else 0, ptr(stats[0]) if stats else None,
-                 ptr(stats[1]) if stats else None, STAT_REPLICAS, flops=flops)
-            return
+                 out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
+                 flops=flops)
+            return mode != 0
         call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1, w_hi, w_lo,
              ptr(bias), cout, out.p, out.ld, 1 if relu else 0, 0, 0, flops=flops)
         if stats:
             call("crimac_colstats", self.prec, out.p, out.ld, B * H * W, cout, ptr(stats[0]), ptr(stats[1]))
+            return True
+        return False
+
+    def _stat_fwd_region(self, b):
+        """The [2][R][cmax] replica accumulators of BN layer b (sum and sumsq, contiguous)."""
+        R = STAT_REPLICAS
+        base = 2 + b.idx * (2 * R + 2) * self.cmax
+        return self.stat[base:base + 2 * R * self.cmax]
 
     def _upconv_fwd(self, x: Act, u, out: Act, B, H, W):
         pk = self.pk[u.key]
@@ -424,11 +446,24 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def _block_bwd(self, tag, b, da: Act, y: Act, x_in: Act, B, h, w, M, dx_out: Act, cs=None):
-        """Backward of conv3x3+BN+ReLU given da (grad of the block output)."""
-        call("crimac_bn_bwd_reduce", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
-             ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
-             ptr(self._stat(b, 2)), ptr(self._stat(b, 3)))
+    def _block_bwd(self, tag, b, da: Act, y: Act, x_in: Act, B, h, w, M, dx_out: Act, reduce_done=False,
+                   next_bn=None, bias_from_stats=None):
+        """Backward of conv3x3+BN+ReLU given da (grad of the block output).
+
+        reduce_done: the producer of ``da`` already accumulated this block's BatchNorm-backward sums
+        into its replica accumulators (conv3x3 stat_mode 2).  next_bn=(block, y): ``dx_out`` is the
+        ``da`` of that block -> fuse ITS sums into the dgrad convolution.  bias_from_stats=(grad, C):
+        also take the per-channel sums of the first C channels of ``dx_out`` (a transposed-conv bias
+        gradient) from the dgrad epilogue.  Returns whether next_bn's sums were fused."""
+        if reduce_done:
+            call("crimac_sum_replicas", ptr(self._stat(b, 0)), STAT_REPLICAS, b.cout, b.cout,
+                 ptr(self._stat(b, 2)), None)
+            call("crimac_sum_replicas", ptr(self._stat(b, 1)), STAT_REPLICAS, b.cout, b.cout,
+                 ptr(self._stat(b, 3)), None)
+        else:
+            call("crimac_bn_bwd_reduce", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
+                 ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
+                 ptr(self._stat(b, 2)), ptr(self._stat(b, 3)))
         dy = Act(self._buf(f"{tag}.dy", (M, b.cout)), b.cout)
         call("crimac_bn_bwd_apply", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
              ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), ptr(self._stat(b, 2)),
@@ -440,9 +475,22 @@ class UNetEngine:
              ptr(dw), self.wgrad_target_blocks, flops=2.0 * 9 * b.cin * b.cout * B * h * w)
         call("crimac_unpack_wgrad_conv3x3", ptr(dw), b.cout, b.cin, b.cin_pad,
              ptr(self.G[b.conv_key + ".weight"]))
+        fused = False
         if dx_out is not None:
-            self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
-                          dgrad=True)
+            stats = None
+            if bias_from_stats is not None and self.conv_impl == "halo":
+                self.bias_scr.zero_()
+                half = self.bias_scr.numel() // 2
+                stats = (self.bias_scr[:half], self.bias_scr[half:])
+            fused = self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                                  dgrad=True, stats=stats, bnb=next_bn if stats is None else None)
+            if stats is not None:
+                grad, C = bias_from_stats
+                call("crimac_sum_replicas", ptr(stats[0]), STAT_REPLICAS, b.cin, C, None, ptr(grad))
+            elif bias_from_stats is not None:
+                grad, C = bias_from_stats
+                call("crimac_colsum_f32", self.prec, dx_out.p, dx_out.ld, M, C, ptr(grad))
+        return fused and next_bn is not None
 
     wgrad_target_blocks = 0      # 0 = let the library pick the pixel-range split
 
@@ -472,13 +520,13 @@ class UNetEngine:
             b1, b2 = self.dec[j]
             x_prev, catA, y1, a1, y2, a2 = s[f"d{j}"]
             da1 = Act(self._buf(f"g.d{j}.a1", (M, c)), c)
-            self._block_bwd(f"g.d{j}.2", b2, d_cur, y2, a1, B, h, w, M, da1)
+            fused = self._block_bwd(f"g.d{j}.2", b2, d_cur, y2, a1, B, h, w, M, da1, next_bn=(b1, y1))
             dcat = Act(self._buf(f"g.d{j}.cat", (M, 2 * c)), 2 * c)
-            self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat)
+            # transposed conv bias gradient (unet.py:130) = column sums of dcat[:, :c]: from the dgrad epilogue
+            self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat, reduce_done=fused,
+                            bias_from_stats=(self.G[u.key + ".bias"], c))
             dup = dcat.slice(0, c)
             skip_grad[L] = dcat.slice(c, c)
-            # transposed conv backward (unet.py:130)
-            call("crimac_colsum_f32", self.prec, dup.p, dup.ld, M, c, ptr(self.G[u.key + ".bias"]))
             hp, wp, Mp = geo[L + 1]
             n = 4 * u.cin * u.cout
             dw = self._dw(u.key, n)
@@ -502,12 +550,12 @@ class UNetEngine:
                 call("crimac_unpool_add", self.prec, d_pool.p, d_pool.ld, a2.p, a2.ld, ds.p, ds.ld,
                      da2.p, da2.ld, B, h, w, c)
             da1 = Act(self._buf(f"g.e{i}.a1", (M, c)), c)
-            self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1)
+            fused = self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1, next_bn=(b1, y1))
             if i > 0:
                 d_pool = Act(self._buf(f"g.e{i}.xin", (M, b1.cin)), b1.cin)
-                self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool)
+                self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool, reduce_done=fused)
             else:
-                self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, None)
+                self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, None, reduce_done=fused)
 
     # ------------------------------------------------------------------------------------------
     # loss and optimiser

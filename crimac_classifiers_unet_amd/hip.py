@@ -25,7 +25,9 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "crimac_igemm_conv": [_i, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i,
                           _vp, _l, _i, _i, _i, _vp],
-    "crimac_conv3x3": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _vp],
+    "crimac_conv3x3": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i,
+                       _vp, _l, _vp, _l, _vp],
+    "crimac_sum_replicas": [_vp, _i, _l, _i, _vp, _vp, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_pack_upconv2x2": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -63,13 +63,21 @@ int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int W
 /* 3x3 convolution, stride 1, pad 1 (nn.Conv2d forward, unet.py:35-44; with the dgrad weight planes
  * of crimac_pack_conv3x3 it is the input gradient): halo tile staged once per channel chunk in LDS,
  * weights streamed two steps ahead, coalesced epilogue.  w_hi/w_lo: bf16 [9][N][Cin].
- * stat_sum/stat_sumsq (both or neither): per-output-channel sum / sum of squares of the STORED
- * output, added to fp64 accumulators [stat_replicas][N] (caller zeroes; workgroups spread over the
- * replicas to avoid same-address atomic serialisation; crimac_bn_finalize sums them) -- BatchNorm
- * batch statistics fused into the convolution (unet.py:78,81,121-122).  Cin % 16 == 0, N % 64 == 0. */
+ * Fused per-channel reductions into fp64 accumulators stat_sum / stat_sumsq [stat_replicas][N] (caller
+ * zeroes; workgroups spread over the replicas to avoid same-address atomic serialisation):
+ *   stat_mode 0: none;
+ *   stat_mode 1: sum / sum of squares of the STORED output -- BatchNorm batch statistics fused into the
+ *                convolution that feeds it (unet.py:78,81,121-122; finish with crimac_bn_finalize);
+ *   stat_mode 2: the output is `da` of a BatchNorm+ReLU backward: with y = bnb_y [pixels][bnb_y_ld] (that
+ *                layer's saved conv output) and bnb_vec rows (mean, invstd, scale, shift; row stride
+ *                bnb_stride): stat_sum += sum dz, stat_sumsq += sum dz*xhat, dz = da*[y*scale+shift > 0]
+ *                -- crimac_bn_bwd_reduce fused into the input-gradient convolution (finish with
+ *                crimac_sum_replicas, then crimac_bn_bwd_apply).
+ * Cin % 16 == 0, N % 64 == 0. */
 int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
                    const void* w_hi, const void* w_lo, const float* bias, void* out, long out_ld,
-                   int relu, double* stat_sum, double* stat_sumsq, int stat_replicas, void* stream);
+                   int relu, int stat_mode, double* stat_sum, double* stat_sumsq, int stat_replicas,
+                   const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, void* stream);
 
 /* Weight gradient (aten::convolution_backward weight half, pipeline.py:177):
  *   dw[t][f][s] += sum_pixels F[p][f] * S[shift_t(p)][s]   (fp32 atomics; caller zeroes dw)
@@ -109,6 +117,9 @@ int crimac_colstats(int prec, const void* y, long ld, long M, int C, double* sum
                     void* stream);
 /* Per-channel sum accumulated into fp32 (bias gradients). */
 int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C, float* sum, void* stream);
+/* dst[i] = sum_r src[r*stride + i], i < n, into fp64 and/or fp32 (either may be NULL). */
+int crimac_sum_replicas(const double* src, int replicas, long stride, int n, double* dst_f64,
+                        float* dst_f32, void* stream);
 /* Train-mode statistics -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale; running stats
  * updated with `momentum` (unbiased variance), num_batches_tracked += 1.
  * sum/sumsq are [replicas][C] partial accumulators that are added up first. */

@@ -36,7 +36,8 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_runs_without_gpu():
     """Argument checks precede any HIP call, so they are testable on the CPU box."""
     lib = hip.load_library()
-    rc = lib.crimac_conv3x3(0, None, 64, 1, 8, 8, 24, 64, None, None, None, None, 64, 0, None, None, 1, None)
+    rc = lib.crimac_conv3x3(0, None, 64, 1, 8, 8, 24, 64, None, None, None, None, 64, 0, 0, None, None, 1,
+                            None, 0, None, 0, None)
     assert rc < 0 and b"Cin" in lib.crimac_last_error()
     rc = lib.crimac_sgd_momentum(None, None, None, 0, 0.1, 0.9, 1.0, 0, None)
     assert rc < 0

@@ -368,9 +368,9 @@ def conv3x3_halo(prec, x_nhwc, in_ld, B, H, W, Cin, Cout, w_hi, w_lo, bias, relu
         out = torch.empty(B * H * W, Cout, dtype=_dt(prec), device="cuda")
     out_ld = out_ld or Cout
     call("crimac_conv3x3", hip.PREC_NAMES[prec], ptr(x_nhwc), in_ld, B, H, W, Cin, Cout, ptr(w_hi),
-         ptr(w_lo), ptr(bias), ptr(out, out_off), out_ld, 1 if relu else 0,
+         ptr(w_lo), ptr(bias), ptr(out, out_off), out_ld, 1 if relu else 0, 1 if stats is not None else 0,
          ptr(stats[0]) if stats is not None else None, ptr(stats[1]) if stats is not None else None,
-         stats.shape[1] if stats is not None else 1)
+         stats.shape[1] if stats is not None else 1, None, 0, None, 0)
     torch.cuda.synchronize()
     return out
 
@@ -413,7 +413,7 @@ def test_conv3x3_halo_strided_io_and_dgrad(prec):
     big_in[:, Ci:] = to_nhwc(x, prec)
     big_out = torch.full((B * H * W, 3 * Co), 7.0, dtype=_dt(prec), device="cuda")
     call("crimac_conv3x3", hip.PREC_NAMES[prec], ptr(big_in, Ci), 2 * Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl),
-         None, ptr(big_out, Co), 3 * Co, 0, None, None, 1)
+         None, ptr(big_out, Co), 3 * Co, 0, 0, None, None, 1, None, 0, None, 0)
     torch.cuda.synchronize()
     assert relerr(from_nhwc(big_out[:, Co:2 * Co].contiguous(), B, H, W), ref) < TOL[prec]
     assert float((big_out[:, :Co].float() - 7).abs().max()) == 0 and \
@@ -423,3 +423,37 @@ def test_conv3x3_halo_strided_io_and_dgrad(prec):
     dyn = to_nhwc(dy, prec)
     dx = conv3x3_halo(prec, dyn, Co, B, H, W, Co, Ci, dh, dl, None)
     assert relerr(from_nhwc(dx, B, H, W), refg) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 24, 40, 128, 64), (2, 32, 32, 128, 256)])
+def test_conv3x3_dgrad_with_fused_bn_backward_sums(prec, shape):
+    """stat_mode 2: the dgrad convolution also produces sum dz / sum dz*xhat of the BatchNorm block its
+    output feeds (== crimac_bn_bwd_reduce on (da, y))."""
+    B, H, W, Ci, Co = shape          # conv Ci -> Co forward; dgrad maps dy[Co] -> da[Ci]
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+    y_prev = _round(torch.randn(B, Ci, H, W, generator=g) * 1.5 + 0.3, prec)     # saved conv output of the fed block
+    mean, invstd = torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5
+    scale, shift = (torch.rand(Ci, generator=g) + 0.5) * invstd, torch.randn(Ci, generator=g) * 0.3
+    _, _, dh, dl = pack_conv(w, prec)
+    M = B * H * W
+    R = 7
+    dyn, yn = to_nhwc(dy, prec), to_nhwc(y_prev, prec)
+    vec = torch.stack([mean, invstd, scale, shift]).contiguous().cuda()      # row stride Ci
+    acc = torch.zeros(2, R, Ci, dtype=torch.float64, device="cuda")
+    da = torch.empty(M, Ci, dtype=_dt(prec), device="cuda")
+    call("crimac_conv3x3", hip.PREC_NAMES[prec], ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dl), None, ptr(da), Ci,
+         0, 2, ptr(acc[0]), ptr(acc[1]), R, ptr(yn), Ci, ptr(vec), Ci)
+    # reference: the stand-alone reduction kernel on the SAME stored da
+    ref = torch.zeros(2, Ci, dtype=torch.float64, device="cuda")
+    call("crimac_bn_bwd_reduce", hip.PREC_NAMES[prec], ptr(da), Ci, ptr(yn), Ci, ptr(vec[2]), ptr(vec[3]),
+         ptr(vec[0]), ptr(vec[1]), M, Ci, ptr(ref[0]), ptr(ref[1]))
+    out = torch.zeros(2, Ci, dtype=torch.float64, device="cuda")
+    call("crimac_sum_replicas", ptr(acc[0]), R, Ci, Ci, ptr(out[0]), None)
+    call("crimac_sum_replicas", ptr(acc[1]), R, Ci, Ci, ptr(out[1]), None)
+    torch.cuda.synchronize()
+    refg = torch.nn.grad.conv2d_input((B, Ci, H, W), _round(w, prec), dy, padding=1)
+    assert relerr(from_nhwc(da, B, H, W), refg) < TOL[prec]
+    assert relerr(out[0].cpu(), ref[0].cpu()) < 1e-5 and relerr(out[1].cpu(), ref[1].cpu()) < 1e-5

@@ -50,7 +50,7 @@ def main():
         def conv():
             if a.impl == "halo":
                 call("crimac_conv3x3", P, ptr(x), Ci, B, H, H, Ci, Co, ptr(w_hi), ptr(w_lo), ptr(bias), ptr(out),
-                     Co, 0, ptr(stats[0]), ptr(stats[1]), 64)
+                     Co, 0, 1, ptr(stats[0]), ptr(stats[1]), 64, None, 0, None, 0)
             else:
                 call("crimac_igemm_conv", P, ptr(x), Ci, B, H, H, H, H, Ci, Co, 9, 3, 1, 1, ptr(w_hi), ptr(w_lo),
                      ptr(bias), Co, ptr(out), Co, 0, 0, 0)
