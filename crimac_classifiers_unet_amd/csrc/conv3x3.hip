@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   if (s < nsteps) step(I0{}, s);
 
   // ---- epilogue (conv_epilogue.h): bias/ReLU, fused reductions, LDS-staged coalesced stores -------
-  conv_epilogue<TA, BN, BM, 256, MT, NT>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
+  conv_epilogue<TA, BN, BM, 256, MT, NT, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
 }
 
 template <typename TA, int NPL, int BN, int BK, int TR>

@@ -26,16 +26,31 @@ struct EpiParams {
   long bnb_stride;
 };
 
-// acc[MT][NT]: wave (wr, wc) holds rows wr*MT*32 + i*32 + ..., cols wc*(BN/2) + j*32 + lane%32.
-template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MT][NT], const EpiParams& e,
+// Accumulator access for the two MFMA shapes (C/D layouts: cdna_hip_programming.md §3):
+//   32x32x16: acc[MT][NT] of f32x16, row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane & 31
+//   16x16x32: acc[MT][NT] of f32x4,  row = (lane>>4)*4 + r,               col = lane & 15
+template <typename ACC> struct AccLayout;
+template <> struct AccLayout<f32x16> {
+  static constexpr int TS = 32, NR = 16;
+  __device__ static __forceinline__ int row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+  __device__ static __forceinline__ int col(int lane) { return lane & 31; }
+};
+template <> struct AccLayout<f32x4> {
+  static constexpr int TS = 16, NR = 4;
+  __device__ static __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
+  __device__ static __forceinline__ int col(int lane) { return lane & 15; }
+};
+
+// acc[MT][NT]: wave (wr, wc) holds rows wr*MT*TS + i*TS + ..., cols wc*(BN/2) + j*TS + ... .
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC>
+__device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
                                               unsigned char* smem, int b, int y0, int x0, int n0,
                                               int tile_rows, int wr, int wc) {
+  using L = AccLayout<ACC>;
   constexpr int TCOLS = 16;
   constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;
   constexpr bool F32 = sizeof(TA) == 4;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int fr = lane & 31, fh = lane >> 5;
   unsigned char* stage = smem;                                           // [BM][STAGE_PITCH]
   float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);     // [2][BN]
   const int mode = e.stat_sum ? e.stat_mode : 0;
@@ -45,15 +60,15 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MT][NT], const
   float cs1[NT], cs2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = wc * (BN / 2) + j * 32 + fr;
+    const int col = wc * (BN / 2) + j * L::TS + L::col(lane);
     const float bv = e.bias ? e.bias[n0 + col] : 0.f;
     cs1[j] = 0.f;
     cs2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * (MT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      for (int r = 0; r < L::NR; ++r) {
+        const int row = wr * (MT * L::TS) + i * L::TS + L::row(r, lane);
         float v = acc[i][j][r] + bv;
         if (e.relu) v = fmaxf(v, 0.f);
         const TA q = (TA)v;
@@ -66,13 +81,18 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MT][NT], const
   }
   __syncthreads();
   if (mode == 1) {
-    // rows live in registers and in the two lane halves: one shuffle, then one LDS add per column
+    // rows live in registers and in the lane groups above the column lanes: fold with shuffles,
+    // then one LDS add per column
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const float t1 = cs1[j] + __shfl_xor(cs1[j], 32, 64);
-      const float t2 = cs2[j] + __shfl_xor(cs2[j], 32, 64);
-      if (fh == 0) {
-        const int col = wc * (BN / 2) + j * 32 + fr;
+      float t1 = cs1[j], t2 = cs2[j];
+#pragma unroll
+      for (int o = L::TS; o < 64; o <<= 1) {
+        t1 += __shfl_xor(t1, o, 64);
+        t2 += __shfl_xor(t2, o, 64);
+      }
+      if (lane < L::TS) {
+        const int col = wc * (BN / 2) + j * L::TS + lane;
         atomicAdd(&sstat[col], t1);
         atomicAdd(&sstat[BN + col], t2);
       }

@@ -342,3 +342,51 @@ def test_train_model_loop_with_logger_and_lr_schedule(tmp_path):
     assert (ckpt / "best.pt").exists() and (ckpt / "last.pt").exists()
     sd = torch.load(ckpt / "last.pt", map_location="cpu")
     assert list(sd.keys()) == list(synth.unet_state_shapes().keys())
+
+
+def test_validation_f1_matches_cpu_reference_path():
+    """The 'F1 vs CPU ref' half of the metric (pipeline.py:242-341): get_predictions_dataloader +
+    compute_evaluation_metrics through the GPU pipeline vs the same steps on the CPU oracle."""
+    import yaml
+    from sklearn.metrics import precision_recall_curve
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(precision="f32x6", save_model_params=False)
+    pipe = pkg.SegPipeUNet(experiment_name="t", **cfg)
+    sd = synth.synth_state_dict(seed=0)
+    pipe.model.load_state_dict(sd)
+    pipe.model.to(pipe.device)
+    rng = np.random.default_rng(3)
+    batches = []
+    for i in range(3):
+        x = synth.synth_echogram_batch(2, 4, 64, 64, seed=40 + i)
+        lab = rng.choice(np.array([0, 1, 2, -100, -70, -50, -30, -10], dtype=np.int16), size=(2, 64, 64),
+                         p=[0.55, 0.12, 0.08, 0.05, 0.05, 0.05, 0.05, 0.05])
+        batches.append({"data": torch.from_numpy(x), "labels": torch.from_numpy(lab),
+                        "center_coordinates": torch.zeros(2, 2, dtype=torch.int64)})
+    crit = pipe.get_criterion()
+    labels, preds, mean_loss = pipe.get_predictions_dataloader(batches, criterion=crit, disable_tqdm=True)
+    preds[labels == -50] = 0
+    l_valid, p_valid = pipe.select_valid_predictions(labels.copy(), preds)
+    f1_gpu = pipe.compute_evaluation_metrics(l_valid, p_valid)["F1"].max()
+
+    # CPU reference path (oracle model, same steps, pipeline.py:242-341)
+    ref_preds, ref_labels, ref_loss = [], [], 0.0
+    for b in batches:
+        logits = orc.predict(sd, b["data"])
+        li = orc.set_label_ignore_val(b["labels"].long())
+        ref_loss += float(orc.weighted_cross_entropy(logits, li))
+        ref_preds.append(torch.softmax(logits, 1)[:, 1].numpy().ravel())
+        ref_labels.append(b["labels"].numpy().ravel())
+    rp = np.hstack(ref_preds).astype(np.float16)
+    rl = np.hstack(ref_labels).astype(np.int8)
+    rp[rl == -50] = 0
+    rl2 = orc.set_label_ignore_val(torch.from_numpy(rl.astype(np.int64))).numpy()
+    keep = rl2 != -100
+    pr, rc, _ = precision_recall_curve(rl2[keep], rp[keep], pos_label=1)
+    den = pr + rc
+    f1_ref = np.divide(2 * pr * rc, den, out=np.zeros_like(den), where=den != 0).max()
+    print(f"F1 gpu {f1_gpu:.6f} vs cpu {f1_ref:.6f}; loss {mean_loss:.6f} vs {ref_loss / 3:.6f}")
+    assert np.array_equal(labels, rl)
+    assert np.mean(preds != rp) < 1e-3               # fp16-rounded probabilities: rare 1-ulp differences
+    assert abs(f1_gpu - f1_ref) < 1e-4
+    assert abs(mean_loss - ref_loss / 3) < 1e-4 * abs(ref_loss / 3)
