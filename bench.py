@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_PATCH = 96.43      # SURVEY.md §8(a) a10, hook-counted on the reference module
 TRAIN_GFLOP_PER_PATCH = 288.98
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32x3": 2500.0 / 3.0}   # MI355X_MICROARCH.md (dense bf16; 3 MFMAs/product)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32x3": 2500.0 / 3.0, "f32x6": 2500.0 / 6.0}   # dense bf16 / MFMAs per product
+DTYPE_LABEL = {"bf16": "bf16", "f32x3": "fp32 storage, 3x bf16 MFMA per product",
+               "f32x6": "fp32 storage, 6x bf16 MFMA per product (fp32-equivalent)"}
 
 
 def cpu_baseline(batch=2, iters=3):
@@ -74,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32x3", "f32x6"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -180,7 +182,7 @@ def main():
             "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "bf16x3(fp32-equivalent)",
+            "dtype": DTYPE_LABEL[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, "
                                    "batch 32 x 4x256x256 per GPU" + (
