@@ -105,7 +105,50 @@ __global__ __launch_bounds__(256) void scatter_patches_kernel(
   }
 }
 
+// Validation metrics (pipeline.py:242-341): histogram of the float16-rounded SANDEEL probability over
+// the valid pixels, split by "label == SANDEEL".  The reference gathers every pixel's probability as
+// float16 on the host and sorts them in sklearn's precision_recall_curve; float16 has < 15362
+// non-negative values up to 1.0, so the two histograms hold exactly the same information.
+__global__ __launch_bounds__(256) void pr_histogram_kernel(const float* __restrict__ logits, int ncls,
+                                                           const void* __restrict__ labels, int lbytes,
+                                                           long npix, long HW, unsigned int* hist_pos,
+                                                           unsigned int* hist_neg) {
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    long l = lbytes == 8 ? ((const long long*)labels)[p] : lbytes == 4 ? ((const int*)labels)[p]
+                                                                       : ((const short*)labels)[p];
+    // set_label_ignore_val (pipeline.py:222-239): overlap / refined boundary / boundary / unused -> ignore
+    if (l == -70 || l == -30 || l == -100 || l == -10) continue;
+    const bool seabed = l == -50;            // below seabed: counts as background with probability 0
+    float prob = 0.f;
+    if (!seabed) {
+      const long b = p / HW, hw = p % HW;
+      float z[8], mx = -INFINITY, den = 0.f;
+      for (int o = 0; o < ncls; ++o) { z[o] = logits[(b * ncls + o) * HW + hw]; mx = fmaxf(mx, z[o]); }
+      for (int o = 0; o < ncls; ++o) { z[o] = expf(z[o] - mx); den += z[o]; }
+      prob = z[1] / den;
+    }
+    const _Float16 h = (_Float16)prob;       // round-to-nearest-even, as numpy .astype(float16)
+    const unsigned short bits = *reinterpret_cast<const unsigned short*>(&h);
+    atomicAdd((!seabed && l == 1) ? &hist_pos[bits] : &hist_neg[bits], 1u);
+  }
+}
+
 }  // namespace
+
+extern "C" int crimac_pr_histogram(const float* logits, int ncls, const void* labels, int label_bytes,
+                                   int B, int H, int W, unsigned int* hist_pos, unsigned int* hist_neg,
+                                   void* stream) {
+  CRIMAC_REQUIRE(logits && labels && hist_pos && hist_neg && B > 0 && H > 0 && W > 0 && ncls >= 2 && ncls <= 8,
+                 "pr_histogram: bad arguments");
+  CRIMAC_REQUIRE(label_bytes == 2 || label_bytes == 4 || label_bytes == 8, "pr_histogram: label_bytes=%d", label_bytes);
+  const long HW = (long)H * W, npix = B * HW;
+  long blocks = (npix + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pr_histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, ncls,
+                     labels, label_bytes, npix, HW, hist_pos, hist_neg);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
 
 extern "C" int crimac_gather_patches(int prec, const float* data, int C, int Wd, int H, const int* centres,
                                      int P, int ph, int pw, void* out, long ld, void* stream) {

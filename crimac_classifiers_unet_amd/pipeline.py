@@ -48,7 +48,8 @@ class SegPipe:
     def __init__(self, checkpoint_dir, data_mode, frequencies, patch_size, loss_type, lr, lr_reduction,
                  lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
-                 precision="bf16", loss_flush=50, gpu_augment=False, random_seed=0, **kwargs):
+                 precision="bf16", loss_flush=50, gpu_augment=False, random_seed=0, gpu_metrics=False,
+                 **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -84,6 +85,9 @@ class SegPipe:
         # run fused on the GPU (BASELINE configs[4]); default keeps the reference's numpy workers
         self.gpu_augment = bool(gpu_augment)
         self.random_seed = int(random_seed)
+        # gpu_metrics: in-training validation builds the PR curve / F1 from GPU histograms instead of
+        # shipping every pixel's probability to sklearn (same numbers; the logger gets no pr_curve)
+        self.gpu_metrics = bool(gpu_metrics)
 
     # ------------------------------------------------------------------------------------------
     def load_model_params(self, checkpoint_path=None):
@@ -216,6 +220,53 @@ class SegPipe:
         mean_loss = (float(sum_loss) if sum_loss is not None else 0.0) / len(dataloader)
         return labels, preds, mean_loss
 
+    # -- histogram form of the same metrics: no per-pixel vectors leave the GPU --------------------
+    PR_BINS = 16384            # float16 bit patterns of [0, 1] are 0 .. 0x3C00
+
+    def get_pr_histograms_dataloader(self, dataloader, criterion=None, disable_tqdm=True):
+        """GPU form of get_predictions_dataloader + the masking of validate_model_training
+        (pipeline.py:242-282, :317-320): returns (hist_pos, hist_neg, mean_loss) where hist_*[k] counts
+        the valid pixels whose float16 sandeel probability has bit pattern k."""
+        from .hip import call, ptr
+        dev = self.device
+        hist = torch.zeros(2, self.PR_BINS, dtype=torch.int32, device=dev)
+        sum_loss = None
+        self.model.eval()
+        with torch.no_grad():
+            for batch in _tqdm(dataloader, desc="Evaluating model", total=len(dataloader), disable=disable_tqdm):
+                logits = self.predict_batch(batch, return_softmax=False)
+                labels = batch["labels"].to(dev)
+                if labels.dtype not in (torch.int16, torch.int32, torch.int64):
+                    labels = labels.long()
+                labels = labels.contiguous()
+                if criterion is not None:
+                    loss = criterion(logits, self.set_label_ignore_val(labels.clone().long()))
+                    sum_loss = loss if sum_loss is None else sum_loss + loss
+                B, nc, H, W = logits.shape
+                call("crimac_pr_histogram", ptr(logits), nc, ptr(labels), labels.element_size(), B, H, W,
+                     ptr(hist[0]), ptr(hist[1]))
+        h = hist.cpu().numpy().astype(np.int64)
+        mean_loss = (float(sum_loss) if sum_loss is not None else 0.0) / len(dataloader)
+        return h[0], h[1], mean_loss
+
+    @staticmethod
+    def compute_evaluation_metrics_from_histograms(hist_pos, hist_neg):
+        """precision_recall_curve (sklearn) + F1 (pipeline.py:284-295) from the two histograms: the same
+        arrays sklearn returns for the float16 prediction vector the reference builds."""
+        bins = np.nonzero((hist_pos + hist_neg) > 0)[0]
+        thr = bins.astype(np.uint16).view(np.float16).astype(np.float64)       # ascending with the bits
+        order = np.argsort(-thr, kind="stable")                                 # sklearn: descending scores
+        tps = np.cumsum(hist_pos[bins][order]).astype(np.float64)
+        fps = np.cumsum(hist_neg[bins][order]).astype(np.float64)
+        ps = tps + fps
+        precision = np.divide(tps, ps, out=np.zeros_like(tps), where=ps != 0)
+        recall = tps / tps[-1] if tps[-1] > 0 else np.ones_like(tps)
+        precision = np.hstack((precision[::-1], 1.0))
+        recall = np.hstack((recall[::-1], 0.0))
+        den = recall + precision
+        f1 = np.divide(2 * recall * precision, den, out=np.zeros_like(den), where=(den != 0))
+        return {"precision": precision, "recall": recall, "thresholds": thr[order][::-1], "F1": f1}
+
     def compute_evaluation_metrics(self, labels, preds):
         """PR curve and F1 (reference pipeline.py:284-295)."""
         from sklearn.metrics import precision_recall_curve
@@ -232,10 +283,15 @@ class SegPipe:
 
     def validate_model_training(self, dataloader_test, criterion, logger, iteration_no):
         """Reference pipeline.py:305-341."""
-        labels, preds, loss_test = self.get_predictions_dataloader(dataloader_test, criterion=criterion)
-        preds[labels == LABEL_SEABED_MASK_VAL] = 0
-        labels, preds = self.select_valid_predictions(labels=labels, preds=preds)
-        metrics = self.compute_evaluation_metrics(labels=labels, preds=preds)
+        if self.gpu_metrics:
+            hp, hn, loss_test = self.get_pr_histograms_dataloader(dataloader_test, criterion=criterion)
+            metrics = self.compute_evaluation_metrics_from_histograms(hp, hn)
+            labels = preds = None
+        else:
+            labels, preds, loss_test = self.get_predictions_dataloader(dataloader_test, criterion=criterion)
+            preds[labels == LABEL_SEABED_MASK_VAL] = 0
+            labels, preds = self.select_valid_predictions(labels=labels, preds=preds)
+            metrics = self.compute_evaluation_metrics(labels=labels, preds=preds)
         F1 = metrics["F1"]
         argmax_F1 = np.argmax(F1)
         iter_step = iteration_no + 1
@@ -246,7 +302,7 @@ class SegPipe:
             logger.add_scalar(tag="test/recall", scalar_value=metrics["recall"][argmax_F1],
                               global_step=iter_step)
             logger.add_scalar(tag="test/loss", scalar_value=loss_test, global_step=iter_step)
-            if hasattr(logger, "add_pr_curve"):
+            if hasattr(logger, "add_pr_curve") and labels is not None:
                 logger.add_pr_curve(tag="test/pr_curve", labels=labels, predictions=preds,
                                     global_step=iter_step)
         if F1[argmax_F1] > self.best_F1_val:

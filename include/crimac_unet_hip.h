@@ -196,6 +196,14 @@ int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int
                            const float* data0, int data_ping0, int data_pings, int seabed_pad, float* out,
                            void* stream);
 
+/* Validation metrics (get_predictions_dataloader + compute_evaluation_metrics, pipeline.py:242-295):
+ * histograms (16384 bins, indexed by the float16 bit pattern of softmax(logits)[SANDEEL]) of the valid
+ * pixels with raw label == SANDEEL (hist_pos) and the others (hist_neg); labels are RAW batch labels:
+ * {-70,-30,-100,-10} are skipped, -50 (below seabed) counts as background with probability 0
+ * (pipeline.py:222-239, :317).  Accumulates (caller zeroes). */
+int crimac_pr_histogram(const float* logits, int ncls, const void* labels, int label_bytes, int B, int H,
+                        int W, unsigned int* hist_pos, unsigned int* hist_neg, void* stream);
+
 /* ---- on-GPU training augmentation + data transform (BASELINE configs[4]) -------------------------- */
 
 /* add_noise + flip_x_axis (batch/data_augmentation/add_noise.py:21-41, flip_x_axis.py:21-25) fused

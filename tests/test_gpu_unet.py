@@ -390,3 +390,35 @@ def test_validation_f1_matches_cpu_reference_path():
     assert np.mean(preds != rp) < 1e-3               # fp16-rounded probabilities: rare 1-ulp differences
     assert abs(f1_gpu - f1_ref) < 1e-4
     assert abs(mean_loss - ref_loss / 3) < 1e-4 * abs(ref_loss / 3)
+
+
+def test_pr_histogram_metrics_equal_sklearn_on_the_vector_path():
+    """PR curve / F1 from GPU histograms == sklearn on the reference's float16 vectors."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(precision="bf16", save_model_params=False)
+    pipe = pkg.SegPipeUNet(experiment_name="t", **cfg)
+    pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+    pipe.model.to(pipe.device)
+    rng = np.random.default_rng(9)
+    batches = []
+    for i in range(3):
+        x = synth.synth_echogram_batch(2, 4, 64, 64, seed=60 + i)
+        lab = rng.choice(np.array([0, 1, 2, -100, -70, -50, -30, -10], dtype=np.int16), size=(2, 64, 64),
+                         p=[0.55, 0.12, 0.08, 0.05, 0.05, 0.05, 0.05, 0.05])
+        batches.append({"data": torch.from_numpy(x), "labels": torch.from_numpy(lab),
+                        "center_coordinates": torch.zeros(2, 2, dtype=torch.int64)})
+    crit = pipe.get_criterion()
+    labels, preds, loss_v = pipe.get_predictions_dataloader(batches, criterion=crit, disable_tqdm=True)
+    preds[labels == -50] = 0
+    l_valid, p_valid = pipe.select_valid_predictions(labels.copy(), preds)
+    ref = pipe.compute_evaluation_metrics(l_valid, p_valid)
+    hp, hn, loss_h = pipe.get_pr_histograms_dataloader(batches, criterion=crit)
+    got = pipe.compute_evaluation_metrics_from_histograms(hp, hn)
+    assert hp.sum() == int((l_valid == 1).sum()) and hn.sum() == int((l_valid != 1).sum())
+    assert abs(loss_h - loss_v) < 1e-6 * abs(loss_v)
+    # sklearn may drop the tail after full recall is first reached; compare on the common part
+    n = len(ref["thresholds"])
+    assert np.array_equal(got["thresholds"][-n:], ref["thresholds"].astype(np.float64))
+    assert np.allclose(got["precision"][-(n + 1):], ref["precision"]) and np.allclose(got["recall"][-(n + 1):], ref["recall"])
+    assert abs(got["F1"].max() - ref["F1"].max()) < 1e-12
