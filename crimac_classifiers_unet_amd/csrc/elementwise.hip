@@ -228,10 +228,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 }
 
 // dst[i] = sum over replicas of src[r*stride + i]  (fp64 and/or fp32 destination);
-// 16 channels per workgroup, 16 threads per channel striding over the replicas
+// 16 channels per workgroup, 16 threads per channel striding over the replicas; blockIdx.y = 1 does
+// the same for the second (src_b -> dst_b) pair
 __global__ __launch_bounds__(256) void sum_replicas_kernel(const double* __restrict__ src, int nrep,
-                                                           long stride, int n, double* dst64, float* dst32) {
+                                                           long stride, int n, double* dst64, float* dst32,
+                                                           const double* __restrict__ src_b, double* dst_b) {
   __shared__ double red[16][17];
+  if (blockIdx.y == 1) { src = src_b; dst64 = dst_b; dst32 = nullptr; }
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + cl;
   double s = 0.0;
@@ -775,11 +778,11 @@ extern "C" int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C
 }
 
 extern "C" int crimac_sum_replicas(const double* src, int replicas, long stride, int n, double* dst_f64,
-                                   float* dst_f32, void* stream) {
-  CRIMAC_REQUIRE(src && (dst_f64 || dst_f32) && replicas >= 1 && n > 0 && stride >= n,
+                                   float* dst_f32, const double* src_b, double* dst_b_f64, void* stream) {
+  CRIMAC_REQUIRE(src && replicas > 0 && n > 0 && stride >= n && (dst_f64 || dst_f32) && (!src_b == !dst_b_f64),
                  "sum_replicas: bad arguments");
-  hipLaunchKernelGGL(sum_replicas_kernel, dim3(cdiv(n, 16)), dim3(256), 0, ST, src, replicas, stride, n,
-                     dst_f64, dst_f32);
+  hipLaunchKernelGGL(sum_replicas_kernel, dim3(cdiv(n, 16), src_b ? 2 : 1), dim3(256), 0, ST, src, replicas,
+                     stride, n, dst_f64, dst_f32, src_b, dst_b_f64);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

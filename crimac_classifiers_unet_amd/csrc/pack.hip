@@ -1,0 +1,187 @@
+// Whole-network weight re-layout in ONE launch each way (CDNA4 / gfx950).
+//
+// Every training step the fp32 master weights change (optim.SGD.step, pipeline.py:178), so the bf16
+// operand planes the MFMA kernels read are rebuilt every step, and every weight gradient comes out of
+// crimac_wgrad in the packed [tap][f][s] order and has to go back to the torch layout.  Per layer
+// these are tiny, badly coalesced transposes (tap-innermost fp32 <-> channel-innermost planes); done
+// layer by layer they cost 44 launches and ~0.45 ms per step.  Here one workgroup owns one
+// 32 x 32 x taps tile of one layer, moves it through LDS so that both the fp32 side and the packed side
+// are accessed in >= 64-byte runs, and finds its layer in a descriptor table passed by value.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxLayers = 32;
+constexpr int TILE = 32;
+
+struct LayerDesc {             // mirrors crimac_layer_desc (include/crimac_unet_hip.h)
+  const float* w;
+  float* grad;
+  const float* dw;
+  unsigned short* fwd_hi;
+  unsigned short* fwd_lo;
+  unsigned short* dg_hi;
+  unsigned short* dg_lo;
+  int kind, Co, Ci, Ci_pad;
+};
+
+struct Table {
+  LayerDesc d[kMaxLayers];
+  int first[kMaxLayers + 1];   // first workgroup of each layer; first[n] = total
+  int n;
+};
+
+// Geometry of a layer seen as [outer][inner][taps] in the torch layout:
+//   kind 0 (conv3x3,  w[Co][Ci][3][3]): outer = co, inner = ci, taps = 9
+//   kind 1 (upconv2x2, w[Ci][Co][2][2]): outer = ci, inner = co, taps = 4
+struct Geo {
+  int outer, inner, inner_pad, taps, tiles_inner;
+};
+__device__ __host__ inline Geo geo_of(int kind, int Co, int Ci, int Ci_pad) {
+  Geo g;
+  if (kind == 0) { g.outer = Co; g.inner = Ci; g.inner_pad = Ci_pad; g.taps = 9; }
+  else { g.outer = Ci; g.inner = Co; g.inner_pad = Co; g.taps = 4; }
+  g.tiles_inner = (g.inner_pad + TILE - 1) / TILE;
+  return g;
+}
+
+__device__ __forceinline__ int find_layer(const Table& tb, int block) {
+  int l = 0;
+  while (l + 1 < tb.n && block >= tb.first[l + 1]) ++l;
+  return l;
+}
+
+// two adjacent values -> plane words; plane 0 -> hi[i/2], planes 1.. -> lo[(k-1)*n/2 + i/2]
+__device__ __forceinline__ void put_planes2(float v0, float v1, int npl, unsigned short* hi, unsigned short* lo,
+                                            long i, long n) {
+  unsigned short b0 = f2bfbits(v0), b1 = f2bfbits(v1);
+  *reinterpret_cast<unsigned int*>(hi + i) = (unsigned int)b0 | ((unsigned int)b1 << 16);
+  for (int k = 1; k < npl; ++k) {
+    v0 -= bfbits2f(b0);
+    v1 -= bfbits2f(b1);
+    b0 = f2bfbits(v0);
+    b1 = f2bfbits(v1);
+    *reinterpret_cast<unsigned int*>(lo + (long)(k - 1) * n + i) = (unsigned int)b0 | ((unsigned int)b1 << 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int npl) {
+  __shared__ float tile[TILE][TILE * 9 + 1];
+  const int l = find_layer(tb, blockIdx.x);
+  const LayerDesc& d = tb.d[l];
+  const Geo g = geo_of(d.kind, d.Co, d.Ci, d.Ci_pad);
+  const int tidx = blockIdx.x - tb.first[l];
+  const int o0 = (tidx / g.tiles_inner) * TILE, i0 = (tidx % g.tiles_inner) * TILE;
+  const int T = g.taps, run = TILE * T;
+  const int valid = (g.inner - i0 < TILE ? (g.inner - i0 > 0 ? g.inner - i0 : 0) : TILE) * T;
+  // fp32 side: per outer index one contiguous run of (inner x taps)
+  for (int idx = threadIdx.x; idx < TILE * run; idx += 256) {
+    const int ol = idx / run, r = idx - ol * run;
+    tile[ol][r] = r < valid ? d.w[((long)(o0 + ol) * g.inner + i0) * T + r] : 0.f;
+  }
+  __syncthreads();
+  const long n = (long)T * g.outer * g.inner_pad;
+  // pass A, inner index fastest: conv3x3 forward panel [t][co][ci_pad] / upconv dgrad panel [ab][ci][co]
+  unsigned short* a_hi = d.kind == 0 ? d.fwd_hi : d.dg_hi;
+  unsigned short* a_lo = d.kind == 0 ? d.fwd_lo : d.dg_lo;
+  if (a_hi) {
+    for (int idx = threadIdx.x; idx < T * TILE * (TILE / 2); idx += 256) {
+      const int il = (idx % (TILE / 2)) * 2, ol = (idx / (TILE / 2)) % TILE, t = idx / (TILE * TILE / 2);
+      if (i0 + il >= g.inner_pad) continue;
+      put_planes2(tile[ol][il * T + t], tile[ol][(il + 1) * T + t], npl, a_hi, a_lo,
+                  ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n);
+    }
+  }
+  // pass B, outer index fastest: conv3x3 dgrad panel [8-t][ci][co] / upconv forward panel [ab][co][ci]
+  unsigned short* b_hi = d.kind == 0 ? d.dg_hi : d.fwd_hi;
+  unsigned short* b_lo = d.kind == 0 ? d.dg_lo : d.fwd_lo;
+  if (b_hi) {
+    for (int idx = threadIdx.x; idx < T * TILE * (TILE / 2); idx += 256) {
+      const int ol = (idx % (TILE / 2)) * 2, il = (idx / (TILE / 2)) % TILE, t = idx / (TILE * TILE / 2);
+      if (i0 + il >= g.inner) continue;
+      const int tt = d.kind == 0 ? T - 1 - t : t;
+      put_planes2(tile[ol][il * T + t], tile[ol + 1][il * T + t], npl, b_hi, b_lo,
+                  ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_layers_kernel(Table tb) {
+  __shared__ float tile[TILE][TILE * 9 + 1];
+  const int l = find_layer(tb, blockIdx.x);
+  const LayerDesc& d = tb.d[l];
+  const Geo g = geo_of(d.kind, d.Co, d.Ci, d.Ci_pad);
+  const int tidx = blockIdx.x - tb.first[l];
+  const int o0 = (tidx / g.tiles_inner) * TILE, i0 = (tidx % g.tiles_inner) * TILE;
+  const int T = g.taps, run = TILE * T;
+  const int nin = g.inner - i0 < TILE ? (g.inner - i0 > 0 ? g.inner - i0 : 0) : TILE;
+  // packed side: dw[t][outer][inner_pad] (conv3x3: [t][co][ci_pad], upconv: [ab][ci][co]), inner fastest
+  for (int idx = threadIdx.x; idx < T * TILE * TILE; idx += 256) {
+    const int il = idx % TILE, ol = (idx / TILE) % TILE, t = idx / (TILE * TILE);
+    if (il < nin) tile[ol][il * T + t] = d.dw[((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il];
+  }
+  __syncthreads();
+  const int valid = nin * T;
+  for (int idx = threadIdx.x; idx < TILE * run; idx += 256) {
+    const int ol = idx / run, r = idx - ol * run;
+    if (r < valid) d.grad[((long)(o0 + ol) * g.inner + i0) * T + r] = tile[ol][r];
+  }
+}
+
+struct HostDesc {              // == crimac_layer_desc
+  const float* w;
+  float* grad;
+  const float* dw;
+  void *fwd_hi, *fwd_lo, *dg_hi, *dg_lo;
+  int kind, Co, Ci, Ci_pad;
+};
+
+// mode 0: pack, 1: unpack
+int run_layers(const HostDesc* descs, int n, int mode, int planes, hipStream_t st) {
+  for (int base = 0; base < n; base += kMaxLayers) {
+    Table tb;
+    tb.n = n - base < kMaxLayers ? n - base : kMaxLayers;
+    int total = 0;
+    for (int i = 0; i < tb.n; ++i) {
+      const HostDesc& h = descs[base + i];
+      CRIMAC_REQUIRE((h.kind == 0 || h.kind == 1) && h.Co > 0 && h.Ci > 0, "layer %d: bad kind/shape", base + i);
+      CRIMAC_REQUIRE(h.Co % TILE == 0 && (h.kind == 0 || h.Ci % TILE == 0),
+                     "layer %d: Co (and the transposed convolution's Ci) must be multiples of %d", base + i, TILE);
+      CRIMAC_REQUIRE(h.kind == 1 || (h.Ci_pad >= h.Ci && h.Ci_pad % 2 == 0), "layer %d: bad Ci_pad", base + i);
+      if (mode == 0) {
+        CRIMAC_REQUIRE(h.w && h.fwd_hi && (planes == 1 || h.fwd_lo) && (planes == 1 || !h.dg_hi || h.dg_lo),
+                       "layer %d: missing weight / plane pointers", base + i);
+        CRIMAC_REQUIRE(h.kind == 1 || !h.dg_hi || h.Ci_pad == h.Ci, "layer %d: dgrad planes need Ci_pad == Ci",
+                       base + i);
+      } else {
+        CRIMAC_REQUIRE(h.dw && h.grad, "layer %d: missing dw / grad pointers", base + i);
+      }
+      LayerDesc& d = tb.d[i];
+      d.w = h.w; d.grad = h.grad; d.dw = h.dw;
+      d.fwd_hi = (unsigned short*)h.fwd_hi; d.fwd_lo = (unsigned short*)h.fwd_lo;
+      d.dg_hi = (unsigned short*)h.dg_hi; d.dg_lo = (unsigned short*)h.dg_lo;
+      d.kind = h.kind; d.Co = h.Co; d.Ci = h.Ci; d.Ci_pad = h.kind == 0 ? h.Ci_pad : h.Ci;
+      const Geo g = geo_of(d.kind, d.Co, d.Ci, d.Ci_pad);
+      tb.first[i] = total;
+      total += (g.outer / TILE) * g.tiles_inner;
+    }
+    tb.first[tb.n] = total;
+    if (total == 0) continue;
+    if (mode == 0) hipLaunchKernelGGL(pack_layers_kernel, dim3(total), dim3(256), 0, st, tb, planes);
+    else hipLaunchKernelGGL(unpack_layers_kernel, dim3(total), dim3(256), 0, st, tb);
+    CRIMAC_LAUNCH_CHECK();
+  }
+  return CRIMAC_OK;
+}
+
+}  // namespace
+
+extern "C" int crimac_pack_layers(const crimac_layer_desc* descs, int n_layers, int planes, void* stream) {
+  CRIMAC_REQUIRE(descs && n_layers > 0 && planes >= 1 && planes <= 3, "pack_layers: bad arguments");
+  return run_layers(reinterpret_cast<const HostDesc*>(descs), n_layers, 0, planes, (hipStream_t)stream);
+}
+
+extern "C" int crimac_unpack_wgrad_layers(const crimac_layer_desc* descs, int n_layers, void* stream) {
+  CRIMAC_REQUIRE(descs && n_layers > 0, "unpack_wgrad_layers: bad arguments");
+  return run_layers(reinterpret_cast<const HostDesc*>(descs), n_layers, 1, 1, (hipStream_t)stream);
+}

@@ -17,6 +17,7 @@ PyTorch supplies memory and streams only; there is no CPU or eager fallback.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import torch
@@ -144,6 +145,7 @@ class UNetEngine:
     def _alloc_static(self):
         dev = self.device
         i16 = torch.int16
+        self._ltab = None
         self.pk = {}      # train-mode operand planes
         self.pk_eval = {}  # eval-mode (BN folded) forward planes + folded bias
         tot_dw = 0
@@ -217,16 +219,51 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     # operand packing
     # ------------------------------------------------------------------------------------------
+    def _layer_table(self):
+        """crimac_layer_desc array of every conv / transposed-conv layer, ordered by the group in which
+        the backward pass completes them (grad_ranges): decoder, bottleneck block, other encoder blocks."""
+        if getattr(self, "_ltab", None) is not None:
+            return self._ltab
+        groups = [[], [], []]
+        for j in range(self.depth - 1):
+            groups[0] += [self.ups[j], *self.dec[j]]
+        for i in range(self.depth):
+            groups[1 if i == self.depth - 1 else 2] += list(self.enc[i])
+        layers = [l for g in groups for l in g]
+        arr = (hip.LayerDesc * len(layers))()
+        for d, l in zip(arr, layers):
+            up = isinstance(l, _UpConv)
+            key = l.key if up else l.conv_key
+            pk = self.pk[key]
+            cin_pad = l.cin if up else l.cin_pad
+            n = (4 if up else 9) * l.cout * cin_pad
+            d.w = self.P[key + ".weight"].data_ptr()
+            d.grad = self.G[key + ".weight"].data_ptr()
+            d.dw = self._dw(key, n).data_ptr()
+            d.fwd_hi, d.fwd_lo = pk["fwd_hi"].data_ptr(), pk["fwd_lo"].data_ptr()
+            d.dg_hi = pk["dg_hi"].data_ptr() if pk["dg_hi"] is not None else None
+            d.dg_lo = pk["dg_lo"].data_ptr() if pk["dg_lo"] is not None else None
+            d.kind, d.Co, d.Ci, d.Ci_pad = (1 if up else 0), l.cout, l.cin, cin_pad
+        bounds, pos = [], 0
+        for g in groups:
+            bounds.append((pos, len(g)))
+            pos += len(g)
+        self._ltab = (arr, bounds)
+        return self._ltab
+
     def _pack_train(self):
         if not self._train_pack_dirty:
             return
-        for b in self.blocks:
-            pk = self.pk[b.conv_key]
-            call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin, b.cin_pad,
-                 None, self.planes, ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(pk["dg_hi"]),
-                 ptr(pk["dg_lo"]))
-        self._pack_ups()
+        arr, _ = self._layer_table()
+        call("crimac_pack_layers", C.byref(arr), len(arr), self.planes)
         self._train_pack_dirty = False
+
+    def _unpack_group(self, gi):
+        """Packed weight gradients of backward group gi -> torch-layout gradients in the flat buffer."""
+        arr, bounds = self._layer_table()
+        first, n = bounds[gi]
+        if n:
+            call("crimac_unpack_wgrad_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n)
 
     def _pack_ups(self):
         for u in self.ups:
@@ -457,9 +494,7 @@ class UNetEngine:
         gradient) from the dgrad epilogue.  Returns whether next_bn's sums were fused."""
         if reduce_done:
             call("crimac_sum_replicas", ptr(self._stat(b, 0)), STAT_REPLICAS, b.cout, b.cout,
-                 ptr(self._stat(b, 2)), None)
-            call("crimac_sum_replicas", ptr(self._stat(b, 1)), STAT_REPLICAS, b.cout, b.cout,
-                 ptr(self._stat(b, 3)), None)
+                 ptr(self._stat(b, 2)), None, ptr(self._stat(b, 1)), ptr(self._stat(b, 3)))
         else:
             call("crimac_bn_bwd_reduce", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
                  ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
@@ -473,8 +508,6 @@ class UNetEngine:
         dw = self._dw(b.conv_key, n)
         call("crimac_wgrad", self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w,
              ptr(dw), self.wgrad_target_blocks, flops=2.0 * 9 * b.cin * b.cout * B * h * w)
-        call("crimac_unpack_wgrad_conv3x3", ptr(dw), b.cout, b.cin, b.cin_pad,
-             ptr(self.G[b.conv_key + ".weight"]))
         fused = False
         if dx_out is not None:
             stats = None
@@ -486,7 +519,7 @@ class UNetEngine:
                                   dgrad=True, stats=stats, bnb=next_bn if stats is None else None)
             if stats is not None:
                 grad, C = bias_from_stats
-                call("crimac_sum_replicas", ptr(stats[0]), STAT_REPLICAS, b.cin, C, None, ptr(grad))
+                call("crimac_sum_replicas", ptr(stats[0]), STAT_REPLICAS, b.cin, C, None, ptr(grad), None, None)
             elif bias_from_stats is not None:
                 grad, C = bias_from_stats
                 call("crimac_colsum_f32", self.prec, dx_out.p, dx_out.ld, M, C, ptr(grad))
@@ -494,8 +527,25 @@ class UNetEngine:
 
     wgrad_target_blocks = 0      # 0 = let the library pick the pixel-range split
 
-    def backward(self, dlogits):
-        """Gradients of every parameter into the flat gradient buffer (overwrites it)."""
+    def grad_ranges(self):
+        """Contiguous ranges of the flat gradient buffer in the order the backward pass completes
+        them: (decoder + head), (bottleneck encoder block), (remaining encoder blocks)."""
+        bot = ".".join(self.enc[self.depth - 1][0].conv_key.split(".")[:2]) + "."
+        dec = self.ups[0].key.split(".")[0] + "."
+        lo_bot = min(o for k, (o, _, _) in self.layout.items() if k.startswith(bot))
+        lo_dec = min(o for k, (o, _, _) in self.layout.items() if k.startswith(dec))
+        for k, (o, _, _) in self.layout.items():
+            late = k.startswith(dec) or k.startswith("conv_final")
+            if (o >= lo_dec) != late or (lo_bot <= o < lo_dec) != k.startswith(bot):
+                raise RuntimeError(f"unexpected parameter order in the flat buffer at {k}")
+        return [(lo_dec, self.n_flat), (lo_bot, lo_dec), (0, lo_bot)]
+
+    def backward(self, dlogits, on_ready=None):
+        """Gradients of every parameter into the flat gradient buffer (overwrites it).
+
+        on_ready(lo, hi): called when flat_g[lo:hi] is final (see grad_ranges) so that the gradient
+        exchange of that range can start while the rest of the backward pass runs."""
+        ranges = self.grad_ranges() if on_ready is not None else None
         s = self.saved
         if s is None:
             raise RuntimeError("backward() needs a preceding train-mode forward()")
@@ -532,10 +582,12 @@ class UNetEngine:
             dw = self._dw(u.key, n)
             call("crimac_wgrad", self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp,
                  wp, ptr(dw), self.wgrad_target_blocks, flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
-            call("crimac_unpack_wgrad_upconv2x2", ptr(dw), u.cin, u.cout, ptr(self.G[u.key + ".weight"]))
             d_prev = Act(self._buf(f"g.d{j}.xprev", (Mp, u.cin)), u.cin)
             self._upconv_dgrad(dup, u, d_prev, B, hp, wp)
             d_cur = d_prev
+        self._unpack_group(0)
+        if on_ready is not None:
+            on_ready(*ranges[0])
         d_pool = None
         for i in reversed(range(D)):
             h, w, M = geo[i]
@@ -556,6 +608,13 @@ class UNetEngine:
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool, reduce_done=fused)
             else:
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, None, reduce_done=fused)
+            if i == D - 1:
+                self._unpack_group(1)
+                if on_ready is not None:
+                    on_ready(*ranges[1])
+        self._unpack_group(2)
+        if on_ready is not None:
+            on_ready(*ranges[2])
 
     # ------------------------------------------------------------------------------------------
     # loss and optimiser
@@ -605,10 +664,14 @@ class UNetEngine:
         sums = self.stat[0:2]
         sums, labels = self.ce_forward(logits, labels, class_w, ignore_index, sums=sums)
         dl = self.ce_backward(logits, labels, class_w, sums, 1.0, ignore_index)
-        self.backward(dl)
         scale = 1.0
-        if grad_sync is not None:
-            scale = grad_sync(self.flat_g)
+        if grad_sync is not None and hasattr(grad_sync, "launch"):
+            self.backward(dl, on_ready=lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi))
+            scale = grad_sync.finish()
+        else:
+            self.backward(dl)
+            if grad_sync is not None:
+                scale = grad_sync(self.flat_g)
         self.sgd_step(lr, momentum, grad_scale=scale)
         return (sums[0] / sums[1]).float()
 

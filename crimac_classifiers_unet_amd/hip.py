@@ -27,12 +27,14 @@ SIGNATURES = {
                           _vp, _l, _i, _i, _i, _vp],
     "crimac_conv3x3": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i,
                        _vp, _l, _vp, _l, _vp],
-    "crimac_sum_replicas": [_vp, _i, _l, _i, _vp, _vp, _vp],
+    "crimac_sum_replicas": [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_pack_upconv2x2": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_unpack_wgrad_conv3x3": [_vp, _i, _i, _i, _vp, _vp],
     "crimac_unpack_wgrad_upconv2x2": [_vp, _i, _i, _vp, _vp],
+    "crimac_pack_layers": [_vp, _i, _i, _vp],
+    "crimac_unpack_wgrad_layers": [_vp, _i, _vp],
     "crimac_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _l, _vp],
     "crimac_colstats": [_i, _vp, _l, _l, _i, _vp, _vp, _vp],
     "crimac_colsum_f32": [_i, _vp, _l, _l, _i, _vp, _vp],
@@ -53,6 +55,14 @@ SIGNATURES = {
     "crimac_scatter_patches": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i,
                                _i, _vp, _vp],
 }
+
+
+
+class LayerDesc(C.Structure):
+    """crimac_layer_desc (include/crimac_unet_hip.h): one Conv2d / ConvTranspose2d layer's buffers."""
+    _fields_ = [("w", _vp), ("grad", _vp), ("dw", _vp), ("fwd_hi", _vp), ("fwd_lo", _vp), ("dg_hi", _vp),
+                ("dg_lo", _vp), ("kind", _i), ("Co", _i), ("Ci", _i), ("Ci_pad", _i)]
+
 
 _lib = None
 

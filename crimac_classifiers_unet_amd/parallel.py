@@ -2,8 +2,9 @@
 
 Training: every rank runs the same step on its own mini-batch shard; the only
 exchange is the gradient all-reduce over the FLAT fp32 gradient buffer (31.04 M floats = 124 MB),
-issued as a few large buckets (xGMI is point-to-point; large messages keep every link busy) and
-averaged by folding 1/world into the SGD kernel's ``grad_scale``.  BatchNorm statistics stay
+issued as a few large buckets (xGMI is point-to-point; large messages keep every link busy), started
+during the backward pass as soon as a contiguous range of the buffer is final, and averaged by folding
+1/world into the SGD kernel's ``grad_scale``.  BatchNorm statistics stay
 per-rank (torch DDP default; SyncBN is out of scope this round -- DESIGN.md).
 
 Inference: patches are independent; patch ``p`` of a chunk goes to rank ``p % world`` and the
@@ -49,23 +50,61 @@ def bucket_bounds(n, bucket_elems):
 
 
 class GradSync:
-    """Bucketed all-reduce (sum) of a flat gradient buffer; returns the 1/world averaging scale."""
+    """Bucketed all-reduce (sum) of the flat gradient buffer, overlapped with the backward pass.
+
+    ``launch(flat_grad, lo, hi)`` may be called as soon as ``flat_grad[lo:hi]`` is final (the engine
+    does so after the decoder and after the bottleneck encoder block, whose 26 M of the 31 M gradients
+    are ready when 40-60 % of the backward pass is still to run); the collectives are issued
+    asynchronously -- on the process group's own stream, ordered after the kernels already queued on
+    the current stream -- and ``finish`` waits for them.  ``__call__`` reduces whatever has not been
+    launched yet, waits for everything and returns the 1/world averaging scale (folded into SGD).
+    """
 
     def __init__(self, bucket_mb=32.0, group=None):
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.group = group
+        self._works = []
+        self._done = []          # [(lo, hi)] ranges already in flight this step
+
+    def world(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
+    def launch(self, flat_grad, lo, hi):
+        if self.world() == 1 or hi <= lo:
+            return
+        for a, b in self._done:
+            if lo < b and a < hi:
+                raise RuntimeError(f"GradSync: range [{lo},{hi}) overlaps [{a},{b}) already in flight")
+        self._done.append((lo, hi))
+        for s, e in bucket_bounds(hi - lo, self.bucket_elems):
+            self._works.append(dist.all_reduce(flat_grad[lo + s:lo + e], op=dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True))
+
+    def pending_ranges(self, n):
+        """Complement of the launched ranges in [0, n)."""
+        out, pos = [], 0
+        for a, b in sorted(self._done):
+            if a > pos:
+                out.append((pos, a))
+            pos = max(pos, b)
+        if pos < n:
+            out.append((pos, n))
+        return out
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        self._works, self._done = [], []
+        return 1.0 / self.world()
 
     def __call__(self, flat_grad):
-        if not (dist.is_available() and dist.is_initialized()):
+        if self.world() == 1:
             return 1.0
-        world = dist.get_world_size(self.group)
-        if world == 1:
-            return 1.0
-        works = [dist.all_reduce(flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for s, e in bucket_bounds(flat_grad.numel(), self.bucket_elems)]
-        for w in works:
-            w.wait()
-        return 1.0 / world
+        for lo, hi in self.pending_ranges(flat_grad.numel()):
+            self.launch(flat_grad, lo, hi)
+        return self.finish()
 
 
 def shard_indices(n_items, rank, world):

@@ -103,6 +103,23 @@ int crimac_pack_upconv2x2(const float* w, int Ci, int Co, int planes, void* fwd_
 int crimac_unpack_wgrad_conv3x3(const float* dw, int Co, int Ci, int Ci_pad, float* grad, void* stream);
 int crimac_unpack_wgrad_upconv2x2(const float* dw, int Ci, int Co, float* grad, void* stream);
 
+/* The same re-layouts for EVERY layer of the network in one launch each way (the weights change every
+ * step, optim.SGD.step pipeline.py:178, so the planes are rebuilt every step).  `descs` is a HOST array;
+ * it is read during the call only.  Co % 32 == 0; kind 1 also needs Ci % 32 == 0. */
+typedef struct crimac_layer_desc {
+  const float* w;      /* fp32 weights: kind 0 [Co][Ci][3][3], kind 1 [Ci][Co][2][2] (device) */
+  float* grad;         /* crimac_unpack_wgrad_layers: gradient, laid out as w (device) */
+  const float* dw;     /* crimac_unpack_wgrad_layers: packed gradient written by crimac_wgrad (device) */
+  void* fwd_hi;        /* crimac_pack_layers: planes as in crimac_pack_conv3x3 / crimac_pack_upconv2x2 */
+  void* fwd_lo;
+  void* dg_hi;         /* may be NULL (no input gradient needed: first layer) */
+  void* dg_lo;
+  int kind;            /* 0: Conv2d 3x3, 1: ConvTranspose2d 2x2 stride 2 */
+  int Co, Ci, Ci_pad;  /* Ci_pad: kind 0 only */
+} crimac_layer_desc;
+int crimac_pack_layers(const crimac_layer_desc* descs, int n_layers, int planes, void* stream);
+int crimac_unpack_wgrad_layers(const crimac_layer_desc* descs, int n_layers, void* stream);
+
 /* ---- layout ---------------------------------------------------------------------------------- */
 
 /* Model input [B][C][H][W] fp32 (pipeline.py:163, :208 `.float().to(device)`) -> NHWC activations
@@ -117,9 +134,10 @@ int crimac_colstats(int prec, const void* y, long ld, long M, int C, double* sum
                     void* stream);
 /* Per-channel sum accumulated into fp32 (bias gradients). */
 int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C, float* sum, void* stream);
-/* dst[i] = sum_r src[r*stride + i], i < n, into fp64 and/or fp32 (either may be NULL). */
+/* dst[i] = sum_r src[r*stride + i], i < n, into fp64 and/or fp32 (either may be NULL); if src_b is
+ * given, dst_b_f64[i] = sum_r src_b[r*stride + i] in the same launch (the two BatchNorm-backward sums). */
 int crimac_sum_replicas(const double* src, int replicas, long stride, int n, double* dst_f64,
-                        float* dst_f32, void* stream);
+                        float* dst_f32, const double* src_b, double* dst_b_f64, void* stream);
 /* Train-mode statistics -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale; running stats
  * updated with `momentum` (unbiased variance), num_batches_tracked += 1.
  * sum/sumsq are [replicas][C] partial accumulators that are added up first. */

@@ -378,10 +378,11 @@ def conv3x3_halo(prec, x_nhwc, in_ld, B, H, W, Cin, Cout, w_hi, w_lo, bias, relu
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (3, 8, 16, 256, 64),
                                    (2, 16, 16, 4, 64), (1, 24, 40, 64, 192), (2, 12, 20, 32, 128),
-                                   (1, 32, 32, 576, 128)])
+                                   (1, 32, 32, 576, 128), (5, 100, 120, 128, 64), (3, 256, 256, 64, 64)])
 def test_conv3x3_halo_forward_stats(prec, shape):
     """Forward incl. fused bias/ReLU and fused BatchNorm statistics; partial tiles (H%8, W%16 != 0);
-    odd number of (chunk, tap) steps (Cin = 64, 576) and even (Cin = 128)."""
+    odd number of (chunk, tap) steps (Cin = 64, 576) and even (Cin = 128); the last two shapes have more
+    tiles than CUs, so the persistent N = 64 kernel walks several tiles per workgroup."""
     B, H, W, Ci, Co = shape
     g = torch.Generator().manual_seed(11)
     x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
@@ -451,9 +452,60 @@ def test_conv3x3_dgrad_with_fused_bn_backward_sums(prec, shape):
     call("crimac_bn_bwd_reduce", hip.PREC_NAMES[prec], ptr(da), Ci, ptr(yn), Ci, ptr(vec[2]), ptr(vec[3]),
          ptr(vec[0]), ptr(vec[1]), M, Ci, ptr(ref[0]), ptr(ref[1]))
     out = torch.zeros(2, Ci, dtype=torch.float64, device="cuda")
-    call("crimac_sum_replicas", ptr(acc[0]), R, Ci, Ci, ptr(out[0]), None)
-    call("crimac_sum_replicas", ptr(acc[1]), R, Ci, Ci, ptr(out[1]), None)
+    call("crimac_sum_replicas", ptr(acc[0]), R, Ci, Ci, ptr(out[0]), None, ptr(acc[1]), ptr(out[1]))
     torch.cuda.synchronize()
     refg = torch.nn.grad.conv2d_input((B, Ci, H, W), _round(w, prec), dy, padding=1)
     assert relerr(from_nhwc(da, B, H, W), refg) < TOL[prec]
     assert relerr(out[0].cpu(), ref[0].cpu()) < 1e-5 and relerr(out[1].cpu(), ref[1].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("planes", [1, 2, 3])
+def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
+    """crimac_pack_layers / crimac_unpack_wgrad_layers (one launch for all layers) are bit-identical to
+    the per-layer kernels, incl. the padded first layer (Ci = 4 -> 16, no dgrad planes)."""
+    import ctypes
+    g = torch.Generator().manual_seed(5)
+    layers = [(0, 64, 4, 16), (0, 128, 64, 64), (1, 64, 128, 128), (0, 64, 192, 192), (1, 32, 64, 64)]
+    keep, descs = [], (hip.LayerDesc * len(layers))()
+    i16 = torch.int16
+    for d, (kind, Co, Ci, Cp) in zip(descs, layers):
+        T = 9 if kind == 0 else 4
+        shape = (Co, Ci, 3, 3) if kind == 0 else (Ci, Co, 2, 2)
+        w = torch.randn(*shape, generator=g).cuda()
+        n = T * Co * Cp
+        dw = torch.randn(n, generator=g).cuda()
+        has_dg = Cp == Ci
+        nl = max(planes - 1, 1)
+        new = {k: torch.full((m,), -1, dtype=i16, device="cuda") for k, m in
+               (("fwd_hi", n), ("fwd_lo", nl * n), ("dg_hi", n), ("dg_lo", nl * n))}
+        old = {k: torch.full_like(v, -1) for k, v in new.items()}
+        grad_new, grad_old = torch.zeros_like(w), torch.zeros_like(w)
+        if kind == 0:
+            call("crimac_pack_conv3x3", ptr(w), Co, Ci, Cp, None, planes, ptr(old["fwd_hi"]), ptr(old["fwd_lo"]),
+                 ptr(old["dg_hi"]) if has_dg else None, ptr(old["dg_lo"]) if has_dg else None)
+            call("crimac_unpack_wgrad_conv3x3", ptr(dw), Co, Ci, Cp, ptr(grad_old))
+        else:
+            call("crimac_pack_upconv2x2", ptr(w), Ci, Co, planes, ptr(old["fwd_hi"]), ptr(old["fwd_lo"]),
+                 ptr(old["dg_hi"]), ptr(old["dg_lo"]))
+            call("crimac_unpack_wgrad_upconv2x2", ptr(dw), Ci, Co, ptr(grad_old))
+        d.w, d.grad, d.dw = w.data_ptr(), grad_new.data_ptr(), dw.data_ptr()
+        d.fwd_hi, d.fwd_lo = new["fwd_hi"].data_ptr(), new["fwd_lo"].data_ptr()
+        d.dg_hi = new["dg_hi"].data_ptr() if has_dg else None
+        d.dg_lo = new["dg_lo"].data_ptr() if has_dg else None
+        d.kind, d.Co, d.Ci, d.Ci_pad = kind, Co, Ci, Cp
+        keep.append((w, dw, new, old, grad_new, grad_old, has_dg))
+    call("crimac_pack_layers", ctypes.byref(descs), len(layers), planes)
+    call("crimac_unpack_wgrad_layers", ctypes.byref(descs), len(layers))
+    # a sub-range of the table (what the engine does per backward group)
+    torch.cuda.synchronize()
+    for li, (w, dw, new, old, grad_new, grad_old, has_dg) in enumerate(keep):
+        for k in new:
+            if planes == 1 and k.endswith("_lo"):
+                continue
+            assert torch.equal(new[k], old[k]), (li, k)
+        assert torch.equal(grad_new, grad_old), li
+    keep[2][4].zero_()
+    keep[1][4].zero_()
+    call("crimac_unpack_wgrad_layers", ctypes.byref(descs, 2 * ctypes.sizeof(hip.LayerDesc)), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(keep[2][4], keep[2][5]) and float(keep[1][4].abs().max()) == 0

@@ -422,3 +422,38 @@ def test_pr_histogram_metrics_equal_sklearn_on_the_vector_path():
     assert np.array_equal(got["thresholds"][-n:], ref["thresholds"].astype(np.float64))
     assert np.allclose(got["precision"][-(n + 1):], ref["precision"]) and np.allclose(got["recall"][-(n + 1):], ref["recall"])
     assert abs(got["F1"].max() - ref["F1"].max()) < 1e-12
+
+
+def test_gradient_ranges_are_final_when_handed_to_the_exchange(full_case):
+    """The overlapped all-reduce (parallel.GradSync.launch) is started from inside the backward pass:
+    every range handed over must already hold its final values, and the ranges must tile the buffer."""
+    _, x, lab = full_case
+    m = make_model("bf16")
+    eng = m.engine
+    cw = torch.tensor([1.0, 2.0, 3.0], device="cuda")
+
+    class Recorder:
+        def __init__(self):
+            self.snaps = []
+
+        def launch(self, flat, lo, hi):
+            self.snaps.append((lo, hi, flat[lo:hi].clone()))
+
+        def finish(self):
+            self.final = eng.flat_g.clone()          # before SGD touches anything
+            return 1.0
+
+    rec = Recorder()
+    eng.train_step(x.cuda(), lab.cuda(), cw, lr=0.0, momentum=0.0, grad_sync=rec)
+    torch.cuda.synchronize()
+    assert [(lo, hi) for lo, hi, _ in rec.snaps] == eng.grad_ranges()
+    spans = sorted((lo, hi) for lo, hi, _ in rec.snaps)
+    assert spans[0][0] == 0 and spans[-1][1] == eng.n_flat
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for lo, hi, snap in rec.snaps:
+        assert torch.equal(snap, rec.final[lo:hi]), (lo, hi)
+        assert float(snap.abs().max()) > 0
+    # the three ranges are what the module prefixes say they are
+    (d0, _), (b0, b1), _ = eng.grad_ranges()
+    assert eng.layout["up_convs.0.upconv.weight"][0] == d0 == b1
+    assert eng.layout["down_convs.4.main.0.weight"][0] == b0

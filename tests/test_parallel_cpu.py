@@ -27,6 +27,20 @@ def _worker(rank, world, port, results):
     scale = parallel.GradSync(bucket_mb=0.001)(flat)          # 262-element buckets
     expect = torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1))
     ok_grad = bool(torch.equal(flat, expect)) and abs(scale - 1.0 / world) < 1e-12
+    # overlapped form: ranges launched out of order while "backward" is still running, rest at the end
+    gs = parallel.GradSync(bucket_mb=0.001)
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    gs.launch(flat, 700, 1000)
+    gs.launch(flat, 300, 700)
+    assert gs.pending_ranges(1000) == [(0, 300)]
+    try:
+        gs.launch(flat, 650, 800)
+        ok_grad = False
+    except RuntimeError:
+        pass
+    scale = gs(flat)
+    ok_grad = ok_grad and bool(torch.equal(flat, expect)) and abs(scale - 1.0 / world) < 1e-12 \
+        and gs.pending_ranges(1000) == [(0, 1000)]
     # SGD with grad_scale=1/world on the summed gradient == SGD on the mean gradient
     # inference: 7 "patches", each rank computes its shard, all-gather restores patch order
     n = 7
