@@ -331,12 +331,12 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
   static const int force_tr = getenv("CRIMAC_CONV_TR") ? atoi(getenv("CRIMAC_CONV_TR")) : 0;
   const bool big = force_tr == 16;
   static const int force_bk = getenv("CRIMAC_CONV_BK") ? atoi(getenv("CRIMAC_CONV_BK")) : 0;
-  // bf16 with 64-deep channel chunks: LDS-DMA streaming kernel (CRIMAC_CONV_GLDS=0 selects the
+  // bf16 with 64-deep channel chunks: LDS-DMA streaming kernels (CRIMAC_CONV_GLDS=0 selects the
   // register-staged kernel below, kept for A/B measurements and as the fp32-mode structure).
-  // Measured (tools/bench_conv.py, B=32): +8-18 % on every layer with N >= 128, -10 % on the N = 64
-  // layers (HBM-heavy, want more workgroups per CU) -> used for N % 128 == 0 only.
+  // Measured (tools/bench_conv.py, B=32): +8-18 % on every layer with N >= 128 (8-wave kernel), +5-13 % on
+  // the N = 64 layers (4-wave kernel, two workgroups per CU).
   static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
-  if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && (use_glds == 2 || (use_glds == 1 && n128)))
+  if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && use_glds)
     return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, e, st);
   if (prec == CRIMAC_PREC_BF16) {
     // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS

@@ -41,7 +41,7 @@ template <> struct AccLayout<f32x4> {
   __device__ static __forceinline__ int col(int lane) { return lane & 15; }
 };
 
-// acc[MT][NT]: wave (wr, wc) holds rows wr*MT*TS + i*TS + ..., cols wc*(BN/2) + j*TS + ... .
+// acc[MT][NT]: wave (wr, wc) holds rows wr*MT*TS + i*TS + ..., cols wc*NT*TS + j*TS + ... .
 template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC>
 __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
                                               unsigned char* smem, int b, int y0, int x0, int n0,
@@ -60,7 +60,7 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
   float cs1[NT], cs2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = wc * (BN / 2) + j * L::TS + L::col(lane);
+    const int col = wc * (NT * L::TS) + j * L::TS + L::col(lane);
     const float bv = e.bias ? e.bias[n0 + col] : 0.f;
     cs1[j] = 0.f;
     cs2[j] = 0.f;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
         t2 += __shfl_xor(t2, o, 64);
       }
       if (lane < L::TS) {
-        const int col = wc * (BN / 2) + j * L::TS + lane;
+        const int col = wc * (NT * L::TS) + j * L::TS + lane;
         atomicAdd(&sstat[col], t1);
         atomicAdd(&sstat[BN + col], t2);
       }

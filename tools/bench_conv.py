@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--layers", default="")
     ap.add_argument("--impl", default="halo")
+    ap.add_argument("--nostat", action="store_true", help="conv without the fused BatchNorm statistics")
     a = ap.parse_args()
     P = hip.PREC_NAMES[a.prec]
     dt = torch.bfloat16 if a.prec == "bf16" else torch.float32
@@ -50,7 +51,7 @@ def main():
         def conv():
             if a.impl == "halo":
                 call("crimac_conv3x3", P, ptr(x), Ci, B, H, H, Ci, Co, ptr(w_hi), ptr(w_lo), ptr(bias), ptr(out),
-                     Co, 0, 1, ptr(stats[0]), ptr(stats[1]), 64, None, 0, None, 0)
+                     Co, 0, 0 if a.nostat else 1, ptr(stats[0]), ptr(stats[1]), 64, None, 0, None, 0)
             else:
                 call("crimac_igemm_conv", P, ptr(x), Ci, B, H, H, H, H, Ci, Co, 9, 3, 1, 1, ptr(w_hi), ptr(w_lo),
                      ptr(bias), Co, ptr(out), Co, 0, 0, 0)
