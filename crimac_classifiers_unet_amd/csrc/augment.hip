@@ -35,7 +35,8 @@ __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0
 template <typename T>
 __global__ __launch_bounds__(256) void augment_db_kernel(
     const float* __restrict__ data, const void* __restrict__ labels_in, int label_bytes,
-    T* __restrict__ out, short* __restrict__ labels_out, int B, int C, int H, int W, int ld,
+    T* __restrict__ out, short* __restrict__ labels_out, unsigned char* __restrict__ aux, int thr_channel,
+    float thr_lo, float thr_hi, int B, int C, int H, int W, int ld,
     unsigned seed_lo, unsigned seed_hi, int do_noise, int do_flip, float p_apply, float p_change) {
   const long HW = (long)H * W, npix = (long)B * HW;
   for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void augment_db_kernel(
     const bool flip = do_flip && u01(s.y) < p_apply;
     const int xo = flip ? W - 1 - x : x;
     float v[16];
-    bool nonfinite0 = false;
+    bool nonfinite0 = false, thr_hit = false;
     for (int c = 0; c < C; ++c) {
       float d = data[((long)b * C + c) * HW + hw];
       if (noisy) {
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void augment_db_kernel(
                                    seed_lo ^ (unsigned)b, seed_hi);
         if (u01(r.x) < p_change) d *= (u01(r.y) < 0.5f) ? (1.0f + 9.0f * u01(r.z)) : u01(r.w);
       }
+      if (c == thr_channel) thr_hit = d > thr_lo && d < thr_hi;      // on the augmented linear value; NaN -> false
       if (!isfinite(d)) { if (c == 0) nonfinite0 = true; d = 0.f; }
       d = 10.f * log10f(d + 1e-10f);
       v[c] = fminf(fmaxf(d, -75.f), 0.f);
@@ -76,22 +78,29 @@ __global__ __launch_bounds__(256) void augment_db_kernel(
         else if (label_bytes == 4) l = ((const int*)labels_in)[pix];
         else l = ((const short*)labels_in)[pix];
       }
-      if (nonfinite0) l = -100;
+      // with `aux` the label transform still has to run (crimac_refine_labels): hand over the raw ids and
+      // the two per-pixel facts it needs from the data, the NaN rule is applied there, after it
+      if (nonfinite0 && !aux) l = -100;
       labels_out[((long)b * H + y) * W + xo] = (short)l;
     }
+    if (aux) aux[((long)b * H + y) * W + xo] = (unsigned char)((thr_hit ? 1 : 0) | (nonfinite0 ? 2 : 0));
   }
 }
 
 }  // namespace
 
 extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* labels_in, int label_bytes,
-                                      void* out, short* labels_out, int B, int C, int H, int W, long ld,
+                                      void* out, short* labels_out, unsigned char* aux_mask, int thr_channel,
+                                      float thr_lo, float thr_hi, int B, int C, int H, int W, long ld,
                                       unsigned long long seed, int do_noise, int do_flip, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "augment_db_nhwc: bad precision %d", prec);
   CRIMAC_REQUIRE(data && out && B > 0 && C > 0 && C <= 16 && H > 0 && W > 0 && ld >= C && ld <= 16 && ld % 8 == 0,
                  "augment_db_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
   CRIMAC_REQUIRE(!labels_in || label_bytes == 2 || label_bytes == 4 || label_bytes == 8,
                  "augment_db_nhwc: label_bytes=%d", label_bytes);
+  CRIMAC_REQUIRE(!aux_mask || (thr_channel >= 0 && thr_channel < C), "augment_db_nhwc: bad threshold channel %d",
+                 thr_channel);
+  if (!aux_mask) thr_channel = -1;
   const long npix = (long)B * H * W;
   long blocks = (npix + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -99,12 +108,12 @@ extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* l
   hipStream_t st = (hipStream_t)stream;
   if (prec == CRIMAC_PREC_BF16)
     hipLaunchKernelGGL(augment_db_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, data, labels_in,
-                       label_bytes, (bf16_t*)out, labels_out, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
-                       0.05f);
+                       label_bytes, (bf16_t*)out, labels_out, aux_mask, thr_channel, thr_lo, thr_hi, B, C, H, W, (int)ld,
+                       lo, hi, do_noise, do_flip, 0.5f, 0.05f);
   else
     hipLaunchKernelGGL(augment_db_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, data, labels_in,
-                       label_bytes, (float*)out, labels_out, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
-                       0.05f);
+                       label_bytes, (float*)out, labels_out, aux_mask, thr_channel, thr_lo, thr_hi, B, C, H, W, (int)ld,
+                       lo, hi, do_noise, do_flip, 0.5f, 0.05f);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

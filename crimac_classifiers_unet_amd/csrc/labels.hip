@@ -1,0 +1,147 @@
+// Training label transform on the GPU (CDNA4 / gfx950): one workgroup per 32-row band of a patch, masks in LDS.
+//
+// Reference (numpy + scipy.ndimage in DataLoader workers), define_label_transform_train
+// (batch/transforms.py:71-78), applied to the AUGMENTED linear-sv crop (batch/dataset.py:89-103):
+//   refine_label_boundary (batch/label_transforms/refine_label_boundary.py:35-104):
+//     crop = bounding box of the pixels whose label is not LABEL_BOUNDARY_VAL (-100); none -> unchanged;
+//     m = (label > 0) & (thr_lo < data[thr_channel] < thr_hi);  closed = binary_closing(m[crop], 7x7 disk)
+//     (dilation, then erosion, both with 0 outside the CROP);  label > 0 and not closed -> -30;
+//   convert_label_indexing (convert_label_indexing.py:24-35): 0 -> 0, 27 -> 1, 1 -> 2, everything else -> -100;
+//   remove_nan_inf's label rule (remove_nan_inf.py:30-32, runs after the label transform): -100 where
+//   channel 0 is not finite.
+// Integer work: bit-exact against oracle/labels_oracle.py, which is pinned on the reference's own output.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;
+
+// 7x7 disk (refine_label_boundary.py:50-58): half-width of the row at vertical offset dy
+__device__ __forceinline__ int disk_hw(int dy) { return dy == 0 ? 3 : (dy == 1 || dy == -1) ? 3 : (dy == 2 || dy == -2) ? 2 : 1; }
+
+__device__ __forceinline__ long load_label(const void* p, int bytes, long i) {
+  if (bytes == 8) return ((const long long*)p)[i];
+  if (bytes == 4) return ((const int*)p)[i];
+  return ((const short*)p)[i];
+}
+
+// One workgroup per (patch, band of BAND rows): it scans the whole patch for the bounding box (a few reads
+// per thread, L2-resident) and then works on its rows plus the 3 + 3 halo rows the two morphology passes need.
+constexpr int BAND = 32;
+
+__global__ __launch_bounds__(kThreads) void refine_labels_kernel(
+    const void* __restrict__ labels_in, int label_bytes, const unsigned char* __restrict__ aux,
+    const float* __restrict__ data, int thr_channel, float thr_lo, float thr_hi, int mode,
+    short* __restrict__ labels_out, int C, int H, int W) {
+  extern __shared__ unsigned char smem[];
+  const int HW = H * W;
+  const int r0 = blockIdx.y * BAND;                     // first output row of this band
+  const int rows = min(BAND, H - r0);
+  const int m_lo = r0 - 6, m_rows = rows + 12;          // threshold-mask rows held in LDS
+  const int d_lo = r0 - 3, d_rows = rows + 6;           // dilation rows held in LDS
+  unsigned char* m0 = smem;                             // [m_rows][W]
+  unsigned char* dil = smem + (BAND + 12) * W;          // [d_rows][W]
+  int* box = reinterpret_cast<int*>(smem + (((2 * BAND + 18) * W + 15) & ~15));   // y0, y1 (exclusive), x0, x1
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long base = (long)b * HW;
+  if (tid == 0) { box[0] = H; box[1] = 0; box[2] = W; box[3] = 0; }
+  __syncthreads();
+  // ---- bounding box of label != -100 over the whole patch -------------------------------------------
+  int y0 = H, y1 = 0, x0 = W, x1 = 0;
+  for (int i = tid; i < HW; i += kThreads) {
+    if (load_label(labels_in, label_bytes, base + i) != -100) {
+      const int y = i / W, x = i - y * W;
+      y0 = min(y0, y); y1 = max(y1, y + 1); x0 = min(x0, x); x1 = max(x1, x + 1);
+    }
+  }
+  atomicMin(&box[0], y0); atomicMax(&box[1], y1); atomicMin(&box[2], x0); atomicMax(&box[3], x1);
+  __syncthreads();
+  y0 = box[0]; y1 = box[1]; x0 = box[2]; x1 = box[3];
+  const bool empty = y1 <= y0;
+  // ---- threshold mask (0 outside the crop: border_value of both morphology passes) ------------------
+  for (int i = tid; i < m_rows * W; i += kThreads) {
+    const int ry = i / W, x = i - ry * W, y = m_lo + ry;
+    bool hit = false;
+    if (!empty && y >= y0 && y < y1 && x >= x0 && x < x1) {
+      const long gi = base + (long)y * W + x;
+      if (load_label(labels_in, label_bytes, gi) > 0) {
+        if (aux) hit = aux[gi] & 1;
+        else {
+          const float d = data[((long)b * C + thr_channel) * HW + (long)y * W + x];
+          hit = d > thr_lo && d < thr_hi;
+        }
+      }
+    }
+    m0[i] = hit;
+  }
+  __syncthreads();
+  // ---- dilation ------------------------------------------------------------------------------------
+  for (int i = tid; i < d_rows * W; i += kThreads) {
+    const int ry = i / W, x = i - ry * W, y = d_lo + ry;
+    bool v = false;
+    if (!empty && y >= y0 && y < y1 && x >= x0 && x < x1) {
+      for (int dy = -3; dy <= 3 && !v; ++dy) {
+        const int yy = y + dy;
+        if (yy < y0 || yy >= y1) continue;
+        const int hw = disk_hw(dy);
+        const int xa = max(x - hw, x0), xb = min(x + hw, x1 - 1);
+        const unsigned char* row = m0 + (yy - m_lo) * W;
+        for (int xx = xa; xx <= xb; ++xx)
+          if (row[xx]) { v = true; break; }
+      }
+    }
+    dil[i] = v;
+  }
+  __syncthreads();
+  // ---- erosion, relabel, convert, NaN rule --------------------------------------------------------
+  for (int i = tid; i < rows * W; i += kThreads) {
+    const int ry = i / W, x = i - ry * W, y = r0 + ry;
+    const long gi = base + (long)y * W + x;
+    long l = load_label(labels_in, label_bytes, gi);
+    if (!empty && l > 0) {        // label > 0 implies inside the crop
+      bool closed = true;
+      for (int dy = -3; dy <= 3 && closed; ++dy) {
+        const int yy = y + dy, hw = disk_hw(dy);
+        if (yy < y0 || yy >= y1 || x - hw < x0 || x + hw >= x1) { closed = false; break; }
+        const unsigned char* row = dil + (yy - d_lo) * W;
+        for (int xx = x - hw; xx <= x + hw; ++xx)
+          if (!row[xx]) { closed = false; break; }
+      }
+      if (!closed) l = -30;
+    }
+    if (mode == 1) {
+      l = l == 0 ? 0 : l == 27 ? 1 : l == 1 ? 2 : -100;
+      bool bad;
+      if (aux) bad = aux[gi] & 2;
+      else bad = !isfinite(data[(long)b * C * HW + (long)y * W + x]);
+      if (bad) l = -100;
+    }
+    labels_out[gi] = (short)l;
+  }
+}
+
+}  // namespace
+
+extern "C" int crimac_refine_labels(const void* labels_in, int label_bytes, const unsigned char* aux_mask,
+                                    const float* data, int thr_channel, float thr_lo, float thr_hi, int mode,
+                                    short* labels_out, int B, int C, int H, int W, void* stream) {
+  CRIMAC_REQUIRE(labels_in && labels_out && (label_bytes == 2 || label_bytes == 4 || label_bytes == 8),
+                 "refine_labels: bad label arguments (label_bytes=%d)", label_bytes);
+  CRIMAC_REQUIRE((aux_mask != nullptr) != (data != nullptr), "refine_labels: pass exactly one of aux_mask / data");
+  CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && W <= 1024 && (long)H * W < (1L << 30),
+                 "refine_labels: patch of %d x %d does not fit", H, W);
+  CRIMAC_REQUIRE(aux_mask || (C > 0 && thr_channel >= 0 && thr_channel < C), "refine_labels: bad channel %d of %d",
+                 thr_channel, C);
+  CRIMAC_REQUIRE(mode == 0 || mode == 1, "refine_labels: bad mode %d", mode);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_labels_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const size_t lds = (size_t)(((2 * BAND + 18) * W + 15) & ~15) + 16;
+  hipLaunchKernelGGL(refine_labels_kernel, dim3(B, cdiv(H, BAND)), dim3(kThreads), lds, (hipStream_t)stream, labels_in,
+                     label_bytes, aux_mask, data, thr_channel, thr_lo, thr_hi, mode, labels_out, C, H, W);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}

@@ -678,10 +678,13 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     # on-GPU augmentation (BASELINE configs[4]; reference: batch/data_augmentation/*)
     # ------------------------------------------------------------------------------------------
-    def augment_batch(self, data_linear, labels, seed, do_noise=True, do_flip=True):
+    def augment_batch(self, data_linear, labels, seed, do_noise=True, do_flip=True, refine_labels=None):
         """add_noise + flip_x_axis + remove_nan_inf + db_with_limits + NCHW->NHWC in one kernel.
 
         data_linear [B,C,H,W] fp32 LINEAR sv on the GPU, labels [B,H,W] int16/32/64 (or None).
+        refine_labels=(thr_channel, thr_lo, thr_hi): ``labels`` are RAW annotation ids and the reference's
+        training label transform (refine_label_boundary + convert_label_indexing, batch/transforms.py:71-78)
+        runs on the GPU between the augmentation and the NaN rule, as in batch/dataset.py:89-103.
         Returns (x_nhwc [B*H*W,16] in the engine's storage type, labels int16 [B,H,W])."""
         self.bind()
         if not data_linear.is_cuda:
@@ -693,15 +696,28 @@ class UNetEngine:
         x = self._buf("x_nhwc", (B * H * W, CIN_PAD))
         lab_out = self._buf("aug.labels", (B, H, W), torch.int16)
         lab_in = None if labels is None else self._labels(labels)
+        aux, thr_c, lo, hi = None, 0, 0.0, 0.0
+        if refine_labels is not None:
+            if lab_in is None:
+                raise ValueError("refine_labels needs labels")
+            thr_c, lo, hi = refine_labels
+            aux = self._buf("aug.aux", (B, H, W), torch.uint8)
         call("crimac_augment_db_nhwc", self.prec, ptr(data_linear), ptr(lab_in),
-             lab_in.element_size() if lab_in is not None else 0, ptr(x), ptr(lab_out), B, C, H, W, CIN_PAD,
-             int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if do_noise else 0, 1 if do_flip else 0)
+             lab_in.element_size() if lab_in is not None else 0, ptr(x), ptr(lab_out), ptr(aux), int(thr_c),
+             float(lo), float(hi), B, C, H, W, CIN_PAD, int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if do_noise else 0,
+             1 if do_flip else 0)
+        if aux is not None:
+            refined = self._buf("aug.labels_refined", (B, H, W), torch.int16)
+            call("crimac_refine_labels", ptr(lab_out), 2, ptr(aux), None, int(thr_c), float(lo), float(hi), 1,
+                 ptr(refined), B, C, H, W)
+            lab_out = refined
         return x, lab_out
 
     def train_step_augmented(self, data_linear, labels, class_w, lr, momentum, seed, grad_sync=None,
-                             do_noise=True, do_flip=True, ignore_index=-100):
-        """Training step on RAW linear-sv crops: augmentation and dB transform run on the GPU."""
+                             do_noise=True, do_flip=True, ignore_index=-100, refine_labels=None):
+        """Training step on RAW linear-sv crops: augmentation and dB transform (and, with ``refine_labels``,
+        the label transform on raw annotation ids) run on the GPU."""
         B, _, H, W = data_linear.shape
-        x, lab = self.augment_batch(data_linear, labels, seed, do_noise, do_flip)
+        x, lab = self.augment_batch(data_linear, labels, seed, do_noise, do_flip, refine_labels)
         logits = self.forward_nhwc(x, B, H, W, training=True)
         return self._loss_backward_update(logits, lab, class_w, lr, momentum, grad_sync, ignore_index)

@@ -49,7 +49,7 @@ class SegPipe:
                  lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
                  precision="bf16", loss_flush=50, gpu_augment=False, random_seed=0, gpu_metrics=False,
-                 **kwargs):
+                 gpu_label_transform=False, **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -84,6 +84,12 @@ class SegPipe:
         # data_transform_function=None) and add_noise / flip_x_axis / remove_nan_inf / db_with_limits
         # run fused on the GPU (BASELINE configs[4]); default keeps the reference's numpy workers
         self.gpu_augment = bool(gpu_augment)
+        # gpu_label_transform (with gpu_augment): the train Dataset also gets label_transform_function=None
+        # and hands RAW annotation ids; refine_label_boundary (threshold channel = last frequency, thresholds
+        # [1e-7, 1e-4], batch/transforms.py:74) + convert_label_indexing run on the GPU
+        self.gpu_label_transform = bool(gpu_label_transform)
+        if self.gpu_label_transform and not self.gpu_augment:
+            raise ValueError("gpu_label_transform needs gpu_augment (the transform runs on the augmented crop)")
         self.random_seed = int(random_seed)
         # gpu_metrics: in-training validation builds the PR curve / F1 from GPU histograms instead of
         # shipping every pixel's probability to sklearn (same numbers; the logger gets no pr_curve)
@@ -148,7 +154,8 @@ class SegPipe:
                 rank = parallel.env_world()[1]
                 loss = engine.train_step_augmented(
                     inputs_train, labels_train, criterion.weight, optimizer.param_groups[0]["lr"],
-                    self.momentum, seed=(self.random_seed << 40) ^ (rank << 32) ^ i, grad_sync=grad_sync)
+                    self.momentum, seed=(self.random_seed << 40) ^ (rank << 32) ^ i, grad_sync=grad_sync,
+                    refine_labels=(len(self.frequencies) - 1, 1e-7, 1e-4) if self.gpu_label_transform else None)
             else:
                 loss = engine.train_step(inputs_train, labels_train, criterion.weight,
                                          optimizer.param_groups[0]["lr"], self.momentum,

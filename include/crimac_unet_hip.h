@@ -227,12 +227,30 @@ int crimac_pr_histogram(const float* logits, int ncls, const void* labels, int l
 /* add_noise + flip_x_axis (batch/data_augmentation/add_noise.py:21-41, flip_x_axis.py:21-25) fused
  * with remove_nan_inf + db_with_limits and the NCHW->NHWC conversion: data [B][C][H][W] fp32 LINEAR sv,
  * labels_in [B][H][W] int16/32/64 (or NULL) -> out NHWC [B*H*W][ld] dB activations, labels_out int16
- * (NULL to skip; flipped with the data, -100 where channel 0 is non-finite).  Per sample with p=.5:
+ * (NULL to skip; flipped with the data, -100 where channel 0 is non-finite).  With aux_mask [B][H][W]
+ * given, labels_out keep the raw ids (no -100 rule) and aux_mask receives bit 0 = thr_lo < augmented linear
+ * data[thr_channel] < thr_hi, bit 1 = channel 0 non-finite -- the inputs of crimac_refine_labels, which
+ * then runs the reference's label transform in its place (batch/dataset.py:89-103).  Per sample with p=.5:
  * 5 % of the values x U(1,10) or x U(0,1) (half each); per sample with p=.5: ping axis flipped.
  * Randomness: Philox4x32-10 keyed on (seed, sample index), counter = element index. */
 int crimac_augment_db_nhwc(int prec, const float* data, const void* labels_in, int label_bytes, void* out,
-                           short* labels_out, int B, int C, int H, int W, long ld,
-                           unsigned long long seed, int do_noise, int do_flip, void* stream);
+                           short* labels_out, unsigned char* aux_mask, int thr_channel, float thr_lo,
+                           float thr_hi, int B, int C, int H, int W, long ld, unsigned long long seed,
+                           int do_noise, int do_flip, void* stream);
+
+/* ---- training label transform ------------------------------------------------ */
+
+/* define_label_transform_train (batch/transforms.py:71-78): refine_label_boundary
+ * (batch/label_transforms/refine_label_boundary.py:35-104: threshold + 7x7-disk binary closing on the crop
+ * of non-boundary labels, unclosed school pixels -> -30), then with mode 1 convert_label_indexing
+ * (convert_label_indexing.py:24-35: 0/27/1 -> 0/1/2, rest -> -100) and remove_nan_inf's label rule
+ * (remove_nan_inf.py:30-32).  labels_in [B][H][W] raw annotation ids (int16/32/64) -> labels_out int16.
+ * The per-pixel data facts come either from `data` [B][C][H][W] fp32 linear sv (thr_lo < data[thr_channel]
+ * < thr_hi; channel 0 finite) or, after crimac_augment_db_nhwc, from its aux_mask [B][H][W] (bit 0 / bit 1);
+ * pass exactly one of the two.  W <= 1024. */
+int crimac_refine_labels(const void* labels_in, int label_bytes, const unsigned char* aux_mask,
+                         const float* data, int thr_channel, float thr_lo, float thr_hi, int mode,
+                         short* labels_out, int B, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

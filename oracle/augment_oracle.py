@@ -33,12 +33,15 @@ def u01(x):
     return (np.asarray(x, dtype=np.uint64) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 
-def augment_db(data, labels, seed, do_noise=True, do_flip=True):
+def augment_db(data, labels, seed, do_noise=True, do_flip=True, return_linear=False):
     """data [B,C,H,W] float32 linear sv, labels [B,H,W] -> (dB data [B,C,H,W] float32, labels int16,
-    noisy[B], flipped[B])."""
+    noisy[B], flipped[B]).  return_linear: instead of the final labels return the RAW labels (flipped with
+    the data, no NaN rule) and the augmented LINEAR data -- the inputs of the label transform, which the
+    reference runs between augmentation and data transform (batch/dataset.py:89-103)."""
     B, C, H, W = data.shape
     out = np.empty_like(data, dtype=np.float32)
     lab_out = np.empty(labels.shape, dtype=np.int16)
+    lin_out = np.empty_like(data, dtype=np.float32)
     noisy_f, flip_f = np.zeros(B, bool), np.zeros(B, bool)
     lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     idx = np.arange(C * H * W, dtype=np.uint64)
@@ -54,14 +57,19 @@ def augment_db(data, labels, seed, do_noise=True, do_flip=True):
             f = np.where(inc, np.float32(1.0) + np.float32(9.0) * u01(r[2]), u01(r[3])).astype(np.float32)
             d = (d.reshape(-1) * np.where(change, f, np.float32(1.0))).reshape(C, H, W).astype(np.float32)
         nonfinite0 = ~np.isfinite(d[0])
+        lin = d.copy()
         d = np.where(np.isfinite(d), d, np.float32(0))
         with np.errstate(divide="ignore"):
             d = np.clip(np.float32(10) * np.log10(d + np.float32(1e-10)), -75, 0).astype(np.float32)
         lab = labels[b].astype(np.int64).copy()
-        lab[nonfinite0] = -100
+        if not return_linear:
+            lab[nonfinite0] = -100
         if flip:
             d = d[:, :, ::-1]
             lab = lab[:, ::-1]
-        out[b], lab_out[b] = d, lab.astype(np.int16)
+            lin = lin[:, :, ::-1]
+        out[b], lab_out[b], lin_out[b] = d, lab.astype(np.int16), lin
         noisy_f[b], flip_f[b] = noisy, flip
+    if return_linear:
+        return out, lab_out, noisy_f, flip_f, lin_out
     return out, lab_out, noisy_f, flip_f

@@ -98,3 +98,39 @@ def test_gpu_augment_equals_oracle(prec):
     l1 = m.engine.train_step_augmented(d, l, cw, 0.005, 0.95, seed=7)
     l2 = m.engine.train_step_augmented(d, l, cw, 0.005, 0.95, seed=7)
     assert bool(torch.isfinite(l1)) and float(l2) < float(l1)
+
+
+@pytest.mark.gpu
+def test_gpu_augment_with_label_transform_equals_oracle_chain():
+    """RAW annotation ids in: augmentation (noise + flip) -> refine_label_boundary + convert_label_indexing on the
+    AUGMENTED linear crop -> NaN rule, the order of the reference's Dataset (batch/dataset.py:89-103)."""
+    import crimac_classifiers_unet_amd as pkg
+    from oracle import labels_oracle as lab_orc
+    rng = np.random.default_rng(8)
+    B, C, H, W = 6, 4, 64, 80
+    data = np.power(10.0, rng.uniform(-9.0, -2.0, (B, C, H, W))).astype(np.float32)
+    labels = np.zeros((B, H, W), dtype=np.int16)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for b in range(B):
+        for k in range(4):
+            cy, cx = rng.integers(0, H), rng.integers(0, W)
+            blob = ((yy - cy) / rng.integers(4, 14)) ** 2 + ((xx - cx) / rng.integers(4, 20)) ** 2 <= 1
+            labels[b][blob] = [27, 1, 12, 27][k]
+            strong = blob & (rng.random((H, W)) < 0.8)
+            data[b, 3][strong] = np.power(10.0, rng.uniform(-6.9, -4.1, int(strong.sum()))).astype(np.float32)
+    labels[1, :, :9] = -100
+    labels[2, 50:] = -100
+    data[0, 0, 3:6, 5:40] = np.nan
+    data[3, 3, 20:24, 10:30] = np.inf
+    seed = 0xABCDEF0123
+    _, raw_lab, noisy, flipped, lin = aug.augment_db(data, labels, seed=seed, return_linear=True)
+    assert noisy.any() and flipped.any() and (~flipped).any()
+    expect = lab_orc.train_label_transform(lin, raw_lab, 3)
+    # the refine step must matter in this test, and depend on the noise (thresholds see augmented values)
+    plain = np.stack([lab_orc.convert_label_indexing(raw_lab[b]) for b in range(B)])
+    assert (expect != plain).sum() > 100
+    m = pkg.UNet_Baseline(3, 4, precision="bf16").cuda()
+    _, lab = m.engine.augment_batch(torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda(), seed,
+                                    refine_labels=(3, 1e-7, 1e-4))
+    assert np.array_equal(lab.cpu().numpy(), expect)
+    assert set(np.unique(expect)) <= {0, 1, 2, -100}

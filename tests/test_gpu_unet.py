@@ -457,3 +457,33 @@ def test_gradient_ranges_are_final_when_handed_to_the_exchange(full_case):
     (d0, _), (b0, b1), _ = eng.grad_ranges()
     assert eng.layout["up_convs.0.upconv.weight"][0] == d0 == b1
     assert eng.layout["down_convs.4.main.0.weight"][0] == b0
+
+
+def test_train_model_on_raw_crops_with_gpu_augment_and_label_transform(tmp_path):
+    """gpu_augment + gpu_label_transform: the loader hands LINEAR sv and RAW annotation ids (27 = sandeel,
+    1 = other, other species ids), everything between the crop and the loss runs on the GPU."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(precision="bf16", batch_size=2, iterations=4, log_step=100, lr_step=100, save_model_params=False,
+               gpu_augment=True, gpu_label_transform=True, random_seed=3)
+    pipe = pkg.SegPipeUNet(checkpoint_dir=None, experiment_name="t", **cfg)
+    pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+    rng = np.random.default_rng(0)
+    x = np.power(10.0, rng.uniform(-9, -2, (2, 4, 64, 64))).astype(np.float32)
+    lab = rng.choice(np.array([0, 0, 0, 27, 1, 12], dtype=np.int16), size=(2, 64, 64))
+    lab[0, :, :5] = -100
+    batch = {"data": torch.from_numpy(x), "labels": torch.from_numpy(lab),
+             "center_coordinates": torch.zeros(2, 2, dtype=torch.int64)}
+
+    class Logger:
+        def __init__(self):
+            self.losses = []
+
+        def add_scalar(self, tag, scalar_value, global_step):
+            if tag == "train/loss":
+                self.losses.append(float(scalar_value))
+    lg = Logger()
+    pipe.train_model([batch] * 4, [batch], lg)
+    assert len(lg.losses) == 4 and all(np.isfinite(lg.losses)) and lg.losses[-1] < lg.losses[0]
+    with pytest.raises(ValueError):
+        pkg.SegPipeUNet(checkpoint_dir=None, experiment_name="t", **{**cfg, "gpu_augment": False})
