@@ -224,11 +224,11 @@ class UNetEngine:
         the backward pass completes them (grad_ranges): decoder, bottleneck block, other encoder blocks."""
         if getattr(self, "_ltab", None) is not None:
             return self._ltab
-        groups = [[], [], []]
+        groups = [[] for _ in range(1 + self.n_enc_groups)]
         for j in range(self.depth - 1):
             groups[0] += [self.ups[j], *self.dec[j]]
         for i in range(self.depth):
-            groups[1 if i == self.depth - 1 else 2] += list(self.enc[i])
+            groups[self._enc_group(i)] += list(self.enc[i])
         layers = [l for g in groups for l in g]
         arr = (hip.LayerDesc * len(layers))()
         for d, l in zip(arr, layers):
@@ -527,18 +527,37 @@ class UNetEngine:
 
     wgrad_target_blocks = 0      # 0 = let the library pick the pixel-range split
 
+    # Backward completes the flat gradient buffer from its end: decoder + head first (group 0), then the
+    # encoder blocks deepest first.  The two deepest encoder blocks get a group each (14.2 M and 3.5 M of the
+    # 31 M gradients), the shallow rest (1.1 M) goes last -- that tail is all that is exchanged after the
+    # backward pass has finished.
+    n_enc_groups = 3
+
+    def _enc_group(self, i):
+        """Backward group (1..n_enc_groups) of encoder block i."""
+        return min(self.depth - i, self.n_enc_groups)
+
     def grad_ranges(self):
-        """Contiguous ranges of the flat gradient buffer in the order the backward pass completes
-        them: (decoder + head), (bottleneck encoder block), (remaining encoder blocks)."""
-        bot = ".".join(self.enc[self.depth - 1][0].conv_key.split(".")[:2]) + "."
+        """Contiguous ranges of the flat gradient buffer in the order the backward pass completes them."""
         dec = self.ups[0].key.split(".")[0] + "."
-        lo_bot = min(o for k, (o, _, _) in self.layout.items() if k.startswith(bot))
         lo_dec = min(o for k, (o, _, _) in self.layout.items() if k.startswith(dec))
+        starts = {}                                   # group -> lowest offset
+        for i in range(self.depth):
+            pre = ".".join(self.enc[i][0].conv_key.split(".")[:2]) + "."
+            lo = min(o for k, (o, _, _) in self.layout.items() if k.startswith(pre))
+            g = self._enc_group(i)
+            starts[g] = min(starts.get(g, lo), lo)
+        bounds = sorted(starts.items(), key=lambda kv: -kv[1])      # deepest group (highest offset) first
+        if [g for g, _ in bounds] != sorted(starts) or bounds[-1][1] != 0 or not bounds[0][1] < lo_dec:
+            raise RuntimeError("unexpected parameter order in the flat buffer")
         for k, (o, _, _) in self.layout.items():
-            late = k.startswith(dec) or k.startswith("conv_final")
-            if (o >= lo_dec) != late or (lo_bot <= o < lo_dec) != k.startswith(bot):
+            if (o >= lo_dec) != (k.startswith(dec) or k.startswith("conv_final")):
                 raise RuntimeError(f"unexpected parameter order in the flat buffer at {k}")
-        return [(lo_dec, self.n_flat), (lo_bot, lo_dec), (0, lo_bot)]
+        ranges, hi = [(lo_dec, self.n_flat)], lo_dec
+        for _, lo in bounds:
+            ranges.append((lo, hi))
+            hi = lo
+        return ranges
 
     def backward(self, dlogits, on_ready=None):
         """Gradients of every parameter into the flat gradient buffer (overwrites it).
@@ -608,13 +627,11 @@ class UNetEngine:
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool, reduce_done=fused)
             else:
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, None, reduce_done=fused)
-            if i == D - 1:
-                self._unpack_group(1)
+            g = self._enc_group(i)
+            if i == 0 or self._enc_group(i - 1) != g:        # last (shallowest) block of its group
+                self._unpack_group(g)
                 if on_ready is not None:
-                    on_ready(*ranges[1])
-        self._unpack_group(2)
-        if on_ready is not None:
-            on_ready(*ranges[2])
+                    on_ready(*ranges[g])
 
     # ------------------------------------------------------------------------------------------
     # loss and optimiser

@@ -454,9 +454,10 @@ def test_gradient_ranges_are_final_when_handed_to_the_exchange(full_case):
         assert torch.equal(snap, rec.final[lo:hi]), (lo, hi)
         assert float(snap.abs().max()) > 0
     # the three ranges are what the module prefixes say they are
-    (d0, _), (b0, b1), _ = eng.grad_ranges()
+    (d0, _), (b0, b1), (c0, c1), (e0, e1) = eng.grad_ranges()
     assert eng.layout["up_convs.0.upconv.weight"][0] == d0 == b1
-    assert eng.layout["down_convs.4.main.0.weight"][0] == b0
+    assert eng.layout["down_convs.4.main.0.weight"][0] == b0 == c1
+    assert eng.layout["down_convs.3.main.0.weight"][0] == c0 == e1 and e0 == 0
 
 
 def test_train_model_on_raw_crops_with_gpu_augment_and_label_transform(tmp_path):
