@@ -7,7 +7,8 @@
 //   * every tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
 //     ds_write; the XOR swizzles are applied on the per-lane SOURCE address (the LDS image of one
 //     wave-instruction is lane-linear: 8 rows x 128 B);
-//   * one workgroup per CU with 8 waves (4 along pixels x 2 along channels, 64 x BN/2 each) on a
+//   * (8-wave kernel; the 4-wave variant further down is the default where a launch has enough tiles)
+//     one workgroup per CU with 8 waves (4 along pixels x 2 along channels, 64 x BN/2 each) on a
 //     16x16-pixel x BN-channel tile: the weight tile of a step is shared by twice as many MFMAs as in
 //     the 128-pixel kernel, and a 3-slot weight ring keeps TWO steps of weights in flight;
 //   * counted `s_waitcnt vmcnt(N)` + raw `s_barrier`: only the tile needed next is waited for, the
@@ -53,6 +54,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  static_assert(N == 0 || N == 1 || N == 2 || N == 4, "add the immediate");
 }
 
 // M16: use v_mfma_f32_16x16x32_bf16 (same LDS bytes per FLOP for the 64 x BN/2 wave tile; the chip
@@ -265,10 +268,15 @@ int launch(ConvParams p, hipStream_t st) {
 // per SIMD serialises LDS-DMA issue, MFMAs and the epilogue), and keeping the 72 KB of weights in
 // registers (36-72 B-fragments per wave; hipcc spills around the epilogue and every scratch reload
 // drains the DMA queue: 470-610 us).
-__global__ __launch_bounds__(256) void conv3x3_glds_n64_kernel(ConvParams p) {
-  constexpr int BN = 64, NW = 4;
-  constexpr int B_BYTES = BN * RB;                 // 8 KB weight slot
-  constexpr int NB = (BN / 8) / NW;                // 2 weight wave-instructions per wave and step
+// BN = 128: the same 4-wave structure with 64 x 128 per wave (0.75 ds_read_b128 per MFMA, 32 MFMAs per
+// wave between barriers) and a 2-slot weight ring (one step ahead), 74 KB: also two workgroups per CU.
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
+void conv3x3_glds_w4_kernel(ConvParams p) {
+  constexpr int NW = 4, NT = BN / 32;
+  constexpr int NSLOT = BN == 64 ? 3 : 2, AHEAD = NSLOT - 1;
+  constexpr int B_BYTES = BN * RB;                 // weight slot: 8 / 16 KB
+  constexpr int NB = (BN / 8) / NW;                // weight wave-instructions per wave and step: 2 / 4
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -325,11 +333,11 @@ __global__ __launch_bounds__(256) void conv3x3_glds_n64_kernel(ConvParams p) {
       glds16(p.w_hi + t * w_tap + b_src[i] + kc * BK, sB(slot) + (wave + NW * i) * 1024);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int fr = lane & 31, fq = lane >> 5;
@@ -346,20 +354,20 @@ __global__ __launch_bounds__(256) void conv3x3_glds_n64_kernel(ConvParams p) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int unit = 2 * ks + fq;
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[2], bfr[NT];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         af[i] = *reinterpret_cast<const bf16x8*>(sA + (a_row0[i] + shift) * RB +
                                                  ((unit ^ (((a_hx0[i] + kx) >> 1) & 7)) << 4));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NT; ++j) {
         const int row = j * 32 + fr;
         bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + ((unit ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   };
@@ -368,25 +376,25 @@ __global__ __launch_bounds__(256) void conv3x3_glds_n64_kernel(ConvParams p) {
   const int nsteps = kchunks * 9;
   issue_halo(0);
   issue_b(0, 0, 0);
-  issue_b(0, 1, 1);
-  wait_vmcnt<NB>();
+  if constexpr (AHEAD == 2) issue_b(0, 1, 1);
+  wait_vmcnt<(AHEAD - 1) * NB>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   int kc = 0, t = 0, slot = 0;
   for (int s = 0; s < nsteps; ++s) {
-    const bool more = s + 2 < nsteps;
+    const bool more = s + AHEAD < nsteps;
     if (more) {
-      int t2 = t + 2, kc2 = kc;
+      int t2 = t + AHEAD, kc2 = kc;
       if (t2 >= 9) { t2 -= 9; kc2 += 1; }
-      int slot2 = slot + 2;
-      if (slot2 >= 3) slot2 -= 3;
+      int slot2 = slot + AHEAD;
+      if (slot2 >= NSLOT) slot2 -= NSLOT;
       issue_b(kc2, t2, slot2);
     }
 #ifndef CRIMAC_EXP_NOCOMPUTE
     compute(sB(slot), t);
 #endif
-    if (more) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+    if (more) wait_vmcnt<(AHEAD - 1) * NB>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (++t == 9) {
       t = 0;
@@ -396,31 +404,33 @@ __global__ __launch_bounds__(256) void conv3x3_glds_n64_kernel(ConvParams p) {
         __builtin_amdgcn_s_barrier();
       }
     }
-    if (++slot == 3) slot = 0;
+    if (++slot == NSLOT) slot = 0;
   }
 #ifdef CRIMAC_EXP_NOEPI
   float sum = 0.f;
   for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
       for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
   if (sum == 12345.678f) reinterpret_cast<float*>(p.epi.out)[tid] = sum;
 #else
-  conv_epilogue<bf16_t, BN, BM, 256, 2, 2, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
+  conv_epilogue<bf16_t, BN, BM, 256, 2, NT, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
 #endif
 }
 
-int launch_n64(ConvParams p, hipStream_t st) {
+template <int BN>
+int launch_w4(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  const size_t lds = (size_t)A_BYTES + 3 * 64 * RB;
+  const size_t lds = (size_t)A_BYTES + (BN == 64 ? 3 : 2) * BN * RB;
+  static_assert(BM * (BN * 2 + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB, "epilogue staging must fit");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_n64_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3x3_glds_n64_kernel, dim3((unsigned)ntiles, p.N / 64), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -434,8 +444,22 @@ int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, in
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
-  static const int n64 = getenv("CRIMAC_CONV_N64") ? atoi(getenv("CRIMAC_CONV_N64")) : 1;
-  if (n64 && N % 128 != 0) return launch_n64(p, st);
+  // N = 64 layers: 4-wave kernel.  N >= 128: the 4-wave kernel too (two workgroups per CU; measured +10-20 %
+  // on every layer, tools/bench_conv.py) unless the launch has fewer than two workgroups per CU to hand out
+  // (the 16x16-pixel bottleneck level at B = 32: 256 tiles) -- then the 8-wave kernel, one workgroup per CU.
+  static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 1;
+  if (N % 128 != 0) return launch_w4<64>(p, st);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+  }
+  const long ntiles = (long)B * cdiv(H, TR) * cdiv(W, TC) * (N / 128);
+  if (w4 == 2 || (w4 == 1 && ntiles >= 2L * n_cu)) return launch_w4<128>(p, st);
   static const int m16 = getenv("CRIMAC_CONV_M16") ? atoi(getenv("CRIMAC_CONV_M16")) : 0;
   if (m16) return N % 128 == 0 ? launch<128, true>(p, st) : launch<64, true>(p, st);
   return N % 128 == 0 ? launch<128, false>(p, st) : launch<64, false>(p, st);
