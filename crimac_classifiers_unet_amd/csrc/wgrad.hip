@@ -30,6 +30,7 @@ struct WgradParams {
   int tiles_y, tiles_x;
   long ntiles;
   int tiles_per_block;
+  int nsplits;
 };
 
 __device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 6; }
@@ -38,16 +39,124 @@ __device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_PTR(bf16x4))(p));
 }
 
+
+// ---- bf16 contraction of one staged tile, hand-placed schedule ------------------------------------------
+// The transposing reads are inline asm:
+//  * through the intrinsic hipcc puts `s_waitcnt vmcnt(0)` in front of the first read of every tile row (an
+//    LDS read "may alias" the LDS-DMA of the NEXT tile, already in flight): the prefetch was drained before
+//    the MFMAs, so loads and MFMAs of a workgroup ran back to back (ablation, 512->512 @32x32: loads 56 us +
+//    MFMA loop 123 us = 179 us vs 171 us together);
+//  * its reads were issued one or two MFMAs ahead of their use (MFMA loop alone at 57 % of the MFMA rate).
+// Here a tile row is split in two halves (A fragment + first taps | remaining taps); the reads of the NEXT
+// half are always issued before the MFMAs of the current one, and since LDS reads return in order
+// `s_waitcnt lgkmcnt(n)` with n = number of reads of the next half releases the current half.
+// Addresses: row r = c + R (c compile-time, R = 8*kh + q per lane), byte = r*128 + (chb ^ swz(r)); swz(r)
+// only depends on (c + R) mod 4, so 4 per-lane bases (by c & 3) + an immediate c*128 cover every read --
+// 5 address registers instead of one per (row, tap).
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr16_asm(unsigned addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+template <int MODE>
+struct WgGeo {
+  static constexpr int TR = MODE == 0 ? 8 : 4, NT = MODE == 0 ? 9 : 4;
+  static constexpr int HA = MODE == 0 ? 4 : 2;            // taps [0,HA) ride with the A fragment
+  static constexpr int srow(int py, int t) {
+    return MODE == 0 ? (py + t / 3) * 18 + t % 3 : (2 * py + (t >> 1)) * 32 + (t & 1) * 16;
+  }
+};
+
+template <int MODE>
+struct WgFrags {
+  bf16x4 a0[2], a1[2], b0[WgGeo<MODE>::NT], b1[WgGeo<MODE>::NT];
+};
+
+template <int MODE, int PY, int T>
+__device__ __forceinline__ void wg_rd_tap(const unsigned (&sv)[4], WgFrags<MODE>& f) {
+  constexpr int c = WgGeo<MODE>::srow(PY, T);
+  f.b0[T] = lds_tr16_asm<c * 128>(sv[c & 3]);
+  f.b1[T] = lds_tr16_asm<(c + 4) * 128>(sv[c & 3]);
+}
+template <int MODE, int PY, int T0, int T1>
+__device__ __forceinline__ void wg_rd_taps(const unsigned (&sv)[4], WgFrags<MODE>& f) {
+  if constexpr (T0 < T1) {
+    wg_rd_tap<MODE, PY, T0>(sv, f);
+    wg_rd_taps<MODE, PY, T0 + 1, T1>(sv, f);
+  }
+}
+template <int MODE, int PY>
+__device__ __forceinline__ void wg_rd_a(unsigned fv, WgFrags<MODE>& f) {
+  f.a0[PY & 1] = lds_tr16_asm<PY * 16 * 128>(fv);
+  f.a1[PY & 1] = lds_tr16_asm<(PY * 16 + 4) * 128>(fv);
+}
+template <int MODE, int T0, int T1, typename ACC>
+__device__ __forceinline__ void wg_fma(const WgFrags<MODE>& f, int set, ACC& acc) {
+  if constexpr (T0 < T1) {
+    const bf16x8 af = __builtin_shufflevector(f.a0[set], f.a1[set], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 bfr = __builtin_shufflevector(f.b0[T0], f.b1[T0], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[T0], 0, 0, 0);
+    wg_fma<MODE, T0 + 1, T1>(f, set, acc);
+  }
+}
+// release the first half of a row (A + taps [0,HA)): at most the NB reads of the second half stay in flight
+template <int MODE>
+__device__ __forceinline__ void wg_release_first(WgFrags<MODE>& f, int set) {
+  if constexpr (MODE == 0)
+    asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(f.a0[set]), "+v"(f.a1[set]), "+v"(f.b0[0]), "+v"(f.b1[0]),
+                 "+v"(f.b0[1]), "+v"(f.b1[1]), "+v"(f.b0[2]), "+v"(f.b1[2]), "+v"(f.b0[3]), "+v"(f.b1[3]) :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a0[set]), "+v"(f.a1[set]), "+v"(f.b0[0]), "+v"(f.b1[0]),
+                 "+v"(f.b0[1]), "+v"(f.b1[1]) :: "memory");
+}
+// release the second half (taps [HA,NT)); LAST: nothing was issued behind it
+template <int MODE, bool LAST>
+__device__ __forceinline__ void wg_release_second(WgFrags<MODE>& f) {
+  if constexpr (MODE == 0) {
+    if constexpr (LAST)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b0[4]), "+v"(f.b1[4]), "+v"(f.b0[5]), "+v"(f.b1[5]), "+v"(f.b0[6]),
+                   "+v"(f.b1[6]), "+v"(f.b0[7]), "+v"(f.b1[7]), "+v"(f.b0[8]), "+v"(f.b1[8]) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(f.b0[4]), "+v"(f.b1[4]), "+v"(f.b0[5]), "+v"(f.b1[5]), "+v"(f.b0[6]),
+                   "+v"(f.b1[6]), "+v"(f.b0[7]), "+v"(f.b1[7]), "+v"(f.b0[8]), "+v"(f.b1[8]) :: "memory");
+  } else {
+    if constexpr (LAST)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b0[2]), "+v"(f.b1[2]), "+v"(f.b0[3]), "+v"(f.b1[3]) :: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f.b0[2]), "+v"(f.b1[2]), "+v"(f.b0[3]), "+v"(f.b1[3]) :: "memory");
+  }
+}
+template <int MODE, int PY, typename ACC>
+__device__ __forceinline__ void wg_row(unsigned fv, const unsigned (&sv)[4], WgFrags<MODE>& f, ACC& acc) {
+  using G = WgGeo<MODE>;
+  wg_rd_taps<MODE, PY, G::HA, G::NT>(sv, f);          // second half of this row in flight
+  wg_release_first<MODE>(f, PY & 1);
+  wg_fma<MODE, 0, G::HA>(f, PY & 1, acc);
+  if constexpr (PY + 1 < G::TR) {
+    wg_rd_a<MODE, PY + 1>(fv, f);                     // first half of the next row in flight
+    wg_rd_taps<MODE, PY + 1, 0, G::HA>(sv, f);
+    wg_release_second<MODE, false>(f);
+  } else {
+    wg_release_second<MODE, true>(f);
+  }
+  wg_fma<MODE, G::HA, G::NT>(f, PY & 1, acc);
+  if constexpr (PY + 1 < G::TR) wg_row<MODE, PY + 1>(fv, sv, f, acc);
+}
+
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
 //
-// bf16 path: tiles go global -> LDS directly (global_load_lds_dwordx4, no registers), double
-// buffered: the loads of tile t+1 are in flight while tile t is contracted; one barrier per tile.
-// The LDS image of such a load is lane-linear (1 KiB = 8 pixel rows per wave-instruction), so the
-// tr-read swizzle is applied on the per-lane SOURCE address.  Pixels outside the image are zeroed
-// with plain LDS stores by the lane that would have loaded them.
+// bf16 path: tiles go global -> LDS directly (LDS-DMA through a buffer resource rebased on the tile origin,
+// no staging registers), double buffered: the loads of tile t+1 are in flight while tile t is contracted;
+// one barrier per tile.  The LDS image of such a load is lane-linear (1 KiB = 8 pixel rows per
+// wave-instruction), so the tr-read swizzle is applied on the per-lane SOURCE offset; lanes whose pixel is
+// outside the image read out of range and the hardware stores zeros.  The contraction itself runs on the
+// hand-placed read/MFMA schedule above (wg_row).
 // fp32 (split-bf16) path: register staging with the hi/lo split, single buffer.
 template <typename TA, int NPL, int MODE>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
+void wgrad_kernel(WgradParams p) {
   constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
   static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
   constexpr int TR = MODE == 0 ? 8 : 4;
@@ -70,7 +179,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int cs_tiles = (p.CS + 63) / 64;
   const int ch_tiles = ((p.CF + 63) / 64) * cs_tiles;
   int qt, split;
-  if (ch_tiles % 8 == 0) {
+  if (p.nsplits % 8 == 0) {
+    // split-major: XCD x owns the pixel ranges x, x+8, ... and runs ALL channel-tile pairs on them, so a
+    // staged F / S tile is fetched into that XCD's L2 once and hit by the other pairs (measured +2 %)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    qt = j % ch_tiles;
+    split = xcd + 8 * (j / ch_tiles);
+  } else if (ch_tiles % 8 == 0) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, R = ch_tiles >> 3;
     qt = xcd * R + j % R;
     split = j / R;
@@ -101,6 +216,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   // contraction over one staged tile: one k16 step per tile row.  Plane k of F at sF + k*F_BYTES,
   // plane k of S at sS + k*S_BYTES.
   auto contract = [&](const unsigned char* sF, const unsigned char* sS) {
+    if constexpr (!X3) {
+      const int R = 8 * kh + q;
+      const unsigned fv = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(sF)) + R * 128 + (f_chb ^ swz_tr(R));
+      const unsigned sb = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(sS)) + R * 128;
+      unsigned sv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv[k] = sb + (s_chb ^ swz_tr(k + R));
+      WgFrags<MODE> f;
+      wg_rd_a<MODE, 0>(fv, f);
+      wg_rd_taps<MODE, 0, 0, WgGeo<MODE>::HA>(sv, f);
+      wg_row<MODE, 0>(fv, sv, f, acc);
+      return;
+    }
 #pragma unroll 1
     for (int py = 0; py < TR; ++py) {
       bf16x8 af[NPL];
@@ -159,68 +287,77 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   if constexpr (!X3) {
     // ---- bf16: direct-to-LDS double buffering ----------------------------------------------------
-    // Per-lane geometry of this wave's wave-instructions is the same for every tile: precompute the
-    // pixel offsets relative to the tile origin once, so a tile costs one add + one bounds test per
-    // instruction instead of div/mod chains (the address VALU work was as long as the MFMA work).
+    // Tiles come in through buffer resources rebased on the tile origin (scalar work): a lane only keeps its
+    // 32-bit offset relative to that origin, and a lane whose pixel is outside the image (or whose channels
+    // are past the tensor's) uses an out-of-range offset -- the hardware then writes ZEROS to its LDS slot
+    // (checked on MI355X), so there is no masked-lane branch, no zero-store path and every wave issues the
+    // same number of DMAs for every tile.
     constexpr int NF = F_ROWS / 8 / 4;                       // F wave-instructions per wave
     constexpr int NS = (S_ROWS_PAD / 8 + 3) / 4;             // S wave-instructions per wave
+    constexpr unsigned OOB = 0x80000000u;                    // >= num_records of the rebased resources
     const int sub = lane >> 3, c = lane & 7;
-    int f_rel[NF], f_yx[NF];          // element offset from the tile origin pixel; packed (ry << 8 | rx)
-    int s_rel[NS], s_yx[NS];          // S: offsets on the S grid (fine grid for MODE 1); -1 = never valid
+    unsigned f_rel[NF], s_rel[NS];    // byte offset from the tile origin pixel (S: origin of the halo / fine patch)
+    auto f_geo = [&](int i, int& ry, int& rx) {
+      const int row = 8 * (wave + 4 * i) + sub;
+      ry = row >> 4;
+      rx = row & 15;
+    };
+    auto s_geo = [&](int i, int& ry, int& rx) {   // relative to (y0 - 1, x0 - 1) for MODE 0, to (2*y0, 2*x0) for MODE 1
+      const int row = 8 * (wave + 4 * i) + sub;
+      if constexpr (MODE == 0) {
+        ry = (row * 3641) >> 16;      // row / 18 for row < 1024
+        rx = row - ry * 18;
+      } else {
+        ry = row >> 5;
+        rx = 2 * (row & 15) + ((row & 31) >> 4);
+      }
+    };
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int row = 8 * (wave + 4 * i) + sub;
       const int u = c ^ (4 * ((row >> 1) & 1));
-      const int ry = row >> 4, rx = row & 15;
-      f_rel[i] = (cf0 + u * 8) < p.CF ? (int)((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) : -1;
-      f_yx[i] = (ry << 8) | rx;
+      int ry, rx;
+      f_geo(i, ry, rx);
+      f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * 2) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int k = wave + 4 * i;
       const int row = 8 * k + sub;
       const int u = c ^ (4 * ((row >> 1) & 1));
-      int ry, rx;                     // relative to (y0 - 1, x0 - 1) for MODE 0, to (2*y0, 2*x0) for MODE 1
-      if constexpr (MODE == 0) {
-        ry = row / 18;
-        rx = row % 18;
-      } else {
-        ry = row >> 5;
-        rx = 2 * (row & 15) + ((row & 31) >> 4);
-      }
+      int ry, rx;
+      s_geo(i, ry, rx);
       const bool ok = k < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
-      s_rel[i] = ok ? (int)((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) : -1;
-      s_yx[i] = (ry << 8) | rx;
+      s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * 2) : OOB;
     }
     auto issue_tile = [&](long tile, int buf) {
       long b; int y0, x0;
       tile_origin(tile, b, y0, x0);
       unsigned char* base = smem + buf * BUF_BYTES;
-      const bf16_t* fbase = fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld;
+      const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        const int k = wave + 4 * i;
-        const bool ok = f_rel[i] >= 0 && (y0 + (f_yx[i] >> 8)) < p.Hf && (x0 + (f_yx[i] & 255)) < p.Wf;
-        if (ok)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fbase + f_rel[i]),
-                                           (__attribute__((address_space(3))) void*)(base + k * 1024), 16, 0, 0);
-        else
-          *reinterpret_cast<u32x4*>(base + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+        int ry, rx;
+        f_geo(i, ry, rx);
+        const bool ok = (y0 + ry) < p.Hf && (x0 + rx) < p.Wf;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
+                                                 16, (int)(ok ? f_rel[i] : OOB), 0, 0, 0);
       }
       unsigned char* sbase = base + F_BYTES;
       const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0, sx0 = MODE == 0 ? x0 - 1 : 2 * x0;
-      const bf16_t* spbase = sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int k = wave + 4 * i;
-        if (k >= S_ROWS_PAD / 8) continue;
-        const int y = sy0 + (s_yx[i] >> 8), x = sx0 + (s_yx[i] & 255);
-        const bool ok = s_rel[i] >= 0 && y >= 0 && y < Hs && x >= 0 && x < Ws;
-        if (ok)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(spbase + s_rel[i]),
-                                           (__attribute__((address_space(3))) void*)(sbase + k * 1024), 16, 0, 0);
-        else
-          *reinterpret_cast<u32x4*>(sbase + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+        if (k >= S_ROWS_PAD / 8) continue;          // wave-uniform
+        int ry, rx;
+        s_geo(i, ry, rx);
+        const unsigned y = (unsigned)(sy0 + ry), x = (unsigned)(sx0 + rx);
+        const bool ok = y < (unsigned)Hs && x < (unsigned)Ws;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sbase + k * 1024), 16,
+                                                 (int)(ok ? s_rel[i] : OOB), 0, 0, 0);
       }
     };
     if (t_begin < t_end) issue_tile(t_begin, 0);
@@ -317,6 +454,7 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   if (splits > p.ntiles) splits = (int)p.ntiles;
   p.tiles_per_block = cdiv(p.ntiles, splits);
   splits = cdiv(p.ntiles, p.tiles_per_block);
+  p.nsplits = splits;
   // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of NPL planes
   const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 : NPL);
   static bool attr_set = false;
