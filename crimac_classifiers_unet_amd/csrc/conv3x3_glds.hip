@@ -1,23 +1,23 @@
-// 3x3 convolution (stride 1, pad 1), bf16, direct-to-LDS streaming variant for CDNA4 (gfx950).
+// 3x3 convolution (stride 1, pad 1), bf16, LDS-DMA kernels for CDNA4 (gfx950).
 //
 // Same contraction and epilogue as conv3x3.hip (reference: nn.Conv2d 3x3 forward and input gradient,
 // unet.py:35-44, pipeline.py:177), restructured after measuring the register-staged kernel
-// (tools/bench_conv.py ablations, 1024->1024 @16x16, B=32): the VGPR->LDS stores of the staged tiles
-// cost 36 % of its time, the loads 24 %, the MFMAs only ~45 %.  Here
-//   * every tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
-//     ds_write; the XOR swizzles are applied on the per-lane SOURCE address (the LDS image of one
-//     wave-instruction is lane-linear: 8 rows x 128 B);
-//   * (8-wave kernel; the 4-wave variant further down is the default where a launch has enough tiles)
-//     one workgroup per CU with 8 waves (4 along pixels x 2 along channels, 64 x BN/2 each) on a
-//     16x16-pixel x BN-channel tile: the weight tile of a step is shared by twice as many MFMAs as in
-//     the 128-pixel kernel, and a 3-slot weight ring keeps TWO steps of weights in flight;
-//   * counted `s_waitcnt vmcnt(N)` + raw `s_barrier`: only the tile needed next is waited for, the
-//     younger loads stay in flight across the barrier (never vmcnt(0) inside the loop);
-//   * halo rows outside the image never change for a workgroup: they are zeroed once, the loads of
-//     those lanes are masked off.
+// (tools/bench_conv.py ablations, 1024->1024 @16x16, B=32): the VGPR->LDS stores of the staged tiles cost
+// 36 % of its time, the loads 24 %, the MFMAs only ~45 %.  Common to both kernels here:
+//   * 16x16-pixel tile, 4 waves, two workgroups per CU (<= 256 registers, <= 74 KB LDS);
+//   * the halo (18x18 pixels x 64 channels) goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no
+//     staging registers, no ds_write; the XOR swizzle is applied on the per-lane SOURCE address (the LDS
+//     image of one wave-instruction is lane-linear: 8 rows x 128 B), and it is read 9x at shifted rows
+//     (im2col-free);
+//   * halo rows outside the image never change for a workgroup: zeroed once, those lanes masked off.
+// conv3x3_wch_kernel  (N % 128 == 0): waves split the output CHANNELS, weights go global -> registers,
+//                     no barrier inside a 64-channel chunk, inline-asm read/MFMA pipeline (1.1-1.4 PFLOP/s);
+// conv3x3_glds_w4_kernel (N = 64):    waves split the PIXELS, weights through a 3-slot LDS ring with counted
+//                     vmcnt + raw s_barrier per tap (the HBM-heavy 256x256 layers).
+// An 8-wave / one-workgroup-per-CU form with a double-buffered halo was the first LDS-DMA kernel; the 4-wave
+// forms beat it by 10-20 % (wch: 20-35 %) on every layer and it was removed.
 #include <stdlib.h>
 
-#include <type_traits>
 
 #include "common.h"
 #include "conv_epilogue.h"
@@ -40,7 +40,6 @@ constexpr int HALO_ROWS = (TR + 2) * HP;          // 324
 constexpr int HALO_INSTR = (HALO_ROWS + 7) / 8;   // 41 wave-instructions of 8 rows
 constexpr int BK = 64, RB = BK * 2;               // 64 channels = 128 B per row
 constexpr int A_BYTES = HALO_INSTR * 1024;        // one halo buffer (padded to whole instructions)
-constexpr int NWAVES = 8;
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
 #ifdef CRIMAC_EXP_NOGLDS
@@ -58,201 +57,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N == 0 || N == 1 || N == 2 || N == 4, "add the immediate");
 }
 
-// M16: use v_mfma_f32_16x16x32_bf16 (same LDS bytes per FLOP for the 64 x BN/2 wave tile; the chip
-// holds a higher clock on this shape under load, MI355X_MICROARCH.md "DVFS give-back" item 7).
-template <int BN, bool M16>
-__global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p) {
-  constexpr int NT = BN / 64;                      // 32-col MFMA tiles per wave
-  constexpr int B_BYTES = BN * RB;                 // one weight slot
-  constexpr int B_INSTR = BN / 8;                  // wave-instructions per weight tile
-  constexpr int NB = B_INSTR / NWAVES;             // ... per wave (2 for BN 128, 1 for BN 64)
-  static_assert(B_INSTR % NWAVES == 0, "weight tile must split evenly over the waves");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  auto sA = [&](int buf) { return smem + buf * A_BYTES; };
-  auto sB = [&](int slot) { return smem + 2 * A_BYTES + slot * B_BYTES; };
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int sub = lane >> 3, c8 = lane & 7;        // LDS-DMA roles: row within the instruction, 16-B slot
-
-  const int tilesN = p.N / BN;
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-  }
-  const int tile_n = bid % tilesN;
-  int tile_m = bid / tilesN;
-  const int txi = tile_m % p.tiles_x;
-  tile_m /= p.tiles_x;
-  const int tyi = tile_m % p.tiles_y;
-  const int b = tile_m / p.tiles_y;
-  const int y0 = tyi * TR, x0 = txi * TC, n0 = tile_n * BN;
-
-  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
-
-  // ---- this wave's halo wave-instructions: k = wave, wave+8, ... (<= 6) ---------------------------
-  constexpr int NH = (HALO_INSTR + NWAVES - 1) / NWAVES;     // 6
-  long h_src[NH];       // element offset of the lane's source unit (without the channel chunk), -1 = masked
-#pragma unroll
-  for (int i = 0; i < NH; ++i) {
-    const int k = wave + NWAVES * i;
-    const int row = 8 * k + sub;
-    h_src[i] = -1;
-    if (k < HALO_INSTR && row < HALO_ROWS) {
-      const int hy = row / HP, hx = row % HP;
-      const int y = y0 + hy - 1, x = x0 + hx - 1;
-      const int u = c8 ^ ((hx >> 1) & 7);                  // source-side swizzle (see conv3x3.hip Sw)
-      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-        h_src[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
-      else {
-        // outside the image for every channel chunk: zero both buffers once
-        *reinterpret_cast<u32x4*>(sA(0) + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
-        *reinterpret_cast<u32x4*>(sA(1) + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
-      }
-    }
-  }
-  auto issue_halo = [&](int kc, int buf) {
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      const int k = wave + NWAVES * i;
-      if (h_src[i] >= 0) glds16(inp + h_src[i] + kc * BK, sA(buf) + k * 1024);
-    }
-  };
-  // ---- weight tile of step (kc, t) -> ring slot ----------------------------------------------------
-  long b_src[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int k = wave + NWAVES * i;
-    const int row = 8 * k + sub;
-    const int u = c8 ^ ((row >> 1) & 7);
-    b_src[i] = (long)(n0 + row) * p.Cin + u * 8;
-  }
-  const long w_tap = (long)p.N * p.Cin;
-  auto issue_b = [&](int kc, int t, int slot) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int k = wave + NWAVES * i;
-      glds16(p.w_hi + t * w_tap + b_src[i] + kc * BK, sB(slot) + k * 1024);
-    }
-  };
-
-  // accumulators: 32x32 tiles (2 x NT of f32x16) or 16x16 tiles (4 x 2NT of f32x4)
-  constexpr int MTA = M16 ? 4 : 2, NTA = M16 ? 2 * NT : NT;
-  using ACC = std::conditional_t<M16, f32x4, f32x16>;
-  ACC acc[MTA][NTA];
-#pragma unroll
-  for (int i = 0; i < MTA; ++i)
-#pragma unroll
-    for (int j = 0; j < NTA; ++j)
-#pragma unroll
-      for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
-
-  // A rows (pixels) of this lane: 32x32 tiles: m = wr*64 + i*32 + lane%32; 16x16: m = wr*64 + i*16 + lane%16
-  constexpr int TS = M16 ? 16 : 32;
-  const int fr = lane & (TS - 1), fq = lane / TS;       // row/col lane, k-group (0..1 or 0..3)
-  int a_row0[MTA], a_hx0[MTA];
-#pragma unroll
-  for (int i = 0; i < MTA; ++i) {
-    const int m = wr * 64 + i * TS + fr;
-    a_row0[i] = (m >> 4) * HP + (m & 15);
-    a_hx0[i] = m & 15;
-  }
-
-  auto compute = [&](const unsigned char* A, const unsigned char* Bs, int t) {
-    const int kx = t % 3;
-    const int shift = (t / 3) * HP + kx;
-    constexpr int KSTEP = M16 ? 32 : 16;              // k per MFMA
-#pragma unroll
-    for (int ks = 0; ks < BK / KSTEP; ++ks) {
-      const int unit = (KSTEP / 8) * ks + fq;         // this lane's 16-byte k-unit
-      bf16x8 af[MTA], bfr[NTA];
-#pragma unroll
-      for (int i = 0; i < MTA; ++i) {
-        const int row = a_row0[i] + shift;
-        const int o = row * RB + ((unit ^ (((a_hx0[i] + kx) >> 1) & 7)) << 4);
-        af[i] = *reinterpret_cast<const bf16x8*>(A + o);
-      }
-#pragma unroll
-      for (int j = 0; j < NTA; ++j) {
-        const int row = wc * (BN / 2) + j * TS + fr;
-        const int o = row * RB + ((unit ^ ((row >> 1) & 7)) << 4);
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + o);
-      }
-#pragma unroll
-      for (int i = 0; i < MTA; ++i)
-#pragma unroll
-        for (int j = 0; j < NTA; ++j) {
-          if constexpr (M16)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-          else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    }
-  };
-
-  const int kchunks = p.Cin / BK;
-  const int nsteps = kchunks * 9;
-
-  // ---- prologue: halo(0), B(step 0), B(step 1) -----------------------------------------------------
-  issue_halo(0, 0);
-  issue_b(0, 0, 0);
-  issue_b(0, 1, 1);                 // nsteps >= 9
-  wait_vmcnt<NB>();                 // everything but B(step 1)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fills
-  __builtin_amdgcn_s_barrier();
-
-  int kc = 0, t = 0, slot = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const bool more = s + 2 < nsteps;
-#ifndef CRIMAC_EXP_NOLOAD
-    if (t == 0 && kc + 1 < kchunks) issue_halo(kc + 1, (kc + 1) & 1);
-    if (more) {
-      int t2 = t + 2, kc2 = kc;
-      if (t2 >= 9) { t2 -= 9; kc2 += 1; }
-      int slot2 = slot + 2;
-      if (slot2 >= 3) slot2 -= 3;
-      issue_b(kc2, t2, slot2);
-    }
-#endif
-#ifndef CRIMAC_EXP_NOCOMPUTE
-    compute(sA(kc & 1), sB(slot), t);
-#endif
-    // B(s+1) (and a halo issued this step) must have landed; B(s+2) stays in flight
-#ifndef CRIMAC_EXP_NOLOAD
-    if (more) wait_vmcnt<NB>(); else wait_vmcnt<0>();
-#endif
-#ifndef CRIMAC_EXP_NOBARRIER
-    __builtin_amdgcn_s_barrier();
-#endif
-    if (++t == 9) { t = 0; ++kc; }
-    if (++slot == 3) slot = 0;
-  }
-
-  // ---- epilogue (conv_epilogue.h): bias/ReLU, fused reductions, LDS-staged coalesced stores -------
-  conv_epilogue<bf16_t, BN, BM, 512, MTA, NTA, ACC>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
-}
-
-template <int BN, bool M16>
-int launch(ConvParams p, hipStream_t st) {
-  p.tiles_y = cdiv(p.H, TR);
-  p.tiles_x = cdiv(p.W, TC);
-  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x * (p.N / BN);
-  const size_t lds = (size_t)2 * A_BYTES + 3 * BN * RB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_kernel<BN, M16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv3x3_glds_kernel<BN, M16>), dim3((unsigned)ntiles), dim3(512), lds, st, p);
-  CRIMAC_LAUNCH_CHECK();
-  return CRIMAC_OK;
-}
-
-
 // ---------------------------------------------------------------------------------------------------
 // N = 64 layers (level 0 / decoder 3: 256x256 images, Cin 64 or 128).  With the 8-wave kernel above a
 // 64-channel tile leaves each wave a 64 x 32 sub-tile: 3 ds_read_b128 per 2 MFMAs, which together with
@@ -268,8 +72,8 @@ int launch(ConvParams p, hipStream_t st) {
 // per SIMD serialises LDS-DMA issue, MFMAs and the epilogue), and keeping the 72 KB of weights in
 // registers (36-72 B-fragments per wave; hipcc spills around the epilogue and every scratch reload
 // drains the DMA queue: 470-610 us).
-// BN = 128: the same 4-wave structure with 64 x 128 per wave (0.75 ds_read_b128 per MFMA, 32 MFMAs per
-// wave between barriers) and a 2-slot weight ring (one step ahead), 74 KB: also two workgroups per CU.
+// (BN = 128 instantiates too -- 64 x 128 per wave, 2-slot ring, 74 KB -- and was the default for N >= 128 until
+// the channel-split kernel below beat it by 12 %; CRIMAC_CONV_W4=1 selects it for A/B runs.)
 template <int BN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void conv3x3_glds_w4_kernel(ConvParams p) {
@@ -435,6 +239,203 @@ int launch_w4(ConvParams p, hipStream_t st) {
   return CRIMAC_OK;
 }
 
+
+// ---- hand-placed LDS-read / MFMA pipeline of the channel-split kernel -----------------------------------
+// A chunk (9 taps x 4 k-steps) is 72 half-k-steps of 4 fragment reads + 4 MFMAs; the reads of half h+1 are
+// issued before the MFMAs of half h (counted lgkmcnt: LDS reads return in order), across k-steps and taps
+// alike -- there is no barrier inside a chunk.  All addresses are one of 12 registers (kx, ks) + immediate.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128_asm(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+struct WchFrags {
+  bf16x8 a[2][4];        // two halves in flight
+  bf16x8 b[2][4];        // weight fragments of the current / next tap (4 k-steps)
+};
+// HPK: halves per k-step (2: a wave owns all 256 pixels of the tile, 1: 128 of them)
+template <int H, int HPK>
+__device__ __forceinline__ void wch_issue_half(const unsigned (&av)[3][4], WchFrags& f) {
+  constexpr int t = H / (4 * HPK), ks = (H / HPK) % 4, half = H % HPK;
+  constexpr int base = (t / 3) * (HP * RB) + half * 4 * (2 * HP * RB);
+  f.a[H & 1][0] = lds_read128_asm<base + 0 * (2 * HP * RB)>(av[t % 3][ks]);
+  f.a[H & 1][1] = lds_read128_asm<base + 1 * (2 * HP * RB)>(av[t % 3][ks]);
+  f.a[H & 1][2] = lds_read128_asm<base + 2 * (2 * HP * RB)>(av[t % 3][ks]);
+  f.a[H & 1][3] = lds_read128_asm<base + 3 * (2 * HP * RB)>(av[t % 3][ks]);
+}
+template <bool LAST>
+__device__ __forceinline__ void wch_release_half(WchFrags& f, int set) {
+  if constexpr (LAST)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
+                 :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
+                 :: "memory");
+}
+__device__ __forceinline__ void wch_load_b(const unsigned short* src, bf16x8 (&bf)[4]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %4, off offset:32\n\t"
+      "global_load_dwordx4 %2, %4, off offset:64\n\t"
+      "global_load_dwordx4 %3, %4, off offset:96"
+      : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
+      : "v"(src)
+      : "memory");
+}
+__device__ __forceinline__ void wch_land_b(bf16x8 (&bf)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) :: "memory");
+}
+// half H of a chunk; wnext_chunk: weight rows of the next chunk's tap 0 (nullptr: none).  Tap t computes from
+// b[t & 1] and requests tap t+1 into the other buffer; tap 8 (b[0]) requests the next chunk's tap 0 into b[1],
+// which tap 0 moves to b[0] once it has landed (a chunk has an odd number of taps).
+template <int H, int HPK, typename ACC>
+__device__ __forceinline__ void wch_half(const unsigned (&av)[3][4], const unsigned short* wtap, long w_tap,
+                                         const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
+  constexpr int t = H / (4 * HPK), ks = (H / HPK) % 4, half = H % HPK, NHALF = 36 * HPK;
+  if constexpr (H % (4 * HPK) == 0) {
+    // first half of tap t: its weights were requested one tap ago; request those of the next tap
+    if constexpr (t == 0) {
+      wch_land_b(f.b[1]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f.b[0][k] = f.b[1][k];
+    } else {
+      wch_land_b(f.b[t & 1]);
+    }
+    if constexpr (t < 8) wch_load_b(wtap + (t + 1) * w_tap, f.b[(t + 1) & 1]);
+    else if (wnext_chunk) wch_load_b(wnext_chunk, f.b[1]);
+  }
+  if constexpr (H + 1 < NHALF) {
+    wch_issue_half<H + 1, HPK>(av, f);
+    wch_release_half<false>(f, H & 1);
+  } else {
+    wch_release_half<true>(f, H & 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc[half * 4 + j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[H & 1][j], f.b[t & 1][ks], acc[half * 4 + j][0],
+                                                                    0, 0, 0);
+  if constexpr (H + 1 < NHALF) wch_half<H + 1, HPK>(av, wtap, w_tap, wnext_chunk, f, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Channel-split variant for N >= 128 ("wch"): each of the 4 waves owns 32 OUTPUT CHANNELS of the whole
+// 16x16-pixel tile (8 x 1 MFMA tiles of 32x32).  Its weight fragments are then private to the wave and come
+// straight from global memory into registers (4 x 16 B per lane and step, prefetched one step ahead) -- no
+// weight tile in LDS, no weight DMA, no weight ds_reads -- and the only LDS content is the halo, which is
+// constant for a whole 64-channel chunk: NO barrier per tap, the waves run free for 288 MFMAs and meet only
+// where the halo is exchanged.  Measured motivation (W4 kernel, 1024->512 @32x32): MFMA loop alone 1.7
+// PFLOP/s, with the weight/halo DMAs sharing the LDS 1.2 PFLOP/s; here the LDS sees 1 ds_read_b128 per MFMA
+// and 4.6 KB of DMA per step instead of 0.75 reads + 20.6 KB.
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv3x3_wch_kernel(ConvParams p) {
+  static_assert(BN == 128 || BN == 64, "32 channels per wave");      // only 128 is instantiated (see dispatch)
+  constexpr int NW = 4, NWC = BN / 32, NWP = NW / NWC;     // waves along channels x along pixels: 4x1 / 2x2
+  constexpr int MT = BM / 32 / NWP;                        // 32-pixel MFMA tiles per wave: 8 / 4
+  constexpr int HPK = MT / 4;
+  constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane >> 3, c8 = lane & 7;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  int tile_m = bid;
+  const int txi = tile_m % p.tiles_x;
+  tile_m /= p.tiles_x;
+  const int tyi = tile_m % p.tiles_y;
+  const int b = tile_m / p.tiles_y;
+  const int y0 = tyi * TR, x0 = txi * TC;
+  const int n0 = blockIdx.y * BN;
+  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
+
+  long h_src[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int k = wave + NW * i;
+    const int row = 8 * k + sub;
+    h_src[i] = -1;
+    if (k < HALO_INSTR && row < HALO_ROWS) {
+      const int hy = row / HP, hx = row % HP;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      const int u = c8 ^ ((hx >> 1) & 7);
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+        h_src[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
+      else
+        *reinterpret_cast<u32x4*>(sA + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
+    }
+  }
+  auto issue_halo = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+      if (h_src[i] >= 0) glds16(inp + h_src[i] + kc * BK, sA + (wave + NW * i) * 1024);
+  };
+
+  const int fr = lane & 31, fq = lane >> 5;
+  const int wc = wave % NWC, wp = wave / NWC;
+  // weight fragments of this lane: row n0 + 32*wc + fr of tap t, k = kc*64 + ks*16 + fq*8 .. +8
+  const unsigned short* wrow = p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
+  const long w_tap = (long)p.N * p.Cin;
+  // A fragment byte offsets: pixel m = wp*(MT*32) + i*32 + fr -> halo row (wp*2*MT + 2i + (fr >> 4)) * HP +
+  // (fr & 15): i enters as an immediate (i * 2 * HP * RB), so does the tap's ky; one register per (kx, ks)
+  unsigned av[3][4];
+  {
+    const int row0 = (wp * 2 * MT + (fr >> 4)) * HP + (fr & 15), hx0 = fr & 15;
+    const unsigned a_lds = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(sA));
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        av[kx][ks] = a_lds + (row0 + kx) * RB + (((2 * ks + fq) ^ (((hx0 + kx) >> 1) & 7)) << 4);
+  }
+
+  f32x16 acc[MT][1];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  const int kchunks = p.Cin / BK;
+  WchFrags f;
+  wch_load_b(wrow, f.b[1]);                    // tap 0 of chunk 0 (tap 0 expects it in b[1])
+  for (int kc = 0; kc < kchunks; ++kc) {
+    issue_halo(kc);
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned short* wtap = wrow + kc * BK;
+    const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
+    wch_issue_half<0, HPK>(av, f);
+    wch_half<0, HPK>(av, wtap, w_tap, wnext, f, acc);
+    __builtin_amdgcn_s_barrier();        // every wave is done reading this chunk's halo
+  }
+  conv_epilogue<bf16_t, BN, BM, 256, MT, 1, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wp, wc);
+}
+
+template <int BN>
+int launch_wch(ConvParams p, hipStream_t st) {
+  p.tiles_y = cdiv(p.H, TR);
+  p.tiles_x = cdiv(p.W, TC);
+  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
+  constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;   // epilogue staging vs halo buffer
+  const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_wch_kernel<BN>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
 }  // namespace
 
 // bf16, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
@@ -444,23 +445,10 @@ int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, in
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
-  // N = 64 layers: 4-wave kernel.  N >= 128: the 4-wave kernel too (two workgroups per CU; measured +10-20 %
-  // on every layer, tools/bench_conv.py) unless the launch has fewer than two workgroups per CU to hand out
-  // (the 16x16-pixel bottleneck level at B = 32: 256 tiles) -- then the 8-wave kernel, one workgroup per CU.
-  static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 1;
+  // N % 128 == 0: channel-split kernel; N = 64 (or 192, ...): pixel-split kernel with the LDS weight ring.
+  // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.4 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
+  // HBM-heavy N = 64 shapes W4<64> (305 / 423 us) beats a 2x2-wave channel split (319 / 458 us).
+  static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
   if (N % 128 != 0) return launch_w4<64>(p, st);
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-  }
-  const long ntiles = (long)B * cdiv(H, TR) * cdiv(W, TC) * (N / 128);
-  if (w4 == 2 || (w4 == 1 && ntiles >= 2L * n_cu)) return launch_w4<128>(p, st);
-  static const int m16 = getenv("CRIMAC_CONV_M16") ? atoi(getenv("CRIMAC_CONV_M16")) : 0;
-  if (m16) return N % 128 == 0 ? launch<128, true>(p, st) : launch<64, true>(p, st);
-  return N % 128 == 0 ? launch<128, false>(p, st) : launch<64, false>(p, st);
+  return w4 == 1 ? launch_w4<128>(p, st) : launch_wch<128>(p, st);
 }
