@@ -15,8 +15,9 @@
 // no register or LDS transpose pass.
 //
 // Workgroup = 64 F-channels x 64 S-channels x ALL taps (the S halo tile is staged once and reused
-// by the 9 shifted reads), 4 waves as 2x2, each wave 32x32 per tap = 9 accumulators.  Pixel tiles
-// are TR x 16 spatial patches; the pixel range is split across workgroups and partial sums are
+// by the 9 shifted reads), 4 waves.  bf16: 2 S halves x 2 tap groups, each wave 64 F x 32 S for its 5 / 4
+// taps (10 / 8 accumulators); fp32 modes: 2x2 over channels, each wave 32x32 per tap (9 accumulators).
+// Pixel tiles are TR x 16 spatial patches; the pixel range is split across workgroups and partial sums are
 // combined with fp32 atomics whose wave shape is two 128-byte row segments (full atomic rate).
 #include "common.h"
 
@@ -41,108 +42,105 @@ __device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
 
 
 // ---- bf16 contraction of one staged tile, hand-placed schedule ------------------------------------------
-// The transposing reads are inline asm:
+// Wave roles (bf16 path): 2 S-channel halves x 2 TAP GROUPS; every wave covers all 64 F channels (two A
+// fragments per tile row) x its 32 S channels x its taps (conv3x3: taps 0-4 | 5-8, up-conv: 0-1 | 2-3).
+// A fragment is then shared by 5 (4) taps x 2 MFMAs: 1.4-1.5 transposing reads per MFMA instead of the 2.2
+// of the 2x2 channel split with all 9 taps per wave -- the LDS was ~80 % busy there.
+// The reads are inline asm:
 //  * through the intrinsic hipcc puts `s_waitcnt vmcnt(0)` in front of the first read of every tile row (an
 //    LDS read "may alias" the LDS-DMA of the NEXT tile, already in flight): the prefetch was drained before
 //    the MFMAs, so loads and MFMAs of a workgroup ran back to back (ablation, 512->512 @32x32: loads 56 us +
 //    MFMA loop 123 us = 179 us vs 171 us together);
 //  * its reads were issued one or two MFMAs ahead of their use (MFMA loop alone at 57 % of the MFMA rate).
-// Here a tile row is split in two halves (A fragment + first taps | remaining taps); the reads of the NEXT
+// Here a tile row is split in two halves (A fragments + first taps | remaining taps); the reads of the NEXT
 // half are always issued before the MFMAs of the current one, and since LDS reads return in order
 // `s_waitcnt lgkmcnt(n)` with n = number of reads of the next half releases the current half.
 // Addresses: row r = c + R (c compile-time, R = 8*kh + q per lane), byte = r*128 + (chb ^ swz(r)); swz(r)
-// only depends on (c + R) mod 4, so 4 per-lane bases (by c & 3) + an immediate c*128 cover every read --
-// 5 address registers instead of one per (row, tap).
+// only depends on (c + R) mod 4, so 4 per-lane bases (by c & 3) + an immediate c*128 cover every S read and
+// 2 bases every F read -- 6 address registers instead of one per (row, tap).
 template <int OFF>
 __device__ __forceinline__ bf16x4 lds_tr16_asm(unsigned addr) {
   bf16x4 v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
 }
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+}
+// consumers of x must stay behind the (volatile, ordered) wait that precedes this statement
+__device__ __forceinline__ void tie(bf16x4& x) { asm volatile("" : "+v"(x)); }
 
-template <int MODE>
-struct WgGeo {
-  static constexpr int TR = MODE == 0 ? 8 : 4, NT = MODE == 0 ? 9 : 4;
-  static constexpr int HA = MODE == 0 ? 4 : 2;            // taps [0,HA) ride with the A fragment
+template <int MODE, int TG>
+struct WgTaps {
+  static constexpr int TR = MODE == 0 ? 8 : 4;
+  static constexpr int T0 = MODE == 0 ? (TG == 0 ? 0 : 5) : (TG == 0 ? 0 : 2);   // first tap of the group
+  static constexpr int N = MODE == 0 ? (TG == 0 ? 5 : 4) : 2;                    // taps of the group
+  static constexpr int HA = MODE == 0 ? 2 : 1;                                   // taps riding with the A fragments
   static constexpr int srow(int py, int t) {
     return MODE == 0 ? (py + t / 3) * 18 + t % 3 : (2 * py + (t >> 1)) * 32 + (t & 1) * 16;
   }
 };
-
-template <int MODE>
 struct WgFrags {
-  bf16x4 a0[2], a1[2], b0[WgGeo<MODE>::NT], b1[WgGeo<MODE>::NT];
+  bf16x4 a0[2][2], a1[2][2];      // [row parity][F half]
+  bf16x4 b0[5], b1[5];            // [local tap]
 };
 
-template <int MODE, int PY, int T>
-__device__ __forceinline__ void wg_rd_tap(const unsigned (&sv)[4], WgFrags<MODE>& f) {
-  constexpr int c = WgGeo<MODE>::srow(PY, T);
-  f.b0[T] = lds_tr16_asm<c * 128>(sv[c & 3]);
-  f.b1[T] = lds_tr16_asm<(c + 4) * 128>(sv[c & 3]);
-}
-template <int MODE, int PY, int T0, int T1>
-__device__ __forceinline__ void wg_rd_taps(const unsigned (&sv)[4], WgFrags<MODE>& f) {
-  if constexpr (T0 < T1) {
-    wg_rd_tap<MODE, PY, T0>(sv, f);
-    wg_rd_taps<MODE, PY, T0 + 1, T1>(sv, f);
+template <int MODE, int TG, int PY, int L0, int L1>
+__device__ __forceinline__ void wg_rd_taps(const unsigned (&sv)[4], WgFrags& f) {
+  if constexpr (L0 < L1) {
+    constexpr int c = WgTaps<MODE, TG>::srow(PY, WgTaps<MODE, TG>::T0 + L0);
+    f.b0[L0] = lds_tr16_asm<c * 128>(sv[c & 3]);
+    f.b1[L0] = lds_tr16_asm<(c + 4) * 128>(sv[c & 3]);
+    wg_rd_taps<MODE, TG, PY, L0 + 1, L1>(sv, f);
   }
 }
-template <int MODE, int PY>
-__device__ __forceinline__ void wg_rd_a(unsigned fv, WgFrags<MODE>& f) {
-  f.a0[PY & 1] = lds_tr16_asm<PY * 16 * 128>(fv);
-  f.a1[PY & 1] = lds_tr16_asm<(PY * 16 + 4) * 128>(fv);
-}
-template <int MODE, int T0, int T1, typename ACC>
-__device__ __forceinline__ void wg_fma(const WgFrags<MODE>& f, int set, ACC& acc) {
-  if constexpr (T0 < T1) {
-    const bf16x8 af = __builtin_shufflevector(f.a0[set], f.a1[set], 0, 1, 2, 3, 4, 5, 6, 7);
-    const bf16x8 bfr = __builtin_shufflevector(f.b0[T0], f.b1[T0], 0, 1, 2, 3, 4, 5, 6, 7);
-    acc[T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[T0], 0, 0, 0);
-    wg_fma<MODE, T0 + 1, T1>(f, set, acc);
+template <int PY>
+__device__ __forceinline__ void wg_rd_a(const unsigned (&fv)[2], WgFrags& f) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f.a0[PY & 1][h] = lds_tr16_asm<PY * 16 * 128>(fv[h]);
+    f.a1[PY & 1][h] = lds_tr16_asm<(PY * 16 + 4) * 128>(fv[h]);
   }
 }
-// release the first half of a row (A + taps [0,HA)): at most the NB reads of the second half stay in flight
-template <int MODE>
-__device__ __forceinline__ void wg_release_first(WgFrags<MODE>& f, int set) {
-  if constexpr (MODE == 0)
-    asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(f.a0[set]), "+v"(f.a1[set]), "+v"(f.b0[0]), "+v"(f.b1[0]),
-                 "+v"(f.b0[1]), "+v"(f.b1[1]), "+v"(f.b0[2]), "+v"(f.b1[2]), "+v"(f.b0[3]), "+v"(f.b1[3]) :: "memory");
-  else
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a0[set]), "+v"(f.a1[set]), "+v"(f.b0[0]), "+v"(f.b1[0]),
-                 "+v"(f.b0[1]), "+v"(f.b1[1]) :: "memory");
-}
-// release the second half (taps [HA,NT)); LAST: nothing was issued behind it
-template <int MODE, bool LAST>
-__device__ __forceinline__ void wg_release_second(WgFrags<MODE>& f) {
-  if constexpr (MODE == 0) {
-    if constexpr (LAST)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b0[4]), "+v"(f.b1[4]), "+v"(f.b0[5]), "+v"(f.b1[5]), "+v"(f.b0[6]),
-                   "+v"(f.b1[6]), "+v"(f.b0[7]), "+v"(f.b1[7]), "+v"(f.b0[8]), "+v"(f.b1[8]) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(f.b0[4]), "+v"(f.b1[4]), "+v"(f.b0[5]), "+v"(f.b1[5]), "+v"(f.b0[6]),
-                   "+v"(f.b1[6]), "+v"(f.b0[7]), "+v"(f.b1[7]), "+v"(f.b0[8]), "+v"(f.b1[8]) :: "memory");
-  } else {
-    if constexpr (LAST)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b0[2]), "+v"(f.b1[2]), "+v"(f.b0[3]), "+v"(f.b1[3]) :: "memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f.b0[2]), "+v"(f.b1[2]), "+v"(f.b0[3]), "+v"(f.b1[3]) :: "memory");
+template <int L0, int L1, typename ACC>
+__device__ __forceinline__ void wg_fma(const WgFrags& f, int set, ACC& acc) {
+  if constexpr (L0 < L1) {
+    const bf16x8 bfr = __builtin_shufflevector(f.b0[L0], f.b1[L0], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bf16x8 af = __builtin_shufflevector(f.a0[set][h], f.a1[set][h], 0, 1, 2, 3, 4, 5, 6, 7);
+      acc[L0][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[L0][h], 0, 0, 0);
+    }
+    wg_fma<L0 + 1, L1>(f, set, acc);
   }
 }
-template <int MODE, int PY, typename ACC>
-__device__ __forceinline__ void wg_row(unsigned fv, const unsigned (&sv)[4], WgFrags<MODE>& f, ACC& acc) {
-  using G = WgGeo<MODE>;
-  wg_rd_taps<MODE, PY, G::HA, G::NT>(sv, f);          // second half of this row in flight
-  wg_release_first<MODE>(f, PY & 1);
-  wg_fma<MODE, 0, G::HA>(f, PY & 1, acc);
+template <int L0, int L1>
+__device__ __forceinline__ void wg_tie_taps(WgFrags& f) {
+  if constexpr (L0 < L1) {
+    tie(f.b0[L0]);
+    tie(f.b1[L0]);
+    wg_tie_taps<L0 + 1, L1>(f);
+  }
+}
+template <int MODE, int TG, int PY, typename ACC>
+__device__ __forceinline__ void wg_row(const unsigned (&fv)[2], const unsigned (&sv)[4], WgFrags& f, ACC& acc) {
+  using G = WgTaps<MODE, TG>;
+  wg_rd_taps<MODE, TG, PY, G::HA, G::N>(sv, f);          // second half of this row in flight
+  wait_lgkm<2 * (G::N - G::HA)>();                       // first half (4 A reads + taps [0,HA)) landed
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { tie(f.a0[PY & 1][h]); tie(f.a1[PY & 1][h]); }
+  wg_tie_taps<0, G::HA>(f);
+  wg_fma<0, G::HA>(f, PY & 1, acc);
   if constexpr (PY + 1 < G::TR) {
-    wg_rd_a<MODE, PY + 1>(fv, f);                     // first half of the next row in flight
-    wg_rd_taps<MODE, PY + 1, 0, G::HA>(sv, f);
-    wg_release_second<MODE, false>(f);
+    wg_rd_a<PY + 1>(fv, f);                              // first half of the next row in flight
+    wg_rd_taps<MODE, TG, PY + 1, 0, G::HA>(sv, f);
+    wait_lgkm<4 + 2 * G::HA>();
   } else {
-    wg_release_second<MODE, true>(f);
+    wait_lgkm<0>();
   }
-  wg_fma<MODE, G::HA, G::NT>(f, PY & 1, acc);
-  if constexpr (PY + 1 < G::TR) wg_row<MODE, PY + 1>(fv, sv, f, acc);
+  wg_tie_taps<G::HA, G::N>(f);
+  wg_fma<G::HA, G::N>(f, PY & 1, acc);
+  if constexpr (PY + 1 < G::TR) wg_row<MODE, TG, PY + 1>(fv, sv, f, acc);
 }
 
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
@@ -216,19 +214,6 @@ void wgrad_kernel(WgradParams p) {
   // contraction over one staged tile: one k16 step per tile row.  Plane k of F at sF + k*F_BYTES,
   // plane k of S at sS + k*S_BYTES.
   auto contract = [&](const unsigned char* sF, const unsigned char* sS) {
-    if constexpr (!X3) {
-      const int R = 8 * kh + q;
-      const unsigned fv = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(sF)) + R * 128 + (f_chb ^ swz_tr(R));
-      const unsigned sb = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(sS)) + R * 128;
-      unsigned sv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) sv[k] = sb + (s_chb ^ swz_tr(k + R));
-      WgFrags<MODE> f;
-      wg_rd_a<MODE, 0>(fv, f);
-      wg_rd_taps<MODE, 0, 0, WgGeo<MODE>::HA>(sv, f);
-      wg_row<MODE, 0>(fv, sv, f, acc);
-      return;
-    }
 #pragma unroll 1
     for (int py = 0; py < TR; ++py) {
       bf16x8 af[NPL];
@@ -360,18 +345,62 @@ void wgrad_kernel(WgradParams p) {
                                                  (int)(ok ? s_rel[i] : OOB), 0, 0, 0);
       }
     };
-    if (t_begin < t_end) issue_tile(t_begin, 0);
-    for (long tile = t_begin; tile < t_end; ++tile) {
-      const int cur = (int)((tile - t_begin) & 1);
-      __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
+    // wave -> (S half ws, tap group tg); the tile loop and the epilogue are instantiated per tap group
+    const int tg = wave >> 1;
+    auto run = [&](auto tgc) {
+      constexpr int TG = decltype(tgc)::value;
+      using G = WgTaps<MODE, TG>;
+      f32x16 acc2[G::N][2];
+#pragma unroll
+      for (int t = 0; t < G::N; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[t][h][r] = 0.f;
+      const int R = 8 * kh + q;
+      const int chb = (16 * cgrp + 4 * pp) * 2;             // lane's 4 channels inside a 32-channel group
+      const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
+      if (t_begin < t_end) issue_tile(t_begin, 0);
+      for (long tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (int)((tile - t_begin) & 1);
+        __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
 #ifndef CRIMAC_EXP_NOLOAD
-      if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+        if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
 #endif
-      const unsigned char* base = smem + cur * BUF_BYTES;
 #ifndef CRIMAC_EXP_NOCOMPUTE
-      contract(base, base + F_BYTES);
+        const unsigned aF = lds0 + cur * BUF_BYTES + R * 128, aS = aF + F_BYTES;
+        unsigned fv[2], sv[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fv[h] = aF + ((h * 64 + chb) ^ swz_tr(R));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv[k] = aS + ((ws * 64 + chb) ^ swz_tr(k + R));
+        WgFrags f;
+        wg_rd_a<0>(fv, f);
+        wg_rd_taps<MODE, TG, 0, 0, G::HA>(sv, f);
+        wg_row<MODE, TG, 0>(fv, sv, f, acc2);
 #endif
-    }
+      }
+      // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps
+      const int col = cs0 + ws * 32 + (lane & 31);
+#ifdef CRIMAC_EXP_NOATOMIC
+      if (col < 0) {
+#else
+      if (col < p.CS) {
+#endif
+#pragma unroll
+        for (int t = 0; t < G::N; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = cf0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              if (row < p.CF) atomicAdd(p.dw + ((long)(G::T0 + t) * p.CF + row) * p.CS + col, acc2[t][h][r]);
+            }
+      }
+    };
+    if (tg == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    return;
   } else {
     // ---- fp32 activations: register staging with the plane split ------------------------------------
     unsigned char* sF = smem;                       // NPL planes of F
