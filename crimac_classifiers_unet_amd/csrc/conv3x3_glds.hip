@@ -327,6 +327,10 @@ __device__ __forceinline__ void wch_half(const unsigned (&av)[3][4], const unsig
 // where the halo is exchanged.  Measured motivation (W4 kernel, 1024->512 @32x32): MFMA loop alone 1.7
 // PFLOP/s, with the weight/halo DMAs sharing the LDS 1.2 PFLOP/s; here the LDS sees 1 ds_read_b128 per MFMA
 // and 4.6 KB of DMA per step instead of 0.75 reads + 20.6 KB.
+// Tried on top and rejected: 32-channel chunks with a double-buffered halo (next halo requested at the start
+// of a chunk behind the weight loads of two taps, counted vmcnt, one barrier per chunk): 2-4 % SLOWER -- the
+// halo exchange bubble is already covered by the second workgroup of the CU; a 2x2-wave (pixels x channels)
+// form for N = 64: slower than the pixel-split kernel on the HBM-heavy 256x256 layers.
 template <int BN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_wch_kernel(ConvParams p) {
