@@ -328,51 +328,122 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
   }
 }
 
-// ---- backward of max-pool + skip add ---------------------------------------------------------------
+
+// Fused BatchNorm+ReLU backward sums (== bn_bwd_reduce on the tensor a kernel has just produced): the
+// producer keeps sum dz / sum dz*xhat of its thread-fixed 8-channel chunk in registers while it still
+// holds `da`; at the end they go through LDS into one of `replicas` fp64 accumulators [replicas][C].
+struct BnbArgs {
+  const void* y;          // saved conv output of the BatchNorm layer `da` feeds, [pixels][y_ld]
+  long y_ld;
+  const float* vec;       // rows mean, invstd, scale, shift; row stride `stride`
+  long stride;
+  double* sum_dz;
+  double* sum_dzx;
+  int replicas;
+};
+struct BnbConst { float sc[8], sh[8], mu[8], is[8]; };
+__device__ __forceinline__ void bnb_load(const BnbArgs& a, int c0, BnbConst& k) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    k.mu[j] = a.vec[c0 + j];
+    k.is[j] = a.vec[a.stride + c0 + j];
+    k.sc[j] = a.vec[2 * a.stride + c0 + j];
+    k.sh[j] = a.vec[3 * a.stride + c0 + j];
+  }
+}
 template <typename T>
+__device__ __forceinline__ void bnb_accum(const BnbArgs& a, const BnbConst& k, long pix, int c0, const float (&g)[8],
+                                          float (&d1)[8], float (&d2)[8]) {
+  float yv[8];
+  load8(reinterpret_cast<const T*>(a.y) + pix * a.y_ld + c0, yv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float dz = (yv[j] * k.sc[j] + k.sh[j]) > 0.f ? g[j] : 0.f;
+    d1[j] += dz;
+    d2[j] += dz * (yv[j] - k.mu[j]) * k.is[j];
+  }
+}
+// lds: [2][C] floats, zeroed and synchronised by the caller; every thread of the block calls this
+__device__ __forceinline__ void bnb_flush(const BnbArgs& a, float* lds, int C, int c0, const float (&d1)[8],
+                                          const float (&d2)[8], int nthreads) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&lds[c0 + j], d1[j]);
+    atomicAdd(&lds[C + c0 + j], d2[j]);
+  }
+  __syncthreads();
+  const long rep = (long)(blockIdx.x % (unsigned)a.replicas) * C;
+  for (int c = threadIdx.x; c < C; c += nthreads) {
+    atomicAdd(&a.sum_dz[rep + c], (double)lds[c]);
+    atomicAdd(&a.sum_dzx[rep + c], (double)lds[C + c]);
+  }
+}
+
+// ---- backward of max-pool + skip add ---------------------------------------------------------------
+// thread -> fixed 8-channel chunk, pooled pixels strided over the grid (channels contiguous across the lanes of
+// a pixel); BNB: da feeds a BatchNorm+ReLU block whose backward sums are accumulated on the fly
+template <typename T, bool BNB>
 __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ dp, long dp_ld,
                                                          const T* __restrict__ a, long a_ld,
                                                          const T* __restrict__ ds, long ds_ld,
                                                          T* __restrict__ da, long da_ld, int B, int H,
-                                                         int W, int C) {
+                                                         int W, int C, BnbArgs bnb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);   // [2][C] (BNB only)
   const int cpr = C / 8;
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int c0 = chunk * 8;
   const int Hp = H / 2, Wp = W / 2;
-  const long total = (long)B * Hp * Wp * cpr;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cpr) * 8;
-    long r = i / cpr;
-    const int xp = (int)(r % Wp);
-    r /= Wp;
-    const int yp = (int)(r % Hp);
-    const long b = r / Hp;
-    float g[8], av[4][8];
-    load8(dp + ((b * Hp + yp) * (long)Wp + xp) * dp_ld + c0, g);
-    long pix[4];
+  const long npool = (long)B * Hp * Wp;
+  BnbConst k;
+  float d1[8], d2[8];
+  if constexpr (BNB) {
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
+    bnb_load(bnb, c0, k);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      pix[d] = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
-      load8(a + pix[d] * a_ld + c0, av[d]);
-    }
-    int arg[8];
+    for (int j = 0; j < 8; ++j) { d1[j] = 0.f; d2[j] = 0.f; }
+    __syncthreads();
+  }
+  if (rl < rpi) {
+    for (long r = (long)blockIdx.x * rpi + rl; r < npool; r += (long)gridDim.x * rpi) {
+      const int xp = (int)(r % Wp);
+      const long t = r / Wp;
+      const int yp = (int)(t % Hp);
+      const long b = t / Hp;
+      float g[8], av[4][8];
+      load8(dp + r * dp_ld + c0, g);
+      long pix[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int best = 0;
-      float bv = av[0][j];
+      for (int d = 0; d < 4; ++d) {
+        pix[d] = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
+        load8(a + pix[d] * a_ld + c0, av[d]);
+      }
+      int arg[8];
 #pragma unroll
-      for (int d = 1; d < 4; ++d)
-        if (av[d][j] > bv) { bv = av[d][j]; best = d; }   // first maximum wins (aten max_pool2d)
-      arg[j] = best;
-    }
+      for (int j = 0; j < 8; ++j) {
+        int best = 0;
+        float bv = av[0][j];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      float o[8];
-      if (ds) load8(ds + pix[d] * ds_ld + c0, o);
+        for (int d = 1; d < 4; ++d)
+          if (av[d][j] > bv) { bv = av[d][j]; best = d; }   // first maximum wins (aten max_pool2d)
+        arg[j] = best;
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f);
-      store8(da + pix[d] * da_ld + c0, o);
+      for (int d = 0; d < 4; ++d) {
+        float o[8];
+        if (ds) load8(ds + pix[d] * ds_ld + c0, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o[j] = (ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f);
+          if constexpr (BNB) o[j] = (float)(T)o[j];          // the sums see da as it is stored
+        }
+        store8(da + pix[d] * da_ld + c0, o);
+        if constexpr (BNB) bnb_accum<T>(bnb, k, pix[d], c0, o, d1, d2);
+      }
     }
   }
+  if constexpr (BNB) bnb_flush(bnb, lds, C, c0, d1, d2, 256);
 }
 
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------------------
@@ -498,18 +569,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int NC>
+template <typename T, int NC, bool BNB>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl,
                                                        const T* __restrict__ x, long x_ld, int Cin,
                                                        const float* __restrict__ w, T* __restrict__ dx,
                                                        long dx_ld, float* dw, float* db, long npix,
-                                                       long HW) {
+                                                       long HW, BnbArgs bnb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* lds = reinterpret_cast<float*>(smem_raw);   // [NC][Cin] + [NC]
-  for (int i = threadIdx.x; i < NC * Cin + NC; i += 256) lds[i] = 0.f;
+  float* lds = reinterpret_cast<float*>(smem_raw);   // [NC][Cin] + [NC]  (+ [2][Cin] for BNB)
+  float* lds_bnb = lds + NC * Cin + NC;
+  for (int i = threadIdx.x; i < NC * Cin + NC + (BNB ? 2 * Cin : 0); i += 256) lds[i] = 0.f;
   __syncthreads();
   const int lp = Cin / 8;
   const int sub = threadIdx.x % lp;
+  BnbConst k;
+  float d1[8], d2[8];
+  if constexpr (BNB) {
+    bnb_load(bnb, sub * 8, k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d1[j] = 0.f; d2[j] = 0.f; }
+  }
   float wr[NC][8], gw[NC][8], gb[NC];
 #pragma unroll
   for (int o = 0; o < NC; ++o) {
@@ -536,7 +615,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     if (sub == 0)
 #pragma unroll
       for (int o = 0; o < NC; ++o) gb[o] += g[o];
+    if constexpr (BNB) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = (float)(T)o8[j];      // the sums see dx as it is stored
+    }
     store8(dx + p * dx_ld + sub * 8, o8);
+    if constexpr (BNB) bnb_accum<T>(bnb, k, p, sub * 8, o8, d1, d2);
   }
 #pragma unroll
   for (int o = 0; o < NC; ++o) {
@@ -547,6 +631,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __syncthreads();
   for (int i = threadIdx.x; i < NC * Cin; i += 256) atomicAdd(&dw[i], lds[i]);
   if (threadIdx.x < NC) atomicAdd(&db[threadIdx.x], lds[NC * Cin + threadIdx.x]);
+  if constexpr (BNB) bnb_flush(bnb, lds_bnb, Cin, sub * 8, d1, d2, 256);
 }
 
 // ---- weighted cross entropy ---------------------------------------------------------------------------------
@@ -842,24 +927,38 @@ extern "C" int crimac_bn_act_pool(int prec, const void* y, long y_ld, const floa
                                          H, W, C, ST);
 }
 
+static bool bnb_args_ok(const void* y, long y_ld, const float* vec, long stride, double* s0, double* s1, int replicas,
+                        int C) {
+  if (!s0) return true;                      // no fused reduction requested
+  return y && vec && s1 && y_ld >= C && y_ld % 8 == 0 && stride >= C && replicas >= 1;
+}
+
 extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const void* a, long a_ld,
                                  const void* ds, long ds_ld, void* da, long da_ld, int B, int H, int W,
-                                 int C, void* stream) {
+                                 int C, const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride,
+                                 double* stat_sum, double* stat_sumsq, int stat_replicas, void* stream) {
   PREC_OK("unpool_add");
   CRIMAC_REQUIRE(dp && a && da && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 &&
-                     C % 8 == 0,
+                     C % 8 == 0 && C <= 2048,
                  "unpool_add: bad arguments");
   CRIMAC_REQUIRE(dp_ld >= C && a_ld >= C && da_ld >= C && (!ds || ds_ld >= C) && dp_ld % 8 == 0 &&
                      a_ld % 8 == 0 && da_ld % 8 == 0 && (!ds || ds_ld % 8 == 0),
                  "unpool_add: bad pixel strides");
+  CRIMAC_REQUIRE(bnb_args_ok(bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas, C),
+                 "unpool_add: bad arguments of the fused BatchNorm-backward sums");
   const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
   const int grid = grid_for(total, 256);
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL(unpool_add_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST, (const bf16_t*)dp, dp_ld,
-                       (const bf16_t*)a, a_ld, (const bf16_t*)ds, ds_ld, (bf16_t*)da, da_ld, B, H, W, C);
-  else
-    hipLaunchKernelGGL(unpool_add_kernel<float>, dim3(grid), dim3(256), 0, ST, (const float*)dp, dp_ld,
-                       (const float*)a, a_ld, (const float*)ds, ds_ld, (float*)da, da_ld, B, H, W, C);
+  BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
+#define UA(T, BNB, LDS)                                                                                   \
+  hipLaunchKernelGGL((unpool_add_kernel<T, BNB>), dim3(grid), dim3(256), LDS, ST, (const T*)dp, dp_ld,     \
+                     (const T*)a, a_ld, (const T*)ds, ds_ld, (T*)da, da_ld, B, H, W, C, bnb)
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (prec == CRIMAC_PREC_BF16) {
+    if (stat_sum) UA(bf16_t, true, lds); else UA(bf16_t, false, 0);
+  } else {
+    if (stat_sum) UA(float, true, lds); else UA(float, false, 0);
+  }
+#undef UA
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -948,16 +1047,20 @@ extern "C" int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, cons
 
 template <typename T>
 static int head_bwd_launch(const float* dl, const void* x, long x_ld, int Cin, const float* w, void* dx,
-                           long dx_ld, float* dw, float* db, long npix, long HW, int ncls,
+                           long dx_ld, float* dw, float* db, long npix, long HW, int ncls, const BnbArgs& bnb,
                            hipStream_t st) {
   const int lp = Cin / 8;
   int grid = grid_for(npix, (256 / lp) * 32);
   if (grid > 1024) grid = 1024;
-  const size_t lds = (size_t)(ncls * Cin + ncls) * sizeof(float);
-#define HB(NC)                                                                                        \
-  hipLaunchKernelGGL((head_bwd_kernel<T, NC>), dim3(grid), dim3(256), lds, st, dl, (const T*)x, x_ld, \
-                     Cin, w, (T*)dx, dx_ld, dw, db, npix, HW)
-  if (ncls == 2) HB(2); else if (ncls == 3) HB(3); else HB(4);
+  const size_t lds = (size_t)(ncls * Cin + ncls + (bnb.sum_dz ? 2 * Cin : 0)) * sizeof(float);
+#define HB(NC, BNB)                                                                                          \
+  hipLaunchKernelGGL((head_bwd_kernel<T, NC, BNB>), dim3(grid), dim3(256), lds, st, dl, (const T*)x, x_ld,   \
+                     Cin, w, (T*)dx, dx_ld, dw, db, npix, HW, bnb)
+  if (bnb.sum_dz) {
+    if (ncls == 2) HB(2, true); else if (ncls == 3) HB(3, true); else HB(4, true);
+  } else {
+    if (ncls == 2) HB(2, false); else if (ncls == 3) HB(3, false); else HB(4, false);
+  }
 #undef HB
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -965,16 +1068,21 @@ static int head_bwd_launch(const float* dl, const void* x, long x_ld, int Cin, c
 
 extern "C" int crimac_head_bwd(int prec, const float* dlogits, const void* x, long x_ld, int Cin,
                                const float* w, void* dx, long dx_ld, float* dw, float* db, int B, int H,
-                               int W, int ncls, void* stream) {
+                               int W, int ncls, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
+                               long bnb_stride, double* stat_sum, double* stat_sumsq, int stat_replicas,
+                               void* stream) {
   PREC_OK("head_bwd");
   CRIMAC_REQUIRE(dlogits && x && w && dx && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
   CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "head_bwd: ncls=%d unsupported (2..4)", ncls);
   CRIMAC_REQUIRE(head_cin_ok(Cin) && x_ld >= Cin && dx_ld >= Cin && x_ld % 8 == 0 && dx_ld % 8 == 0,
                  "head_bwd: Cin=%d must be 8*2^k <= 512", Cin);
+  CRIMAC_REQUIRE(bnb_args_ok(bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas, Cin),
+                 "head_bwd: bad arguments of the fused BatchNorm-backward sums");
   const long HW = (long)H * W;
+  const BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
   return prec == CRIMAC_PREC_BF16
-             ? head_bwd_launch<bf16_t>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, ST)
-             : head_bwd_launch<float>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, ST);
+             ? head_bwd_launch<bf16_t>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, bnb, ST)
+             : head_bwd_launch<float>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, bnb, ST);
 }
 
 extern "C" int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes,

@@ -342,6 +342,15 @@ class UNetEngine:
             return True
         return False
 
+    def _bnb_args(self, blk, y):
+        """The seven trailing arguments of a producer kernel that also takes the BatchNorm-backward sums of the
+        block its output feeds (y: that block's saved conv output; None: no fusion)."""
+        if y is None:
+            return (None, 0, None, 0, None, None, 1)
+        self._stat_fwd_region(blk).zero_()
+        return (y.p, y.ld, ptr(self._bnf(blk, 0)), self.cmax, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1)),
+                STAT_REPLICAS)
+
     def _stat_fwd_region(self, b):
         """The [2][R][cmax] replica accumulators of BN layer b (sum and sumsq, contiguous)."""
         R = STAT_REPLICAS
@@ -577,9 +586,12 @@ class UNetEngine:
         head_in = s["head_in"]
         h, w, M = geo[0]
         d_cur = Act(self._buf("g.head", (M, self.sf)), self.sf)
+        # d_cur is the `da` of the last decoder block's second BatchNorm: its backward sums are taken here
+        head_fused = self.fuse_bn_bwd and D >= 2
         call("crimac_head_bwd", self.prec, ptr(dlogits), head_in.p, head_in.ld, self.sf,
              ptr(self.P["conv_final.weight"]), d_cur.p, d_cur.ld, ptr(self.G["conv_final.weight"]),
-             ptr(self.G["conv_final.bias"]), B, H, W, self.n_classes)
+             ptr(self.G["conv_final.bias"]), B, H, W, self.n_classes,
+             *self._bnb_args(self.dec[D - 2][1], s[f"d{D - 2}"][4] if head_fused else None))
         skip_grad = {}
         for j in reversed(range(D - 1)):
             L = D - 2 - j
@@ -589,7 +601,8 @@ class UNetEngine:
             b1, b2 = self.dec[j]
             x_prev, catA, y1, a1, y2, a2 = s[f"d{j}"]
             da1 = Act(self._buf(f"g.d{j}.a1", (M, c)), c)
-            fused = self._block_bwd(f"g.d{j}.2", b2, d_cur, y2, a1, B, h, w, M, da1, next_bn=(b1, y1))
+            fused = self._block_bwd(f"g.d{j}.2", b2, d_cur, y2, a1, B, h, w, M, da1, next_bn=(b1, y1),
+                                    reduce_done=head_fused and j == D - 2)
             dcat = Act(self._buf(f"g.d{j}.cat", (M, 2 * c)), 2 * c)
             # transposed conv bias gradient (unet.py:130) = column sums of dcat[:, :c]: from the dgrad epilogue
             self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat, reduce_done=fused,
@@ -619,9 +632,10 @@ class UNetEngine:
                 da2 = Act(self._buf(f"g.e{i}.a2", (M, c)), c)
                 ds = skip_grad[i]
                 call("crimac_unpool_add", self.prec, d_pool.p, d_pool.ld, a2.p, a2.ld, ds.p, ds.ld,
-                     da2.p, da2.ld, B, h, w, c)
+                     da2.p, da2.ld, B, h, w, c, *self._bnb_args(b2, y2 if self.fuse_bn_bwd else None))
             da1 = Act(self._buf(f"g.e{i}.a1", (M, c)), c)
-            fused = self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1, next_bn=(b1, y1))
+            fused = self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1, next_bn=(b1, y1),
+                                    reduce_done=self.fuse_bn_bwd and i != D - 1)
             if i > 0:
                 d_pool = Act(self._buf(f"g.e{i}.xin", (M, b1.cin)), b1.cin)
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool, reduce_done=fused)

@@ -40,12 +40,14 @@ SIGNATURES = {
     "crimac_colsum_f32": [_i, _vp, _l, _l, _i, _vp, _vp],
     "crimac_bn_finalize": [_vp, _vp, _i, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "crimac_bn_act_pool": [_i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
-    "crimac_unpool_add": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
+    "crimac_unpool_add": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _i,
+                          _vp],
     "crimac_bn_bwd_reduce": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp],
     "crimac_bn_bwd_apply": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp,
                             _vp, _vp, _vp],
     "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp],
+    "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp,
+                        _i, _vp],
     "crimac_wce_fwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "crimac_wce_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp],
     "crimac_sgd_momentum": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp],

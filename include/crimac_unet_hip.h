@@ -151,9 +151,15 @@ int crimac_bn_act_pool(int prec, const void* y, long y_ld, const float* scale, c
                        int relu, void* out, long out_ld, void* pool_out, long pool_ld, int B, int H,
                        int W, int C, void* stream);
 /* Backward of [pool ->] (skip add): da = ds + unpool(dp) with first-max tie rule of
- * aten::max_pool2d; `a` is the forward activation that was pooled.  ds may be NULL. */
+ * aten::max_pool2d; `a` is the forward activation that was pooled.  ds may be NULL.
+ * stat_sum != NULL: `da` feeds a BatchNorm+ReLU block; its backward sums (as crimac_conv3x3 stat_mode 2:
+ * y = bnb_y, rows of bnb_vec = mean, invstd, scale, shift) are accumulated into [stat_replicas][C] while
+ * da is produced (crimac_bn_bwd_reduce fused away; finish with crimac_sum_replicas).  crimac_head_bwd
+ * takes the same seven arguments for its dx. */
 int crimac_unpool_add(int prec, const void* dp, long dp_ld, const void* a, long a_ld, const void* ds,
-                      long ds_ld, void* da, long da_ld, int B, int H, int W, int C, void* stream);
+                      long ds_ld, void* da, long da_ld, int B, int H, int W, int C, const void* bnb_y,
+                      long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
+                      double* stat_sumsq, int stat_replicas, void* stream);
 /* BatchNorm+ReLU backward, pass 1: sum_dz, sum_dz_xhat (fp64, caller zeroes) with
  * dz = da * (y*scale+shift > 0), xhat = (y-mean)*invstd. */
 int crimac_bn_bwd_reduce(int prec, const void* da, long da_ld, const void* y, long y_ld,
@@ -176,7 +182,8 @@ int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, const float* w,
                     float* logits, int B, int H, int W, int ncls, int softmax, void* stream);
 int crimac_head_bwd(int prec, const float* dlogits, const void* x, long x_ld, int Cin, const float* w,
                     void* dx, long dx_ld, float* dw, float* db, int B, int H, int W, int ncls,
-                    void* stream);
+                    const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
+                    double* stat_sumsq, int stat_replicas, void* stream);
 /* nn.CrossEntropyLoss(weight) (pipeline.py:132-141): sums[0] += sum w[y]*nll, sums[1] += sum w[y]
  * over pixels with y != ignore_index.  labels: int16/int32/int64 selected by label_bytes. */
 int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes, const float* class_w,

@@ -239,10 +239,20 @@ def test_batchnorm_train_forward_backward_pool(prec, C):
     da = torch.empty(M, C, dtype=_dt(prec), device=d)
     dpn, dsn = to_nhwc(dp, prec), to_nhwc(ds, prec)
     call("crimac_unpool_add", P, ptr(dpn), C, ptr(a), C, ptr(dsn), C, ptr(da), C,
-         B, H, W, C)
+         B, H, W, C, None, 0, None, 0, None, None, 1)
     s2 = torch.zeros(2, C, dtype=torch.float64, device=d)
     call("crimac_bn_bwd_reduce", P, ptr(da), C, ptr(yn), C, ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]), M,
          C, ptr(s2[0]), ptr(s2[1]))
+    # the same sums taken inside unpool_add (7 replicas), identical da
+    R = 7
+    vec = torch.stack([st[0], st[1], st[2], st[3]]).contiguous()          # mean, invstd, scale, shift
+    rep = torch.zeros(2, R, C, dtype=torch.float64, device=d)
+    da_f = torch.empty_like(da)
+    call("crimac_unpool_add", P, ptr(dpn), C, ptr(a), C, ptr(dsn), C, ptr(da_f), C,
+         B, H, W, C, ptr(yn), C, ptr(vec), C, ptr(rep[0]), ptr(rep[1]), R)
+    torch.cuda.synchronize()
+    assert torch.equal(da_f, da)
+    assert relerr(rep[0].sum(0).cpu(), s2[0].cpu()) < 1e-5 and relerr(rep[1].sum(0).cpu(), s2[1].cpu()) < 1e-5
     dy = torch.empty(M, C, dtype=_dt(prec), device=d)
     dg, db, dbias = (torch.zeros(C, dtype=torch.float32, device=d) for _ in range(3))
     call("crimac_bn_bwd_apply", P, ptr(da), C, ptr(yn), C, ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]),
@@ -270,7 +280,7 @@ def test_unpool_first_max_tie_rule(prec):
     da = torch.empty(4, C, dtype=_dt(prec), device="cuda")
     dpn, an = to_nhwc(dp, prec), to_nhwc(a, prec)
     call("crimac_unpool_add", hip.PREC_NAMES[prec], ptr(dpn), C, ptr(an), C,
-         None, 0, ptr(da), C, B, H, W, C)
+         None, 0, ptr(da), C, B, H, W, C, None, 0, None, 0, None, None, 1)
     torch.cuda.synchronize()
     assert torch.equal(from_nhwc(da, B, H, W), ar.grad)
 
@@ -312,8 +322,25 @@ def test_head_and_weighted_ce(prec, ncls):
     dx = torch.empty(B * H * W, C, dtype=_dt(prec), device=d)
     dw = torch.zeros(ncls, C, dtype=torch.float32, device=d)
     dbv = torch.zeros(ncls, dtype=torch.float32, device=d)
-    call("crimac_head_bwd", P, ptr(dl), ptr(xn), C, C, ptr(wd), ptr(dx), C, ptr(dw), ptr(dbv), B, H, W, ncls)
+    call("crimac_head_bwd", P, ptr(dl), ptr(xn), C, C, ptr(wd), ptr(dx), C, ptr(dw), ptr(dbv), B, H, W, ncls,
+         None, 0, None, 0, None, None, 1)
     torch.cuda.synchronize()
+    # fused BatchNorm-backward sums of the block dx feeds == bn_bwd_reduce on the stored dx
+    Mh = B * H * W
+    yb = torch.randn(Mh, C, generator=g).to(_dt(prec)).cuda()
+    vec = torch.stack([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5,
+                       torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3]).contiguous().cuda()
+    rep = torch.zeros(2, 5, C, dtype=torch.float64, device=d)
+    dx2, dw2, db2 = torch.empty_like(dx), torch.zeros_like(dw), torch.zeros_like(dbv)
+    call("crimac_head_bwd", P, ptr(dl), ptr(xn), C, C, ptr(wd), ptr(dx2), C, ptr(dw2), ptr(db2), B, H, W, ncls,
+         ptr(yb), C, ptr(vec), C, ptr(rep[0]), ptr(rep[1]), 5)
+    ref = torch.zeros(2, C, dtype=torch.float64, device=d)
+    call("crimac_bn_bwd_reduce", P, ptr(dx2), C, ptr(yb), C, ptr(vec[2]), ptr(vec[3]), ptr(vec[0]), ptr(vec[1]), Mh,
+         C, ptr(ref[0]), ptr(ref[1]))
+    torch.cuda.synchronize()
+    # (the two instantiations may contract the 3-term dot products differently: last-bit differences in dx)
+    assert relerr(dx2, dx) < (1e-2 if prec == "bf16" else 1e-6)
+    assert relerr(rep[0].sum(0).cpu(), ref[0].cpu()) < 1e-5 and relerr(rep[1].sum(0).cpu(), ref[1].cpu()) < 1e-5
     assert relerr(from_nhwc(dx, B, H, W), xr.grad) < (1e-2 if prec == "bf16" else 1e-4)
     assert relerr(dw.cpu().reshape(ncls, C, 1, 1), wr.grad) < 1e-4
     assert relerr(dbv.cpu(), br.grad) < 1e-4
