@@ -117,11 +117,18 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
 
     ``reader``: the reference's zarr reader API (shape, get_data_slice, get_label_slice, get_seabed,
     get_seabed_mask); ``segpipe``: a ``SegPipeUNet`` with loaded parameters.
+
+    Three stages overlap: a host thread reads chunk i+1 from ``reader`` (numpy / zarr I/O, no GPU calls)
+    while the GPU gathers, predicts and scatters chunk i, and the result of chunk i-1 comes back through a
+    pinned buffer (asynchronous D2H) before it is handed to the caller.
     """
+    from concurrent.futures import ThreadPoolExecutor
     n_pings, n_range = reader.shape
     model = segpipe.model.to(segpipe.device).eval()
     cp = ChunkPredictor(model, n_range, patch_size, patch_overlap, batch_size)
-    for s, e in plan_chunks(start_ping, n_pings, preload_n_pings):
+    chunks = plan_chunks(start_ping, n_pings, preload_n_pings)
+
+    def fetch(s, e):
         max_seabed = reader.get_seabed(s, e - s, return_numpy=False).max().values
         grid = plan_grid(n_range, max_seabed, s, e, patch_size, patch_overlap)
         lo = max(0, int(grid[0, 1]) - patch_size[1] // 2)              # dataset.py:175-177
@@ -130,6 +137,28 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                                      return_numpy=True)
         labels = reader.get_label_slice(idx_ping=s, n_pings=e - s, return_numpy=True) if labels_available else None
         mask = np.asarray(reader.get_seabed_mask(s, e - s, 0, n_range, seabed_pad=0))
-        cp.load_chunk(data, lo, labels, mask, s, e)
-        out = cp.predict(grid)
-        yield s, e, out.cpu().numpy()
+        return grid, lo, np.ascontiguousarray(data, dtype=np.float32), labels, mask
+
+    widest = max(e - s for s, e in chunks)
+    pinned = [torch.empty((2, n_range, widest), dtype=torch.float32).pin_memory() for _ in range(2)]
+    events = [torch.cuda.Event() for _ in range(2)]
+    pending = None                      # (s, e, slot) of the chunk whose D2H copy is in flight
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        fut = pool.submit(fetch, *chunks[0])
+        for i, (s, e) in enumerate(chunks):
+            grid, lo, data, labels, mask = fut.result()
+            if i + 1 < len(chunks):
+                fut = pool.submit(fetch, *chunks[i + 1])
+            cp.load_chunk(data, lo, labels, mask, s, e)
+            out = cp.predict(grid)
+            slot = i & 1
+            pinned[slot][:, :, :e - s].copy_(out, non_blocking=True)
+            events[slot].record()
+            if pending is not None:
+                ps, pe, pslot = pending
+                events[pslot].synchronize()
+                yield ps, pe, pinned[pslot][:, :, :pe - ps].numpy().copy()
+            pending = (s, e, slot)
+        ps, pe, pslot = pending
+        events[pslot].synchronize()
+        yield ps, pe, pinned[pslot][:, :, :pe - ps].numpy().copy()
