@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const double* __restrict__ sum_dz,
-    const double* __restrict__ sum_dzx, long M, int C, T* __restrict__ dy, long dy_ld, float* dgamma,
+    const double* __restrict__ sum_dzx, long M, long count, int C, T* __restrict__ dy, long dy_ld, float* dgamma,
     float* dbeta, float* dbias) {
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       dbeta[c] = (float)sum_dz[c];
     }
   }
-  const double invM = 1.0 / (double)M;
+  const double invM = 1.0 / (double)count;       // pixels the sums were taken over (all ranks under SyncBN)
   const int c0t = (threadIdx.x % (C / 8)) * 8;
   float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
@@ -989,12 +989,13 @@ extern "C" int crimac_bn_bwd_reduce(int prec, const void* da, long da_ld, const 
 extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, long y_ld,
                                    const float* scale, const float* shift, const float* mean,
                                    const float* invstd, const double* sum_dz,
-                                   const double* sum_dz_xhat, long M, int C, void* dy, long dy_ld,
+                                   const double* sum_dz_xhat, long M, long count, int C, void* dy, long dy_ld,
                                    float* dgamma, float* dbeta, float* dbias, void* stream) {
   PREC_OK("bn_bwd_apply");
   CRIMAC_REQUIRE(da && y && scale && shift && mean && invstd && sum_dz && sum_dz_xhat && dy && dgamma &&
-                     dbeta && dbias && M > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                     dbeta && dbias && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (count == 0 || count >= M),
                  "bn_bwd_apply: bad arguments");
+  if (count == 0) count = M;
   CRIMAC_REQUIRE(da_ld >= C && y_ld >= C && dy_ld >= C && da_ld % 8 == 0 && y_ld % 8 == 0 &&
                      dy_ld % 8 == 0,
                  "bn_bwd_apply: bad pixel strides");
@@ -1003,11 +1004,11 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
   if (prec == CRIMAC_PREC_BF16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, ST, (const bf16_t*)da,
                        da_ld, (const bf16_t*)y, y_ld, scale, shift, mean, invstd, sum_dz, sum_dz_xhat, M,
-                       C, (bf16_t*)dy, dy_ld, dgamma, dbeta, dbias);
+                       count, C, (bf16_t*)dy, dy_ld, dgamma, dbeta, dbias);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), lds, ST, (const float*)da,
                        da_ld, (const float*)y, y_ld, scale, shift, mean, invstd, sum_dz, sum_dz_xhat, M,
-                       C, (float*)dy, dy_ld, dgamma, dbeta, dbias);
+                       count, C, (float*)dy, dy_ld, dgamma, dbeta, dbias);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

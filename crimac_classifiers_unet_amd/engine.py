@@ -370,8 +370,41 @@ class UNetEngine:
              2, ptr(pk["dg_hi"]), ptr(pk["dg_lo"]), None, 0, out.p, out.ld, 0, 0, 0,
              flops=2.0 * 4 * u.cin * u.cout * B * H * W)
 
+    # SyncBN (optional, N > 1): BatchNorm statistics over the GLOBAL batch.  Per BN layer one all-reduce of
+    # (sum y, sum y^2) [2 x cmax fp64] in the forward pass and one of (sum dz, sum dz*xhat) in the backward
+    # pass, on a process group of their own so they do not queue behind the gradient buckets.  With it an
+    # N-rank step equals a single-rank step on the concatenated batch (loss = mean of the per-rank losses).
+    sync_bn = False
+    _bn_group = None
+
+    def _sync_world(self):
+        import torch.distributed as dist
+        if not (self.sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return 1
+        if UNetEngine._bn_group is None:
+            UNetEngine._bn_group = dist.new_group()
+        return dist.get_world_size()
+
+    def _stat_pair(self, b):
+        """The two adjacent [cmax] fp64 slots (sum_dz | sum_dz_xhat) of BN layer b."""
+        o = 2 + b.idx * (2 * STAT_REPLICAS + 2) * self.cmax + 2 * STAT_REPLICAS * self.cmax
+        return self.stat[o:o + 2 * self.cmax]
+
     def _bn_train(self, b, y: Act, M):
         """Batch statistics were accumulated by the conv epilogue; finish them."""
+        world = self._sync_world()
+        if world > 1:
+            import torch.distributed as dist
+            tmp = self._buf("syncbn.fwd", (2, self.cmax), torch.float64)   # (the backward slots must stay zero)
+            call("crimac_sum_replicas", ptr(self._stat(b, 0)), STAT_REPLICAS, b.cout, b.cout,
+                 ptr(tmp[0]), None, ptr(self._stat(b, 1)), ptr(tmp[1]))
+            dist.all_reduce(tmp, group=UNetEngine._bn_group)
+            call("crimac_bn_finalize", ptr(tmp[0]), ptr(tmp[1]), 1, M * world, b.cout,
+                 ptr(self.P[b.bn_key + ".weight"]), ptr(self.P[b.bn_key + ".bias"]), BN_EPS, BN_MOMENTUM,
+                 ptr(self.Bf[b.bn_key + ".running_mean"]), ptr(self.Bf[b.bn_key + ".running_var"]),
+                 ptr(self.Bf[b.bn_key + ".num_batches_tracked"]), ptr(self._bnf(b, 0)),
+                 ptr(self._bnf(b, 1)), ptr(self._bnf(b, 2)), ptr(self._bnf(b, 3)))
+            return
         call("crimac_bn_finalize", ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), STAT_REPLICAS, M, b.cout,
              ptr(self.P[b.bn_key + ".weight"]), ptr(self.P[b.bn_key + ".bias"]), BN_EPS, BN_MOMENTUM,
              ptr(self.Bf[b.bn_key + ".running_mean"]), ptr(self.Bf[b.bn_key + ".running_var"]),
@@ -509,10 +542,21 @@ class UNetEngine:
                  ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
                  ptr(self._stat(b, 2)), ptr(self._stat(b, 3)))
         dy = Act(self._buf(f"{tag}.dy", (M, b.cout)), b.cout)
+        world = self._sync_world()
+        dgamma, dbeta = self.G[b.bn_key + ".weight"], self.G[b.bn_key + ".bias"]
+        if world > 1:
+            # gamma / beta gradients are this rank's LOCAL sums (the gradient exchange adds the ranks up); the
+            # input gradient needs the GLOBAL sums and the global pixel count
+            import torch.distributed as dist
+            dgamma.copy_(self._stat(b, 3))
+            dbeta.copy_(self._stat(b, 2))
+            dist.all_reduce(self._stat_pair(b), group=UNetEngine._bn_group)
+            scr = self._buf("g.syncbn.scratch", (2, self.cmax), torch.float32)
+            dgamma, dbeta = scr[0], scr[1]
         call("crimac_bn_bwd_apply", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
              ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), ptr(self._stat(b, 2)),
-             ptr(self._stat(b, 3)), M, b.cout, dy.p, dy.ld, ptr(self.G[b.bn_key + ".weight"]),
-             ptr(self.G[b.bn_key + ".bias"]), ptr(self.G[b.conv_key + ".bias"]))
+             ptr(self._stat(b, 3)), M, M * world, b.cout, dy.p, dy.ld, ptr(dgamma), ptr(dbeta),
+             ptr(self.G[b.conv_key + ".bias"]))
         n = 9 * b.cout * b.cin_pad
         dw = self._dw(b.conv_key, n)
         call("crimac_wgrad", self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w,

@@ -49,7 +49,7 @@ class SegPipe:
                  lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
                  precision="bf16", loss_flush=50, gpu_augment=False, random_seed=0, gpu_metrics=False,
-                 gpu_label_transform=False, **kwargs):
+                 gpu_label_transform=False, sync_bn=False, **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -87,6 +87,9 @@ class SegPipe:
         # gpu_label_transform (with gpu_augment): the train Dataset also gets label_transform_function=None
         # and hands RAW annotation ids; refine_label_boundary (threshold channel = last frequency, thresholds
         # [1e-7, 1e-4], batch/transforms.py:74) + convert_label_indexing run on the GPU
+        # sync_bn (N > 1): BatchNorm statistics over the global batch (engine.sync_bn); default keeps them per
+        # rank like torch DDP
+        self.sync_bn = bool(sync_bn)
         self.gpu_label_transform = bool(gpu_label_transform)
         if self.gpu_label_transform and not self.gpu_augment:
             raise ValueError("gpu_label_transform needs gpu_augment (the transform runs on the augmented crop)")
@@ -134,6 +137,7 @@ class SegPipe:
         scheduler = ExponentialLR(optimizer, gamma=self.lr_reduction)
         criterion = self.get_criterion()
         engine = self.model.engine
+        engine.sync_bn = self.sync_bn
         grad_sync = parallel.GradSync()
         is_rank0 = parallel.env_world()[1] == 0
         pending = []

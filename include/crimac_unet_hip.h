@@ -166,13 +166,14 @@ int crimac_bn_bwd_reduce(int prec, const void* da, long da_ld, const void* y, lo
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, long M, int C, double* sum_dz, double* sum_dz_xhat,
                          void* stream);
-/* pass 2: dy = scale*(dz - sum_dz/M - xhat*sum_dz_xhat/M); dgamma = sum_dz_xhat, dbeta = sum_dz;
+/* pass 2 over M pixels: dy = scale*(dz - sum_dz/count - xhat*sum_dz_xhat/count), count = number of pixels
+ * the sums were taken over (0 = M; larger when they were all-reduced over ranks, SyncBN); dgamma =
+ * sum_dz_xhat, dbeta = sum_dz;
  * dbias (conv bias in front of the BN, may be NULL) += sum over pixels of dy (caller zeroes). */
 int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, long y_ld,
-                        const float* scale, const float* shift, const float* mean,
-                        const float* invstd, const double* sum_dz, const double* sum_dz_xhat, long M,
-                        int C, void* dy, long dy_ld, float* dgamma, float* dbeta, float* dbias,
-                        void* stream);
+                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                        const double* sum_dz, const double* sum_dz_xhat, long M, long count, int C, void* dy,
+                        long dy_ld, float* dgamma, float* dbeta, float* dbias, void* stream);
 
 /* ---- 1x1 head, loss, optimiser --------------------------------------------------------------- */
 

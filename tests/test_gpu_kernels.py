@@ -256,7 +256,7 @@ def test_batchnorm_train_forward_backward_pool(prec, C):
     dy = torch.empty(M, C, dtype=_dt(prec), device=d)
     dg, db, dbias = (torch.zeros(C, dtype=torch.float32, device=d) for _ in range(3))
     call("crimac_bn_bwd_apply", P, ptr(da), C, ptr(yn), C, ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]),
-         ptr(s2[0]), ptr(s2[1]), M, C, ptr(dy), C, ptr(dg), ptr(db), ptr(dbias))
+         ptr(s2[0]), ptr(s2[1]), M, 0, C, ptr(dy), C, ptr(dg), ptr(db), ptr(dbias))
     torch.cuda.synchronize()
     if prec == "bf16":
         # bf16-rounded activations tie inside 2x2 windows far more often than fp32 ones; a tie routes

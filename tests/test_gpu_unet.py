@@ -488,3 +488,69 @@ def test_train_model_on_raw_crops_with_gpu_augment_and_label_transform(tmp_path)
     assert len(lg.losses) == 4 and all(np.isfinite(lg.losses)) and lg.losses[-1] < lg.losses[0]
     with pytest.raises(ValueError):
         pkg.SegPipeUNet(checkpoint_dir=None, experiment_name="t", **{**cfg, "gpu_augment": False})
+
+
+def _syncbn_worker(rank, world, port, x, lab, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", CRIMAC_DIST_BACKEND="gloo")
+    from crimac_classifiers_unet_amd import parallel
+    parallel.init_distributed(backend="gloo")          # both ranks share the one GPU of the box: gloo, not RCCL
+    m = make_model("f32x6").train()
+    eng = m.engine
+    eng.sync_bn = True
+    n = x.shape[0] // world
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    loss = eng.train_step(x[rank * n:(rank + 1) * n].cuda(), lab[rank * n:(rank + 1) * n].cuda(), cw, lr=0.0,
+                          momentum=0.0, grad_sync=parallel.GradSync())      # overlapped exchange (4 ranges)
+    torch.cuda.synchronize()
+    if rank == 0:
+        out["loss"] = float(loss)
+        out["grad"] = (eng.flat_g / world).cpu()        # SGD folds 1/world in; lr = 0 left flat_g as summed
+        out["layout"] = dict(eng.layout)
+        out["rm"] = m.state_dict()["down_convs.0.main.1.running_mean"].cpu()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_two_ranks_equal_one_rank_on_the_concatenated_batch(full_case):
+    """sync_bn: 2 ranks x 2 patches == the CPU oracle on the 4-patch batch with loss = mean of the per-rank
+    losses (train-mode BatchNorm over all 4 patches).  Ranks exchange through gloo and share the GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    _, x2, lab2 = full_case
+    x = torch.cat([x2, torch.from_numpy(synth.synth_echogram_batch(2, 4, 256, 256, seed=11))])[:, :, :64, :64]
+    lab = torch.cat([lab2, torch.from_numpy(synth.synth_labels(2, 256, 256, seed=12))])[:, :64, :64]
+    x, lab = x.contiguous(), lab.contiguous()
+    # oracle: one network over the concatenated batch, loss = mean over ranks of the local weighted CE
+    state = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in synth.synth_state_dict(seed=0).items()}
+    for k in orc.trainable_keys(state):
+        state[k].requires_grad_(True)
+    logits, _ = orc.unet_forward(state, x.double(), training=True)
+    cw = torch.tensor(orc.CE_CLASS_WEIGHTS, dtype=torch.float64)
+    losses = [orc.weighted_cross_entropy(logits[r * 2:(r + 1) * 2], lab[r * 2:(r + 1) * 2].long(), cw) for r in range(2)]
+    ref_loss = (losses[0] + losses[1]) / 2
+    keys = orc.trainable_keys(state)
+    ref = dict(zip(keys, torch.autograd.grad(ref_loss, [state[k] for k in keys])))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, x, lab, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        got, layout, loss0 = out["grad"], out["layout"], out["loss"]
+    assert abs(loss0 - float(losses[0])) < 1e-5 * abs(float(losses[0]))      # rank 0's local loss, global BN
+    worst = 0.0
+    for k in keys:
+        if PRE_BN_BIAS.fullmatch(k):
+            continue
+        o, n, shp = layout[k]
+        g = got[o:o + n].view(shp).double()
+        r = l2rel(g, ref[k])
+        worst = max(worst, r)
+        assert r < 1e-2, (k, r)          # fp32-equivalent path vs fp64 oracle: the net's own chaos floor (3e-3)
+    print("SyncBN worst grad L2-rel vs fp64 oracle:", worst)
