@@ -137,7 +137,7 @@ __global__ void unpack_wgrad_upconv_kernel(const float* __restrict__ dw, int Ci,
 
 // ---- per-channel reductions over an [M][C] (pixel-major) matrix ---------------------------------
 // Thread -> (8-channel chunk, row lane).  OP produces up to two quantities per element.
-template <typename T, typename ACC, int NQ, typename OP>
+template <typename T, typename ACC, int NQ, int UNR = 2, typename OP>
 __device__ __forceinline__ void colreduce(long M, int C, OP op, ACC* out0, ACC* out1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);   // [NQ][C]
@@ -152,17 +152,19 @@ __device__ __forceinline__ void colreduce(long M, int C, OP op, ACC* out0, ACC* 
   if (rl < rpi && cpr <= 256) {
     const long stride = (long)gridDim.x * rpi;
     long m = (long)blockIdx.x * rpi + rl;
-    for (; m + stride < M; m += 2 * stride) {      // two independent rows in flight
-      float q0[8], q1[8], r0[8], r1[8];
-      op(m, chunk * 8, q0, q1);
-      op(m + stride, chunk * 8, r0, r1);
+    for (; m + (UNR - 1) * stride < M; m += UNR * stride) {      // UNR independent rows in flight
+      float q0[UNR][8], q1[UNR][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s0[j] += q0[j] + r0[j];
-        if (NQ > 1) s1[j] += q1[j] + r1[j];
-      }
+      for (int u = 0; u < UNR; ++u) op(m + u * stride, chunk * 8, q0[u], q1[u]);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s0[j] += q0[u][j];
+          if (NQ > 1) s1[j] += q1[u][j];
+        }
     }
-    if (m < M) {
+    for (; m < M; m += stride) {
       float q0[8], q1[8];
       op(m, chunk * 8, q0, q1);
 #pragma unroll
@@ -175,6 +177,7 @@ __device__ __forceinline__ void colreduce(long M, int C, OP op, ACC* out0, ACC* 
     }
   }
   __syncthreads();
+  if (!out0) return;        // nothing to accumulate into (bn_bwd_apply without a bias gradient)
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(&out0[c], (ACC)lds[c]);
     if (NQ > 1) atomicAdd(&out1[c], (ACC)lds[C + c]);
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     k1[j] = (float)(sum_dz[c0t + j] * invM);
     k2[j] = (float)(sum_dzx[c0t + j] * invM);
   }
-  colreduce<T, float, 1>(M, C,
+  colreduce<T, float, 1, 1>(M, C,
                          [&](long m, int c0, float (&q0)[8], float (&q1)[8]) {
                            float g[8], yv[8], o[8];
                            load8(da + m * da_ld + c0, g);
@@ -993,7 +996,7 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
                                    float* dgamma, float* dbeta, float* dbias, void* stream) {
   PREC_OK("bn_bwd_apply");
   CRIMAC_REQUIRE(da && y && scale && shift && mean && invstd && sum_dz && sum_dz_xhat && dy && dgamma &&
-                     dbeta && dbias && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (count == 0 || count >= M),
+                     dbeta && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (count == 0 || count >= M),
                  "bn_bwd_apply: bad arguments");
   if (count == 0) count = M;
   CRIMAC_REQUIRE(da_ld >= C && y_ld >= C && dy_ld >= C && da_ld % 8 == 0 && y_ld % 8 == 0 &&
