@@ -84,7 +84,8 @@ int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, in
  *   mode 0 (conv3x3): F=dY [B][Hf][Wf][CF=Cout], S=X same grid [CS=Cin], 9 taps
  *   mode 1 (upconv):  F=X  [B][Hf][Wf][CF=Cin],  S=dY [B][2Hf][2Wf][CS=Cout], 4 taps (a,b)
  *   target_blocks: workgroups to aim for when splitting the pixel range; <= 0: automatic (about
- *   1024 workgroups, but never fewer than ~4096 pixels per split: each split costs one atomic pass). */
+ *   512 workgroups = one resident round, but never fewer than ~4096 pixels per split: each split costs
+ *   one atomic pass). */
 int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld,
                  int CS, int B, int Hf, int Wf, float* dw, int target_blocks, void* stream);
 
