@@ -183,7 +183,9 @@ class UNetEngine:
         # sum[R][C], sumsq[R][C] (R replicas filled by the conv epilogues), sum_dz[C], sum_dz_xhat[C]
         self.stat = torch.zeros(2 + nb * (2 * STAT_REPLICAS + 2) * cmax, dtype=torch.float64, device=dev)
         self.cmax = cmax
-        self.bias_scr = torch.zeros(2 * STAT_REPLICAS * 2 * cmax, dtype=torch.float64, device=dev)
+        # transposed-conv bias gradients come out of the dgrad epilogue of the block above: [level][2][R][2*cmax]
+        self.bias_scr = torch.zeros(max(self.depth - 1, 1) * 2 * STAT_REPLICAS * 2 * cmax, dtype=torch.float64,
+                                    device=dev)
         # fp32 per BN layer: mean, invstd, scale, shift
         self.bnf = torch.zeros(nb * 4 * cmax, dtype=torch.float32, device=dev)
         self.class_w = None
@@ -328,7 +330,6 @@ class UNetEngine:
                 mode, s0, s1 = 1, ptr(stats[0]), ptr(stats[1])
             elif bnb is not None and self.fuse_bn_bwd:
                 blk, y = bnb
-                self._stat_fwd_region(blk).zero_()
                 mode, s0, s1 = 2, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1))
                 by, by_ld, bvec = y.p, y.ld, ptr(self._bnf(blk, 0))
             call("crimac_conv3x3", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
@@ -347,15 +348,8 @@ class UNetEngine:
         block its output feeds (y: that block's saved conv output; None: no fusion)."""
         if y is None:
             return (None, 0, None, 0, None, None, 1)
-        self._stat_fwd_region(blk).zero_()
         return (y.p, y.ld, ptr(self._bnf(blk, 0)), self.cmax, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1)),
                 STAT_REPLICAS)
-
-    def _stat_fwd_region(self, b):
-        """The [2][R][cmax] replica accumulators of BN layer b (sum and sumsq, contiguous)."""
-        R = STAT_REPLICAS
-        base = 2 + b.idx * (2 * R + 2) * self.cmax
-        return self.stat[base:base + 2 * R * self.cmax]
 
     def _upconv_fwd(self, x: Act, u, out: Act, B, H, W):
         pk = self.pk[u.key]
@@ -531,7 +525,7 @@ class UNetEngine:
 
         reduce_done: the producer of ``da`` already accumulated this block's BatchNorm-backward sums
         into its replica accumulators (conv3x3 stat_mode 2).  next_bn=(block, y): ``dx_out`` is the
-        ``da`` of that block -> fuse ITS sums into the dgrad convolution.  bias_from_stats=(grad, C):
+        ``da`` of that block -> fuse ITS sums into the dgrad convolution.  bias_from_stats=(grad, C, level):
         also take the per-channel sums of the first C channels of ``dx_out`` (a transposed-conv bias
         gradient) from the dgrad epilogue.  Returns whether next_bn's sums were fused."""
         if reduce_done:
@@ -566,16 +560,17 @@ class UNetEngine:
         if dx_out is not None:
             stats = None
             if bias_from_stats is not None and self.conv_impl == "halo":
-                self.bias_scr.zero_()
-                half = self.bias_scr.numel() // 2
-                stats = (self.bias_scr[:half], self.bias_scr[half:])
+                per = 2 * STAT_REPLICAS * 2 * self.cmax                  # this level's slice (zeroed in backward())
+                lvl = bias_from_stats[2]
+                scr = self.bias_scr[lvl * per:(lvl + 1) * per]
+                stats = (scr[:per // 2], scr[per // 2:])
             fused = self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                   dgrad=True, stats=stats, bnb=next_bn if stats is None else None)
             if stats is not None:
-                grad, C = bias_from_stats
+                grad, C = bias_from_stats[:2]
                 call("crimac_sum_replicas", ptr(stats[0]), STAT_REPLICAS, b.cin, C, None, ptr(grad), None, None)
             elif bias_from_stats is not None:
-                grad, C = bias_from_stats
+                grad, C = bias_from_stats[:2]
                 call("crimac_colsum_f32", self.prec, dx_out.p, dx_out.ld, M, C, ptr(grad))
         return fused and next_bn is not None
 
@@ -627,6 +622,10 @@ class UNetEngine:
         D = self.depth
         self.flat_g.zero_()
         self.dw_packed.zero_()
+        # the fused BatchNorm-backward reductions accumulate into the replica slots the forward statistics used:
+        # one fill for all layers (and one for the transposed-conv bias sums) instead of one per fused block
+        self.stat[2:].zero_()
+        self.bias_scr.zero_()
         dlogits = dlogits.contiguous().float()
         head_in = s["head_in"]
         h, w, M = geo[0]
@@ -651,7 +650,7 @@ class UNetEngine:
             dcat = Act(self._buf(f"g.d{j}.cat", (M, 2 * c)), 2 * c)
             # transposed conv bias gradient (unet.py:130) = column sums of dcat[:, :c]: from the dgrad epilogue
             self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat, reduce_done=fused,
-                            bias_from_stats=(self.G[u.key + ".bias"], c))
+                            bias_from_stats=(self.G[u.key + ".bias"], c, j))
             dup = dcat.slice(0, c)
             skip_grad[L] = dcat.slice(c, c)
             hp, wp, Mp = geo[L + 1]
