@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libcrimac_unet_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["conv3x3.hip", "conv3x3_glds.hip", "igemm.hip", "wgrad.hip", "elementwise.hip", "pack.hip", "tiling.hip", "augment.hip", "labels.hip"]
+SOURCES = ["conv3x3.hip", "conv3x3_glds.hip", "igemm.hip", "upconv.hip", "wgrad.hip", "elementwise.hip", "pack.hip", "tiling.hip", "augment.hip", "labels.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "crimac_unet_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",

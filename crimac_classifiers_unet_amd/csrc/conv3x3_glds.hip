@@ -295,15 +295,16 @@ __device__ __forceinline__ void wch_half(const unsigned (&av)[3][4], const unsig
   constexpr int t = H / (4 * HPK), ks = (H / HPK) % 4, half = H % HPK, NHALF = 36 * HPK;
   if constexpr (H % (4 * HPK) == 0) {
     // first half of tap t: its weights were requested one tap ago; request those of the next tap
-    if constexpr (t == 0) {
-      wch_land_b(f.b[1]);
+    if constexpr (t == 0) {               // (landed at the end of the previous chunk / in the prologue)
 #pragma unroll
       for (int k = 0; k < 4; ++k) f.b[0][k] = f.b[1][k];
     } else {
       wch_land_b(f.b[t & 1]);
     }
+    // unconditional (the last chunk re-requests tap 0 of itself): a load inside a branch would make its
+    // destination a phi whose resolving copies read the registers while the load is in flight
     if constexpr (t < 8) wch_load_b(wtap + (t + 1) * w_tap, f.b[(t + 1) & 1]);
-    else if (wnext_chunk) wch_load_b(wnext_chunk, f.b[1]);
+    else wch_load_b(wnext_chunk ? wnext_chunk : wtap, f.b[1]);
   }
   if constexpr (H + 1 < NHALF) {
     wch_issue_half<H + 1, HPK>(av, f);
@@ -408,6 +409,7 @@ void conv3x3_wch_kernel(ConvParams p) {
   const int kchunks = p.Cin / BK;
   WchFrags f;
   wch_load_b(wrow, f.b[1]);                    // tap 0 of chunk 0 (tap 0 expects it in b[1])
+  wch_land_b(f.b[1]);
   for (int kc = 0; kc < kchunks; ++kc) {
     issue_halo(kc);
     wait_vmcnt<0>();
@@ -417,6 +419,9 @@ void conv3x3_wch_kernel(ConvParams p) {
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
     wch_issue_half<0, HPK>(av, f);
     wch_half<0, HPK>(av, wtap, w_tap, wnext, f, acc);
+    // land the next chunk's tap-0 weights here, in the straight-line code that requested them: between an asm
+    // load and its wait the compiler believes the registers are valid and may copy them at the loop back-edge
+    wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();        // every wave is done reading this chunk's halo
   }
   conv_epilogue<bf16_t, BN, BM, 256, MT, 1, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wp, wc);

@@ -22,6 +22,8 @@
 //            TA = float   -> fp32 activations split on the fly into bf16 hi+lo, weights pre-split;
 //                            3 MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate: ~2^-16 relative
 //                            per product, the parity mode (bf16 alone misses 1e-3).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -295,6 +297,11 @@ int dispatch(const IgemmParams& p, hipStream_t st) {
 
 }  // namespace
 
+// upconv.hip: channel-split LDS-DMA kernel for the two bf16 transposed-convolution contractions
+bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, long out_ld);
+int crimac_upconv_wch_bf16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N,
+                           const void* w, const float* bias, int cout_up, void* out, long out_ld, hipStream_t st);
+
 extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int Wi, int Ho,
                                  int Wo, int Cin, int N, int ntaps, int tw, int pad, int stride,
                                  const void* w_hi, const void* w_lo, const float* bias, int bias_mod,
@@ -321,6 +328,17 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   p.out = out; p.out_ld = out_ld; p.relu = relu; p.cout_up = cout_up;
   p.M = (long)B * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (prec == CRIMAC_PREC_BF16 && !relu) {
+    // ConvTranspose2d(k2, s2): forward (1 tap, scatter) and input gradient (4 taps, stride 2) go to upconv.hip
+    static const int use_wch = getenv("CRIMAC_UPCONV_WCH") ? atoi(getenv("CRIMAC_UPCONV_WCH")) : 1;
+    const long in_bytes = (((long)B * Hi * Wi - 1) * in_ld + Cin) * 2;
+    const bool fwd = out_mode == 1 && ntaps == 1 && stride == 1 && pad == 0 && Hi == Ho && Wi == Wo &&
+                     (!bias || bias_mod == cout_up);
+    const bool dgr = out_mode == 0 && ntaps == 4 && tw == 2 && stride == 2 && pad == 0 && Hi == 2 * Ho &&
+                     Wi == 2 * Wo && !bias;
+    if (use_wch && (fwd || dgr) && crimac_upconv_wch_ok(ntaps, in_bytes, Cin, N, cout_up, out_ld))
+      return crimac_upconv_wch_bf16(ntaps, in, in_ld, B, Ho, Wo, Cin, N, w_hi, bias, cout_up, out, out_ld, st);
+  }
   if (prec == CRIMAC_PREC_BF16)
     return out_mode == 0 ? dispatch<bf16_t, 1, 0>(p, st) : dispatch<bf16_t, 1, 1>(p, st);
   if (prec == CRIMAC_PREC_F32X3)

@@ -1,0 +1,264 @@
+// ConvTranspose2d(k=2, s=2) forward and input gradient on MFMA for CDNA4 (gfx950), bf16, NHWC.
+//
+// Reference op: nn.ConvTranspose2d(k2, s2) (unet.py:47-49, :130): four independent 1x1 GEMMs, no overlap-add
+// (SURVEY.md A2).  Both directions are plain GEMMs over a 16x16 tile of COARSE pixels:
+//   forward : C[m][(ab, co)] = sum_ci X[m][ci] * W[ci][co][ab]            K = Cin,      N = 4*Cout, scatter
+//   dgrad   : C[m][ci]       = sum_ab sum_co dY[fine(m, ab)][co] * W[ci][co][ab]   K = 4*Cout, N = Cin
+// Same structure as the channel-split 3x3 kernel (conv3x3_glds.hip, conv3x3_wch_kernel): 4 waves, each owns
+// 32 output columns of the whole 256-pixel tile and takes its weight fragments straight from global memory
+// into registers; the A operand (256 pixel rows x 64 channels = 32 KB per K-chunk) arrives by LDS-DMA through
+// a buffer resource (per-lane 32-bit offsets; the tap / chunk offset is a scalar; out-of-image lanes read out
+// of range and get zeros), double-buffered: chunk c+1 is requested when chunk c starts.  One barrier per
+// chunk (32 MFMAs per wave), fragment reads one half k-step ahead of the MFMAs (inline asm, counted lgkmcnt).
+// Two workgroups per CU (70.6 KB LDS: the epilogue staging tile).  Replaces the register-staged igemm kernel
+// for these two ops (0.43 -> see DESIGN.md PFLOP/s); igemm remains for the fp32 parity modes and odd shapes.
+#include "common.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int TP = 16;                 // tile: TP x TP coarse pixels
+constexpr int BM = TP * TP;            // 256 GEMM rows
+constexpr int BN = 128, BK = 64, RB = BK * 2;
+constexpr int A_BYTES = BM * RB;       // 32 KB per chunk
+constexpr int NW = 4;
+constexpr int NA = A_BYTES / 1024 / NW;   // 8 DMA wave-instructions per wave and chunk
+
+struct UpParams {
+  const void* in;
+  long in_ld;
+  int B, H, W;          // COARSE grid
+  int K;                // channels per tap of the A operand (forward: Cin; dgrad: Cout)
+  int N;                // GEMM columns (forward: 4*Cout; dgrad: Cin)
+  int ntaps;            // 1 (forward) or 4 (dgrad: A row of tap (a,b) = fine pixel (2y+a, 2x+b))
+  const unsigned short* w;   // [ntaps][N][K] bf16
+  const float* bias;    // forward: [Cout]
+  int cout;             // forward: columns per (a,b) group
+  void* out;
+  long out_ld;
+  EpiParams epi;        // dgrad epilogue (dense tile)
+  int tiles_y, tiles_x;
+};
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128_asm(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+struct Frags {
+  bf16x8 a[2][4];        // two halves in flight
+  bf16x8 b[2][4];        // [0]: this chunk's weight fragments (4 k-steps), [1]: landing zone of the next chunk's
+};
+template <int H>
+__device__ __forceinline__ void issue_half(const unsigned (&av)[4], Frags& f) {
+  constexpr int ks = H / 2, half = H % 2;
+  f.a[H & 1][0] = lds_read128_asm<(half * 4 + 0) * 32 * RB>(av[ks]);
+  f.a[H & 1][1] = lds_read128_asm<(half * 4 + 1) * 32 * RB>(av[ks]);
+  f.a[H & 1][2] = lds_read128_asm<(half * 4 + 2) * 32 * RB>(av[ks]);
+  f.a[H & 1][3] = lds_read128_asm<(half * 4 + 3) * 32 * RB>(av[ks]);
+}
+template <bool LAST>
+__device__ __forceinline__ void release_half(Frags& f, int set) {
+  if constexpr (LAST)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
+                 :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
+                 :: "memory");
+}
+template <int H, typename ACC>
+__device__ __forceinline__ void half(const unsigned (&av)[4], Frags& f, ACC& acc) {
+  constexpr int ks = H / 2, hf = H % 2;
+  if constexpr (H + 1 < 8) {
+    issue_half<H + 1>(av, f);
+    release_half<false>(f, H & 1);
+  } else {
+    release_half<true>(f, H & 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc[hf * 4 + j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[H & 1][j], f.b[0][ks], acc[hf * 4 + j][0], 0, 0, 0);
+  if constexpr (H + 1 < 8) half<H + 1>(av, f, acc);
+}
+__device__ __forceinline__ void load_b(const unsigned short* src, bf16x8 (&bf)[4]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %4, off offset:32\n\t"
+      "global_load_dwordx4 %2, %4, off offset:64\n\t"
+      "global_load_dwordx4 %3, %4, off offset:96"
+      : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
+      : "v"(src)
+      : "memory");
+}
+
+// SCATTER: forward (output on the fine grid, column group (a,b) -> pixel (2y+a, 2x+b)); else dense dgrad tile
+template <bool SCATTER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void upconv_wch_kernel(UpParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = bid % 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+  }
+  int tile_m = bid;
+  const int txi = tile_m % p.tiles_x;
+  tile_m /= p.tiles_x;
+  const int tyi = tile_m % p.tiles_y;
+  const int b = tile_m / p.tiles_y;
+  const int y0 = tyi * TP, x0 = txi * TP;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- A operand: lane -> (tile row, 16-byte unit); source unit = unit ^ swizzle(row) ----------------
+  // forward: row r reads coarse pixel (y, x); dgrad: fine pixel (2y + a, 2x + b) of dY, the tap's (a, b) part of
+  // the offset is the same for every lane and rides in the scalar offset with the K-chunk
+  const int Hi = SCATTER ? p.H : 2 * p.H, Wi = SCATTER ? p.W : 2 * p.W;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.in), 0, (int)((((long)p.B * Hi * Wi - 1) * p.in_ld + p.K) * 2), 0x00020000);
+  unsigned voff[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = 8 * (wave + NW * i) + (lane >> 3);
+    const int y = y0 + (row >> 4), x = x0 + (row & 15);
+    const int us = (lane & 7) ^ ((row >> 1) & 7);
+    const long pix = SCATTER ? ((long)b * Hi + y) * Wi + x : ((long)b * Hi + 2 * y) * Wi + 2 * x;
+    voff[i] = (y < p.H && x < p.W) ? (unsigned)((pix * p.in_ld + us * 8) * 2) : 0x80000000u;
+  }
+  const int kchunks = p.K / BK, nchunks = p.ntaps * kchunks;
+  auto chunk_soff = [&](int c) {          // byte offset of chunk c = (tap, k-chunk) relative to tap 0, chunk 0
+    const int t = c / kchunks, kc = c - t * kchunks;
+    return (int)((((long)(t >> 1) * Wi + (t & 1)) * p.in_ld + kc * BK) * 2);
+  };
+  auto issue_a = [&](int c, int buf) {
+    const int soff = chunk_soff(c);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(smem + buf * A_BYTES + (wave + NW * i) * 1024), 16,
+          (int)voff[i], soff, 0, 0);
+  };
+
+  // ---- B operand: this wave's 32 columns, row n of w[tap][N][K], k = kc*64 + ks*16 + fq*8 -------------
+  const int fr = lane & 31, fq = lane >> 5;
+  const unsigned short* wrow = p.w + (long)(n0 + 32 * wave + fr) * p.K + fq * 8;
+  const long w_tap = (long)p.N * p.K;
+  auto b_src = [&](int c) {
+    const int t = c / kchunks, kc = c - t * kchunks;
+    return wrow + t * w_tap + kc * BK;
+  };
+
+  unsigned av0[4];
+  {
+    const unsigned a_lds = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) av0[ks] = a_lds + fr * RB + (((2 * ks + fq) ^ ((fr >> 1) & 7)) << 4);
+  }
+
+  f32x16 acc[8][1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  // NOTE on the asm loads: between a load and the wait that lands it the compiler believes the destination
+  // registers hold their values and may copy them (at a loop back-edge, or to resolve a phi after a branch) --
+  // so a load is issued unconditionally and landed (waited for and tied) in the same straight-line code.
+  Frags f;
+  load_b(b_src(0), f.b[1]);
+  issue_a(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[1][2]), "+v"(f.b[1][3]) :: "memory");
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    __builtin_amdgcn_s_barrier();        // chunk c landed for every wave; the other buffer is no longer read
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f.b[0][k] = f.b[1][k];
+    // the weight load is UNCONDITIONAL (the last chunk re-requests its own fragments): a load inside a branch
+    // makes its destination a phi, and the copies that resolve it would read the registers while in flight
+    load_b(b_src(c + 1 < nchunks ? c + 1 : c), f.b[1]);
+    if (c + 1 < nchunks) issue_a(c + 1, buf ^ 1);
+    unsigned av[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) av[ks] = av0[ks] + buf * A_BYTES;
+    issue_half<0>(av, f);
+    half<0>(av, f, acc);
+    // chunk c+1's A tile and weight fragments were requested 32 MFMAs ago
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[1][2]), "+v"(f.b[1][3]) :: "memory");
+  }
+  __syncthreads();                       // staging below reuses the A buffers
+
+  if constexpr (!SCATTER) {
+    conv_epilogue<bf16_t, BN, BM, 256, 8, 1, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
+  } else {
+    // bias, then the tile through LDS: [256 rows][128 cols + pad] bf16, then 16-byte stores scattered to the
+    // fine grid: column n = (a*2 + bb) * cout + co -> pixel (2y + a, 2x + bb), channel co
+    constexpr int PITCH = BN * 2 + 16;
+    {
+      const int col = wave * 32 + (lane & 31);
+      const float bv = p.bias ? p.bias[(n0 + col) % p.cout] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          *reinterpret_cast<bf16_t*>(smem + row * PITCH + col * 2) = (bf16_t)(acc[i][0][r] + bv);
+        }
+    }
+    __syncthreads();
+    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+    const int c8 = tid & 15, r0 = tid >> 4;          // 16 chunks of 8 columns per row, 16 rows per pass
+    const int n = n0 + c8 * 8;
+    const int ab = n / p.cout, co = n - ab * p.cout;
+#pragma unroll
+    for (int rr = 0; rr < BM / 16; ++rr) {
+      const int row = r0 + rr * 16;
+      const int y = y0 + (row >> 4), x = x0 + (row & 15);
+      if (y < p.H && x < p.W) {
+        const long pix = ((long)b * 2 * p.H + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+        *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) =
+            *reinterpret_cast<const u32x4*>(smem + row * PITCH + c8 * 16);
+      }
+    }
+  }
+}
+
+template <bool SCATTER>
+int launch(UpParams p, hipStream_t st) {
+  p.tiles_y = cdiv(p.H, TP);
+  p.tiles_x = cdiv(p.W, TP);
+  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
+  constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;
+  const size_t lds = stage > 2 * (size_t)A_BYTES ? stage : 2 * (size_t)A_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+}  // namespace
+
+// Called by crimac_igemm_conv (igemm.hip) for the bf16 transposed-convolution shapes this kernel covers.
+// forward: in [B][H][W][K=Cin], w [1][N=4*Cout][K], out [B][2H][2W] (out_ld), bias [Cout]
+// dgrad  : in = dY [B][2H][2W][K=Cout], w [4][N=Cin][K], out [B][H][W] (out_ld)
+bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, long out_ld) {
+  if (in_bytes >= (1L << 31) || K % BK != 0 || N % BN != 0 || out_ld % 8 != 0) return false;
+  if (ntaps == 1) return cout_up % 32 == 0 && cout_up % 8 == 0;
+  return ntaps == 4;
+}
+
+int crimac_upconv_wch_bf16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N,
+                           const void* w, const float* bias, int cout_up, void* out, long out_ld, hipStream_t st) {
+  UpParams p;
+  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.ntaps = ntaps;
+  p.w = (const unsigned short*)w; p.bias = bias; p.cout = cout_up; p.out = out; p.out_ld = out_ld;
+  p.epi = EpiParams{};
+  p.epi.bias = nullptr; p.epi.out = out; p.epi.out_ld = out_ld; p.epi.relu = 0; p.epi.H = H; p.epi.W = W; p.epi.N = N;
+  p.epi.stat_sum = nullptr; p.epi.stat_sumsq = nullptr; p.epi.stat_replicas = 1; p.epi.stat_mode = 0;
+  return ntaps == 1 ? launch<true>(p, st) : launch<false>(p, st);
+}

@@ -77,6 +77,39 @@ def main():
                 tot_w += us
             print(f"{nm:5s} {name:22s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
     print(f"total conv {tot_c:.0f} us, wgrad {tot_w:.0f} us")
+    if a.what in ("all", "upconv"):
+        tot = 0.0
+        for (h, Ci, Co) in ((16, 1024, 512), (32, 512, 256), (64, 256, 128), (128, 128, 64)):
+            M = B * h * h
+            x = torch.randn(M, Ci, device="cuda").to(dt)
+            dy = torch.randn(4 * M, Co, device="cuda").to(dt)
+            wf = torch.randint(-3000, 3000, (2 * 4 * Ci * Co,), dtype=torch.int16, device="cuda")
+            bias = torch.randn(Co, device="cuda")
+            out = torch.empty(4 * M, 2 * Co, device="cuda", dtype=dt)
+            dx = torch.empty(M, Ci, device="cuda", dtype=dt)
+            flops = 2.0 * 4 * Ci * Co * M
+
+            def fwd():
+                call("crimac_igemm_conv", P, ptr(x), Ci, B, h, h, h, h, Ci, 4 * Co, 1, 1, 0, 1, ptr(wf), ptr(wf),
+                     ptr(bias), Co, ptr(out), 2 * Co, 0, 1, Co)
+
+            def dgr():
+                call("crimac_igemm_conv", P, ptr(dy), Co, B, 2 * h, 2 * h, h, h, Co, Ci, 4, 2, 0, 2, ptr(wf), ptr(wf),
+                     None, 0, ptr(dx), Ci, 0, 0, 0)
+
+            for nm, fn in (("upfwd", fwd), ("updgr", dgr)):
+                fn(); fn()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(a.iters):
+                    fn()
+                e.record()
+                torch.cuda.synchronize()
+                us = 1e3 * s.elapsed_time(e) / a.iters
+                tot += us
+                print(f"{nm:5s} {Ci}->{Co}@{h}          {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+        print(f"total upconv fwd+dgrad {tot:.0f} us")
 
 
 if __name__ == "__main__":
