@@ -331,11 +331,11 @@ __device__ __forceinline__ void wch_half(const unsigned (&av)[3][4], const unsig
 // Tried on top and rejected: 32-channel chunks with a double-buffered halo (next halo requested at the start
 // of a chunk behind the weight loads of two taps, counted vmcnt, one barrier per chunk): 2-4 % SLOWER -- the
 // halo exchange bubble is already covered by the second workgroup of the CU; a 2x2-wave (pixels x channels)
-// form for N = 64: slower than the pixel-split kernel on the HBM-heavy 256x256 layers.
+// form for N = 64 (the body below instantiates for BN = 64): 319 / 458 us at two workgroups per CU, 297 / 425 us
+// at three (168 registers, 3 spilled) vs 297 / 427 us for the pixel-split kernel -- no gain, not used.
 template <int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv3x3_wch_kernel(ConvParams p) {
-  static_assert(BN == 128 || BN == 64, "32 channels per wave");      // only 128 is instantiated (see dispatch)
+__device__ __forceinline__ void conv3x3_wch_body(ConvParams p) {
+  static_assert(BN == 128 || BN == 64, "32 channels per wave");
   constexpr int NW = 4, NWC = BN / 32, NWP = NW / NWC;     // waves along channels x along pixels: 4x1 / 2x2
   constexpr int MT = BM / 32 / NWP;                        // 32-pixel MFMA tiles per wave: 8 / 4
   constexpr int HPK = MT / 4;
@@ -358,28 +358,29 @@ void conv3x3_wch_kernel(ConvParams p) {
   const int b = tile_m / p.tiles_y;
   const int y0 = tyi * TR, x0 = txi * TC;
   const int n0 = blockIdx.y * BN;
-  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
 
-  long h_src[NH];
+  // halo through a buffer resource: 32-bit per-lane offsets; lanes outside the image (and the padding rows
+  // of the last wave-instruction) use an out-of-range offset -> the hardware writes zeros, no masked lanes
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.in), 0, (int)((((long)p.B * p.H * p.W - 1) * p.in_ld + p.Cin) * 2), 0x00020000);
+  unsigned h_off[NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
     const int k = wave + NW * i;
     const int row = 8 * k + sub;
-    h_src[i] = -1;
-    if (k < HALO_INSTR && row < HALO_ROWS) {
-      const int hy = row / HP, hx = row % HP;
-      const int y = y0 + hy - 1, x = x0 + hx - 1;
-      const int u = c8 ^ ((hx >> 1) & 7);
-      if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-        h_src[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
-      else
-        *reinterpret_cast<u32x4*>(sA + k * 1024 + lane * 16) = u32x4{0, 0, 0, 0};
-    }
+    const int hy = row / HP, hx = row - hy * HP;
+    const unsigned y = (unsigned)(y0 + hy - 1), x = (unsigned)(x0 + hx - 1);
+    const bool ok = k < HALO_INSTR && row < HALO_ROWS && y < (unsigned)p.H && x < (unsigned)p.W;
+    h_off[i] = ok ? (unsigned)(((((long)b * p.H + y) * p.W + x) * p.in_ld + (c8 ^ ((hx >> 1) & 7)) * 8) * 2)
+                  : 0x80000000u;
   }
   auto issue_halo = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NH; ++i)
-      if (h_src[i] >= 0) glds16(inp + h_src[i] + kc * BK, sA + (wave + NW * i) * 1024);
+      if (wave + NW * i < HALO_INSTR)           // wave-uniform: the 41st..44th instruction slots do not exist
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void*)(sA + (wave + NW * i) * 1024), 16, (int)h_off[i],
+            kc * BK * 2, 0, 0);
   };
 
   const int fr = lane & 31, fq = lane >> 5;
@@ -426,6 +427,11 @@ void conv3x3_wch_kernel(ConvParams p) {
   }
   conv_epilogue<bf16_t, BN, BM, 256, MT, 1, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wp, wc);
 }
+template <int BN> __global__ void conv3x3_wch_kernel(ConvParams p);
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel<128>(ConvParams p) {
+  conv3x3_wch_body<128>(p);
+}
 
 template <int BN>
 int launch_wch(ConvParams p, hipStream_t st) {
@@ -459,5 +465,6 @@ int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, in
   // HBM-heavy N = 64 shapes W4<64> (305 / 423 us) beats a 2x2-wave channel split (319 / 458 us).
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
   if (N % 128 != 0) return launch_w4<64>(p, st);
-  return w4 == 1 ? launch_w4<128>(p, st) : launch_wch<128>(p, st);
+  const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
+  return (w4 == 1 || !small) ? launch_w4<128>(p, st) : launch_wch<128>(p, st);
 }
