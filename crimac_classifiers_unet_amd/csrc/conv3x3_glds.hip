@@ -11,7 +11,8 @@
 //     (im2col-free);
 //   * halo rows outside the image never change for a workgroup: zeroed once, those lanes masked off.
 // conv3x3_wch_kernel  (N % 128 == 0): waves split the output CHANNELS, weights go global -> registers,
-//                     no barrier inside a 64-channel chunk, inline-asm read/MFMA pipeline (1.1-1.4 PFLOP/s);
+//                     no barrier inside a 64-channel chunk, inline-asm read/MFMA pipeline, 16x16x32 MFMAs
+//                     (1.1-1.6 PFLOP/s);
 // conv3x3_glds_w4_kernel (N = 64):    waves split the PIXELS, weights through a 3-slot LDS ring with counted
 //                     vmcnt + raw s_barrier per tap (the HBM-heavy 256x256 layers).
 // An 8-wave / one-workgroup-per-CU form with a double-buffered halo was the first LDS-DMA kernel; the 4-wave
@@ -77,7 +78,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 template <int BN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void conv3x3_glds_w4_kernel(ConvParams p) {
-  constexpr int NW = 4, NT = BN / 32;
+  constexpr int NW = 4, NT = BN / 16;
   constexpr int NSLOT = BN == 64 ? 3 : 2, AHEAD = NSLOT - 1;
   constexpr int B_BYTES = BN * RB;                 // weight slot: 8 / 16 KB
   constexpr int NB = (BN / 8) / NW;                // weight wave-instructions per wave and step: 2 / 4
@@ -137,42 +138,36 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
       glds16(p.w_hi + t * w_tap + b_src[i] + kc * BK, sB(slot) + (wave + NW * i) * 1024);
   };
 
-  f32x16 acc[2][NT];
+  // 16x16x32 MFMAs: M tile i = image row 4*wave + i of the pixel tile, N tile j = 16 channels
+  f32x4 acc[4][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int fr = lane & 31, fq = lane >> 5;
-  int a_row0[2], a_hx0[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = wave * 64 + i * 32 + fr;
-    a_row0[i] = (m >> 4) * HP + (m & 15);
-    a_hx0[i] = m & 15;
-  }
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 15, fq = lane >> 4;
   auto compute = [&](const unsigned char* Bs, int t) {
     const int kx = t % 3;
-    const int shift = (t / 3) * HP + kx;
+    const unsigned char* a0 = sA + ((wave * 4 + t / 3) * HP + fr + kx) * RB;
+    const int aswz = ((fr + kx) >> 1) & 7;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int unit = 2 * ks + fq;
-      bf16x8 af[2], bfr[NT];
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int unit = 4 * ks + fq;
+      bf16x8 af[4], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sA + (a_row0[i] + shift) * RB +
-                                                 ((unit ^ (((a_hx0[i] + kx) >> 1) & 7)) << 4));
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(a0 + i * (HP * RB) + ((unit ^ aswz) << 4));
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int row = j * 32 + fr;
+        const int row = j * 16 + fr;
         bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + ((unit ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -212,12 +207,12 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
   }
 #ifdef CRIMAC_EXP_NOEPI
   float sum = 0.f;
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
     for (int j = 0; j < NT; ++j)
-      for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+      for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
   if (sum == 12345.678f) reinterpret_cast<float*>(p.epi.out)[tid] = sum;
 #else
-  conv_epilogue<bf16_t, BN, BM, 256, 2, NT, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
+  conv_epilogue<bf16_t, BN, BM, 256, 4, NT, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
 #endif
 }
 
@@ -241,31 +236,17 @@ int launch_w4(ConvParams p, hipStream_t st) {
 
 
 // ---- hand-placed LDS-read / MFMA pipeline of the channel-split kernel -----------------------------------
-// A chunk (9 taps x 4 k-steps) is 72 half-k-steps of 4 fragment reads + 4 MFMAs; the reads of half h+1 are
-// issued before the MFMAs of half h (counted lgkmcnt: LDS reads return in order), across k-steps and taps
-// alike -- there is no barrier inside a chunk.  All addresses are one of 12 registers (kx, ks) + immediate.
+// A chunk (9 taps x 2 k-steps of 32) is 72 groups of 4 fragment reads + 8 MFMAs; the reads of group h+1 are
+// issued before the MFMAs of group h (counted lgkmcnt: LDS reads return in order), across k-steps and taps
+// alike -- there is no barrier inside a chunk.  All addresses are one of 6 registers (kx, ks) + immediate.
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read128_asm(unsigned addr) {
   bf16x8 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
 }
-struct WchFrags {
-  bf16x8 a[2][4];        // two halves in flight
-  bf16x8 b[2][4];        // weight fragments of the current / next tap (4 k-steps)
-};
-// HPK: halves per k-step (2: a wave owns all 256 pixels of the tile, 1: 128 of them)
-template <int H, int HPK>
-__device__ __forceinline__ void wch_issue_half(const unsigned (&av)[3][4], WchFrags& f) {
-  constexpr int t = H / (4 * HPK), ks = (H / HPK) % 4, half = H % HPK;
-  constexpr int base = (t / 3) * (HP * RB) + half * 4 * (2 * HP * RB);
-  f.a[H & 1][0] = lds_read128_asm<base + 0 * (2 * HP * RB)>(av[t % 3][ks]);
-  f.a[H & 1][1] = lds_read128_asm<base + 1 * (2 * HP * RB)>(av[t % 3][ks]);
-  f.a[H & 1][2] = lds_read128_asm<base + 2 * (2 * HP * RB)>(av[t % 3][ks]);
-  f.a[H & 1][3] = lds_read128_asm<base + 3 * (2 * HP * RB)>(av[t % 3][ks]);
-}
-template <bool LAST>
-__device__ __forceinline__ void wch_release_half(WchFrags& f, int set) {
+template <bool LAST, typename F>
+__device__ __forceinline__ void wch_release(F& f, int set) {
   if constexpr (LAST)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
                  :: "memory");
@@ -273,77 +254,90 @@ __device__ __forceinline__ void wch_release_half(WchFrags& f, int set) {
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
                  :: "memory");
 }
-__device__ __forceinline__ void wch_load_b(const unsigned short* src, bf16x8 (&bf)[4]) {
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off\n\t"
-      "global_load_dwordx4 %1, %4, off offset:32\n\t"
-      "global_load_dwordx4 %2, %4, off offset:64\n\t"
-      "global_load_dwordx4 %3, %4, off offset:96"
-      : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
-      : "v"(src)
-      : "memory");
-}
 __device__ __forceinline__ void wch_land_b(bf16x8 (&bf)[4]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) :: "memory");
 }
-// half H of a chunk; wnext_chunk: weight rows of the next chunk's tap 0 (nullptr: none).  Tap t computes from
-// b[t & 1] and requests tap t+1 into the other buffer; tap 8 (b[0]) requests the next chunk's tap 0 into b[1],
-// which tap 0 moves to b[0] once it has landed (a chunk has an odd number of taps).
-template <int H, int HPK, typename ACC>
-__device__ __forceinline__ void wch_half(const unsigned (&av)[3][4], const unsigned short* wtap, long w_tap,
-                                         const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
-  constexpr int t = H / (4 * HPK), ks = (H / HPK) % 4, half = H % HPK, NHALF = 36 * HPK;
-  if constexpr (H % (4 * HPK) == 0) {
-    // first half of tap t: its weights were requested one tap ago; request those of the next tap
-    if constexpr (t == 0) {               // (landed at the end of the previous chunk / in the prologue)
+
+// ---------------------------------------------------------------------------------------------------
+// Channel-split kernel for N % 128 == 0 ("wch"): each of the 4 waves owns 32 OUTPUT CHANNELS of the whole
+// 16x16-pixel tile.  Its weight fragments are then private to the wave and come straight from global memory
+// into registers (4 x 16 B per lane and tap, prefetched one tap ahead) -- no weight tile in LDS, no weight DMA,
+// no weight ds_reads -- and the only LDS content is the halo, which is constant for a whole 64-channel chunk:
+// NO barrier per tap, the waves run free for 576 MFMAs and meet only where the halo is exchanged.
+// MFMA shape: v_mfma_f32_16x16x32_bf16, 16 x 2 tiles per wave -- an M tile is one image row of the pixel tile,
+// every A fragment feeds two MFMAs (the two 16-channel halves).  The 32x32x16 form of this kernel (8 x 1 tiles,
+// same reads, same registers, same cycle count) was 7-11 % SLOWER on every layer (1.40 vs 1.58 PFLOP/s on
+// 1024->512 @32x32): under a dense MFMA stream the chip holds a higher clock with the 16x16x32 shape
+// (MI355X_MICROARCH.md, clocks under load (7)).
+// Measured motivation for the structure (W4 kernel, 1024->512 @32x32): MFMA loop alone 1.7 PFLOP/s, with the
+// weight/halo DMAs sharing the LDS 1.2 PFLOP/s; here the LDS sees 1 ds_read_b128 per 2 MFMAs and 4.6 KB of DMA
+// per step.  Tried on top and rejected: 32-channel chunks with a double-buffered halo (next halo requested at
+// the start of a chunk behind the weight loads of two taps, counted vmcnt, one barrier per chunk): 2-4 % SLOWER
+// -- the halo exchange bubble is already covered by the second workgroup of the CU; a 2x2-wave (pixels x
+// channels) form for N = 64: 319 / 458 us at two workgroups per CU, 297 / 425 us at three (168 registers, 3
+// spilled) vs 297 / 427 us for the pixel-split kernel -- no gain, not used.
+struct WchFrags {
+  bf16x8 a[2][4];
+  bf16x8 b[2][4];        // [tap parity][ks2 * 2 + nb]
+};
+template <int H>
+__device__ __forceinline__ void wch_issue(const unsigned (&av)[3][2], WchFrags& f) {
+  constexpr int t = H / 8, ks2 = (H / 4) % 2, q = H % 4;
+  constexpr int base = (t / 3 + 4 * q) * (HP * RB);
+  f.a[H & 1][0] = lds_read128_asm<base + 0 * (HP * RB)>(av[t % 3][ks2]);
+  f.a[H & 1][1] = lds_read128_asm<base + 1 * (HP * RB)>(av[t % 3][ks2]);
+  f.a[H & 1][2] = lds_read128_asm<base + 2 * (HP * RB)>(av[t % 3][ks2]);
+  f.a[H & 1][3] = lds_read128_asm<base + 3 * (HP * RB)>(av[t % 3][ks2]);
+}
+__device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsigned short* s1, bf16x8 (&bf)[4]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %5, off\n\t"
+      "global_load_dwordx4 %2, %4, off offset:64\n\t"
+      "global_load_dwordx4 %3, %5, off offset:64"
+      : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
+      : "v"(s0), "v"(s1)
+      : "memory");
+}
+template <int H, typename ACC>
+__device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsigned short* wtap, long w_tap, long w_nb,
+                                           const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
+  constexpr int t = H / 8, ks2 = (H / 4) % 2, q = H % 4, NH = 72;
+  if constexpr (H % 8 == 0) {
+    if constexpr (t == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) f.b[0][k] = f.b[1][k];
     } else {
       wch_land_b(f.b[t & 1]);
     }
-    // unconditional (the last chunk re-requests tap 0 of itself): a load inside a branch would make its
-    // destination a phi whose resolving copies read the registers while the load is in flight
-    if constexpr (t < 8) wch_load_b(wtap + (t + 1) * w_tap, f.b[(t + 1) & 1]);
-    else wch_load_b(wnext_chunk ? wnext_chunk : wtap, f.b[1]);
+    if constexpr (t < 8) {
+      const unsigned short* s = wtap + (t + 1) * w_tap;
+      wch_load_b(s, s + w_nb, f.b[(t + 1) & 1]);
+    } else {
+      const unsigned short* s = wnext_chunk ? wnext_chunk : wtap;
+      wch_load_b(s, s + w_nb, f.b[1]);
+    }
   }
-  if constexpr (H + 1 < NHALF) {
-    wch_issue_half<H + 1, HPK>(av, f);
-    wch_release_half<false>(f, H & 1);
+  if constexpr (H + 1 < NH) {
+    wch_issue<H + 1>(av, f);
+    wch_release<false>(f, H & 1);
   } else {
-    wch_release_half<true>(f, H & 1);
+    wch_release<true>(f, H & 1);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    acc[half * 4 + j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[H & 1][j], f.b[t & 1][ks], acc[half * 4 + j][0],
-                                                                    0, 0, 0);
-  if constexpr (H + 1 < NHALF) wch_half<H + 1, HPK>(av, wtap, w_tap, wnext_chunk, f, acc);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+      acc[4 * q + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[H & 1][j], f.b[t & 1][ks2 * 2 + nb],
+                                                                    acc[4 * q + j][nb], 0, 0, 0);
+  if constexpr (H + 1 < NH) wch_step<H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Channel-split variant for N >= 128 ("wch"): each of the 4 waves owns 32 OUTPUT CHANNELS of the whole
-// 16x16-pixel tile (8 x 1 MFMA tiles of 32x32).  Its weight fragments are then private to the wave and come
-// straight from global memory into registers (4 x 16 B per lane and step, prefetched one step ahead) -- no
-// weight tile in LDS, no weight DMA, no weight ds_reads -- and the only LDS content is the halo, which is
-// constant for a whole 64-channel chunk: NO barrier per tap, the waves run free for 288 MFMAs and meet only
-// where the halo is exchanged.  Measured motivation (W4 kernel, 1024->512 @32x32): MFMA loop alone 1.7
-// PFLOP/s, with the weight/halo DMAs sharing the LDS 1.2 PFLOP/s; here the LDS sees 1 ds_read_b128 per MFMA
-// and 4.6 KB of DMA per step instead of 0.75 reads + 20.6 KB.
-// Tried on top and rejected: 32-channel chunks with a double-buffered halo (next halo requested at the start
-// of a chunk behind the weight loads of two taps, counted vmcnt, one barrier per chunk): 2-4 % SLOWER -- the
-// halo exchange bubble is already covered by the second workgroup of the CU; a 2x2-wave (pixels x channels)
-// form for N = 64 (the body below instantiates for BN = 64): 319 / 458 us at two workgroups per CU, 297 / 425 us
-// at three (168 registers, 3 spilled) vs 297 / 427 us for the pixel-split kernel -- no gain, not used.
-template <int BN>
-__device__ __forceinline__ void conv3x3_wch_body(ConvParams p) {
-  static_assert(BN == 128 || BN == 64, "32 channels per wave");
-  constexpr int NW = 4, NWC = BN / 32, NWP = NW / NWC;     // waves along channels x along pixels: 4x1 / 2x2
-  constexpr int MT = BM / 32 / NWP;                        // 32-pixel MFMA tiles per wave: 8 / 4
-  constexpr int HPK = MT / 4;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel(ConvParams p) {
+  constexpr int BN = 128, NW = 4;
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
-
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane >> 3, c8 = lane & 7;
   int bid = blockIdx.x;
@@ -359,8 +353,6 @@ __device__ __forceinline__ void conv3x3_wch_body(ConvParams p) {
   const int y0 = tyi * TR, x0 = txi * TC;
   const int n0 = blockIdx.y * BN;
 
-  // halo through a buffer resource: 32-bit per-lane offsets; lanes outside the image (and the padding rows
-  // of the last wave-instruction) use an out-of-range offset -> the hardware writes zeros, no masked lanes
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.in), 0, (int)((((long)p.B * p.H * p.W - 1) * p.in_ld + p.Cin) * 2), 0x00020000);
   unsigned h_off[NH];
@@ -377,39 +369,39 @@ __device__ __forceinline__ void conv3x3_wch_body(ConvParams p) {
   auto issue_halo = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NH; ++i)
-      if (wave + NW * i < HALO_INSTR)           // wave-uniform: the 41st..44th instruction slots do not exist
+      if (wave + NW * i < HALO_INSTR)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rsrc, (__attribute__((address_space(3))) void*)(sA + (wave + NW * i) * 1024), 16, (int)h_off[i],
             kc * BK * 2, 0, 0);
   };
 
-  const int fr = lane & 31, fq = lane >> 5;
-  const int wc = wave % NWC, wp = wave / NWC;
-  // weight fragments of this lane: row n0 + 32*wc + fr of tap t, k = kc*64 + ks*16 + fq*8 .. +8
+  const int fr = lane & 15, fq = lane >> 4;
+  const int wc = wave;
+  // weight fragments of this lane: rows n0 + 32*wc + nb*16 + fr of tap t, k = kc*64 + ks2*32 + fq*8 .. +8
   const unsigned short* wrow = p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
-  const long w_tap = (long)p.N * p.Cin;
-  // A fragment byte offsets: pixel m = wp*(MT*32) + i*32 + fr -> halo row (wp*2*MT + 2i + (fr >> 4)) * HP +
-  // (fr & 15): i enters as an immediate (i * 2 * HP * RB), so does the tap's ky; one register per (kx, ks)
-  unsigned av[3][4];
+  const long w_tap = (long)p.N * p.Cin, w_nb = 16L * p.Cin;
+  // A fragment: M tile i = image row i of the tile, lane's pixel column fr -> halo row (i + ky) * HP + fr + kx
+  unsigned av[3][2];
   {
-    const int row0 = (wp * 2 * MT + (fr >> 4)) * HP + (fr & 15), hx0 = fr & 15;
     const unsigned a_lds = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(sA));
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        av[kx][ks] = a_lds + (row0 + kx) * RB + (((2 * ks + fq) ^ (((hx0 + kx) >> 1) & 7)) << 4);
+      for (int ks2 = 0; ks2 < 2; ++ks2)
+        av[kx][ks2] = a_lds + (fr + kx) * RB + (((4 * ks2 + fq) ^ (((fr + kx) >> 1) & 7)) << 4);
   }
 
-  f32x16 acc[MT][1];
+  f32x4 acc[16][2];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   const int kchunks = p.Cin / BK;
   WchFrags f;
-  wch_load_b(wrow, f.b[1]);                    // tap 0 of chunk 0 (tap 0 expects it in b[1])
+  wch_load_b(wrow, wrow + w_nb, f.b[1]);
   wch_land_b(f.b[1]);
   for (int kc = 0; kc < kchunks; ++kc) {
     issue_halo(kc);
@@ -418,35 +410,28 @@ __device__ __forceinline__ void conv3x3_wch_body(ConvParams p) {
     __builtin_amdgcn_s_barrier();
     const unsigned short* wtap = wrow + kc * BK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
-    wch_issue_half<0, HPK>(av, f);
-    wch_half<0, HPK>(av, wtap, w_tap, wnext, f, acc);
-    // land the next chunk's tap-0 weights here, in the straight-line code that requested them: between an asm
-    // load and its wait the compiler believes the registers are valid and may copy them at the loop back-edge
+    wch_issue<0>(av, f);
+    wch_step<0>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
-    __builtin_amdgcn_s_barrier();        // every wave is done reading this chunk's halo
+    __builtin_amdgcn_s_barrier();
   }
-  conv_epilogue<bf16_t, BN, BM, 256, MT, 1, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wp, wc);
-}
-template <int BN> __global__ void conv3x3_wch_kernel(ConvParams p);
-template <>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel<128>(ConvParams p) {
-  conv3x3_wch_body<128>(p);
+  conv_epilogue<bf16_t, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
 }
 
-template <int BN>
 int launch_wch(ConvParams p, hipStream_t st) {
+  constexpr int BN = 128;
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;   // epilogue staging vs halo buffer
+  constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;
   const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_wch_kernel<BN>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(conv3x3_wch_kernel, dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -461,10 +446,10 @@ int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, in
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
   // N % 128 == 0: channel-split kernel; N = 64 (or 192, ...): pixel-split kernel with the LDS weight ring.
-  // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.4 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
+  // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.6 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
   // HBM-heavy N = 64 shapes W4<64> (305 / 423 us) beats a 2x2-wave channel split (319 / 458 us).
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
   if (N % 128 != 0) return launch_w4<64>(p, st);
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
-  return (w4 == 1 || !small) ? launch_w4<128>(p, st) : launch_wch<128>(p, st);
+  return (w4 == 1 || !small) ? launch_w4<128>(p, st) : launch_wch(p, st);
 }
