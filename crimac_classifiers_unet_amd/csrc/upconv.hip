@@ -9,7 +9,7 @@
 // into registers; the A operand (256 pixel rows x 64 channels = 32 KB per K-chunk) arrives by LDS-DMA through
 // a buffer resource (per-lane 32-bit offsets; the tap / chunk offset is a scalar; out-of-image lanes read out
 // of range and get zeros), double-buffered: chunk c+1 is requested when chunk c starts.  One barrier per
-// chunk (32 MFMAs per wave), fragment reads one half k-step ahead of the MFMAs (inline asm, counted lgkmcnt).
+// chunk (64 MFMAs of 16x16x32 per wave), fragment reads one group ahead of the MFMAs (inline asm, counted lgkmcnt).
 // Two workgroups per CU (70.6 KB LDS: the epilogue staging tile).  Replaces the register-staged igemm kernel
 // for these two ops (0.43 -> see DESIGN.md PFLOP/s); igemm remains for the fp32 parity modes and odd shapes.
 #include "common.h"
@@ -46,17 +46,19 @@ __device__ __forceinline__ bf16x8 lds_read128_asm(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
 }
+// MFMA shape 16x16x32 (16 x 2 tiles per wave; the 32x32x16 form is ~8 % slower, see conv3x3_glds.hip): a chunk
+// is 8 groups of 4 fragment reads + 8 MFMAs, group H = (k-step H / 4, M tiles 4 * (H % 4) .. + 3)
 struct Frags {
-  bf16x8 a[2][4];        // two halves in flight
-  bf16x8 b[2][4];        // [0]: this chunk's weight fragments (4 k-steps), [1]: landing zone of the next chunk's
+  bf16x8 a[2][4];        // two groups in flight
+  bf16x8 b[2][4];        // [0]: this chunk's weight fragments [ks * 2 + nb], [1]: landing zone of the next chunk's
 };
 template <int H>
-__device__ __forceinline__ void issue_half(const unsigned (&av)[4], Frags& f) {
-  constexpr int ks = H / 2, half = H % 2;
-  f.a[H & 1][0] = lds_read128_asm<(half * 4 + 0) * 32 * RB>(av[ks]);
-  f.a[H & 1][1] = lds_read128_asm<(half * 4 + 1) * 32 * RB>(av[ks]);
-  f.a[H & 1][2] = lds_read128_asm<(half * 4 + 2) * 32 * RB>(av[ks]);
-  f.a[H & 1][3] = lds_read128_asm<(half * 4 + 3) * 32 * RB>(av[ks]);
+__device__ __forceinline__ void issue_half(const unsigned (&av)[2], Frags& f) {
+  constexpr int ks = H / 4, q = H % 4;
+  f.a[H & 1][0] = lds_read128_asm<(q * 4 + 0) * 16 * RB>(av[ks]);
+  f.a[H & 1][1] = lds_read128_asm<(q * 4 + 1) * 16 * RB>(av[ks]);
+  f.a[H & 1][2] = lds_read128_asm<(q * 4 + 2) * 16 * RB>(av[ks]);
+  f.a[H & 1][3] = lds_read128_asm<(q * 4 + 3) * 16 * RB>(av[ks]);
 }
 template <bool LAST>
 __device__ __forceinline__ void release_half(Frags& f, int set) {
@@ -68,8 +70,8 @@ __device__ __forceinline__ void release_half(Frags& f, int set) {
                  :: "memory");
 }
 template <int H, typename ACC>
-__device__ __forceinline__ void half(const unsigned (&av)[4], Frags& f, ACC& acc) {
-  constexpr int ks = H / 2, hf = H % 2;
+__device__ __forceinline__ void half(const unsigned (&av)[2], Frags& f, ACC& acc) {
+  constexpr int ks = H / 4, q = H % 4;
   if constexpr (H + 1 < 8) {
     issue_half<H + 1>(av, f);
     release_half<false>(f, H & 1);
@@ -78,17 +80,21 @@ __device__ __forceinline__ void half(const unsigned (&av)[4], Frags& f, ACC& acc
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    acc[hf * 4 + j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[H & 1][j], f.b[0][ks], acc[hf * 4 + j][0], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+      acc[q * 4 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[H & 1][j], f.b[0][ks * 2 + nb], acc[q * 4 + j][nb],
+                                                                    0, 0, 0);
   if constexpr (H + 1 < 8) half<H + 1>(av, f, acc);
 }
-__device__ __forceinline__ void load_b(const unsigned short* src, bf16x8 (&bf)[4]) {
+// s0: row of the wave's first 16 columns, s1: of the second 16; fragments [ks * 2 + nb]
+__device__ __forceinline__ void load_b(const unsigned short* s0, const unsigned short* s1, bf16x8 (&bf)[4]) {
   asm volatile(
       "global_load_dwordx4 %0, %4, off\n\t"
-      "global_load_dwordx4 %1, %4, off offset:32\n\t"
+      "global_load_dwordx4 %1, %5, off\n\t"
       "global_load_dwordx4 %2, %4, off offset:64\n\t"
-      "global_load_dwordx4 %3, %4, off offset:96"
+      "global_load_dwordx4 %3, %5, off offset:64"
       : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
-      : "v"(src)
+      : "v"(s0), "v"(s1)
       : "memory");
 }
 
@@ -140,33 +146,35 @@ void upconv_wch_kernel(UpParams p) {
           (int)voff[i], soff, 0, 0);
   };
 
-  // ---- B operand: this wave's 32 columns, row n of w[tap][N][K], k = kc*64 + ks*16 + fq*8 -------------
-  const int fr = lane & 31, fq = lane >> 5;
+  // ---- B operand: this wave's 32 columns, rows n (+16) of w[tap][N][K], k = kc*64 + ks*32 + fq*8 -----
+  const int fr = lane & 15, fq = lane >> 4;
   const unsigned short* wrow = p.w + (long)(n0 + 32 * wave + fr) * p.K + fq * 8;
-  const long w_tap = (long)p.N * p.K;
+  const long w_tap = (long)p.N * p.K, w_nb = 16L * p.K;
   auto b_src = [&](int c) {
     const int t = c / kchunks, kc = c - t * kchunks;
     return wrow + t * w_tap + kc * BK;
   };
 
-  unsigned av0[4];
+  unsigned av0[2];
   {
     const unsigned a_lds = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) av0[ks] = a_lds + fr * RB + (((2 * ks + fq) ^ ((fr >> 1) & 7)) << 4);
+    for (int ks = 0; ks < 2; ++ks) av0[ks] = a_lds + fr * RB + (((4 * ks + fq) ^ ((fr >> 1) & 7)) << 4);
   }
 
-  f32x16 acc[8][1];
+  f32x4 acc[16][2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   // NOTE on the asm loads: between a load and the wait that lands it the compiler believes the destination
   // registers hold their values and may copy them (at a loop back-edge, or to resolve a phi after a branch) --
   // so a load is issued unconditionally and landed (waited for and tied) in the same straight-line code.
   Frags f;
-  load_b(b_src(0), f.b[1]);
+  load_b(b_src(0), b_src(0) + w_nb, f.b[1]);
   issue_a(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[1][2]), "+v"(f.b[1][3]) :: "memory");
   for (int c = 0; c < nchunks; ++c) {
@@ -176,33 +184,37 @@ void upconv_wch_kernel(UpParams p) {
     for (int k = 0; k < 4; ++k) f.b[0][k] = f.b[1][k];
     // the weight load is UNCONDITIONAL (the last chunk re-requests its own fragments): a load inside a branch
     // makes its destination a phi, and the copies that resolve it would read the registers while in flight
-    load_b(b_src(c + 1 < nchunks ? c + 1 : c), f.b[1]);
+    {
+      const unsigned short* s = b_src(c + 1 < nchunks ? c + 1 : c);
+      load_b(s, s + w_nb, f.b[1]);
+    }
     if (c + 1 < nchunks) issue_a(c + 1, buf ^ 1);
-    unsigned av[4];
+    unsigned av[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) av[ks] = av0[ks] + buf * A_BYTES;
+    for (int ks = 0; ks < 2; ++ks) av[ks] = av0[ks] + buf * A_BYTES;
     issue_half<0>(av, f);
     half<0>(av, f, acc);
-    // chunk c+1's A tile and weight fragments were requested 32 MFMAs ago
+    // chunk c+1's A tile and weight fragments were requested 64 MFMAs ago
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[1][2]), "+v"(f.b[1][3]) :: "memory");
   }
   __syncthreads();                       // staging below reuses the A buffers
 
   if constexpr (!SCATTER) {
-    conv_epilogue<bf16_t, BN, BM, 256, 8, 1, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
+    conv_epilogue<bf16_t, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
   } else {
     // bias, then the tile through LDS: [256 rows][128 cols + pad] bf16, then 16-byte stores scattered to the
     // fine grid: column n = (a*2 + bb) * cout + co -> pixel (2y + a, 2x + bb), channel co
     constexpr int PITCH = BN * 2 + 16;
-    {
-      const int col = wave * 32 + (lane & 31);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int col = wave * 32 + nb * 16 + (lane & 15);
       const float bv = p.bias ? p.bias[(n0 + col) % p.cout] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 16; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          *reinterpret_cast<bf16_t*>(smem + row * PITCH + col * 2) = (bf16_t)(acc[i][0][r] + bv);
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + (lane >> 4) * 4 + r;
+          *reinterpret_cast<bf16_t*>(smem + row * PITCH + col * 2) = (bf16_t)(acc[i][nb][r] + bv);
         }
     }
     __syncthreads();

@@ -42,22 +42,28 @@ __device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
 
 
 // ---- bf16 contraction of one staged tile, hand-placed schedule ------------------------------------------
-// Wave roles (bf16 path): 2 S-channel halves x 2 TAP GROUPS; every wave covers all 64 F channels (two A
-// fragments per tile row) x its 32 S channels x its taps (conv3x3: taps 0-4 | 5-8, up-conv: 0-1 | 2-3).
-// A fragment is then shared by 5 (4) taps x 2 MFMAs: 1.4-1.5 transposing reads per MFMA instead of the 2.2
-// of the 2x2 channel split with all 9 taps per wave -- the LDS was ~80 % busy there.
-// The reads are inline asm:
-//  * through the intrinsic hipcc puts `s_waitcnt vmcnt(0)` in front of the first read of every tile row (an
-//    LDS read "may alias" the LDS-DMA of the NEXT tile, already in flight): the prefetch was drained before
-//    the MFMAs, so loads and MFMAs of a workgroup ran back to back (ablation, 512->512 @32x32: loads 56 us +
-//    MFMA loop 123 us = 179 us vs 171 us together);
-//  * its reads were issued one or two MFMAs ahead of their use (MFMA loop alone at 57 % of the MFMA rate).
-// Here a tile row is split in two halves (A fragments + first taps | remaining taps); the reads of the NEXT
-// half are always issued before the MFMAs of the current one, and since LDS reads return in order
-// `s_waitcnt lgkmcnt(n)` with n = number of reads of the next half releases the current half.
-// Addresses: row r = c + R (c compile-time, R = 8*kh + q per lane), byte = r*128 + (chb ^ swz(r)); swz(r)
-// only depends on (c + R) mod 4, so 4 per-lane bases (by c & 3) + an immediate c*128 cover every S read and
-// 2 bases every F read -- 6 address registers instead of one per (row, tap).
+// Wave roles (bf16 path): 2 S-channel halves x 2 TAP GROUPS; every wave covers all 64 F channels x its 32 S
+// channels x its taps (conv3x3: taps 0-4 | 5-8, up-conv: 0-1 | 2-3).
+// MFMA shape v_mfma_f32_16x16x32_bf16 (4 x 2 tiles per tap): K = 32 pixels = TWO tile rows; the chip holds a
+// higher clock under a dense stream of this shape than with 32x32x16 (MI355X_MICROARCH.md, clocks under load
+// (7); conv3x3_glds.hip measured 8-10 %).  k index -> pixel (any bijection works, both operands use the same):
+// lane block g = lane / 16 holds k = 8g .. 8g+7 = tile row 2*rp + (g >> 1), x = 4*(g & 1) + {0..3} (first
+// transposing read) and x + 8 (second read).  A half-wave (blocks g, g^1) therefore reads 8 CONSECUTIVE pixel
+// rows of one 32-byte channel slot per cycle: conflict-free iff the slot index is XORed with TWO row bits
+// (swz16: bits 1 and 2; the 128-byte row pitch contributes bit 0).
+// Schedule: a row pair is N steps (one per tap of the wave's group), a step = 8 MFMAs (4 F x 2 S fragments)
+// on the S fragments requested one step earlier (2-deep ring).  The F fragments are single-buffered: in the
+// last step of a row pair each fragment's two MFMAs are followed by the reads of the same fragment of the
+// NEXT row pair (in-order issue: the MFMAs have taken their operands), and the first step of that row pair
+// releases them one by one.  LDS reads return in order, so `s_waitcnt lgkmcnt(n)`, n = reads issued after
+// the ones needed, releases exactly the fragments of the next MFMAs.
+// The reads are inline asm: through the intrinsic hipcc puts `s_waitcnt vmcnt(0)` in front of the first read
+// of every tile row (an LDS read "may alias" the LDS-DMA of the NEXT tile, already in flight), which drained
+// the prefetch before the MFMAs.
+// Addresses: S row r = c + R (c compile-time, R per lane), byte = r*128 + ((slot ^ swz16(r)) << 5) + 8*pp;
+// swz16(r) depends on (c + R) mod 8: 4 per-lane bases (by c & 3; c & 4 exchanges the two slots) + the immediate
+// c*128 cover every S read of one 16-channel slot, `^ 32` gives the other; F rows are multiples of 8 -> one
+// base, `^ (fh << 5)`.
 template <int OFF>
 __device__ __forceinline__ bf16x4 lds_tr16_asm(unsigned addr) {
   bf16x4 v;
@@ -70,77 +76,81 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
 // consumers of x must stay behind the (volatile, ordered) wait that precedes this statement
 __device__ __forceinline__ void tie(bf16x4& x) { asm volatile("" : "+v"(x)); }
 
+__device__ __forceinline__ int swz16(int row) { return (((row >> 1) & 1) << 6) | (((row >> 2) & 1) << 5); }
+
 template <int MODE, int TG>
 struct WgTaps {
   static constexpr int TR = MODE == 0 ? 8 : 4;
+  static constexpr int NRP = TR / 2;                                             // row pairs per tile
+  static constexpr int RS = MODE == 0 ? 18 : 64;                                 // S rows between tile rows
   static constexpr int T0 = MODE == 0 ? (TG == 0 ? 0 : 5) : (TG == 0 ? 0 : 2);   // first tap of the group
   static constexpr int N = MODE == 0 ? (TG == 0 ? 5 : 4) : 2;                    // taps of the group
-  static constexpr int HA = MODE == 0 ? 2 : 1;                                   // taps riding with the A fragments
   static constexpr int srow(int py, int t) {
     return MODE == 0 ? (py + t / 3) * 18 + t % 3 : (2 * py + (t >> 1)) * 32 + (t & 1) * 16;
   }
 };
 struct WgFrags {
-  bf16x4 a0[2][2], a1[2][2];      // [row parity][F half]
-  bf16x4 b0[5], b1[5];            // [local tap]
+  bf16x4 a[4][2];         // [F fragment][read]
+  bf16x4 b[2][2][2];      // [step parity][S fragment][read]
 };
-
-template <int MODE, int TG, int PY, int L0, int L1>
-__device__ __forceinline__ void wg_rd_taps(const unsigned (&sv)[4], WgFrags& f) {
-  if constexpr (L0 < L1) {
-    constexpr int c = WgTaps<MODE, TG>::srow(PY, WgTaps<MODE, TG>::T0 + L0);
-    f.b0[L0] = lds_tr16_asm<c * 128>(sv[c & 3]);
-    f.b1[L0] = lds_tr16_asm<(c + 4) * 128>(sv[c & 3]);
-    wg_rd_taps<MODE, TG, PY, L0 + 1, L1>(sv, f);
-  }
+// both reads of F fragment FH of row pair RP
+template <int RP, int FH>
+__device__ __forceinline__ void wg_rd_a(unsigned fv0, WgFrags& f) {
+  f.a[FH][0] = lds_tr16_asm<(RP * 32) * 128>(fv0 ^ (FH << 5));
+  f.a[FH][1] = lds_tr16_asm<(RP * 32 + 8) * 128>(fv0 ^ (FH << 5));
 }
-template <int PY>
-__device__ __forceinline__ void wg_rd_a(const unsigned (&fv)[2], WgFrags& f) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    f.a0[PY & 1][h] = lds_tr16_asm<PY * 16 * 128>(fv[h]);
-    f.a1[PY & 1][h] = lds_tr16_asm<(PY * 16 + 4) * 128>(fv[h]);
-  }
-}
-template <int L0, int L1, typename ACC>
-__device__ __forceinline__ void wg_fma(const WgFrags& f, int set, ACC& acc) {
-  if constexpr (L0 < L1) {
-    const bf16x8 bfr = __builtin_shufflevector(f.b0[L0], f.b1[L0], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bf16x8 af = __builtin_shufflevector(f.a0[set][h], f.a1[set][h], 0, 1, 2, 3, 4, 5, 6, 7);
-      acc[L0][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[L0][h], 0, 0, 0);
-    }
-    wg_fma<L0 + 1, L1>(f, set, acc);
-  }
-}
-template <int L0, int L1>
-__device__ __forceinline__ void wg_tie_taps(WgFrags& f) {
-  if constexpr (L0 < L1) {
-    tie(f.b0[L0]);
-    tie(f.b1[L0]);
-    wg_tie_taps<L0 + 1, L1>(f);
-  }
-}
-template <int MODE, int TG, int PY, typename ACC>
-__device__ __forceinline__ void wg_row(const unsigned (&fv)[2], const unsigned (&sv)[4], WgFrags& f, ACC& acc) {
+// S fragments of step S (row pair S / N, local tap S % N).  swz16(c + 4 + R) = swz16(c + R) ^ 32: the bases of
+// the classes c & 7 >= 4 are those of c & 3 with the two 16-channel slots exchanged -> 4 registers, not 8.
+template <int MODE, int TG, int S>
+__device__ __forceinline__ void wg_rd_b(const unsigned (&sv)[4], WgFrags& f) {
   using G = WgTaps<MODE, TG>;
-  wg_rd_taps<MODE, TG, PY, G::HA, G::N>(sv, f);          // second half of this row in flight
-  wait_lgkm<2 * (G::N - G::HA)>();                       // first half (4 A reads + taps [0,HA)) landed
+  constexpr int c = G::srow(2 * (S / G::N), G::T0 + S % G::N);
+  constexpr int x = (c >> 2) & 1;
+  const unsigned s0 = sv[c & 3], s1 = s0 ^ 32;
+  f.b[S & 1][x][0] = lds_tr16_asm<c * 128>(s0);
+  f.b[S & 1][x][1] = lds_tr16_asm<(c + 8) * 128>(s0);
+  f.b[S & 1][x ^ 1][0] = lds_tr16_asm<c * 128>(s1);
+  f.b[S & 1][x ^ 1][1] = lds_tr16_asm<(c + 8) * 128>(s1);
+}
+// F fragment FH of step S: wait for it (first step of a row pair), 2 MFMAs, then (last step of a row pair)
+// request the same fragment of the next row pair into the registers just consumed
+template <int MODE, int TG, int S, int FH, typename ACC>
+__device__ __forceinline__ void wg_fh(unsigned fv0, WgFrags& f, ACC& acc) {
+  using G = WgTaps<MODE, TG>;
+  constexpr int NSTEP = G::NRP * G::N, rp = S / G::N, L = S % G::N;
+  constexpr int nb = S + 1 < NSTEP ? 4 : 0;          // S reads of the next step, issued at the top of this one
+  if constexpr (L == 0) {
+    if constexpr (rp > 0 || FH == 0) wait_lgkm<nb + (rp > 0 ? 2 * (3 - FH) : 0)>();
+    if constexpr (FH == 0) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) { tie(f.a0[PY & 1][h]); tie(f.a1[PY & 1][h]); }
-  wg_tie_taps<0, G::HA>(f);
-  wg_fma<0, G::HA>(f, PY & 1, acc);
-  if constexpr (PY + 1 < G::TR) {
-    wg_rd_a<PY + 1>(fv, f);                              // first half of the next row in flight
-    wg_rd_taps<MODE, TG, PY + 1, 0, G::HA>(sv, f);
-    wait_lgkm<4 + 2 * G::HA>();
-  } else {
-    wait_lgkm<0>();
+      for (int sh = 0; sh < 2; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
+    }
+    if constexpr (rp > 0) { tie(f.a[FH][0]); tie(f.a[FH][1]); }
+    else if constexpr (FH == 0) {
+#pragma unroll
+      for (int fh = 0; fh < 4; ++fh) { tie(f.a[fh][0]); tie(f.a[fh][1]); }
+    }
+  } else if constexpr (FH == 0) {
+    wait_lgkm<nb>();
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
   }
-  wg_tie_taps<G::HA, G::N>(f);
-  wg_fma<G::HA, G::N>(f, PY & 1, acc);
-  if constexpr (PY + 1 < G::TR) wg_row<MODE, TG, PY + 1>(fv, sv, f, acc);
+  const bf16x8 af = __builtin_shufflevector(f.a[FH][0], f.a[FH][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int sh = 0; sh < 2; ++sh) {
+    const bf16x8 bfr = __builtin_shufflevector(f.b[S & 1][sh][0], f.b[S & 1][sh][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[L][FH][sh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[L][FH][sh], 0, 0, 0);
+  }
+  if constexpr (L == G::N - 1 && rp + 1 < G::NRP) wg_rd_a<rp + 1, FH>(fv0, f);
+  if constexpr (FH + 1 < 4) wg_fh<MODE, TG, S, FH + 1>(fv0, f, acc);
+}
+template <int MODE, int TG, int S, typename ACC>
+__device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], WgFrags& f, ACC& acc) {
+  using G = WgTaps<MODE, TG>;
+  constexpr int NSTEP = G::NRP * G::N;
+  if constexpr (S + 1 < NSTEP) wg_rd_b<MODE, TG, S + 1>(sv, f);
+  wg_fh<MODE, TG, S, 0>(fv0, f, acc);
+  if constexpr (S + 1 < NSTEP) wg_step<MODE, TG, S + 1>(fv0, sv, f, acc);
 }
 
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
@@ -300,7 +310,7 @@ void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int row = 8 * (wave + 4 * i) + sub;
-      const int u = c ^ (4 * ((row >> 1) & 1));
+      const int u = c ^ (swz16(row) >> 4);
       int ry, rx;
       f_geo(i, ry, rx);
       f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * 2) : OOB;
@@ -309,7 +319,7 @@ void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < NS; ++i) {
       const int k = wave + 4 * i;
       const int row = 8 * k + sub;
-      const int u = c ^ (4 * ((row >> 1) & 1));
+      const int u = c ^ (swz16(row) >> 4);
       int ry, rx;
       s_geo(i, ry, rx);
       const bool ok = k < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
@@ -350,15 +360,18 @@ void wgrad_kernel(WgradParams p) {
     auto run = [&](auto tgc) {
       constexpr int TG = decltype(tgc)::value;
       using G = WgTaps<MODE, TG>;
-      f32x16 acc2[G::N][2];
+      f32x4 acc2[G::N][4][2];
 #pragma unroll
       for (int t = 0; t < G::N; ++t)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int fh = 0; fh < 4; ++fh)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc2[t][h][r] = 0.f;
-      const int R = 8 * kh + q;
-      const int chb = (16 * cgrp + 4 * pp) * 2;             // lane's 4 channels inside a 32-channel group
+          for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[t][fh][sh][r] = 0.f;
+      // lane's k block g = lane / 16: tile row (g >> 1) of the row pair, x = 4 * (g & 1) + q (+ 8: second read)
+      const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
+      const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
       const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
       if (t_begin < t_end) issue_tile(t_begin, 0);
       for (long tile = t_begin; tile < t_end; ++tile) {
@@ -368,34 +381,39 @@ void wgrad_kernel(WgradParams p) {
         if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
 #endif
 #ifndef CRIMAC_EXP_NOCOMPUTE
-        const unsigned aF = lds0 + cur * BUF_BYTES + R * 128, aS = aF + F_BYTES;
-        unsigned fv[2], sv[4];
+        const unsigned aF = lds0 + cur * BUF_BYTES, aS = aF + F_BYTES;
+        const unsigned fv0 = aF + RF * 128 + 8 * pp + swz16(RF);
+        unsigned sv[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) fv[h] = aF + ((h * 64 + chb) ^ swz_tr(R));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sv[k] = aS + ((ws * 64 + chb) ^ swz_tr(k + R));
+        for (int k = 0; k < 4; ++k) sv[k] = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(k + RSl));
         WgFrags f;
-        wg_rd_a<0>(fv, f);
-        wg_rd_taps<MODE, TG, 0, 0, G::HA>(sv, f);
-        wg_row<MODE, TG, 0>(fv, sv, f, acc2);
+        wg_rd_a<0, 0>(fv0, f);
+        wg_rd_a<0, 1>(fv0, f);
+        wg_rd_a<0, 2>(fv0, f);
+        wg_rd_a<0, 3>(fv0, f);
+        wg_rd_b<MODE, TG, 0>(sv, f);
+        wg_step<MODE, TG, 0>(fv0, sv, f, acc2);
 #endif
       }
       // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps
-      const int col = cs0 + ws * 32 + (lane & 31);
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) {
+        const int col = cs0 + ws * 32 + sh * 16 + (lane & 15);
 #ifdef CRIMAC_EXP_NOATOMIC
-      if (col < 0) {
+        if (col < 0) {
 #else
-      if (col < p.CS) {
+        if (col < p.CS) {
 #endif
 #pragma unroll
-        for (int t = 0; t < G::N; ++t)
+          for (int t = 0; t < G::N; ++t)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+            for (int fh = 0; fh < 4; ++fh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = cf0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              if (row < p.CF) atomicAdd(p.dw + ((long)(G::T0 + t) * p.CF + row) * p.CS + col, acc2[t][h][r]);
-            }
+              for (int r = 0; r < 4; ++r) {
+                const int row = cf0 + fh * 16 + (lane >> 4) * 4 + r;
+                if (row < p.CF) atomicAdd(p.dw + ((long)(G::T0 + t) * p.CF + row) * p.CS + col, acc2[t][fh][sh][r]);
+              }
+        }
       }
     };
     if (tg == 0) run(std::integral_constant<int, 0>{});
