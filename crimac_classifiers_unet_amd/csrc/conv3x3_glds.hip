@@ -42,6 +42,22 @@ constexpr int HALO_INSTR = (HALO_ROWS + 7) / 8;   // 41 wave-instructions of 8 r
 constexpr int BK = 64, RB = BK * 2;               // 64 channels = 128 B per row
 constexpr int A_BYTES = HALO_INSTR * 1024;        // one halo buffer (padded to whole instructions)
 
+// XOR swizzle of the 16-byte unit index of halo column hx (0..17).  A 16x16x32 A fragment is read by
+// ds_read_b128 with lane -> (column fr + kx, unit 4*ks + lane / 16); the hardware serves it in four groups of
+// 16 lanes that mix two k units ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS table), so the plain
+// (hx >> 1) & 7 swizzle of the 32x32x16 layout is 2-way conflicted for kx = 1, 2 (8 LDS cycles instead of 4,
+// by the model).  This table (exhaustive search) is conflict-free for kx = 0, 1, 2: 3 bits per column.
+// rocprofv3 PMC, 1024->512 @32x32: SQ_LDS_BANK_CONFLICT 126.5 M -> 0.66 M cycles, SQ_LDS_IDX_ACTIVE 321 M ->
+// 195 M; run time unchanged (196 us either way: the MFMA stream, not the LDS, bounds the kernel) -- kept for
+// the idle LDS cycles it leaves to the halo DMA.  -DCRIMAC_EXP_OLDSWZ restores the plain swizzle for A/B runs.
+__device__ __forceinline__ int halo_swz(int hx) {
+#ifdef CRIMAC_EXP_OLDSWZ
+  return (hx >> 1) & 7;
+#else
+  return (int)((0xd92dad912240ull >> (3 * hx)) & 7);
+#endif
+}
+
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
 #ifdef CRIMAC_EXP_NOGLDS
   return;
@@ -113,7 +129,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
     if (k < HALO_INSTR && row < HALO_ROWS) {
       const int hy = row / HP, hx = row % HP;
       const int y = y0 + hy - 1, x = x0 + hx - 1;
-      const int u = c8 ^ ((hx >> 1) & 7);
+      const int u = c8 ^ halo_swz(hx);
       if (y >= 0 && y < p.H && x >= 0 && x < p.W)
         h_src[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
       else
@@ -150,7 +166,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
   auto compute = [&](const unsigned char* Bs, int t) {
     const int kx = t % 3;
     const unsigned char* a0 = sA + ((wave * 4 + t / 3) * HP + fr + kx) * RB;
-    const int aswz = ((fr + kx) >> 1) & 7;
+    const int aswz = halo_swz(fr + kx);
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       const int unit = 4 * ks + fq;
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hy = row / HP, hx = row - hy * HP;
     const unsigned y = (unsigned)(y0 + hy - 1), x = (unsigned)(x0 + hx - 1);
     const bool ok = k < HALO_INSTR && row < HALO_ROWS && y < (unsigned)p.H && x < (unsigned)p.W;
-    h_off[i] = ok ? (unsigned)(((((long)b * p.H + y) * p.W + x) * p.in_ld + (c8 ^ ((hx >> 1) & 7)) * 8) * 2)
+    h_off[i] = ok ? (unsigned)(((((long)b * p.H + y) * p.W + x) * p.in_ld + (c8 ^ halo_swz(hx)) * 8) * 2)
                   : 0x80000000u;
   }
   auto issue_halo = [&](int kc) {
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2)
-        av[kx][ks2] = a_lds + (fr + kx) * RB + (((4 * ks2 + fq) ^ (((fr + kx) >> 1) & 7)) << 4);
+        av[kx][ks2] = a_lds + (fr + kx) * RB + (((4 * ks2 + fq) ^ halo_swz(fr + kx)) << 4);
   }
 
   f32x4 acc[16][2];
