@@ -84,7 +84,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 //     3-slot weight ring: 65 KB of LDS, so TWO workgroups share a CU.
 // Measured (64->64 @256x256, B=32): 305 us vs 321 us register-staged / 366 us for the 8-wave form;
 // 128->64: 428 vs 494 us.  Ablations: loads alone 80 us, MFMA loop alone 145 us, stores 55 us, statistics
-// 23 us -- they add up, i.e. the phases of co-resident workgroups do not overlap.  Tried and rejected:
+// 23 us -- they add up.  Not a lockstep effect: delaying every second workgroup of the first round (by block
+// parity, or by the HW_ID workgroup slot so that the two co-resident ones are half a lifetime apart) changes
+// nothing, nor does a third workgroup per CU; the kernel behaves as if bounded by energy (MFMA stream + HBM
+// traffic under one power cap -- all-zero inputs run 25 % faster), which scheduling cannot buy back.  Tried and rejected:
 // a persistent 4-wave form with next-tile halo prefetch and a dedicated staging tile (378 us: one wave
 // per SIMD serialises LDS-DMA issue, MFMAs and the epilogue), and keeping the 72 KB of weights in
 // registers (36-72 B-fragments per wave; hipcc spills around the epilogue and every scratch reload
