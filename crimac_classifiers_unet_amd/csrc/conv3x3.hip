@@ -298,6 +298,8 @@ int launch(ConvParams p, hipStream_t st) {
 // conv3x3_glds.hip: bf16 direct-to-LDS variant
 int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
                              const void* w_hi, const EpiParams& epi, hipStream_t st);
+int crimac_conv3x3_c16_bf16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
+                            const EpiParams& epi, hipStream_t st);
 
 extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
                               const void* w_hi, const void* w_lo, const float* bias, void* out,
@@ -338,6 +340,9 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
   static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
   if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && use_glds)
     return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, e, st);
+  // first layer (4 input channels padded to 16): one-barrier kernel, 181 -> see DESIGN.md us at B = 32
+  if (prec == CRIMAC_PREC_BF16 && Cin == 16 && N == 64 && use_glds)
+    return crimac_conv3x3_c16_bf16(in, in_ld, B, H, W, N, w_hi, e, st);
   if (prec == CRIMAC_PREC_BF16) {
     // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
     // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128

@@ -87,7 +87,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // 23 us -- they add up.  Not a lockstep effect: delaying every second workgroup of the first round (by block
 // parity, or by the HW_ID workgroup slot so that the two co-resident ones are half a lifetime apart) changes
 // nothing, nor does a third workgroup per CU; the kernel behaves as if bounded by energy (MFMA stream + HBM
-// traffic under one power cap -- all-zero inputs run 25 % faster), which scheduling cannot buy back.  Tried and rejected:
+// traffic under one power cap; all-zero inputs run measurably faster), which scheduling cannot buy back.  Tried and rejected:
 // a persistent 4-wave form with next-tile halo prefetch and a dedicated staging tile (378 us: one wave
 // per SIMD serialises LDS-DMA issue, MFMAs and the epilogue), and keeping the 72 KB of weights in
 // registers (36-72 B-fragments per wave; hipcc spills around the epilogue and every scratch reload
@@ -455,7 +455,202 @@ int launch_wch(ConvParams p, hipStream_t st) {
   return CRIMAC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// First layer (unet.py:77 with in_channels = 4, padded to 16): K = 9 x 16 = 144 -- 80 MFMAs per wave and tile,
+// the kernel is its output stream (32 KB + BatchNorm statistics per tile against 10 KB of input).  The generic
+// register-staged kernel spent 9 staged K steps with two barriers each on it (181 us at B = 32).  Measured on
+// the way here (one tile per workgroup, shared epilogue): 145 us without / 180 us with statistics, of which
+// the halo + weight loads 50 us (30 us alone: their latency is not hidden by anything) and the per-tile
+// statistics atomics 35 us.  Hence a PERSISTENT kernel:
+//   * all weights (18 KB, L2) go to LDS ONCE per workgroup; 5 k-steps of v_mfma_f32_16x16x32_bf16 pair two taps
+//     per step (k = 16 channels of tap 2s | 16 channels of tap 2s+1; the tenth half-step has zero weights);
+//   * the next tile's halo (18x18 pixels x 32 B) is fetched into registers before the current tile's MFMAs and
+//     output, so its latency hides behind them;
+//   * wave w owns image rows 4w .. 4w+3 x all 64 channels and writes them through a private LDS slab, one
+//     16-pixel row (2 KB contiguous in HBM) at a time -- no workgroup barrier in the epilogue;
+//   * the statistics stay in registers across tiles and are flushed once per workgroup.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 registers: 4 workgroups/CU
+void conv3x3_c16_kernel(ConvParams p, int ntiles) {
+  constexpr int BN = 64, CB = 32;                 // bytes per halo pixel
+  constexpr int NHU = (HALO_ROWS * 2 + 255) / 256;   // halo 16-byte units per thread: 3
+  constexpr int SLAB_PITCH = BN * 2 + 16, SLAB = 16 * SLAB_PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* slab = smem + HALO_ROWS * CB + wave * SLAB;
+  float* sstat = reinterpret_cast<float*>(smem + HALO_ROWS * CB + 4 * SLAB);      // [2][64]
+  unsigned char* wlds = smem + HALO_ROWS * CB + 4 * SLAB + 2 * BN * 4;
+  const EpiParams& e = p.epi;
+  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
+  bf16_t* outp = reinterpret_cast<bf16_t*>(e.out);
+  const bool stats = e.stat_sum != nullptr && e.stat_mode == 1;
+  if (tid < 2 * BN) sstat[tid] = 0.f;
+
+  // weights [tap][n][16] (18 KB) -> LDS once per workgroup; fragment (s, j) of a lane = row j*16 + fr of tap
+  // 2s + (fq >> 1), channels (fq & 1)*8 .. +8 (same 32-byte pitch as the halo: conflict-free ds_read_b128)
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int u = tid; u < 9 * BN * 2; u += 256)
+    *reinterpret_cast<u32x4*>(wlds + u * 16) = *reinterpret_cast<const u32x4*>(p.w_hi + (long)u * 8);
+  int b_off[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    int t = 2 * s + (fq >> 1);
+    if (t > 8) t = 8;
+    b_off[s] = (t * BN + fr) * CB + (fq & 1) * 16;
+  }
+  const bool tap9 = (fq >> 1) == 1;             // this lane's half of k-step 4 is the non-existent tenth tap
+  float bv[4], cs1[4], cs2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bv[j] = e.bias ? e.bias[j * 16 + fr] : 0.f;
+    cs1[j] = 0.f;
+    cs2[j] = 0.f;
+  }
+  // A fragment addresses per k-step (tap 2s + (fq >> 1), clamped where the weights are zero)
+  int a_off[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    int t = 2 * s + (fq >> 1);
+    if (t > 8) t = 8;
+    a_off[s] = ((wave * 4 + t / 3) * HP + fr + t % 3) * CB + (fq & 1) * 16;
+  }
+
+  auto tile_geo = [&](int tile, int& b, int& y0, int& x0) {
+    const int txi = tile % p.tiles_x;
+    const int tt = tile / p.tiles_x;
+    b = tt / p.tiles_y;
+    y0 = (tt % p.tiles_y) * TR;
+    x0 = txi * TC;
+  };
+  u32x4 hreg[NHU];
+  auto fetch_halo = [&](int tile) {
+    int b, y0, x0;
+    tile_geo(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < NHU; ++i) {
+      const int u = tid + i * 256;
+      const int row = u >> 1, half = u & 1;
+      const int hy = row / HP, hx = row - hy * HP;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      hreg[i] = u32x4{0, 0, 0, 0};
+      if (u < HALO_ROWS * 2 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+        hreg[i] = *reinterpret_cast<const u32x4*>(inp + (((long)b * p.H + y) * p.W + x) * p.in_ld + half * 8);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch_halo(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    int b, y0, x0;
+    tile_geo(tile, b, y0, x0);
+    __syncthreads();                            // every wave is done reading the previous halo
+#pragma unroll
+    for (int i = 0; i < NHU; ++i) {
+      const int u = tid + i * 256;
+      if (u < HALO_ROWS * 2) *reinterpret_cast<u32x4*>(halo + u * 16) = hreg[i];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch_halo(tile + gridDim.x);
+
+    // two image rows (M tiles) at a time: 32 accumulator registers, the weight fragments are re-read from LDS
+#pragma unroll 1
+    for (int ih = 0; ih < 2; ++ih) {
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+      const unsigned char* hrow = halo + ih * (2 * HP * CB);
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        bf16x8 af[2], bw[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hrow + a_off[s] + i * (HP * CB));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bw[j] = *reinterpret_cast<const bf16x8*>(wlds + b_off[s] + j * (16 * CB));
+          if (s == 4 && tap9) bw[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bw[j], acc[i][j], 0, 0, 0);
+      }
+      // output: image row y0 + 4*wave + 2*ih + i = M tile i; accumulator element r of N tile j is pixel
+      // (lane >> 4)*4 + r, channel j*16 + fr
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int y = y0 + wave * 4 + ih * 2 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int px = (lane >> 4) * 4 + r;
+            float v = acc[i][j][r] + bv[j];
+            if (e.relu) v = fmaxf(v, 0.f);
+            const bf16_t q = (bf16_t)v;
+            *reinterpret_cast<bf16_t*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
+            const float vs = (float)q;            // statistics of the value as STORED
+            const bool ok = y < p.H && x0 + px < p.W;
+            cs1[j] += ok ? vs : 0.f;
+            cs2[j] += ok ? vs * vs : 0.f;
+          }
+        // (wave-private slab: LDS operations of one wave execute in order, no barrier)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int u = lane + k * 64, px = u >> 3, c8 = u & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(slab + px * SLAB_PITCH + c8 * 16);
+          if (y < p.H && x0 + px < p.W)
+            *reinterpret_cast<u32x4*>(outp + (((long)b * p.H + y) * p.W + x0 + px) * e.out_ld + c8 * 8) = v;
+        }
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t1 = cs1[j], t2 = cs2[j];
+      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (lane < 16) {
+        atomicAdd(&sstat[j * 16 + lane], t1);
+        atomicAdd(&sstat[BN + j * 16 + lane], t2);
+      }
+    }
+    __syncthreads();
+    const long rep = (long)(blockIdx.x % (unsigned)e.stat_replicas) * e.N;
+    if (tid < BN) {
+      atomicAdd(&e.stat_sum[rep + tid], (double)sstat[tid]);
+      atomicAdd(&e.stat_sumsq[rep + tid], (double)sstat[BN + tid]);
+    }
+  }
+}
+
+int launch_c16(ConvParams p, hipStream_t st) {
+  p.tiles_y = cdiv(p.H, TR);
+  p.tiles_x = cdiv(p.W, TC);
+  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
+  constexpr size_t lds = (size_t)HALO_ROWS * 32 + 4 * 16 * (64 * 2 + 16) + 2 * 64 * 4 + 9 * 64 * 32;   // 38.6 KB
+  const long grid = ntiles < 1024 ? ntiles : 1024;          // 4 workgroups per CU
+  hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)grid), dim3(256), lds, st, p, (int)ntiles);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
 }  // namespace
+
+// first layer: bf16, Cin == 16 (4 real channels), N == 64
+int crimac_conv3x3_c16_bf16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
+                            const EpiParams& epi, hipStream_t st) {
+  ConvParams p;
+  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = 16; p.N = N;
+  p.w_hi = (const unsigned short*)w_hi;
+  p.epi = epi;
+  return launch_c16(p, st);
+}
 
 // bf16, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
 int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,

@@ -1,3 +1,4 @@
+#include <stdlib.h>
 // HBM-bound kernels of the U-Net hot path for CDNA4 (gfx950): BatchNorm statistics / apply /
 // backward, ReLU, 2x2 max-pool and its backward, layout conversion, weight packing, SGD.
 // All tensor accesses are 16-byte vectors over the contiguous NHWC channel axis; per-channel
@@ -29,13 +30,27 @@ inline int grid_for(long work_items, int per_block) {
   return (int)b;
 }
 
+// pixel index -> (image, pixel in image); 32-bit divide when the operands fit (a 64-bit divide is ~4x the
+// instructions, noticeable in the one-pixel-per-thread kernels)
+__device__ __forceinline__ void pix_split(long p, long HW, long& b, long& hw) {
+  if (((p | HW) >> 31) == 0) {
+    const unsigned q = (unsigned)p / (unsigned)HW;
+    b = q;
+    hw = (unsigned)p - q * (unsigned)HW;
+  } else {
+    b = p / HW;
+    hw = p % HW;
+  }
+}
+
 // ---- layout: NCHW fp32 -> NHWC (channel padded) -----------------------------------------------
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int C, long HW,
                                     long npix, long ld) {
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix;
        p += (long)gridDim.x * blockDim.x) {
-    const long b = p / HW, hw = p % HW;
+    long b, hw;
+    pix_split(p, HW, b, hw);
     const float* src = in + b * C * HW + hw;
     T* dst = out + p * ld;
     for (int c0 = 0; c0 < ld; c0 += 8) {
@@ -366,6 +381,16 @@ __device__ __forceinline__ void bnb_accum(const BnbArgs& a, const BnbConst& k, l
     d2[j] += dz * (yv[j] - k.mu[j]) * k.is[j];
   }
 }
+// same with y already in registers
+__device__ __forceinline__ void bnb_accum_v(const BnbConst& k, const float (&yv)[8], const float (&g)[8],
+                                            float (&d1)[8], float (&d2)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float dz = (yv[j] * k.sc[j] + k.sh[j]) > 0.f ? g[j] : 0.f;
+    d1[j] += dz;
+    d2[j] += dz * (yv[j] - k.mu[j]) * k.is[j];
+  }
+}
 // lds: [2][C] floats, zeroed and synchronised by the caller; every thread of the block calls this
 __device__ __forceinline__ void bnb_flush(const BnbArgs& a, float* lds, int C, int c0, const float (&d1)[8],
                                           const float (&d2)[8], int nthreads) {
@@ -565,7 +590,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int o = 0; o < NC; ++o) z[o] /= den;
       }
-      const long b = p / HW, hw = p % HW;
+      long b, hw;
+    pix_split(p, HW, b, hw);
 #pragma unroll
       for (int o = 0; o < NC; ++o) logits[(b * NC + o) * HW + hw] = z[o];
     }
@@ -600,30 +626,55 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int j = 0; j < 8; ++j) { wr[o][j] = w[o * Cin + sub * 8 + j]; gw[o][j] = 0.f; }
   }
   const long ppb = 256 / lp;
-  for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
-    const long p = p0 + threadIdx.x / lp;
-    if (p >= npix) continue;
-    const long b = p / HW, hw = p % HW;
-    float g[NC], v[8], o8[8];
+  // Two pixels per iteration, every load (x, y of the BatchNorm sums, dlogits) issued before the first use:
+  // with one pixel and the y load behind the dx store the loop was two dependent memory round trips per
+  // pixel.  (image, pixel-in-image) advance incrementally -- no 64-bit divide per pixel.
+  constexpr int UNR = 2;
+  const long step = (long)gridDim.x * ppb;
+  const long step_b = (UNR * step) / HW, step_hw = (UNR * step) % HW;
+  long p = (long)blockIdx.x * ppb + threadIdx.x / lp;
+  long pb[UNR], phw[UNR];
 #pragma unroll
-    for (int o = 0; o < NC; ++o) g[o] = dl[(b * NC + o) * HW + hw];
-    load8(x + p * x_ld + sub * 8, v);
+  for (int u = 0; u < UNR; ++u) { pb[u] = (p + u * step) / HW; phw[u] = (p + u * step) % HW; }
+  for (; p < npix; p += UNR * step) {
+    float g[UNR][NC], v[UNR][8], yv[UNR][8];
+    bool ok[UNR];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float s = 0.f;
+    for (int u = 0; u < UNR; ++u) {
+      const long pu = p + u * step;
+      ok[u] = pu < npix;
+      if (phw[u] >= HW) { phw[u] -= HW; pb[u] += 1; }
+      if (ok[u]) {
 #pragma unroll
-      for (int o = 0; o < NC; ++o) { s += g[o] * wr[o][j]; gw[o][j] += g[o] * v[j]; }
-      o8[j] = s;
+        for (int o = 0; o < NC; ++o) g[u][o] = dl[(pb[u] * NC + o) * HW + phw[u]];
+        load8(x + pu * x_ld + sub * 8, v[u]);
+        if constexpr (BNB) load8(reinterpret_cast<const T*>(bnb.y) + pu * bnb.y_ld + sub * 8, yv[u]);
+      }
+      pb[u] += step_b;
+      phw[u] += step_hw;
     }
-    if (sub == 0)
 #pragma unroll
-      for (int o = 0; o < NC; ++o) gb[o] += g[o];
-    if constexpr (BNB) {
+    for (int u = 0; u < UNR; ++u) {
+      if (!ok[u]) continue;
+      const long pu = p + u * step;
+      float o8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o8[j] = (float)(T)o8[j];      // the sums see dx as it is stored
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < NC; ++o) { s += g[u][o] * wr[o][j]; gw[o][j] += g[u][o] * v[u][j]; }
+        o8[j] = s;
+      }
+      if (sub == 0)
+#pragma unroll
+        for (int o = 0; o < NC; ++o) gb[o] += g[u][o];
+      if constexpr (BNB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (float)(T)o8[j];      // the sums see dx as it is stored
+      }
+      store8(dx + pu * dx_ld + sub * 8, o8);
+      if constexpr (BNB) bnb_accum_v(k, yv[u], o8, d1, d2);
     }
-    store8(dx + p * dx_ld + sub * 8, o8);
-    if constexpr (BNB) bnb_accum<T>(bnb, k, p, sub * 8, o8, d1, d2);
   }
 #pragma unroll
   for (int o = 0; o < NC; ++o) {
@@ -655,7 +706,8 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
        p += (long)gridDim.x * blockDim.x) {
     const long y = load_label(labels, lbytes, p);
     if (y == ignore) continue;
-    const long b = p / HW, hw = p % HW;
+    long b, hw;
+    pix_split(p, HW, b, hw);
     float z[NC];
     float mx = -INFINITY;
 #pragma unroll
@@ -691,7 +743,8 @@ __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ 
   for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix;
        p += (long)gridDim.x * blockDim.x) {
     const long y = load_label(labels, lbytes, p);
-    const long b = p / HW, hw = p % HW;
+    long b, hw;
+    pix_split(p, HW, b, hw);
     float z[NC];
     if (y == ignore) {
 #pragma unroll
