@@ -4,8 +4,8 @@ Training: every rank runs the same step on its own mini-batch s
 exchange is the gradient all-reduce over the FLAT fp32 gradient buffer (31.04 M floats = 124 MB),
 issued as a few large buckets (xGMI is point-to-point; large messages keep every link busy), started
 during the backward pass as soon as a contiguous range of the buffer is final, and averaged by folding
-1/world into the SGD kernel's ``grad_scale``.  BatchNorm statistics stay
-per-rank (torch DDP default; SyncBN is out of scope this round -- DESIGN.md).
+1/world into the SGD kernel's ``grad_scale``.  BatchNorm statistics stay per-rank by default (torch DDP
+default); ``sync_bn=True`` (engine / pipeline) all-reduces the per-channel sums on a process group of its own.
 
 Inference: patches are independent; patch ``p`` of a chunk goes to rank ``p % world`` and the
 per-rank softmax slabs are all-gathered.
