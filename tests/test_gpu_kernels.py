@@ -197,6 +197,39 @@ def test_conv3x3_wgrad(prec, shape, target_blocks):
     assert relerr(grad.cpu(), ref) < (1e-4 if prec != "f32x6" else 5e-6)
 
 
+@pytest.mark.parametrize("mode,shape", [(0, (2, 128, 128, 128, 64)), (0, (1, 256, 256, 64, 64)),
+                                        (0, (2, 100, 120, 64, 128)), (1, (2, 64, 64, 128, 64))])
+def test_wgrad_many_workgroups_auto_split(mode, shape):
+    """bf16 weight gradient with the library's own pixel split (target_blocks = 0): hundreds of workgroups in
+    flight, several tiles per workgroup -- the hand-placed LDS-read pipeline (asm loads, counted waits) only
+    shows ordering mistakes under this kind of load.  mode 0: conv3x3, mode 1: transposed conv."""
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(17)
+    prec = "bf16"
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    P = hip.PREC_NAMES[prec]
+    if mode == 0:
+        dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+        ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), dy, padding=1)
+        dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+        dyn, xn = to_nhwc(dy, prec), to_nhwc(x, prec)       # (kept alive: the call is asynchronous)
+        call("crimac_wgrad", P, 0, ptr(dyn), Co, Co, ptr(xn), Ci, Ci, B, H, W, ptr(dwp), 0)
+        grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+        call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+    else:
+        dy = _round(torch.randn(B, Co, 2 * H, 2 * W, generator=g), prec)
+        wg = torch.zeros(Ci, Co, 2, 2, requires_grad=True)
+        F.conv_transpose2d(x, wg, None, stride=2).backward(dy)
+        ref = wg.grad
+        dwp = torch.zeros(4 * Ci * Co, dtype=torch.float32, device="cuda")
+        dyn, xn = to_nhwc(dy, prec), to_nhwc(x, prec)
+        call("crimac_wgrad", P, 1, ptr(xn), Ci, Ci, ptr(dyn), Co, Co, B, H, W, ptr(dwp), 0)
+        grad = torch.empty(Ci, Co, 2, 2, dtype=torch.float32, device="cuda")
+        call("crimac_unpack_wgrad_upconv2x2", ptr(dwp), Ci, Co, ptr(grad))
+    torch.cuda.synchronize()
+    assert relerr(grad.cpu(), ref) < 2e-4
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("C", [64, 256, 1024])
 def test_batchnorm_train_forward_backward_pool(prec, C):
