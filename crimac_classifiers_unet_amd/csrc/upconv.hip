@@ -264,13 +264,46 @@ bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, l
   return ntaps == 4;
 }
 
-int crimac_upconv_wch_bf16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N,
-                           const void* w, const float* bias, int cout_up, void* out, long out_ld, hipStream_t st) {
+static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
+                      const float* bias, int cout_up, void* out, long out_ld, const EpiParams* bnb, hipStream_t st) {
   UpParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.ntaps = ntaps;
   p.w = (const unsigned short*)w; p.bias = bias; p.cout = cout_up; p.out = out; p.out_ld = out_ld;
   p.epi = EpiParams{};
   p.epi.bias = nullptr; p.epi.out = out; p.epi.out_ld = out_ld; p.epi.relu = 0; p.epi.H = H; p.epi.W = W; p.epi.N = N;
   p.epi.stat_sum = nullptr; p.epi.stat_sumsq = nullptr; p.epi.stat_replicas = 1; p.epi.stat_mode = 0;
+  if (bnb) {
+    p.epi.stat_mode = 2; p.epi.stat_sum = bnb->stat_sum; p.epi.stat_sumsq = bnb->stat_sumsq;
+    p.epi.stat_replicas = bnb->stat_replicas; p.epi.bnb_y = bnb->bnb_y; p.epi.bnb_y_ld = bnb->bnb_y_ld;
+    p.epi.bnb_vec = bnb->bnb_vec; p.epi.bnb_stride = bnb->bnb_stride;
+  }
   return ntaps == 1 ? launch<true>(p, st) : launch<false>(p, st);
+}
+
+int crimac_upconv_wch_bf16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N,
+                           const void* w, const float* bias, int cout_up, void* out, long out_ld, hipStream_t st) {
+  return upconv_run(ntaps, in, in_ld, B, H, W, K, N, w, bias, cout_up, out, out_ld, nullptr, st);
+}
+
+// Input gradient of the transposed convolution whose result is the `da` of a BatchNorm+ReLU block: that
+// block's backward sums (sum dz, sum dz*xhat; conv_epilogue.h stat_mode 2) are taken in the epilogue, which
+// removes a bn_bwd_reduce pass over (da, y) -- 4 launches, 0.21 ms per step at B = 32.
+extern "C" int crimac_upconv2x2_dgrad_bnb(const void* dy, long dy_ld, int B, int H, int W, int Cout, int Cin,
+                                          const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y,
+                                          long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
+                                          double* stat_sumsq, int stat_replicas, void* stream) {
+  CRIMAC_REQUIRE(dy && w_dg_hi && dx && B > 0 && H > 0 && W > 0, "upconv2x2_dgrad_bnb: bad arguments");
+  CRIMAC_REQUIRE(dy_ld >= Cout && dy_ld % 8 == 0 && dx_ld >= Cin && dx_ld % 8 == 0,
+                 "upconv2x2_dgrad_bnb: bad pixel strides (dy_ld=%ld dx_ld=%ld)", dy_ld, dx_ld);
+  const long in_bytes = (((long)B * 2 * H * 2 * W - 1) * dy_ld + Cout) * 2;
+  CRIMAC_REQUIRE(Cout > 0 && Cin > 0 && crimac_upconv_wch_ok(4, in_bytes, Cout, Cin, 0, dx_ld),
+                 "upconv2x2_dgrad_bnb: needs Cout %% 64 == 0, Cin %% 128 == 0 and a gradient tensor below 2 GiB "
+                 "(got Cout=%d Cin=%d); use crimac_igemm_conv + crimac_bn_bwd_reduce", Cout, Cin);
+  CRIMAC_REQUIRE(bnb_y && bnb_vec && stat_sum && stat_sumsq && stat_replicas >= 1 && bnb_y_ld >= Cin &&
+                     bnb_y_ld % 8 == 0 && bnb_stride >= Cin,
+                 "upconv2x2_dgrad_bnb: bad arguments of the fused BatchNorm-backward sums");
+  EpiParams e{};
+  e.stat_sum = stat_sum; e.stat_sumsq = stat_sumsq; e.stat_replicas = stat_replicas;
+  e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
+  return upconv_run(4, dy, dy_ld, B, H, W, Cout, Cin, w_dg_hi, nullptr, 0, dx, dx_ld, &e, (hipStream_t)stream);
 }

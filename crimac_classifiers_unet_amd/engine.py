@@ -315,6 +315,7 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
     fuse_bn_bwd = os.environ.get("CRIMAC_FUSE_BNB", "1") != "0"   # BN-backward sums inside the dgrad conv
+    fuse_up_bnb = os.environ.get("CRIMAC_FUSE_UPBNB", "1") != "0"  # ... and inside the transposed-conv dgrad
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
                  stats=None, bnb=None):
@@ -357,8 +358,22 @@ class UNetEngine:
              ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(self.P[u.key + ".bias"]), u.cout, out.p, out.ld,
              0, 1, u.cout, flops=2.0 * 4 * u.cin * u.cout * B * H * W)
 
-    def _upconv_dgrad(self, dy: Act, u, out: Act, B, H, W):
-        """dy on the fine grid [B,2H,2W,cout] -> dx on the coarse grid [B,H,W,cin]."""
+    def _upconv_dgrad(self, dy: Act, u, out: Act, B, H, W, next_bn=None):
+        """dy on the fine grid [B,2H,2W,cout] -> dx on the coarse grid [B,H,W,cin].
+
+        next_bn=(block, y): dx is the ``da`` of that BatchNorm block -> take its backward sums in the epilogue
+        (bf16 kernel shapes only).  Returns whether they were taken."""
+        pk = self.pk[u.key]
+        if (next_bn is not None and self.fuse_bn_bwd and self.fuse_up_bnb and self.prec == hip.PREC_NAMES["bf16"]
+                and u.cout % 64 == 0 and u.cin % 128 == 0 and 8 * B * H * W * dy.ld < (1 << 31)):
+            blk, y = next_bn
+            call("crimac_upconv2x2_dgrad_bnb", dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]), out.p, out.ld,
+                 *self._bnb_args(blk, y), flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+            return True
+        self._upconv_dgrad_plain(dy, u, out, B, H, W)
+        return False
+
+    def _upconv_dgrad_plain(self, dy: Act, u, out: Act, B, H, W):
         pk = self.pk[u.key]
         call("crimac_igemm_conv", self.prec, dy.p, dy.ld, B, 2 * H, 2 * W, H, W, u.cout, u.cin, 4, 2, 0,
              2, ptr(pk["dg_hi"]), ptr(pk["dg_lo"]), None, 0, out.p, out.ld, 0, 0, 0,
@@ -637,6 +652,7 @@ class UNetEngine:
              ptr(self.G["conv_final.bias"]), B, H, W, self.n_classes,
              *self._bnb_args(self.dec[D - 2][1], s[f"d{D - 2}"][4] if head_fused else None))
         skip_grad = {}
+        cur_done = head_fused            # BatchNorm-backward sums of d_cur's block already taken by its producer
         for j in reversed(range(D - 1)):
             L = D - 2 - j
             h, w, M = geo[L]
@@ -646,7 +662,7 @@ class UNetEngine:
             x_prev, catA, y1, a1, y2, a2 = s[f"d{j}"]
             da1 = Act(self._buf(f"g.d{j}.a1", (M, c)), c)
             fused = self._block_bwd(f"g.d{j}.2", b2, d_cur, y2, a1, B, h, w, M, da1, next_bn=(b1, y1),
-                                    reduce_done=head_fused and j == D - 2)
+                                    reduce_done=cur_done)
             dcat = Act(self._buf(f"g.d{j}.cat", (M, 2 * c)), 2 * c)
             # transposed conv bias gradient (unet.py:130) = column sums of dcat[:, :c]: from the dgrad epilogue
             self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat, reduce_done=fused,
@@ -659,7 +675,9 @@ class UNetEngine:
             call("crimac_wgrad", self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp,
                  wp, ptr(dw), self.wgrad_target_blocks, flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
             d_prev = Act(self._buf(f"g.d{j}.xprev", (Mp, u.cin)), u.cin)
-            self._upconv_dgrad(dup, u, d_prev, B, hp, wp)
+            # d_prev is the `da` of the next coarser block (decoder j-1, or the bottleneck encoder block)
+            nxt = (self.dec[j - 1][1], s[f"d{j - 1}"][4]) if j > 0 else (self.enc[D - 1][1], s[f"e{D - 1}"][3])
+            cur_done = self._upconv_dgrad(dup, u, d_prev, B, hp, wp, next_bn=nxt)
             d_cur = d_prev
         self._unpack_group(0)
         if on_ready is not None:
@@ -679,7 +697,7 @@ class UNetEngine:
                      da2.p, da2.ld, B, h, w, c, *self._bnb_args(b2, y2 if self.fuse_bn_bwd else None))
             da1 = Act(self._buf(f"g.e{i}.a1", (M, c)), c)
             fused = self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1, next_bn=(b1, y1),
-                                    reduce_done=self.fuse_bn_bwd and i != D - 1)
+                                    reduce_done=(self.fuse_bn_bwd and i != D - 1) or (i == D - 1 and cur_done))
             if i > 0:
                 d_pool = Act(self._buf(f"g.e{i}.xin", (M, b1.cin)), b1.cin)
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool, reduce_done=fused)

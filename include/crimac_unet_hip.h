@@ -60,6 +60,20 @@ int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int W
                       const void* w_lo, const float* bias, int bias_mod, void* out, long out_ld,
                       int relu, int out_mode, int cout_up, void* stream);
 
+/* Input gradient of nn.ConvTranspose2d k2 s2 (unet.py:47-49, :130; aten::convolution_backward, pipeline.py:177)
+ * when the result is the gradient `da` of a BatchNorm+ReLU block's output (unet.py:121-122, :135-136): that
+ * block's BatchNorm-backward sums are accumulated in the epilogue exactly as crimac_conv3x3 stat_mode 2 does
+ * (bnb_y = the block's saved conv output on the COARSE grid [B][H][W], bnb_vec rows mean | invstd | scale |
+ * shift with row stride bnb_stride, fp64 accumulators [stat_replicas][Cin]).  bf16 only.
+ *   dy [B][2H][2W] (dy_ld) fine grid, Cout channels; w_dg_hi: dgrad planes of crimac_pack_upconv2x2 /
+ *   crimac_pack_layers, bf16 [4][Cin][Cout]; dx [B][H][W] (dx_ld), Cin channels.
+ *   Cout % 64 == 0, Cin % 128 == 0, dy below 2 GiB; otherwise an error (use crimac_igemm_conv +
+ *   crimac_bn_bwd_reduce). */
+int crimac_upconv2x2_dgrad_bnb(const void* dy, long dy_ld, int B, int H, int W, int Cout, int Cin,
+                               const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y, long bnb_y_ld,
+                               const float* bnb_vec, long bnb_stride, double* stat_sum, double* stat_sumsq,
+                               int stat_replicas, void* stream);
+
 /* 3x3 convolution, stride 1, pad 1 (nn.Conv2d forward, unet.py:35-44; with the dgrad weight planes
  * of crimac_pack_conv3x3 it is the input gradient): halo tile staged once per channel chunk in LDS,
  * weights streamed two steps ahead, coalesced epilogue.  w_hi/w_lo: bf16 [9][N][Cin].
