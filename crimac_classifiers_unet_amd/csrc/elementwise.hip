@@ -551,9 +551,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ logits, long npix, long HW,
-                                                       int softmax) {
+                                                       int softmax, const float* __restrict__ bn_scale,
+                                                       const float* __restrict__ bn_shift) {
   const int lp = Cin / 8;               // lanes per pixel (power of two <= 64)
   const int sub = threadIdx.x % lp;
+  // bn_scale: x is the raw conv output of the last BatchNorm block, its activation relu(x*scale+shift)
+  // (rounded to the storage type, as bn_act would have stored it) is formed here -- one pass over it saved
+  float bsc[8], bsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bsc[j] = bn_scale ? bn_scale[sub * 8 + j] : 1.f;
+    bsh[j] = bn_scale ? bn_shift[sub * 8 + j] : 0.f;
+  }
   float wr[NC][8];
 #pragma unroll
   for (int o = 0; o < NC; ++o)
@@ -568,6 +577,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
     if (p < npix) {
       float v[8];
       load8(x + p * x_ld + sub * 8, v);
+      if (bn_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)(T)fmaxf(v[j] * bsc[j] + bsh[j], 0.f);
+      }
 #pragma unroll
       for (int o = 0; o < NC; ++o)
 #pragma unroll
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       if (ok[u]) {
 #pragma unroll
         for (int o = 0; o < NC; ++o) g[u][o] = dl[(pb[u] * NC + o) * HW + phw[u]];
-        load8(x + pu * x_ld + sub * 8, v[u]);
+        if (x) load8(x + pu * x_ld + sub * 8, v[u]);
         if constexpr (BNB) load8(reinterpret_cast<const T*>(bnb.y) + pu * bnb.y_ld + sub * 8, yv[u]);
       }
       pb[u] += step_b;
@@ -658,6 +671,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       if (!ok[u]) continue;
       const long pu = p + u * step;
       float o8[8];
+      if constexpr (BNB) {
+        if (!x) {        // the head input is the activation of the block whose y is at hand: rebuild it
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = (float)(T)fmaxf(yv[u][j] * k.sc[j] + k.sh[j], 0.f);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float s = 0.f;
@@ -1071,12 +1090,13 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
 
 template <typename T>
 static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, const float* b,
-                           float* logits, long npix, long HW, int ncls, int softmax, hipStream_t st) {
+                           float* logits, long npix, long HW, int ncls, int softmax, const float* bn_scale,
+                           const float* bn_shift, hipStream_t st) {
   const int lp = Cin / 8;
   const int grid = grid_for(npix, (256 / lp) * 8);
 #define HF(NC)                                                                                      \
   hipLaunchKernelGGL((head_fwd_kernel<T, NC>), dim3(grid), dim3(256), 0, st, (const T*)x, x_ld, Cin, \
-                     w, b, logits, npix, HW, softmax)
+                     w, b, logits, npix, HW, softmax, bn_scale, bn_shift)
   if (ncls == 2) HF(2); else if (ncls == 3) HF(3); else HF(4);
 #undef HF
   CRIMAC_LAUNCH_CHECK();
@@ -1090,16 +1110,17 @@ static bool head_cin_ok(int Cin) {
 
 extern "C" int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, const float* w,
                                const float* b, float* logits, int B, int H, int W, int ncls,
-                               int softmax, void* stream) {
+                               int softmax, const float* bn_scale, const float* bn_shift, void* stream) {
   PREC_OK("head_fwd");
   CRIMAC_REQUIRE(x && w && b && logits && B > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
   CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "head_fwd: ncls=%d unsupported (2..4)", ncls);
   CRIMAC_REQUIRE(head_cin_ok(Cin) && x_ld >= Cin && x_ld % 8 == 0,
                  "head_fwd: Cin=%d must be 8*2^k <= 512", Cin);
+  CRIMAC_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "head_fwd: bn_scale and bn_shift go together");
   const long HW = (long)H * W;
   return prec == CRIMAC_PREC_BF16
-             ? head_fwd_launch<bf16_t>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, ST)
-             : head_fwd_launch<float>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, ST);
+             ? head_fwd_launch<bf16_t>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale, bn_shift, ST)
+             : head_fwd_launch<float>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale, bn_shift, ST);
 }
 
 template <typename T>
@@ -1129,9 +1150,10 @@ extern "C" int crimac_head_bwd(int prec, const float* dlogits, const void* x, lo
                                long bnb_stride, double* stat_sum, double* stat_sumsq, int stat_replicas,
                                void* stream) {
   PREC_OK("head_bwd");
-  CRIMAC_REQUIRE(dlogits && x && w && dx && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
+  CRIMAC_REQUIRE(dlogits && w && dx && dw && db && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
+  CRIMAC_REQUIRE(x || (bnb_y && stat_sum), "head_bwd: x may only be NULL together with the fused BatchNorm sums");
   CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "head_bwd: ncls=%d unsupported (2..4)", ncls);
-  CRIMAC_REQUIRE(head_cin_ok(Cin) && x_ld >= Cin && dx_ld >= Cin && x_ld % 8 == 0 && dx_ld % 8 == 0,
+  CRIMAC_REQUIRE(head_cin_ok(Cin) && (!x || (x_ld >= Cin && x_ld % 8 == 0)) && dx_ld >= Cin && dx_ld % 8 == 0,
                  "head_bwd: Cin=%d must be 8*2^k <= 512", Cin);
   CRIMAC_REQUIRE(bnb_args_ok(bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas, Cin),
                  "head_bwd: bad arguments of the fused BatchNorm-backward sums");

@@ -316,6 +316,9 @@ class UNetEngine:
     conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
     fuse_bn_bwd = os.environ.get("CRIMAC_FUSE_BNB", "1") != "0"   # BN-backward sums inside the dgrad conv
     fuse_up_bnb = os.environ.get("CRIMAC_FUSE_UPBNB", "1") != "0"  # ... and inside the transposed-conv dgrad
+    # BatchNorm+ReLU of the last decoder block applied inside the 1x1 head (needs fuse_bn_bwd: the head's backward
+    # rebuilds its input from the y it reads for the fused sums)
+    fuse_head_bn = fuse_bn_bwd and os.environ.get("CRIMAC_FUSE_HEADBN", "1") != "0"
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
                  stats=None, bnb=None):
@@ -462,6 +465,7 @@ class UNetEngine:
             self._pack_eval()
         cur = Act(xin, CIN_PAD)
         saved = {"B": B, "H": H, "W": W, "x0": cur}
+        head_bn = None
         for i in range(D):
             h, w, M = geo[i]
             c = self.sf * 2 ** i
@@ -517,7 +521,13 @@ class UNetEngine:
                 self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
                               relu=False, stats=(self._stat(b2, 0), self._stat(b2, 1)))
                 self._bn_train(b2, y2, M)
-                self._act(b2, y2, a2, None, B, h, w)
+                if j == D - 2 and self.fuse_head_bn and self.fuse_bn_bwd:
+                    # the last block's activation only feeds the 1x1 head: formed on the fly there (forward and
+                    # backward) from y2 -- one read + one write of the largest activation saved, twice
+                    head_bn = b2
+                    a2 = y2
+                else:
+                    self._act(b2, y2, a2, None, B, h, w)
                 saved[f"d{j}"] = (cur, catA, y1, a1, y2, a2)
             else:
                 pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
@@ -526,8 +536,10 @@ class UNetEngine:
             cur = a2
         logits = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=self.device)
         call("crimac_head_fwd", self.prec, cur.p, cur.ld, self.sf, ptr(self.P["conv_final.weight"]),
-             ptr(self.P["conv_final.bias"]), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0)
-        saved["head_in"] = cur
+             ptr(self.P["conv_final.bias"]), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0,
+             ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
+             ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
+        saved["head_in"] = cur if head_bn is None else None
         self.saved = saved if training else None
         return logits
 
@@ -647,7 +659,10 @@ class UNetEngine:
         d_cur = Act(self._buf("g.head", (M, self.sf)), self.sf)
         # d_cur is the `da` of the last decoder block's second BatchNorm: its backward sums are taken here
         head_fused = self.fuse_bn_bwd and D >= 2
-        call("crimac_head_bwd", self.prec, ptr(dlogits), head_in.p, head_in.ld, self.sf,
+        if head_in is None and not head_fused:
+            raise RuntimeError("head input was not materialised (fuse_head_bn) but the fused BatchNorm sums are off")
+        call("crimac_head_bwd", self.prec, ptr(dlogits), head_in.p if head_in is not None else None,
+             head_in.ld if head_in is not None else 0, self.sf,
              ptr(self.P["conv_final.weight"]), d_cur.p, d_cur.ld, ptr(self.G["conv_final.weight"]),
              ptr(self.G["conv_final.bias"]), B, H, W, self.n_classes,
              *self._bnb_args(self.dec[D - 2][1], s[f"d{D - 2}"][4] if head_fused else None))

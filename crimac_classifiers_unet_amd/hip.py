@@ -46,7 +46,7 @@ SIGNATURES = {
     "crimac_bn_bwd_reduce": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp],
     "crimac_bn_bwd_apply": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _vp, _l, _vp,
                             _vp, _vp, _vp],
-    "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp,
                         _i, _vp],
     "crimac_wce_fwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -193,9 +193,14 @@ int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, lon
 /* ---- 1x1 head, loss, optimiser --------------------------------------------------------------- */
 
 /* conv_final 1x1 (unet.py:59-60, :342): logits [B][ncls][H][W] fp32 (NCHW, as the reference
- * returns them); softmax != 0 applies F.softmax(dim=1) (pipeline.py:218). ncls in 2..4. */
+ * returns them); softmax != 0 applies F.softmax(dim=1) (pipeline.py:218). ncls in 2..4.
+ * bn_scale / bn_shift (both or neither; NULL = x is the activation itself): x is the raw conv output of
+ * the last BatchNorm block (unet.py:121-122, :136) and its BatchNorm+ReLU is applied on the fly -- the
+ * activation is never written.  crimac_head_bwd with x == NULL (only together with the fused sums, bnb_*)
+ * rebuilds it the same way from bnb_y and the scale / shift rows of bnb_vec. */
 int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, const float* w, const float* b,
-                    float* logits, int B, int H, int W, int ncls, int softmax, void* stream);
+                    float* logits, int B, int H, int W, int ncls, int softmax, const float* bn_scale,
+                    const float* bn_shift, void* stream);
 int crimac_head_bwd(int prec, const float* dlogits, const void* x, long x_ld, int Cin, const float* w,
                     void* dx, long dx_ld, float* dw, float* db, int B, int H, int W, int ncls,
                     const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,

@@ -320,6 +320,46 @@ def test_unpool_first_max_tie_rule(prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+def test_head_with_batchnorm_relu_applied_on_the_fly(prec):
+    """head_fwd(bn_scale, bn_shift) on the raw conv output == head_fwd on the stored activation; head_bwd with
+    x == NULL rebuilds that activation from bnb_y: identical dw / db / dx / fused sums."""
+    B, H, W, C, ncls = 2, 24, 40, 64, 3
+    g = torch.Generator().manual_seed(31)
+    P, d = hip.PREC_NAMES[prec], "cuda"
+    M = B * H * W
+    y = (torch.randn(M, C, generator=g) * 1.3 + 0.2).to(_dt(prec)).cuda()
+    vec = torch.stack([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5,
+                       torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3]).contiguous().cuda()
+    wd = (torch.randn(ncls, C, generator=g) / 8).cuda()
+    bd = (torch.randn(ncls, generator=g) * 0.1).cuda()
+    a = torch.empty_like(y)                      # the activation as bn_act stores it
+    call("crimac_bn_act_pool", P, ptr(y), C, ptr(vec[2]), ptr(vec[3]), 1, ptr(a), C, None, 0, B, H, W, C)
+    z_ref = torch.empty(B, ncls, H, W, dtype=torch.float32, device=d)
+    z = torch.empty_like(z_ref)
+    call("crimac_head_fwd", P, ptr(a), C, C, ptr(wd), ptr(bd), ptr(z_ref), B, H, W, ncls, 0, None, None)
+    call("crimac_head_fwd", P, ptr(y), C, C, ptr(wd), ptr(bd), ptr(z), B, H, W, ncls, 0, ptr(vec[2]), ptr(vec[3]))
+    torch.cuda.synchronize()
+    assert torch.equal(z, z_ref)
+    dl = torch.randn(B, ncls, H, W, generator=g).cuda()
+    outs = []
+    for xin in (a, None):
+        dx = torch.empty(M, C, dtype=_dt(prec), device=d)
+        dw = torch.zeros(ncls, C, dtype=torch.float32, device=d)
+        db = torch.zeros(ncls, dtype=torch.float32, device=d)
+        rep = torch.zeros(2, 4, C, dtype=torch.float64, device=d)
+        call("crimac_head_bwd", P, ptr(dl), ptr(xin) if xin is not None else None, C if xin is not None else 0, C,
+             ptr(wd), ptr(dx), C, ptr(dw), ptr(db), B, H, W, ncls, ptr(y), C, ptr(vec), C, ptr(rep[0]), ptr(rep[1]), 4)
+        torch.cuda.synchronize()
+        outs.append((dx, dw, db, rep.sum(1)))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert relerr(outs[1][1], outs[0][1]) < 1e-5 and relerr(outs[1][2], outs[0][2]) < 1e-5
+    assert relerr(outs[1][3], outs[0][3]) < 1e-9
+    with pytest.raises(hip.HipLibraryError):     # x == NULL without the fused sums
+        call("crimac_head_bwd", P, ptr(dl), None, 0, C, ptr(wd), ptr(dx), C, ptr(dw), ptr(db), B, H, W, ncls,
+             None, 0, None, 0, None, None, 1)
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("ncls", [3, 2])
 def test_head_and_weighted_ce(prec, ncls):
     B, H, W, C = 2, 16, 16, 64
@@ -335,8 +375,8 @@ def test_head_and_weighted_ce(prec, ncls):
     wd, bd, cwd = w.to(d), b.to(d), cw.to(d)
     logits = torch.empty(B, ncls, H, W, dtype=torch.float32, device=d)
     soft = torch.empty_like(logits)
-    call("crimac_head_fwd", P, ptr(xn), C, C, ptr(wd), ptr(bd), ptr(logits), B, H, W, ncls, 0)
-    call("crimac_head_fwd", P, ptr(xn), C, C, ptr(wd), ptr(bd), ptr(soft), B, H, W, ncls, 1)
+    call("crimac_head_fwd", P, ptr(xn), C, C, ptr(wd), ptr(bd), ptr(logits), B, H, W, ncls, 0, None, None)
+    call("crimac_head_fwd", P, ptr(xn), C, C, ptr(wd), ptr(bd), ptr(soft), B, H, W, ncls, 1, None, None)
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     zr = F.conv2d(xr, wr, br)
     loss_r = F.cross_entropy(zr, labels, weight=cw, ignore_index=-100)
