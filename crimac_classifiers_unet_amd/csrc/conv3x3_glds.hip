@@ -640,6 +640,265 @@ int launch_c16(ConvParams p, hipStream_t st) {
   return CRIMAC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 64 -> 64 channels at 256x256 (level 0 / last decoder level, forward and input gradient: 4 launches per
+// step): PERSISTENT kernel, one workgroup of 8 waves per CU.
+//   * ALL weights (9 x 64 x 64 bf16 = 72 KB) are loaded into LDS once per workgroup: no weight DMA per tile
+//     (64 % of the W4 kernel's LDS-DMA traffic), no weight ring, NO barrier inside the 9-tap loop;
+//   * two teams of 4 waves, each with its own 16x16-pixel tile and halo buffer (2 x 40.5 KB); wave w of a team
+//     owns image rows 4w .. 4w+3 x 64 channels (4 x 4 tiles of 16x16x32), as in the W4 kernel;
+//   * the NEXT tile's halo travels global -> registers (11 x 16 B per thread) while the current tile is
+//     computed and written, and moves registers -> LDS after it (the c16 kernel's scheme);
+//   * output through wave-private slabs inside the (then dead) halo buffer, one 16-pixel image row (2 KB
+//     contiguous) at a time; BatchNorm statistics (mode 1) and BatchNorm-backward sums (mode 2) stay in
+//     registers across tiles and are flushed once per workgroup.
+// Three workgroup barriers per tile (halo written | halo consumed | slabs consumed) instead of 9+.
+template <int MODE>        // statistics mode of the epilogue (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv3x3_p64_kernel(ConvParams p, int ntiles) {
+  constexpr int BN = 64, NT = 4;
+  constexpr int W_BYTES = 9 * BN * RB;               // 73728
+  constexpr int H_BYTES = HALO_ROWS * RB;            // 41472
+  constexpr int NHU = (HALO_ROWS * 8 + 255) / 256;   // 16-byte halo units per thread: 11
+  constexpr int SLAB_PITCH = BN * 2 + 16, SLAB = 16 * SLAB_PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;
+  const int tid = threadIdx.x, team = tid >> 8, tt = tid & 255, lane = tid & 63, wave = tt >> 6;
+  unsigned char* halo = smem + W_BYTES + team * H_BYTES;
+  unsigned char* slab = halo + wave * SLAB;
+  float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);          // [2][64]
+  const EpiParams& e = p.epi;
+  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
+  bf16_t* outp = reinterpret_cast<bf16_t*>(e.out);
+  constexpr int mode = MODE;
+  if (tid < 2 * BN) sstat[tid] = 0.f;
+
+  // weights: LDS unit c of row (t, n) holds source unit c ^ swizzle(n) (as the W4 weight slots)
+  for (int u = tid; u < 9 * BN * 8; u += 512) {
+    const int row = u >> 3, c = u & 7, n = row & (BN - 1);
+    *reinterpret_cast<u32x4*>(wl + u * 16) =
+        *reinterpret_cast<const u32x4*>(p.w_hi + (long)row * BN + ((c ^ ((n >> 1) & 7)) * 8));
+  }
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int bsw = (fr >> 1) & 7;                     // weight-row swizzle of rows j*16 + fr
+  int asw[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) asw[kx] = halo_swz(fr + kx);
+  float bv[NT], cs1[NT], cs2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bv[j] = e.bias ? e.bias[j * 16 + fr] : 0.f;
+    cs1[j] = 0.f;
+    cs2[j] = 0.f;
+  }
+  // mode 2: this lane always stores channel chunk c8 = lane & 7 -> its BatchNorm constants live in registers
+  const int c8 = lane & 7;
+  float sc[8], sh[8], mu[8], d1[8], d2[8];        // (d2 accumulates dz * (y - mean); invstd is applied at the flush)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c8 * 8 + k;
+    mu[k] = mode == 2 ? e.bnb_vec[c] : 0.f;
+    sc[k] = mode == 2 ? e.bnb_vec[2 * e.bnb_stride + c] : 0.f;
+    sh[k] = mode == 2 ? e.bnb_vec[3 * e.bnb_stride + c] : 0.f;
+    d1[k] = 0.f;
+    d2[k] = 0.f;
+  }
+
+  auto tile_geo = [&](int tile, int& b, int& y0, int& x0) {
+    const int txi = tile % p.tiles_x;
+    const int q = tile / p.tiles_x;
+    b = q / p.tiles_y;
+    y0 = (q % p.tiles_y) * TR;
+    x0 = txi * TC;
+  };
+  u32x4 hreg[NHU];
+  auto fetch_halo = [&](int tile) {
+    int b, y0, x0;
+    tile_geo(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < NHU; ++i) {
+      const int u = tt + i * 256;
+      const int row = u >> 3, c = u & 7;
+      const int hy = row / HP, hx = row - hy * HP;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      hreg[i] = u32x4{0, 0, 0, 0};
+      if (u < HALO_ROWS * 8 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+        hreg[i] = *reinterpret_cast<const u32x4*>(inp + (((long)b * p.H + y) * p.W + x) * p.in_ld +
+                                                  ((c ^ halo_swz(hx)) * 8));
+    }
+  };
+
+  const int stride = 2 * gridDim.x;
+  int tile = 2 * blockIdx.x + team;
+  if (tile < ntiles) fetch_halo(tile);
+  // both teams run the same number of iterations (the barriers are workgroup-wide); a team without a tile idles
+  const int niter = (ntiles - 2 * (int)blockIdx.x + stride - 1) / stride;
+  for (int it = 0; it < niter; ++it, tile += stride) {
+    const bool active = tile < ntiles;
+    int b = 0, y0 = 0, x0 = 0;
+    if (active) tile_geo(tile, b, y0, x0);
+    __syncthreads();                            // slabs of the previous tile consumed (and weights in place)
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < NHU; ++i) {
+        const int u = tt + i * 256;
+        if (u < HALO_ROWS * 8) *reinterpret_cast<u32x4*>(halo + u * 16) = hreg[i];
+      }
+    }
+    __syncthreads();                            // halo in place
+    if (tile + stride < ntiles) fetch_halo(tile + stride);
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    if (active) {
+      // (tap rows not unrolled: a fully unrolled 9-tap body lets the compiler hoist fragment reads until the
+      // long-lived statistics registers spill)
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t = ky * 3 + kx;
+        const unsigned char* a0 = halo + ((wave * 4 + ky) * HP + fr + kx) * RB;
+        const unsigned char* b0 = wl + (t * BN + fr) * RB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int unit = 4 * ks + fq;
+          bf16x8 af[4], bfr[NT];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(a0 + i * (HP * RB) + ((unit ^ asw[kx]) << 4));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8*>(b0 + j * (16 * RB) + ((unit ^ bsw) << 4));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                            // halo consumed: its buffer now holds the output slabs
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int y = y0 + wave * 4 + i;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int px = (lane >> 4) * 4 + r;
+            float v = acc[i][j][r] + bv[j];
+            if (e.relu) v = fmaxf(v, 0.f);
+            const bf16_t q = (bf16_t)v;
+            *reinterpret_cast<bf16_t*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
+            if (mode == 1) {
+              const float vs = (float)q;        // statistics of the value as STORED
+              const bool ok = y < p.H && x0 + px < p.W;
+              cs1[j] += ok ? vs : 0.f;
+              cs2[j] += ok ? vs * vs : 0.f;
+            }
+          }
+        // (wave-private slab: the LDS operations of one wave execute in order)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int px = (lane >> 3) + 8 * k;
+          const bf16_t* sp = reinterpret_cast<const bf16_t*>(slab + px * SLAB_PITCH) + c8 * 8;
+          if (y < p.H && x0 + px < p.W) {
+            const long pix = ((long)b * p.H + y) * p.W + x0 + px;
+            *reinterpret_cast<u32x4*>(outp + pix * e.out_ld + c8 * 8) = *reinterpret_cast<const u32x4*>(sp);
+            if (mode == 2) {
+              float g[8], yv[8];
+              load8(sp, g);
+              load8(reinterpret_cast<const bf16_t*>(e.bnb_y) + pix * e.bnb_y_ld + c8 * 8, yv);
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) {
+                const float dz = (yv[kk] * sc[kk] + sh[kk]) > 0.f ? g[kk] : 0.f;
+                d1[kk] += dz;
+                d2[kk] += dz * (yv[kk] - mu[kk]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (mode == 1) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float t1 = cs1[j], t2 = cs2[j];
+      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (lane < 16) {
+        atomicAdd(&sstat[j * 16 + lane], t1);
+        atomicAdd(&sstat[BN + j * 16 + lane], t2);
+      }
+    }
+  } else if (mode == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        d1[k] += __shfl_xor(d1[k], o, 64);
+        d2[k] += __shfl_xor(d2[k], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&sstat[c8 * 8 + k], d1[k]);
+        atomicAdd(&sstat[BN + c8 * 8 + k], d2[k] * e.bnb_vec[e.bnb_stride + c8 * 8 + k]);
+      }
+    }
+  }
+  if (mode) {
+    __syncthreads();
+    const long rep = (long)(blockIdx.x % (unsigned)e.stat_replicas) * e.N;
+    if (tid < BN) {
+      atomicAdd(&e.stat_sum[rep + tid], (double)sstat[tid]);
+      atomicAdd(&e.stat_sumsq[rep + tid], (double)sstat[BN + tid]);
+    }
+  }
+}
+
+int launch_p64(ConvParams p, hipStream_t st) {
+  p.tiles_y = cdiv(p.H, TR);
+  p.tiles_x = cdiv(p.W, TC);
+  const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
+  constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4;     // 157184 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  long grid = (ntiles + 1) / 2;
+  if (grid > ncu) grid = ncu;
+  const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
+  if (mode == 0) hipLaunchKernelGGL(conv3x3_p64_kernel<0>, dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else if (mode == 1) hipLaunchKernelGGL(conv3x3_p64_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else hipLaunchKernelGGL(conv3x3_p64_kernel<2>, dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
 }  // namespace
 
 // first layer: bf16, Cin == 16 (4 real channels), N == 64
@@ -663,6 +922,9 @@ int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, in
   // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.6 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
   // HBM-heavy N = 64 shapes W4<64> (305 / 423 us) beats a 2x2-wave channel split (319 / 458 us).
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
+  // 64 -> 64 with many tiles: persistent kernel with LDS-resident weights (CRIMAC_CONV_P64=0: W4 for A/B runs)
+  static const int p64 = getenv("CRIMAC_CONV_P64") ? atoi(getenv("CRIMAC_CONV_P64")) : 1;
+  if (p64 && N == 64 && Cin == 64 && (long)B * cdiv(H, TR) * cdiv(W, TC) >= 512) return launch_p64(p, st);
   if (N % 128 != 0) return launch_w4<64>(p, st);
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
   return (w4 == 1 || !small) ? launch_w4<128>(p, st) : launch_wch(p, st);

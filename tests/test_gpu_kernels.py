@@ -480,7 +480,8 @@ def conv3x3_halo(prec, x_nhwc, in_ld, B, H, W, Cin, Cout, w_hi, w_lo, bias, relu
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (3, 8, 16, 256, 64),
                                    (2, 16, 16, 4, 64), (1, 24, 40, 64, 192), (2, 12, 20, 32, 128),
                                    (1, 32, 32, 576, 128), (5, 100, 120, 128, 64), (3, 256, 256, 64, 64),
-                                   (2, 64, 64, 256, 256), (3, 21, 37, 4, 64), (2, 256, 256, 4, 64)])
+                                   (2, 64, 64, 256, 256), (3, 21, 37, 4, 64), (2, 256, 256, 4, 64),
+                                   (10, 100, 120, 64, 64)])       # (the last: persistent 64->64 kernel, ragged tiles)
 def test_conv3x3_halo_forward_stats(prec, shape):
     """Forward incl. fused bias/ReLU and fused BatchNorm statistics; partial tiles (H%8, W%16 != 0);
     odd number of (chunk, tap) steps (Cin = 64, 576) and even (Cin = 128); the last two shapes have more
@@ -529,7 +530,8 @@ def test_conv3x3_halo_strided_io_and_dgrad(prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 24, 40, 128, 64), (2, 32, 32, 128, 256)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 24, 40, 128, 64), (2, 32, 32, 128, 256),
+                                   (3, 256, 256, 64, 64), (7, 120, 100, 64, 64)])     # (persistent 64->64 kernel)
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(prec, shape):
     """stat_mode 2: the dgrad convolution also produces sum dz / sum dz*xhat of the BatchNorm block its
     output feeds (== crimac_bn_bwd_reduce on (da, y))."""
