@@ -653,6 +653,12 @@ int launch_c16(ConvParams p, hipStream_t st) {
 //     contiguous) at a time; BatchNorm statistics (mode 1) and BatchNorm-backward sums (mode 2) stay in
 //     registers across tiles and are flushed once per workgroup.
 // Three workgroup barriers per tile (halo written | halo consumed | slabs consumed) instead of 9+.
+// Measured (64->64 @256x256, B = 32, no statistics): 195 us vs 252-263 us (W4); MFMAs + loads alone 83 us, loads +
+// output alone 110 us -- the two still add up, because all 8 waves are in the same phase.  Tried: the two teams in
+// OPPOSITE roles (one runs its MFMAs while the other writes out and refills its halo; 8-pixel slabs outside the
+// halo buffers, one barrier per role switch): 195 us again -- a compiler-scheduled MFMA loop with ONE wave per
+// SIMD takes twice as long as with two, which cancels the overlap; it would need the hand-placed read pipeline
+// of the channel-split kernel with both operands in LDS.
 template <int MODE>        // statistics mode of the epilogue (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_p64_kernel(ConvParams p, int ntiles) {
