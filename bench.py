@@ -12,7 +12,7 @@ The inference rate (eval forward + softmax, pipeline.py:205-219) is measured nex
 reported in the same JSON line as ``infer_patches_per_s``.
 
 ``roofline``: the dominant kernel is the halo-staged implicit-GEMM 3x3 convolution (crimac_conv3x3 =
-conv3x3_wch_kernel / conv3x3_glds_w4_kernel / conv3x3_c16_kernel by layer shape): algorithmic
+conv3x3_wch_kernel / conv3x3_p64_kernel / conv3x3_glds_w4_kernel / conv3x3_c16_kernel by layer shape): algorithmic
 FLOPs of its launches (2*taps*Cin*N*M each) / their HIP-event durations, measured
 inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
 ``cpu_baseline``: the CPU oracle (oracle/unet_oracle.py, kind "port") timed on this box's host
@@ -194,7 +194,7 @@ def main():
             "infer_patches_per_s": infer,
             "infer_tflops": infer * FWD_GFLOP_PER_PATCH / 1e3 if infer else None,
             "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "kernel": "crimac_conv3x3: conv3x3_wch_kernel + conv3x3_glds_w4_kernel + conv3x3_c16_kernel "
+            "roofline": {"bound": "mfma", "kernel": "crimac_conv3x3: conv3x3_wch_kernel + conv3x3_p64_kernel + conv3x3_glds_w4_kernel + conv3x3_c16_kernel "
                                                            "(halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
