@@ -659,6 +659,15 @@ int launch_c16(ConvParams p, hipStream_t st) {
 // halo buffers, one barrier per role switch): 195 us again -- a compiler-scheduled MFMA loop with ONE wave per
 // SIMD takes twice as long as with two, which cancels the overlap; it would need the hand-placed read pipeline
 // of the channel-split kernel with both operands in LDS.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for every
+// outstanding global STORE and prefetch load of the wave -- in a persistent kernel that drains the memory
+// pipeline at every barrier and serialises the output stream with the MFMA phase.
+__device__ __forceinline__ void wg_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int MODE>        // statistics mode of the epilogue (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_p64_kernel(ConvParams p, int ntiles) {
@@ -744,7 +753,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
     const bool active = tile < ntiles;
     int b = 0, y0 = 0, x0 = 0;
     if (active) tile_geo(tile, b, y0, x0);
-    __syncthreads();                            // slabs of the previous tile consumed (and weights in place)
+    wg_barrier_lds();                           // slabs of the previous tile consumed (and weights in place)
     if (active) {
 #pragma unroll
       for (int i = 0; i < NHU; ++i) {
@@ -752,7 +761,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         if (u < HALO_ROWS * 8) *reinterpret_cast<u32x4*>(halo + u * 16) = hreg[i];
       }
     }
-    __syncthreads();                            // halo in place
+    wg_barrier_lds();                           // halo in place
     if (tile + stride < ntiles) fetch_halo(tile + stride);
 
     f32x4 acc[4][NT];
@@ -790,7 +799,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         }
       }
     }
-    __syncthreads();                            // halo consumed: its buffer now holds the output slabs
+    wg_barrier_lds();                           // halo consumed: its buffer now holds the output slabs
     if (active) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
