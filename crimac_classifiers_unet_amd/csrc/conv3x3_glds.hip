@@ -656,9 +656,10 @@ int launch_c16(ConvParams p, hipStream_t st) {
 // Measured (64->64 @256x256, B = 32, no statistics): 195 us vs 252-263 us (W4); MFMAs + loads alone 83 us, loads +
 // output alone 110 us -- the two still add up, because all 8 waves are in the same phase.  Tried: the two teams in
 // OPPOSITE roles (one runs its MFMAs while the other writes out and refills its halo; 8-pixel slabs outside the
-// halo buffers, one barrier per role switch): 195 us again -- a compiler-scheduled MFMA loop with ONE wave per
-// SIMD takes twice as long as with two, which cancels the overlap; it would need the hand-placed read pipeline
-// of the channel-split kernel with both operands in LDS.
+// halo buffers, one LDS-only barrier per role switch): 188 us.  The MFMA role alone (one wave per SIMD, no
+// output) still takes only 82 us in that form and the output role alone 115 us, yet together 188 us: it is not
+// a scheduling artefact (nor the vmcnt(0) drain of __syncthreads -- the barriers here wait for LDS only) but
+// the MFMA stream slowing down while the HBM stream runs, as everywhere else in this file.
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for every
 // outstanding global STORE and prefetch load of the wave -- in a persistent kernel that drains the memory
 // pipeline at every barrier and serialises the output stream with the MFMA phase.
