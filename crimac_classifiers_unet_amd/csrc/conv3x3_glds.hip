@@ -805,6 +805,9 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = y0 + wave * 4 + i;
+        float okm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) okm[r] = (y < p.H && x0 + (lane >> 4) * 4 + r < p.W) ? 1.f : 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -816,9 +819,9 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
             *reinterpret_cast<bf16_t*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
             if (mode == 1) {
               const float vs = (float)q;        // statistics of the value as STORED
-              const bool ok = y < p.H && x0 + px < p.W;
-              cs1[j] += ok ? vs : 0.f;
-              cs2[j] += ok ? vs * vs : 0.f;
+              const float vm = vs * okm[r];     // (0 for pixels outside the image: partial tiles)
+              cs1[j] += vm;
+              cs2[j] += vm * vs;
             }
           }
         // (wave-private slab: the LDS operations of one wave execute in order)
