@@ -101,29 +101,35 @@ __device__ __forceinline__ void wg_rd_a(unsigned fv0, WgFrags& f) {
 }
 // S fragments of step S (row pair S / N, local tap S % N).  swz16(c + 4 + R) = swz16(c + R) ^ 32: the bases of
 // the classes c & 7 >= 4 are those of c & 3 with the two 16-channel slots exchanged -> 4 registers, not 8.
-template <int MODE, int TG, int S>
+// NARROW: only the first 16-channel S fragment of the wave is real (first layer: 4 input channels padded to 16)
+template <int MODE, int TG, int S, bool NARROW>
 __device__ __forceinline__ void wg_rd_b(const unsigned (&sv)[4], WgFrags& f) {
   using G = WgTaps<MODE, TG>;
   constexpr int c = G::srow(2 * (S / G::N), G::T0 + S % G::N);
   constexpr int x = (c >> 2) & 1;
   const unsigned s0 = sv[c & 3], s1 = s0 ^ 32;
-  f.b[S & 1][x][0] = lds_tr16_asm<c * 128>(s0);
-  f.b[S & 1][x][1] = lds_tr16_asm<(c + 8) * 128>(s0);
-  f.b[S & 1][x ^ 1][0] = lds_tr16_asm<c * 128>(s1);
-  f.b[S & 1][x ^ 1][1] = lds_tr16_asm<(c + 8) * 128>(s1);
+  if constexpr (!NARROW || x == 0) {
+    f.b[S & 1][x][0] = lds_tr16_asm<c * 128>(s0);
+    f.b[S & 1][x][1] = lds_tr16_asm<(c + 8) * 128>(s0);
+  }
+  if constexpr (!NARROW || x == 1) {
+    f.b[S & 1][x ^ 1][0] = lds_tr16_asm<c * 128>(s1);
+    f.b[S & 1][x ^ 1][1] = lds_tr16_asm<(c + 8) * 128>(s1);
+  }
 }
 // F fragment FH of step S: wait for it (first step of a row pair), 2 MFMAs, then (last step of a row pair)
 // request the same fragment of the next row pair into the registers just consumed
-template <int MODE, int TG, int S, int FH, typename ACC>
+template <int MODE, int TG, int S, int FH, bool NARROW, typename ACC>
 __device__ __forceinline__ void wg_fh(unsigned fv0, WgFrags& f, ACC& acc) {
   using G = WgTaps<MODE, TG>;
   constexpr int NSTEP = G::NRP * G::N, rp = S / G::N, L = S % G::N;
-  constexpr int nb = S + 1 < NSTEP ? 4 : 0;          // S reads of the next step, issued at the top of this one
+  constexpr int NSH = NARROW ? 1 : 2;
+  constexpr int nb = S + 1 < NSTEP ? 2 * NSH : 0;    // S reads of the next step, issued at the top of this one
   if constexpr (L == 0) {
     if constexpr (rp > 0 || FH == 0) wait_lgkm<nb + (rp > 0 ? 2 * (3 - FH) : 0)>();
     if constexpr (FH == 0) {
 #pragma unroll
-      for (int sh = 0; sh < 2; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
+      for (int sh = 0; sh < NSH; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
     }
     if constexpr (rp > 0) { tie(f.a[FH][0]); tie(f.a[FH][1]); }
     else if constexpr (FH == 0) {
@@ -133,24 +139,24 @@ __device__ __forceinline__ void wg_fh(unsigned fv0, WgFrags& f, ACC& acc) {
   } else if constexpr (FH == 0) {
     wait_lgkm<nb>();
 #pragma unroll
-    for (int sh = 0; sh < 2; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
+    for (int sh = 0; sh < NSH; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
   }
   const bf16x8 af = __builtin_shufflevector(f.a[FH][0], f.a[FH][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-  for (int sh = 0; sh < 2; ++sh) {
+  for (int sh = 0; sh < NSH; ++sh) {
     const bf16x8 bfr = __builtin_shufflevector(f.b[S & 1][sh][0], f.b[S & 1][sh][1], 0, 1, 2, 3, 4, 5, 6, 7);
     acc[L][FH][sh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[L][FH][sh], 0, 0, 0);
   }
   if constexpr (L == G::N - 1 && rp + 1 < G::NRP) wg_rd_a<rp + 1, FH>(fv0, f);
-  if constexpr (FH + 1 < 4) wg_fh<MODE, TG, S, FH + 1>(fv0, f, acc);
+  if constexpr (FH + 1 < 4) wg_fh<MODE, TG, S, FH + 1, NARROW>(fv0, f, acc);
 }
-template <int MODE, int TG, int S, typename ACC>
+template <int MODE, int TG, int S, bool NARROW, typename ACC>
 __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], WgFrags& f, ACC& acc) {
   using G = WgTaps<MODE, TG>;
   constexpr int NSTEP = G::NRP * G::N;
-  if constexpr (S + 1 < NSTEP) wg_rd_b<MODE, TG, S + 1>(sv, f);
-  wg_fh<MODE, TG, S, 0>(fv0, f, acc);
-  if constexpr (S + 1 < NSTEP) wg_step<MODE, TG, S + 1>(fv0, sv, f, acc);
+  if constexpr (S + 1 < NSTEP) wg_rd_b<MODE, TG, S + 1, NARROW>(sv, f);
+  wg_fh<MODE, TG, S, 0, NARROW>(fv0, f, acc);
+  if constexpr (S + 1 < NSTEP) wg_step<MODE, TG, S + 1, NARROW>(fv0, sv, f, acc);
 }
 
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
@@ -162,7 +168,7 @@ __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], W
 // outside the image read out of range and the hardware stores zeros.  The contraction itself runs on the
 // hand-placed read/MFMA schedule above (wg_row).
 // fp32 (split-bf16) path: register staging with the hi/lo split, single buffer.
-template <typename TA, int NPL, int MODE>
+template <typename TA, int NPL, int MODE, bool NARROW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void wgrad_kernel(WgradParams p) {
   constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
@@ -387,12 +393,16 @@ void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) sv[k] = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(k + RSl));
         WgFrags f;
-        wg_rd_a<0, 0>(fv0, f);
-        wg_rd_a<0, 1>(fv0, f);
-        wg_rd_a<0, 2>(fv0, f);
-        wg_rd_a<0, 3>(fv0, f);
-        wg_rd_b<MODE, TG, 0>(sv, f);
-        wg_step<MODE, TG, 0>(fv0, sv, f, acc2);
+        // NARROW (first layer, CS <= 16): only S fragment 0 of the ws = 0 waves is real; the ws = 1 waves just
+        // move tiles
+        if (!NARROW || ws == 0) {
+          wg_rd_a<0, 0>(fv0, f);
+          wg_rd_a<0, 1>(fv0, f);
+          wg_rd_a<0, 2>(fv0, f);
+          wg_rd_a<0, 3>(fv0, f);
+          wg_rd_b<MODE, TG, 0, NARROW>(sv, f);
+          wg_step<MODE, TG, 0, NARROW>(fv0, sv, f, acc2);
+        }
 #endif
       }
       // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps
@@ -476,7 +486,7 @@ void wgrad_kernel(WgradParams p) {
   }
 }
 
-template <typename TA, int NPL, int MODE>
+template <typename TA, int NPL, int MODE, bool NARROW = false>
 int launch(WgradParams p, int target_blocks, hipStream_t st) {
   constexpr int TR = MODE == 0 ? 8 : 4;
   constexpr int F_ROWS = TR * 16;
@@ -509,11 +519,11 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 : NPL);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, NPL, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, NPL, MODE, NARROW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE>), dim3(ch_tiles * splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE, NARROW>), dim3(ch_tiles * splits), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -532,8 +542,10 @@ extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF
   p.f = f; p.f_ld = f_ld; p.CF = CF; p.s = s; p.s_ld = s_ld; p.CS = CS;
   p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw;
   hipStream_t st = (hipStream_t)stream;
-  if (prec == CRIMAC_PREC_BF16)
+  if (prec == CRIMAC_PREC_BF16) {
+    if (mode == 0 && CS <= 16) return launch<bf16_t, 1, 0, true>(p, target_blocks, st);     // first layer
     return mode == 0 ? launch<bf16_t, 1, 0>(p, target_blocks, st) : launch<bf16_t, 1, 1>(p, target_blocks, st);
+  }
   if (prec == CRIMAC_PREC_F32X3)
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
   return mode == 0 ? launch<float, 3, 0>(p, target_blocks, st) : launch<float, 3, 1>(p, target_blocks, st);

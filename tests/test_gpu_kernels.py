@@ -198,7 +198,8 @@ def test_conv3x3_wgrad(prec, shape, target_blocks):
 
 
 @pytest.mark.parametrize("mode,shape", [(0, (2, 128, 128, 128, 64)), (0, (1, 256, 256, 64, 64)),
-                                        (0, (2, 100, 120, 64, 128)), (1, (2, 64, 64, 128, 64))])
+                                        (0, (2, 100, 120, 64, 128)), (1, (2, 64, 64, 128, 64)),
+                                        (0, (2, 128, 128, 16, 64))])      # (the last: first-layer narrow-S kernel)
 def test_wgrad_many_workgroups_auto_split(mode, shape):
     """bf16 weight gradient with the library's own pixel split (target_blocks = 0): hundreds of workgroups in
     flight, several tiles per workgroup -- the hand-placed LDS-read pipeline (asm loads, counted waits) only
