@@ -167,6 +167,9 @@ __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], W
 // wave-instruction), so the tr-read swizzle is applied on the per-lane SOURCE offset; lanes whose pixel is
 // outside the image read out of range and the hardware stores zeros.  The contraction itself runs on the
 // hand-placed read/MFMA schedule above (wg_row).
+// Tried and rejected: warming the XCD's L2 two tiles ahead with one ordinary 4-byte load per 128-byte line (the
+// LDS budget allows only one tile in flight per workgroup and the level-0 shapes wait for their tiles at
+// 3.9 TB/s): every shape got 8-15 % SLOWER (2.49 vs 2.25 ms over the 13 conv shapes).
 // fp32 (split-bf16) path: register staging with the hi/lo split, single buffer.
 template <typename TA, int NPL, int MODE, bool NARROW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
