@@ -260,8 +260,38 @@ class UNetEngine:
         call("crimac_pack_layers", C.byref(arr), len(arr), self.planes)
         self._train_pack_dirty = False
 
+    # Weight gradients on a second stream: wgrad(layer) and the input-gradient convolution of the same layer
+    # both only read dz, so they can share the GPU -- the ragged last round of one kernel and the launch gap
+    # behind it are filled by the other.  The packed gradients are joined back before they are unpacked.
+    # (CRIMAC_WGRAD_STREAM = number of side streams, round-robin; 0 = everything on the caller's stream)
+    wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
+    _side = None
+    _side_events = None
+
+    def _wgrad(self, *args, flops=None):
+        if self.wgrad_side_streams <= 0:
+            call("crimac_wgrad", *args, flops=flops)
+            return
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.wgrad_side_streams)]
+            self._side_events = [torch.cuda.Event() for _ in range(32)]
+            self._side_i = 0
+        ev = self._side_events[self._side_i % len(self._side_events)]
+        side = self._side[self._side_i % len(self._side)]
+        self._side_i += 1
+        ev.record()                                   # everything wgrad reads has been queued on this stream
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            call("crimac_wgrad", *args, flops=flops)
+
+    def _join_wgrad(self):
+        if self._side is not None:
+            for side in self._side:
+                torch.cuda.current_stream().wait_stream(side)
+
     def _unpack_group(self, gi):
         """Packed weight gradients of backward group gi -> torch-layout gradients in the flat buffer."""
+        self._join_wgrad()
         arr, bounds = self._layer_table()
         first, n = bounds[gi]
         if n:
@@ -581,7 +611,7 @@ class UNetEngine:
              #            (the reference holds ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
         n = 9 * b.cout * b.cin_pad
         dw = self._dw(b.conv_key, n)
-        call("crimac_wgrad", self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w,
+        self._wgrad(self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w,
              ptr(dw), self.wgrad_target_blocks, flops=2.0 * 9 * b.cin * b.cout * B * h * w)
         fused = False
         if dx_out is not None:
@@ -687,7 +717,7 @@ class UNetEngine:
             hp, wp, Mp = geo[L + 1]
             n = 4 * u.cin * u.cout
             dw = self._dw(u.key, n)
-            call("crimac_wgrad", self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp,
+            self._wgrad(self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp,
                  wp, ptr(dw), self.wgrad_target_blocks, flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
             d_prev = Act(self._buf(f"g.d{j}.xprev", (Mp, u.cin)), u.cin)
             # d_prev is the `da` of the next coarser block (decoder j-1, or the bottleneck encoder block)
