@@ -265,6 +265,7 @@ class UNetEngine:
     # behind it are filled by the other.  The packed gradients are joined back before they are unpacked.
     # (CRIMAC_WGRAD_STREAM = number of side streams, round-robin; 0 = everything on the caller's stream)
     wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
+    unpack_on_side = os.environ.get("CRIMAC_UNPACK_SIDE", "1") != "0"
     _side = None
     _side_events = None
 
@@ -289,13 +290,31 @@ class UNetEngine:
             for side in self._side:
                 torch.cuda.current_stream().wait_stream(side)
 
-    def _unpack_group(self, gi):
-        """Packed weight gradients of backward group gi -> torch-layout gradients in the flat buffer."""
-        self._join_wgrad()
+    def _unpack_group(self, gi, on_ready=None, rng=None):
+        """Packed weight gradients of backward group gi -> torch-layout gradients in the flat buffer; then
+        ``on_ready(*rng)`` (the gradient exchange of that range).  With ONE side stream both are queued behind
+        the weight gradients on that stream -- the caller's stream is not held up (it joins at the end of the
+        backward pass); a collective launched there orders itself after the side stream."""
         arr, bounds = self._layer_table()
         first, n = bounds[gi]
+        side = self._side[0] if (self._side is not None and len(self._side) == 1 and self.unpack_on_side) else None
+        if side is not None:
+            # bias / BatchNorm gradients of the range are written on the caller's stream: order them first
+            ev = self._side_events[self._side_i % len(self._side_events)]
+            self._side_i += 1
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                if n:
+                    call("crimac_unpack_wgrad_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n)
+                if on_ready is not None:
+                    on_ready(*rng)
+            return
+        self._join_wgrad()
         if n:
             call("crimac_unpack_wgrad_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n)
+        if on_ready is not None:
+            on_ready(*rng)
 
     def _pack_ups(self):
         for u in self.ups:
@@ -724,9 +743,7 @@ class UNetEngine:
             nxt = (self.dec[j - 1][1], s[f"d{j - 1}"][4]) if j > 0 else (self.enc[D - 1][1], s[f"e{D - 1}"][3])
             cur_done = self._upconv_dgrad(dup, u, d_prev, B, hp, wp, next_bn=nxt)
             d_cur = d_prev
-        self._unpack_group(0)
-        if on_ready is not None:
-            on_ready(*ranges[0])
+        self._unpack_group(0, on_ready, ranges[0] if ranges else None)
         d_pool = None
         for i in reversed(range(D)):
             h, w, M = geo[i]
@@ -750,9 +767,8 @@ class UNetEngine:
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, None, reduce_done=fused)
             g = self._enc_group(i)
             if i == 0 or self._enc_group(i - 1) != g:        # last (shallowest) block of its group
-                self._unpack_group(g)
-                if on_ready is not None:
-                    on_ready(*ranges[g])
+                self._unpack_group(g, on_ready, ranges[g] if ranges else None)
+        self._join_wgrad()
 
     # ------------------------------------------------------------------------------------------
     # loss and optimiser
