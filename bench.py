@@ -131,6 +131,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
     prof_timed, hip.PROFILE = hip.PROFILE, None
+    final_loss = float(loss)                    # (loss of the last timed step)
     # Per-kernel durations: in the timed region the weight gradients run on a side stream CONCURRENTLY with the
     # input-gradient convolutions (engine._wgrad), so the HIP-event intervals of the two overlap and each contains
     # the other's share of the GPU.  The roofline figures therefore come from a second, serialized pass (same
@@ -154,7 +155,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss)
     assert final_loss == final_loss, "training diverged (NaN loss)"
 
     # dominant-kernel roofline
