@@ -266,11 +266,23 @@ class UNetEngine:
     # (CRIMAC_WGRAD_STREAM = number of side streams, round-robin; 0 = everything on the caller's stream)
     wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
     unpack_on_side = os.environ.get("CRIMAC_UNPACK_SIDE", "1") != "0"
+    # launch the gradient collectives from the side stream too (they then never hold up the caller's stream)
+    exchange_on_side = os.environ.get("CRIMAC_EXCHANGE_SIDE", "0") != "0"
     _side = None
     _side_events = None
 
+    @staticmethod
+    def _gloo_ranks():
+        """More than one rank over gloo (CPU-side rehearsals of the multi-GPU path): gloo's CUDA collectives
+        synchronise with the device in a way that stalls for ~1 s per step once a second stream carries work
+        (measured: 32 ms -> 870-1900 ms per step, two ranks on one GPU); RCCL (backend "nccl") orders itself with
+        stream events and is what multi-GPU runs use."""
+        import torch.distributed as dist
+        return (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and dist.get_backend() == "gloo")
+
     def _wgrad(self, *args, flops=None):
-        if self.wgrad_side_streams <= 0:
+        if self.wgrad_side_streams <= 0 or self._gloo_ranks():
             call("crimac_wgrad", *args, flops=flops)
             return
         if self._side is None:
@@ -307,8 +319,11 @@ class UNetEngine:
                 side.wait_event(ev)
                 if n:
                     call("crimac_unpack_wgrad_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n)
-                if on_ready is not None:
+                if on_ready is not None and self.exchange_on_side:
                     on_ready(*rng)
+            if on_ready is not None and not self.exchange_on_side:
+                torch.cuda.current_stream().wait_stream(side)       # the collective is queued on the caller's stream
+                on_ready(*rng)
             return
         self._join_wgrad()
         if n:
@@ -820,7 +835,8 @@ class UNetEngine:
         dl = self.ce_backward(logits, labels, class_w, sums, 1.0, ignore_index)
         scale = 1.0
         if grad_sync is not None and hasattr(grad_sync, "launch"):
-            self.backward(dl, on_ready=lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi))
+            single = hasattr(grad_sync, "world") and grad_sync.world() == 1       # nothing to exchange
+            self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
             scale = grad_sync.finish()
         else:
             self.backward(dl)
