@@ -25,6 +25,24 @@ import torch
 from . import hip
 from .hip import Act, call, ptr
 
+
+def _on_device(fn):
+    """Run an engine entry point with the engine's GPU as the current device: the kernels are launched on
+    ``torch.cuda.current_stream()``, which is per device (a model on cuda:1 used while cuda:0 is current would
+    otherwise be launched on the wrong GPU's stream)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if getattr(self, "device", None) is None:
+            self.bind()                               # (first use: learn which GPU the parameters live on)
+        dev = self.device
+        if dev is None or dev.type != "cuda":
+            return fn(self, *a, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **kw)
+    return wrapped
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 CIN_PAD = 16          # first-layer input channels are zero-padded to one MFMA k-step
@@ -507,12 +525,14 @@ class UNetEngine:
         call("crimac_nchw_to_nhwc", self.prec, ptr(x), ptr(xin), B, self.in_channels, H, W, CIN_PAD)
         return xin, B, H, W
 
+    @_on_device
     def forward(self, x, training, softmax=False):
         """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs."""
         self.bind()
         xin, B, H, W = self._input(x)
         return self.forward_nhwc(xin, B, H, W, training, softmax)
 
+    @_on_device
     def forward_nhwc(self, xin, B, H, W, training, softmax=False):
         """Same, from an NHWC activation matrix [B*H*W, 16] already in the engine's storage type
         (what ``crimac_gather_patches`` writes for the tiled-inference path)."""
@@ -699,6 +719,7 @@ class UNetEngine:
             hi = lo
         return ranges
 
+    @_on_device
     def backward(self, dlogits, on_ready=None):
         """Gradients of every parameter into the flat gradient buffer (overwrites it).
 
@@ -795,6 +816,7 @@ class UNetEngine:
             labels = labels.long()
         return labels.contiguous()
 
+    @_on_device
     def ce_forward(self, logits, labels, class_w, ignore_index=-100, sums=None):
         """Accumulate (sum w*nll, sum w) into ``sums`` (fp64[2], zeroed by the caller or here)."""
         labels = self._labels(labels)
@@ -807,6 +829,7 @@ class UNetEngine:
              ignore_index, B, H, W, ptr(sums))
         return sums, labels
 
+    @_on_device
     def ce_backward(self, logits, labels, class_w, sums, upstream=1.0, ignore_index=-100):
         B, nc, H, W = logits.shape
         dl = self._buf("g.dlogits", (B, nc, H, W), torch.float32)
@@ -814,11 +837,13 @@ class UNetEngine:
              ignore_index, B, H, W, ptr(sums), float(upstream), ptr(dl))
         return dl
 
+    @_on_device
     def sgd_step(self, lr, momentum, grad_scale=1.0, zero_grad=False):
         call("crimac_sgd_momentum", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
              float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0)
         self.mark_dirty()
 
+    @_on_device
     def train_step(self, x, labels, class_w, lr, momentum, grad_sync=None, ignore_index=-100):
         """Fused step: forward + weighted CE + backward (+ gradient exchange) + SGD.
 
@@ -848,6 +873,7 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     # on-GPU augmentation (BASELINE configs[4]; reference: batch/data_augmentation/*)
     # ------------------------------------------------------------------------------------------
+    @_on_device
     def augment_batch(self, data_linear, labels, seed, do_noise=True, do_flip=True, refine_labels=None):
         """add_noise + flip_x_axis + remove_nan_inf + db_with_limits + NCHW->NHWC in one kernel.
 
@@ -883,6 +909,7 @@ class UNetEngine:
             lab_out = refined
         return x, lab_out
 
+    @_on_device
     def train_step_augmented(self, data_linear, labels, class_w, lr, momentum, seed, grad_sync=None,
                              do_noise=True, do_flip=True, ignore_index=-100, refine_labels=None):
         """Training step on RAW linear-sv crops: augmentation and dB transform (and, with ``refine_labels``,
