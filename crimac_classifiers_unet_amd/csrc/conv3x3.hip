@@ -297,15 +297,15 @@ int launch(ConvParams p, hipStream_t st) {
 
 // conv3x3_glds.hip: bf16 direct-to-LDS variant
 int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                             const void* w_hi, const EpiParams& epi, hipStream_t st);
+                             const void* w_hi, const EpiParams& epi, hipStream_t st, int n_first, int n_count);
 int crimac_conv3x3_c16_bf16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
                             const EpiParams& epi, hipStream_t st);
 
-extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                              const void* w_hi, const void* w_lo, const float* bias, void* out,
-                              long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
-                              int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
-                              long bnb_stride, void* stream) {
+static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                       const void* w_hi, const void* w_lo, const float* bias, void* out,
+                       long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
+                       int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
+                       long bnb_stride, int n_first, int n_count, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
@@ -338,8 +338,12 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
   // Measured (tools/bench_conv.py, B=32): +8-18 % on every layer with N >= 128 (8-wave kernel), +5-13 % on
   // the N = 64 layers (4-wave kernel, two workgroups per CU).
   static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
+  const bool ranged = n_first != 0 || n_count != N;
+  CRIMAC_REQUIRE(!ranged || (n_first >= 0 && n_count > 0 && n_first + n_count <= N && prec == CRIMAC_PREC_BF16 &&
+                             Cin % 64 == 0 && use_glds),
+                 "conv3x3_cols: a channel range needs the bf16 LDS-DMA kernels (Cin %% 64 == 0)");
   if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && use_glds)
-    return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, e, st);
+    return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count);
   // first layer (4 input channels padded to 16): one-barrier kernel, 181 -> see DESIGN.md us at B = 32
   if (prec == CRIMAC_PREC_BF16 && Cin == 16 && N == 64 && use_glds)
     return crimac_conv3x3_c16_bf16(in, in_ld, B, H, W, N, w_hi, e, st);
@@ -360,4 +364,26 @@ extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H
   }
   if (Cin % 32 == 0) return n128 ? launch<float, 3, 128, 32, 8>(p, st) : launch<float, 3, 64, 32, 8>(p, st);
   return n128 ? launch<float, 3, 128, 16, 8>(p, st) : launch<float, 3, 64, 16, 8>(p, st);
+}
+
+extern "C" int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                              const void* w_hi, const void* w_lo, const float* bias, void* out,
+                              long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
+                              int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
+                              long bnb_stride, void* stream) {
+  return conv3x3_run(prec, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld, relu, stat_mode, stat_sum,
+                     stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, 0, N, stream);
+}
+
+// The same convolution restricted to the output channels [n_first, n_first + n_count): every pointer (weights,
+// bias, out, accumulators) is that of the FULL N-channel convolution.  Lets the input gradient of a decoder
+// block's first convolution be produced in two launches -- the half that the up-convolution's backward needs at
+// once, and the skip-connection half, which is not needed until the encoder level is reached (side stream).
+extern "C" int crimac_conv3x3_cols(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                                   const void* w_hi, const void* w_lo, const float* bias, void* out,
+                                   long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
+                                   int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
+                                   long bnb_stride, int n_first, int n_count, void* stream) {
+  return conv3x3_run(prec, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld, relu, stat_mode, stat_sum,
+                     stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, n_first, n_count, stream);
 }

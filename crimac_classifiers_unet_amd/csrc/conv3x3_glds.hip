@@ -33,6 +33,7 @@ struct ConvParams {
   const unsigned short* w_hi;
   EpiParams epi;
   int tiles_y, tiles_x;
+  int n_first, n_count;      // output-channel range of this launch (crimac_conv3x3_cols); default the whole N
 };
 
 constexpr int TR = 16, TC = 16, HP = TC + 2;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tyi = tile_m % p.tiles_y;
   const int b = tile_m / p.tiles_y;
   const int y0 = tyi * TR, x0 = txi * TC;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = p.n_first + blockIdx.y * BN;
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.in), 0, (int)((((long)p.B * p.H * p.W - 1) * p.in_ld + p.Cin) * 2), 0x00020000);
@@ -450,7 +451,7 @@ int launch_wch(ConvParams p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3x3_wch_kernel, dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(conv3x3_wch_kernel, dim3((unsigned)ntiles, p.n_count / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -692,8 +693,9 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   // weights: LDS unit c of row (t, n) holds source unit c ^ swizzle(n) (as the W4 weight slots)
   for (int u = tid; u < 9 * BN * 8; u += 512) {
     const int row = u >> 3, c = u & 7, n = row & (BN - 1);
-    *reinterpret_cast<u32x4*>(wl + u * 16) =
-        *reinterpret_cast<const u32x4*>(p.w_hi + (long)row * BN + ((c ^ ((n >> 1) & 7)) * 8));
+    const int t = row >> 6;                      // (rows of a range: tap stride N * Cin, first row n_first)
+    *reinterpret_cast<u32x4*>(wl + u * 16) = *reinterpret_cast<const u32x4*>(
+        p.w_hi + ((long)t * p.N + p.n_first + n) * BN + ((c ^ ((n >> 1) & 7)) * 8));
   }
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -704,7 +706,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   float bv[NT], cs1[NT], cs2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    bv[j] = e.bias ? e.bias[j * 16 + fr] : 0.f;
+    bv[j] = e.bias ? e.bias[p.n_first + j * 16 + fr] : 0.f;
     cs1[j] = 0.f;
     cs2[j] = 0.f;
   }
@@ -713,7 +715,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   float sc[8], sh[8], mu[8], d1[8], d2[8];        // (d2 accumulates dz * (y - mean); invstd is applied at the flush)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int c = c8 * 8 + k;
+    const int c = p.n_first + c8 * 8 + k;
     mu[k] = mode == 2 ? e.bnb_vec[c] : 0.f;
     sc[k] = mode == 2 ? e.bnb_vec[2 * e.bnb_stride + c] : 0.f;
     sh[k] = mode == 2 ? e.bnb_vec[3 * e.bnb_stride + c] : 0.f;
@@ -831,11 +833,11 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
           const bf16_t* sp = reinterpret_cast<const bf16_t*>(slab + px * SLAB_PITCH) + c8 * 8;
           if (y < p.H && x0 + px < p.W) {
             const long pix = ((long)b * p.H + y) * p.W + x0 + px;
-            *reinterpret_cast<u32x4*>(outp + pix * e.out_ld + c8 * 8) = *reinterpret_cast<const u32x4*>(sp);
+            *reinterpret_cast<u32x4*>(outp + pix * e.out_ld + p.n_first + c8 * 8) = *reinterpret_cast<const u32x4*>(sp);
             if (mode == 2) {
               float g[8], yv[8];
               load8(sp, g);
-              load8(reinterpret_cast<const bf16_t*>(e.bnb_y) + pix * e.bnb_y_ld + c8 * 8, yv);
+              load8(reinterpret_cast<const bf16_t*>(e.bnb_y) + pix * e.bnb_y_ld + p.n_first + c8 * 8, yv);
 #pragma unroll
               for (int kk = 0; kk < 8; ++kk) {
                 const float dz = (yv[kk] * sc[kk] + sh[kk]) > 0.f ? g[kk] : 0.f;
@@ -872,7 +874,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         atomicAdd(&sstat[c8 * 8 + k], d1[k]);
-        atomicAdd(&sstat[BN + c8 * 8 + k], d2[k] * e.bnb_vec[e.bnb_stride + c8 * 8 + k]);
+        atomicAdd(&sstat[BN + c8 * 8 + k], d2[k] * e.bnb_vec[e.bnb_stride + p.n_first + c8 * 8 + k]);
       }
     }
   }
@@ -880,8 +882,8 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
     __syncthreads();
     const long rep = (long)(blockIdx.x % (unsigned)e.stat_replicas) * e.N;
     if (tid < BN) {
-      atomicAdd(&e.stat_sum[rep + tid], (double)sstat[tid]);
-      atomicAdd(&e.stat_sumsq[rep + tid], (double)sstat[BN + tid]);
+      atomicAdd(&e.stat_sum[rep + p.n_first + tid], (double)sstat[tid]);
+      atomicAdd(&e.stat_sumsq[rep + p.n_first + tid], (double)sstat[BN + tid]);
     }
   }
 }
@@ -927,16 +929,29 @@ int crimac_conv3x3_c16_bf16(const void* in, long in_ld, int B, int H, int W, int
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = 16; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
+  p.n_first = 0; p.n_count = N;
   return launch_c16(p, st);
 }
 
 // bf16, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
 int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                             const void* w_hi, const EpiParams& epi, hipStream_t st) {
+                             const void* w_hi, const EpiParams& epi, hipStream_t st, int n_first, int n_count) {
   ConvParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
+  p.n_first = n_first; p.n_count = n_count;
+  if (n_first != 0 || n_count != N) {
+    // a range of output channels (crimac_conv3x3_cols): 64 of them with the persistent 64-channel kernel,
+    // multiples of 128 with the channel-split kernel
+    const long nt = (long)B * cdiv(H, TR) * cdiv(W, TC);
+    if (n_count == 64 && Cin == 64 && nt >= 512) return launch_p64(p, st);
+    const bool small_t = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
+    CRIMAC_REQUIRE(n_first % 128 == 0 && n_count % 128 == 0 && small_t,
+                   "conv3x3_cols: channel range [%d, +%d) of %d not supported (multiples of 128, or 64 of a "
+                   "64-input-channel convolution with >= 512 tiles)", n_first, n_count, N);
+    return launch_wch(p, st);
+  }
   // N % 128 == 0: channel-split kernel; N = 64 (or 192, ...): pixel-split kernel with the LDS weight ring.
   // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.6 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
   // HBM-heavy N = 64 shapes W4<64> (305 / 423 us) beats a 2x2-wave channel split (319 / 458 us).

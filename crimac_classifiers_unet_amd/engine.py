@@ -284,6 +284,7 @@ class UNetEngine:
     # (CRIMAC_WGRAD_STREAM = number of side streams, round-robin; 0 = everything on the caller's stream)
     wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
     unpack_on_side = os.environ.get("CRIMAC_UNPACK_SIDE", "1") != "0"
+    split_skip_dgrad = os.environ.get("CRIMAC_SPLIT_SKIP", "1") != "0"    # skip half of decoder dgrads on the side stream
     # launch the gradient collectives from the side stream too (they then never hold up the caller's stream)
     exchange_on_side = os.environ.get("CRIMAC_EXCHANGE_SIDE", "0") != "0"
     _side = None
@@ -403,7 +404,7 @@ class UNetEngine:
     fuse_head_bn = fuse_bn_bwd and os.environ.get("CRIMAC_FUSE_HEADBN", "1") != "0"
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
-                 stats=None, bnb=None):
+                 stats=None, bnb=None, cols=None):
         """3x3 conv (forward planes, or dgrad planes).  ``stats=(sum, sumsq)``: fused statistics of
         the stored output (stat_mode 1).  ``bnb=(block, y)``: the output is the ``da`` of that
         BatchNorm block -> its backward sums are fused in (stat_mode 2, into the block's replica
@@ -418,6 +419,11 @@ class UNetEngine:
                 blk, y = bnb
                 mode, s0, s1 = 2, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1))
                 by, by_ld, bvec = y.p, y.ld, ptr(self._bnf(blk, 0))
+            if cols is not None:                      # a range of the output channels (crimac_conv3x3_cols)
+                call("crimac_conv3x3_cols", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
+                     out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
+                     cols[0], cols[1], flops=flops * cols[1] / cout)
+                return mode != 0
             call("crimac_conv3x3", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
                  out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
                  flops=flops)
@@ -675,8 +681,30 @@ class UNetEngine:
                 lvl = bias_from_stats[2]
                 scr = self.bias_scr[lvl * per:(lvl + 1) * per]
                 stats = (scr[:per // 2], scr[per // 2:])
-            fused = self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
-                                  dgrad=True, stats=stats, bnb=next_bn if stats is None else None)
+            C_up = bias_from_stats[1] if bias_from_stats is not None else 0
+            side = self._side[0] if (self._side is not None and len(self._side) == 1) else None
+            if (stats is not None and side is not None and self.split_skip_dgrad and not self._gloo_ranks()
+                    and b.cin == 2 * C_up and b.cout % 64 == 0 and self.prec == hip.PREC_NAMES["bf16"]
+                    and (C_up % 128 == 0 or (C_up == 64 and b.cout == 64 and B * ((h + 15) // 16) * ((w + 15) // 16) >= 512))):
+                # decoder conv1: dx_out = d(concat [up | skip]).  The up half (and its column sums = the transposed
+                # convolution's bias gradient) is needed at once; the skip half only when the encoder level is
+                # reached -> side stream, off the critical path
+                self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                              dgrad=True, stats=stats, cols=(0, C_up))
+                ev = self._side_events[self._side_i % len(self._side_events)]
+                self._side_i += 1
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                                  dgrad=True, cols=(C_up, C_up))
+                    done = torch.cuda.Event()
+                    done.record()
+                self._skip_done[bias_from_stats[2]] = done
+                fused = True
+            else:
+                fused = self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                                      dgrad=True, stats=stats, bnb=next_bn if stats is None else None)
             if stats is not None:
                 grad, C = bias_from_stats[:2]
                 call("crimac_sum_replicas", ptr(stats[0]), STAT_REPLICAS, b.cin, C, None, ptr(grad), None, None)
@@ -732,6 +760,7 @@ class UNetEngine:
         B, H, W = s["B"], s["H"], s["W"]
         geo = self._geom(B, H, W)
         D = self.depth
+        self._skip_done = {}
         self.flat_g.zero_()
         self.dw_packed.zero_()
         # the fused BatchNorm-backward reductions accumulate into the replica slots the forward statistics used:
@@ -791,6 +820,9 @@ class UNetEngine:
             else:
                 da2 = Act(self._buf(f"g.e{i}.a2", (M, c)), c)
                 ds = skip_grad[i]
+                ev = self._skip_done.pop(D - 2 - i, None)
+                if ev is not None:                      # skip half of d(concat) was produced on the side stream
+                    torch.cuda.current_stream().wait_event(ev)
                 call("crimac_unpool_add", self.prec, d_pool.p, d_pool.ld, a2.p, a2.ld, ds.p, ds.ld,
                      da2.p, da2.ld, B, h, w, c, *self._bnb_args(b2, y2 if self.fuse_bn_bwd else None))
             da1 = Act(self._buf(f"g.e{i}.a1", (M, c)), c)

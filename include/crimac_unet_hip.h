@@ -93,6 +93,18 @@ int crimac_conv3x3(int prec, const void* in, long in_ld, int B, int H, int W, in
                    int relu, int stat_mode, double* stat_sum, double* stat_sumsq, int stat_replicas,
                    const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, void* stream);
 
+/* crimac_conv3x3 restricted to the output channels [n_first, n_first + n_count) of the N-channel convolution;
+ * every pointer (weights, bias, out, statistic accumulators) is that of the FULL convolution.  Used for the
+ * input gradient of a decoder block's first convolution (unet.py:114-119 after the concat at :132): the half
+ * that feeds the transposed convolution's backward is produced at once, the skip-connection half
+ * (encoder_outs, unet.py:336) on a side stream -- it is not needed until the encoder level is reached.
+ * bf16, Cin % 64 == 0; ranges in multiples of 128 channels, or 64 channels of a 64-input-channel convolution
+ * with >= 512 tiles of 16x16 pixels; anything else is an error. */
+int crimac_conv3x3_cols(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                   const void* w_hi, const void* w_lo, const float* bias, void* out, long out_ld,
+                   int relu, int stat_mode, double* stat_sum, double* stat_sumsq, int stat_replicas,
+                   const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, int n_first, int n_count, void* stream);
+
 /* Weight gradient (aten::convolution_backward weight half, pipeline.py:177):
  *   dw[t][f][s] += sum_pixels F[p][f] * S[shift_t(p)][s]   (fp32 atomics; caller zeroes dw)
  *   mode 0 (conv3x3): F=dY [B][Hf][Wf][CF=Cout], S=X same grid [CS=Cin], 9 taps

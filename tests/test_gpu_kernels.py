@@ -608,6 +608,42 @@ def test_upconv_dgrad_with_fused_bn_backward_sums(shape):
              ptr(acc[0]), ptr(acc[1]), R)
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 40, 128, 256), (3, 256, 256, 64, 128), (1, 16, 16, 64, 128)])
+def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape):
+    """crimac_conv3x3_cols on [0, N/2) and [N/2, N) (weights / bias / out / accumulators of the FULL convolution)
+    reproduces crimac_conv3x3 bit for bit, statistics included; unsupported ranges fail loudly.  The second shape
+    takes the persistent 64-channel kernel for each half, the first the channel-split kernel."""
+    B, H, W, Ci, Co = shape
+    prec = "bf16"
+    P = hip.PREC_NAMES[prec]
+    g = torch.Generator().manual_seed(41)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    bd = torch.randn(Co, generator=g).cuda()
+    fh, fl, _, _ = pack_conv(w, prec, Ci, dgrad=False)
+    xin = to_nhwc(x, prec)
+    M = B * H * W
+    full = torch.empty(M, Co, dtype=torch.bfloat16, device="cuda")
+    st_full = torch.zeros(2, 4, Co, dtype=torch.float64, device="cuda")
+    call("crimac_conv3x3", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(full), Co, 1, 1,
+         ptr(st_full[0]), ptr(st_full[1]), 4, None, 0, None, 0)
+    half = Co // 2
+    supported = half % 128 == 0 or (half == 64 and Ci == 64 and B * ((H + 15) // 16) * ((W + 15) // 16) >= 512)
+    parts = torch.zeros(M, Co, dtype=torch.bfloat16, device="cuda")
+    st = torch.zeros(2, 4, Co, dtype=torch.float64, device="cuda")
+    args = lambda n0: ("crimac_conv3x3_cols", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(parts), Co,
+                       1, 1, ptr(st[0]), ptr(st[1]), 4, None, 0, None, 0, n0, half)
+    if not supported:
+        with pytest.raises(hip.HipLibraryError):
+            call(*args(0))
+        return
+    call(*args(0))
+    call(*args(half))
+    torch.cuda.synchronize()
+    assert torch.equal(parts, full)
+    assert relerr(st.sum(1), st_full.sum(1)) < 1e-6       # (fp32 partial sums are grouped differently)
+
+
 @pytest.mark.parametrize("planes", [1, 2, 3])
 def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
     """crimac_pack_layers / crimac_unpack_wgrad_layers (one launch for all layers) are bit-identical to
