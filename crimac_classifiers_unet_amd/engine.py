@@ -379,8 +379,11 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     # buffers
     # ------------------------------------------------------------------------------------------
+    _buf_prefix = ""             # (eval forward on two streams: each half batch has its own activation buffers)
+
     def _buf(self, key, shape, dtype=None):
         dtype = dtype or self.act_dtype
+        key = self._buf_prefix + key
         t = self._bufs.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
             t = torch.empty(shape, dtype=dtype, device=self.device)
@@ -535,11 +538,47 @@ class UNetEngine:
     def forward(self, x, training, softmax=False):
         """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs."""
         self.bind()
+        if (not training and self.eval_two_streams and x.dim() == 4 and x.shape[0] >= 16 and x.shape[0] % 2 == 0
+                and x.is_cuda and not self._gloo_ranks()):
+            return self._forward_eval_two_streams(x, softmax)
         xin, B, H, W = self._input(x)
         return self.forward_nhwc(xin, B, H, W, training, softmax)
 
+    # Inference: the two halves of a batch run on two streams (own activation buffers each).  The kernels of one
+    # half fill the ragged last rounds and the launch gaps of the other -- the same effect the side stream has in
+    # the backward pass.
+    eval_two_streams = os.environ.get("CRIMAC_EVAL_STREAMS", "1") != "0"
+
+    def _forward_eval_two_streams(self, x, softmax):
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device)]
+            self._side_events = [torch.cuda.Event() for _ in range(32)]
+            self._side_i = 0
+        side = self._side[0]
+        B, _, H, W = x.shape
+        h = B // 2
+        self._check_versions()
+        self._pack_eval()                              # (on the caller's stream, before either half starts)
+        logits = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=self.device)
+        ev = self._side_events[self._side_i % len(self._side_events)]
+        self._side_i += 1
+        ev.record()
+        try:
+            self._buf_prefix = "h0."
+            xin, _, _, _ = self._input(x[:h])
+            self.forward_nhwc(xin, h, H, W, False, softmax, out=logits[:h])
+            self._buf_prefix = "h1."
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                xin, _, _, _ = self._input(x[h:])
+                self.forward_nhwc(xin, h, H, W, False, softmax, out=logits[h:])
+        finally:
+            self._buf_prefix = ""
+        torch.cuda.current_stream().wait_stream(side)
+        return logits
+
     @_on_device
-    def forward_nhwc(self, xin, B, H, W, training, softmax=False):
+    def forward_nhwc(self, xin, B, H, W, training, softmax=False, out=None):
         """Same, from an NHWC activation matrix [B*H*W, 16] already in the engine's storage type
         (what ``crimac_gather_patches`` writes for the tiled-inference path)."""
         self.bind()
@@ -624,7 +663,8 @@ class UNetEngine:
                 self._conv3x3(catA, pe1, pe1["bias"], a1, B, h, w, 2 * c, c, relu=True)
                 self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
             cur = a2
-        logits = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=self.device)
+        logits = out if out is not None else torch.empty((B, self.n_classes, H, W), dtype=torch.float32,
+                                                         device=self.device)
         call("crimac_head_fwd", self.prec, cur.p, cur.ld, self.sf, ptr(self.P["conv_final.weight"]),
              ptr(self.P["conv_final.bias"]), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0,
              ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
