@@ -284,6 +284,7 @@ class UNetEngine:
     # (CRIMAC_WGRAD_STREAM = number of side streams, round-robin; 0 = everything on the caller's stream)
     wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
     unpack_on_side = os.environ.get("CRIMAC_UNPACK_SIDE", "1") != "0"
+    early_sgd = os.environ.get("CRIMAC_EARLY_SGD", "1") != "0"
     split_skip_dgrad = os.environ.get("CRIMAC_SPLIT_SKIP", "1") != "0"    # skip half of decoder dgrads on the side stream
     # launch the gradient collectives from the side stream too (they then never hold up the caller's stream)
     exchange_on_side = os.environ.get("CRIMAC_EXCHANGE_SIDE", "0") != "0"
@@ -340,6 +341,9 @@ class UNetEngine:
                     call("crimac_unpack_wgrad_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n)
                 if on_ready is not None and self.exchange_on_side:
                     on_ready(*rng)
+                done = torch.cuda.Event()
+                done.record()
+                self._unpacked[gi] = done             # (gradient range gi is final on the side stream from here)
             if on_ready is not None and not self.exchange_on_side:
                 torch.cuda.current_stream().wait_stream(side)       # the collective is queued on the caller's stream
                 on_ready(*rng)
@@ -788,7 +792,7 @@ class UNetEngine:
         return ranges
 
     @_on_device
-    def backward(self, dlogits, on_ready=None):
+    def backward(self, dlogits, on_ready=None, before_join=None):
         """Gradients of every parameter into the flat gradient buffer (overwrites it).
 
         on_ready(lo, hi): called when flat_g[lo:hi] is final (see grad_ranges) so that the gradient
@@ -801,6 +805,7 @@ class UNetEngine:
         geo = self._geom(B, H, W)
         D = self.depth
         self._skip_done = {}
+        self._unpacked = {}
         self.flat_g.zero_()
         self.dw_packed.zero_()
         # the fused BatchNorm-backward reductions accumulate into the replica slots the forward statistics used:
@@ -876,6 +881,8 @@ class UNetEngine:
             g = self._enc_group(i)
             if i == 0 or self._enc_group(i - 1) != g:        # last (shallowest) block of its group
                 self._unpack_group(g, on_ready, ranges[g] if ranges else None)
+        if before_join is not None:
+            before_join()                             # the caller's stream has nothing left of the backward pass
         self._join_wgrad()
 
     # ------------------------------------------------------------------------------------------
@@ -931,8 +938,15 @@ class UNetEngine:
         sums, labels = self.ce_forward(logits, labels, class_w, ignore_index, sums=sums)
         dl = self.ce_backward(logits, labels, class_w, sums, 1.0, ignore_index)
         scale = 1.0
+        single = grad_sync is None or (hasattr(grad_sync, "world") and grad_sync.world() == 1)
+        if single and self.early_sgd and self._side is not None and len(self._side) == 1 and self.unpack_on_side:
+            self._sgd_left = None
+            self.backward(dl, before_join=lambda: self._early_sgd(lr, momentum))
+            for lo, hi in (self._sgd_left if self._sgd_left is not None else [(0, self.n_flat)]):
+                self._sgd_range(lo, hi, lr, momentum)
+            self.mark_dirty()
+            return (sums[0] / sums[1]).float()
         if grad_sync is not None and hasattr(grad_sync, "launch"):
-            single = hasattr(grad_sync, "world") and grad_sync.world() == 1       # nothing to exchange
             self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
             scale = grad_sync.finish()
         else:
@@ -941,6 +955,24 @@ class UNetEngine:
                 scale = grad_sync(self.flat_g)
         self.sgd_step(lr, momentum, grad_scale=scale)
         return (sums[0] / sums[1]).float()
+
+    def _early_sgd(self, lr, momentum):
+        """Single GPU: while the side stream still runs the last (small) weight gradients, the caller's stream
+        is idle -- apply the gradient ranges that are already final there.  Returns the ranges left over."""
+        ranges = self.grad_ranges()
+        left = []
+        for g, (lo, hi) in enumerate(ranges):
+            ev = self._unpacked.get(g)
+            if ev is None or g == len(ranges) - 1:
+                left.append((lo, hi))
+                continue
+            torch.cuda.current_stream().wait_event(ev)
+            self._sgd_range(lo, hi, lr, momentum)
+        self._sgd_left = left
+
+    def _sgd_range(self, lo, hi, lr, momentum):
+        call("crimac_sgd_momentum", ptr(self.flat_p, lo), ptr(self.flat_g, lo), ptr(self.flat_v, lo), hi - lo,
+             float(lr), float(momentum), 1.0, 0)
 
     # ------------------------------------------------------------------------------------------
     # on-GPU augmentation (BASELINE configs[4]; reference: batch/data_augmentation/*)
