@@ -228,6 +228,7 @@ class UNetEngine:
 
     def mark_dirty(self):
         self._train_pack_dirty = self._eval_pack_dirty = True
+        self._packed_groups = set()       # layer groups whose train-mode planes were re-packed after this change
 
     def _check_versions(self):
         """Detect in-place edits made through torch (load_state_dict, manual init, optimizers)."""
@@ -271,11 +272,24 @@ class UNetEngine:
         self._ltab = (arr, bounds)
         return self._ltab
 
+    def _pack_group(self, gi):
+        arr, bounds = self._layer_table()
+        first, n = bounds[gi]
+        if n:
+            call("crimac_pack_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n, self.planes)
+
     def _pack_train(self):
         if not self._train_pack_dirty:
             return
-        arr, _ = self._layer_table()
-        call("crimac_pack_layers", C.byref(arr), len(arr), self.planes)
+        arr, bounds = self._layer_table()
+        done = getattr(self, "_packed_groups", set())
+        if done:                                      # (groups re-packed right behind their optimiser step)
+            for gi in range(len(bounds)):
+                if gi not in done:
+                    self._pack_group(gi)
+        else:
+            call("crimac_pack_layers", C.byref(arr), len(arr), self.planes)
+        self._packed_groups = set()
         self._train_pack_dirty = False
 
     # Weight gradients on a second stream: wgrad(layer) and the input-gradient convolution of the same layer
@@ -285,6 +299,7 @@ class UNetEngine:
     wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
     unpack_on_side = os.environ.get("CRIMAC_UNPACK_SIDE", "1") != "0"
     early_sgd = os.environ.get("CRIMAC_EARLY_SGD", "1") != "0"
+    early_pack = os.environ.get("CRIMAC_EARLY_PACK", "1") != "0"
     split_skip_dgrad = os.environ.get("CRIMAC_SPLIT_SKIP", "1") != "0"    # skip half of decoder dgrads on the side stream
     # launch the gradient collectives from the side stream too (they then never hold up the caller's stream)
     exchange_on_side = os.environ.get("CRIMAC_EXCHANGE_SIDE", "0") != "0"
@@ -941,10 +956,10 @@ class UNetEngine:
         single = grad_sync is None or (hasattr(grad_sync, "world") and grad_sync.world() == 1)
         if single and self.early_sgd and self._side is not None and len(self._side) == 1 and self.unpack_on_side:
             self._sgd_left = None
+            self.mark_dirty()                         # (before the early re-packs register themselves)
             self.backward(dl, before_join=lambda: self._early_sgd(lr, momentum))
             for lo, hi in (self._sgd_left if self._sgd_left is not None else [(0, self.n_flat)]):
                 self._sgd_range(lo, hi, lr, momentum)
-            self.mark_dirty()
             return (sums[0] / sums[1]).float()
         if grad_sync is not None and hasattr(grad_sync, "launch"):
             self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
@@ -968,6 +983,9 @@ class UNetEngine:
                 continue
             torch.cuda.current_stream().wait_event(ev)
             self._sgd_range(lo, hi, lr, momentum)
+            if self.early_pack:
+                self._pack_group(g)                   # its weight planes for the next step, while this stream is idle
+                self._packed_groups.add(g)
         self._sgd_left = left
 
     def _sgd_range(self, lo, hi, lr, momentum):
