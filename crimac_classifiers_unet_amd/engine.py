@@ -786,6 +786,13 @@ class UNetEngine:
 
     def grad_ranges(self):
         """Contiguous ranges of the flat gradient buffer in the order the backward pass completes them."""
+        if getattr(self, "_granges", None) is not None and self._granges[0] is self.layout:
+            return self._granges[1]
+        r = self._grad_ranges()
+        self._granges = (self.layout, r)
+        return r
+
+    def _grad_ranges(self):
         dec = self.ups[0].key.split(".")[0] + "."
         lo_dec = min(o for k, (o, _, _) in self.layout.items() if k.startswith(dec))
         starts = {}                                   # group -> lowest offset
