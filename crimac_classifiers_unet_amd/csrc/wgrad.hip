@@ -167,6 +167,11 @@ __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], W
 // wave-instruction), so the tr-read swizzle is applied on the per-lane SOURCE offset; lanes whose pixel is
 // outside the image read out of range and the hardware stores zeros.  The contraction itself runs on the
 // hand-placed read/MFMA schedule above (wg_row).
+// Tried and rejected: 16-row tiles in ONE buffer (73 KB; half the barriers and fragment prologues per MFMA, 1.27x
+// instead of 1.41x halo re-read; the two workgroups of a CU covering each other's tile loads as in the
+// convolution kernels): 2.26 vs 2.23 ms over the 13 conv shapes, the 64->64 @256x256 shape 8 % slower -- the
+// prefetch of the double-buffered form is worth more than the saved barriers.  (Its first build ran 6x slower:
+// the tile-DMA lambda had stopped being inlined and every call went through the scratch stack.)
 // Tried and rejected: warming the XCD's L2 two tiles ahead with one ordinary 4-byte load per 128-byte line (the
 // LDS budget allows only one tile in flight per workgroup and the level-0 shapes wait for their tiles at
 // 3.9 TB/s): every shape got 8-15 % SLOWER (2.49 vs 2.25 ms over the 13 conv shapes).
