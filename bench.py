@@ -2,47 +2,80 @@
 """Benchmark of the U-Net hot path on MI355X (BASELINE.json: echogram patches/sec, 4ch 256x256).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one batch of synthetic echogram patches already resident
-in HBM: the full training step of the reference loop (forward + weighted CE + backward + SGD,
-pipeline.py:163-178), batch 32 per GPU (BASELINE.json configs[1]); for N>1 the mini-batches shard
-over ranks and gradients are all-reduced over RCCL every step (configs[2], weak scaling).
-The inference rate (eval forward + softmax, pipeline.py:205-219) is measured next to it and
-reported in the same JSON line as ``infer_patches_per_s``.
+N > 1 without a torchrun environment: this process spawns N ranks itself (one per GPU, RCCL) BEFORE touching
+the GPU and prints rank 0's JSON line; under ``python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`` it is one of the N ranks (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
 
-``roofline`` (per-kernel HIP-event durations; taken in a serialized pass right after the timed region because
-the timed region runs the weight gradients concurrently on a side stream): the dominant kernel is the halo-staged implicit-GEMM 3x3 convolution (crimac_conv3x3 =
-conv3x3_wch_kernel / conv3x3_p64_kernel / conv3x3_glds_w4_kernel / conv3x3_c16_kernel by layer shape): algorithmic
-FLOPs of its launches (2*taps*Cin*N*M each) / their HIP-event durations, measured
-inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
-``cpu_baseline``: the CPU oracle (oracle/unet_oracle.py, kind "port") timed on this box's host
-cores on a bounded sample (batch 2, a few steps), rank 0, N=1 only.
+A "step" is one pass of the hot path over one batch of synthetic echogram patches already resident in HBM: the
+full training step of the reference loop (forward + weighted CE + backward + SGD, pipeline.py:163-178), batch 32
+per GPU (BASELINE.json configs[1]); for N > 1 the mini-batches shard over ranks and gradients are exchanged
+over RCCL every step (configs[2], weak scaling).  The JSON line also carries
+  * ``infer_patches_per_s``   eval forward + softmax (pipeline.py:205-219) on the same batch;
+  * ``parity_mode``           the same two measurements in the precision that meets the north-star parity bar
+                              (f32x6: <= 1e-3 rel on logits, bit-exact argmax), with its own roofline;
+  * ``tiled``                 BASELINE configs[3]: tiled whole-survey inference (save_predict.py path), synthetic
+                              survey 4 x 65536 pings x 1024 range, preload_n_pings 4096, host reader + H2D + crop/dB +
+                              U-Net + softmax + scatter + D2H all inside the timed region;
+  * ``roofline``              dominant kernel (3x3 implicit-GEMM convolution, all launches): algorithmic FLOPs
+                              (2*9*Cin*Cout*B*H*W per launch) / HIP-event durations taken in a
+                              serialized pass right after the timed region (the timed region overlaps the weight
+                              gradients on a side stream), against the dense bf16 MFMA peak of 2.5 PFLOP/s;
+  * ``cpu_baseline``          the CPU oracle (oracle/unet_oracle.py, kind "port") on this box's host cores,
+                              bounded sample, rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FWD_GFLOP_PER_PATCH = 96.43      # SURVEY.md §8(a) a10, hook-counted on the reference module
+FWD_GFLOP_PER_PATCH = 96.43      # SURVEY.md §8(a) a10, hook-counted on the reference module (start_filts 64)
 TRAIN_GFLOP_PER_PATCH = 288.98
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32x3": 2500.0 / 3.0, "f32x6": 2500.0 / 6.0}   # dense bf16 / MFMAs per product
-DTYPE_LABEL = {"bf16": "bf16", "f32x3": "fp32 storage, 3x bf16 MFMA per product",
+# dense 16-bit MFMA peak / MFMAs per product of the mode
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32x3": 2500.0 / 3.0, "f32x6": 2500.0 / 6.0}
+DTYPE_LABEL = {"bf16": "bf16", "fp16": "fp16", "f32x3": "fp32 storage, 3x bf16 MFMA per product",
                "f32x6": "fp32 storage, 6x bf16 MFMA per product (fp32-equivalent)"}
+CONV_KERNELS = ("crimac_conv3x3: conv3x3_wch_kernel + conv3x3_p64_kernel + conv3x3_glds_w4_kernel + "
+                "conv3x3_c16_kernel (halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)")
 
 
-def cpu_baseline(batch=2, iters=3):
-    """Time the oracle's training step and eval forward on the host cores (bounded sample)."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
+    ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))
+    ap.add_argument("--start-filts", type=int, default=64, help="128 = BASELINE configs[4] (2x channels)")
+    ap.add_argument("--gpu-augment", action="store_true",
+                    help="train on raw linear sv with add_noise / flip / dB on the GPU (configs[4])")
+    ap.add_argument("--parity-precision", default="f32x6", choices=["f32x3", "f32x6"])
+    ap.add_argument("--tiled-pings", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true")
+    ap.add_argument("--no-tiled", action="store_true")
+    ap.add_argument("--spawn-selftest", action="store_true",
+                    help="only start the ranks, all-reduce their ids and print the census (tests/test_bench_spawn.py)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle, "port")
+# ----------------------------------------------------------------------------------------------------------
+def cpu_baseline():
+    """Oracle train step and eval forward on the host cores, bounded to ~25 s (same synthetic
+    crops, B = 2 and B = 32, median after warm-ups; the B = 32 train step is a single iteration)."""
+    import torch
     from crimac_classifiers_unet_amd import synth
     from oracle import unet_oracle as orc
-    # host cores actually usable: affinity mask, capped at the GPU box's CPU share (16 per GPU);
-    # oversubscribing a cgroup-limited box with one thread per visible core stalls for minutes
+    # threads actually used: the affinity mask, capped at the GPU box's CPU share (16 per GPU) -- one thread per
+    # VISIBLE core (256) on a cgroup-limited box stalls for minutes
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -51,93 +84,105 @@ def cpu_baseline(batch=2, iters=3):
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()})", file=sys.stderr, flush=True)
     sd = synth.synth_state_dict(seed=0)
-    x = torch.from_numpy(synth.synth_echogram_batch(batch, 4, 256, 256, seed=1))
-    lab = torch.from_numpy(synth.synth_labels(batch, 256, 256, seed=2))
-    vel = {}
-    orc.loss_and_grads(sd, x, lab)        # warm-up
-    t0 = time.perf_counter()
-    state = sd
-    for _ in range(iters):
-        loss, _, grads, stats = orc.loss_and_grads(state, x, lab)
-        state, vel = orc.sgd_momentum_step(dict(state), grads, vel, 0.005, 0.95)
-        state.update(stats)
-    t_train = (time.perf_counter() - t0) / iters
-    orc.predict(sd, x)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        orc.predict(sd, x, return_softmax=True)
-    t_inf = (time.perf_counter() - t0) / iters
-    return {"value": batch / t_train, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"oracle train step, batch {batch} x 4x256x256 fp32, {iters} iters after 1 warm-up",
-            "infer_value": batch / t_inf}
+
+    def data(batch):
+        return (torch.from_numpy(synth.synth_echogram_batch(batch, 4, 256, 256, seed=1)),
+                torch.from_numpy(synth.synth_labels(batch, 256, 256, seed=2)))
+
+    def train_times(x, lab, warm, iters):
+        state, vel, ts = sd, {}, []
+        for i in range(warm + iters):
+            t0 = time.perf_counter()
+            _, _, grads, stats = orc.loss_and_grads(state, x, lab)
+            state, vel = orc.sgd_momentum_step(dict(state), grads, vel, 0.005, 0.95)
+            state.update(stats)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return ts
+
+    def infer_times(x, warm, iters):
+        ts = []
+        for i in range(warm + iters):
+            t0 = time.perf_counter()
+            orc.predict(sd, x, return_softmax=True)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return ts
+
+    x2, l2 = data(2)
+    t_train2 = statistics.median(train_times(x2, l2, 2, 5))
+    t_inf2 = statistics.median(infer_times(x2, 2, 5))
+    x32, l32 = data(32)
+    t_inf32 = statistics.median(infer_times(x32, 1, 3))
+    t_train32 = train_times(x32, l32, 0, 1)[0]
+    return {"value": 2 / t_train2, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "oracle (torch CPU fp32) train step, batch 2 x 4x256x256, median of 5 after 2 warm-ups",
+            "infer_value": 2 / t_inf2,
+            "batch32": {"train_value": 32 / t_train32, "train_sample": "1 iteration, no warm-up",
+                        "infer_value": 32 / t_inf32, "infer_sample": "median of 3 after 1 warm-up"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32x3", "f32x6"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-infer", action="store_true")
-    args = ap.parse_args()
-
-    import crimac_classifiers_unet_amd as pkg
-    from crimac_classifiers_unet_amd import parallel, synth, hip
-
-    world, rank, local = parallel.init_distributed()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    local = local % max(torch.cuda.device_count(), 1)     # (rehearsals with several ranks on one GPU)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+# ----------------------------------------------------------------------------------------------------------
+# one precision mode: train step + inference + serialized per-kernel pass
+# ----------------------------------------------------------------------------------------------------------
+def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, infer=True, log=print):
+    import torch
     import torch.distributed as dist
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import hip, synth
 
-    model = pkg.UNet_Baseline(3, 4, precision=args.precision)
-    model.load_state_dict(synth.synth_state_dict(seed=0))      # random-init weights of the architecture
+    sf = args.start_filts
+    model = pkg.UNet_Baseline(3, 4, start_filts=sf, precision=precision)
+    model.load_state_dict(synth.synth_state_dict(start_filts=sf, seed=0))      # random-init weights of the architecture
     model.to(dev).train()
     eng = model.engine
     B = args.batch
-    x = torch.from_numpy(synth.synth_echogram_batch(B, 4, 256, 256, seed=100 + rank)).to(dev)
     lab = torch.from_numpy(synth.synth_labels(B, 256, 256, seed=200 + rank)).to(dev)
     cw = torch.tensor([10.0, 300.0, 250.0], device=dev)
-    grad_sync = parallel.GradSync()
+    x = torch.from_numpy(synth.synth_echogram_batch(B, 4, 256, 256, seed=100 + rank)).to(dev)
+    if args.gpu_augment:
+        x_lin = torch.pow(10.0, x / 10.0)             # raw linear sv crops, as the reader hands them over
+        it = [0]
 
-    def step():
-        return eng.train_step(x, lab, cw, lr=0.005, momentum=0.95, grad_sync=grad_sync)
+        def step():
+            it[0] += 1
+            return eng.train_step_augmented(x_lin, lab, cw, 0.005, 0.95, seed=(rank << 32) ^ it[0],
+                                            grad_sync=grad_sync)
+    else:
+        def step():
+            return eng.train_step(x, lab, cw, lr=0.005, momentum=0.95, grad_sync=grad_sync)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def log(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    def max_over_ranks(t):
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt)
+        return t
 
-    log(f"model ready on {dev}, precision {args.precision}, batch {B}/GPU, world {world}")
-    for _ in range(args.warmup):
+    log(f"{precision}: model ready on {dev} (start_filts {sf}), batch {B}/GPU, world {world}")
+    for _ in range(warmup):
         loss = step()
     barrier()
-    log("warm-up done")
-    # HIP-event instrumentation of the dominant kernel (igemm conv launches) inside the timed region
-    hip.PROFILE = []
+    hip.PROFILE = []                 # HIP-event instrumentation of the conv / wgrad launches inside the timed region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     prof_timed, hip.PROFILE = hip.PROFILE, None
-    final_loss = float(loss)                    # (loss of the last timed step)
+    final_loss = float(loss)
+    assert final_loss == final_loss, "training diverged (NaN loss)"
+    log(f"{precision}: timed region done: {1e3 * elapsed / steps:.2f} ms/step")
+
     # Per-kernel durations: in the timed region the weight gradients run on a side stream CONCURRENTLY with the
-    # input-gradient convolutions (engine._wgrad), so the HIP-event intervals of the two overlap and each contains
-    # the other's share of the GPU.  The roofline figures therefore come from a second, serialized pass (same
-    # steps, side stream off) right after the timed region; the overlapped averages are reported next to them.
-    prof = prof_timed
-    serialized = False
+    # input-gradient convolutions, so their HIP-event intervals overlap.  The roofline figures come from a second,
+    # serialized pass (same steps, side stream off) right after the timed region.
+    prof, serialized = prof_timed, False
     if eng.wgrad_side_streams > 0:
         saved_cfg = (eng.wgrad_side_streams, eng._side)
         eng.wgrad_side_streams, eng._side = 0, None
@@ -145,100 +190,200 @@ def main():
             step()
         barrier()
         hip.PROFILE = []
-        for _ in range(max(3, min(args.steps, 10))):
-            loss = step()
+        for _ in range(max(3, min(steps, 10))):
+            step()
         barrier()
         prof, hip.PROFILE = hip.PROFILE, None
         eng.wgrad_side_streams, eng._side = saved_cfg
         serialized = True
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    assert final_loss == final_loss, "training diverged (NaN loss)"
 
-    # dominant-kernel roofline
-    def kernel_rate(kname, records=None):
-        sel = [(f, s.elapsed_time(e)) for n, f, s, e in (prof if records is None else records) if n == kname]
+    def kernel_rate(kname, records):
+        sel = [(f, s.elapsed_time(e)) for n, f, s, e in records if n == kname]
         fl, ms_ = sum(f for f, _ in sel), sum(m for _, m in sel)
         return (fl / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0), ms_, len(sel)
 
-    achieved, ms, n_launch = kernel_rate("crimac_conv3x3")
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    # (tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); bench.py
-    # itself cannot collect counters
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        sel = [v for k, v in pmc.items() if k.startswith("conv3x3")]
-        nl = sum(v["launches"] for v in sel)
-        traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
-    except Exception:
-        pass
-    wg_achieved, wg_ms, wg_n = kernel_rate("crimac_wgrad")
-    peak = MFMA_PEAK_TFLOPS[args.precision]
+    peak = MFMA_PEAK_TFLOPS[precision]
+    scale_f = (sf / 64.0) ** 2        # conv FLOPs scale with the square of the width (first / last layer aside)
 
-    infer = None
-    if not args.no_infer:
+    def roofline(kname, label):
+        ach, ms, n = kernel_rate(kname, prof)
+        _, ms_t, n_t = kernel_rate(kname, prof_timed)
+        return {"bound": "mfma", "kernel": label, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None,
+                "algorithmic_flops_per_launch": (ach * 1e12) * (ms * 1e-3) / max(n, 1), "launches": n,
+                "avg_launch_us": 1e3 * ms / max(n, 1),
+                "measured": ("serialized pass after the timed region (weight-gradient side stream off); in the "
+                             "timed region these launches overlap the weight gradients" if serialized else "timed region"),
+                "avg_launch_us_timed_region_overlapped": 1e3 * ms_t / max(n_t, 1)}
+
+    res = {"precision": precision, "dtype": DTYPE_LABEL[precision],
+           "train_patches_per_s": world * B * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+           "train_tflops": world * B * steps / elapsed * TRAIN_GFLOP_PER_PATCH * scale_f / 1e3,
+           "final_loss": final_loss,
+           "roofline": roofline("crimac_conv3x3", CONV_KERNELS if precision in ("bf16", "fp16") else
+                                "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)"),
+           "roofline_wgrad": roofline("crimac_wgrad", "wgrad_kernel (weight gradient, all shapes)")}
+    if infer:
         model.eval()
         with torch.no_grad():
-            for _ in range(max(args.warmup // 2, 2)):
+            for _ in range(max(warmup // 2, 2)):
                 model.predict_softmax(x)
             barrier()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 model.predict_softmax(x)
             barrier()
-            ti = time.perf_counter() - t1
+            ti = max_over_ranks(time.perf_counter() - t1)
+        res["infer_patches_per_s"] = world * B * steps / ti
+        res["infer_tflops"] = res["infer_patches_per_s"] * FWD_GFLOP_PER_PATCH * scale_f / 1e3
+    return res, model
+
+
+def measure_tiled(model, args, log):
+    """BASELINE configs[3]: whole-survey tiled inference, end to end (host reader included)."""
+    import types
+    import torch
+    from crimac_classifiers_unet_amd import synth, tiled_inference as ti
+    n_pings, n_range, preload = args.tiled_pings, 1024, 4096
+    t0 = time.perf_counter()
+    reader = synth.SyntheticSurveyReader(n_pings=n_pings, n_range=n_range, seabed_index=900, block=preload)
+    log(f"tiled: synthetic survey 4 x {n_pings} x {n_range} built in {time.perf_counter() - t0:.1f} s")
+    pipe = types.SimpleNamespace(model=model, device=next(model.parameters()).device, frequencies=[18, 38, 120, 200])
+    for _ in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, start_ping=n_pings - preload):
+        pass                                             # warm-up on the last chunk
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_patches, written = 0, 0
+    for s, e, out in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload):
+        n_patches += len(ti.plan_grid(n_range, 900, s, e))
+        written += int((out[0, :, ::64] != 0).sum())
+    dt = time.perf_counter() - t0
+    return {"workload": f"BASELINE configs[3]: synthetic survey sv [4, {n_pings}, {n_range}] fp32, flat seabed 900, "
+                        f"preload_n_pings {preload}, patch 256, overlap 20, batch {args.batch}, 1 GPU streamed",
+            "patches_per_s": n_patches / dt, "pings_per_s": n_pings / dt, "n_patches": n_patches, "seconds": dt,
+            "precision": model.precision,
+            "timed": "host reader + H2D + crop/dB gather + U-Net + softmax + scatter + D2H of [2, range, pings]",
+            "written_frac_sampled": written / (n_range * ((n_pings + 63) // 64))}
+
+
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+# ----------------------------------------------------------------------------------------------------------
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+    from crimac_classifiers_unet_amd import parallel
+
+    world, rank, local = parallel.init_distributed()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; measuring WORLD_SIZE ranks", file=sys.stderr)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    if args.spawn_selftest:
+        # census of the ranks that really started (CPU-testable: gloo when there is no GPU)
+        t = torch.ones(1)
+        if torch.cuda.is_available():
+            t = t.cuda(local % max(torch.cuda.device_count(), 1))
         if world > 1:
-            t = torch.tensor([ti], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ti = float(t)
-        infer = world * B * args.steps / ti
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "ranks_counted": int(t.item()),
+                              "backend": dist.get_backend() if world > 1 else None,
+                              "self_launched": os.environ.get("CRIMAC_SELF_LAUNCHED") == "1"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    local = local % max(torch.cuda.device_count(), 1)     # (rehearsals with several ranks on one GPU)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    grad_sync = parallel.GradSync()
+    main, model = measure_mode(args, args.precision, args.steps, args.warmup, world, rank, dev, grad_sync,
+                               infer=not args.no_infer, log=log)
+    tiled = None
+    if world == 1 and not args.no_tiled and args.start_filts == 64:
+        tiled = measure_tiled(model, args, log)
+        log(f"tiled: {tiled['patches_per_s']:.0f} patches/s end to end")
+    del model
+    parity = None
+    if world == 1 and not args.no_parity_mode and args.precision != args.parity_precision and args.start_filts == 64:
+        torch.cuda.empty_cache()
+        parity, pm = measure_mode(args, args.parity_precision, max(3, args.steps // 2), 2, world, rank, dev,
+                                  grad_sync, infer=not args.no_infer, log=log)
+        del pm
+        parity["meets"] = "north-star parity bar: logits <= 1e-3 rel, bit-exact argmax (tests/test_gpu_unet.py)"
 
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        sf = args.start_filts
+        rl = main["roofline"]
+        pmc = load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")
+        if pmc and args.precision == "bf16" and sf == 64:
+            sel = [v for k, v in pmc["kernels"].items() if k.startswith("conv3x3")]
+            nl = sum(v["launches"] for v in sel)
+            rl["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
+            rl["traffic_note"] = "HBM (L2-miss) bytes per launch, rocprofv3 PMC passes (profiles/*_pmc_traffic.json)"
+        util = load_profile_json("r02_mfma_util.json")
+        if util and args.precision == "bf16" and sf == 64:
+            rl["mfma_busy_frac"] = util.get("conv3x3", {}).get("mfma_busy_frac")
+            rl["clock_ghz"] = util.get("conv3x3", {}).get("clock_ghz")
+            rl["util_note"] = util.get("note")
+            main["roofline_wgrad"]["mfma_busy_frac"] = util.get("wgrad", {}).get("mfma_busy_frac")
+            main["roofline_wgrad"]["clock_ghz"] = util.get("wgrad", {}).get("clock_ghz")
+        workload = ("BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, batch 32 x 4x256x256 per GPU"
+                    if sf == 64 else
+                    f"BASELINE configs[4]: wide U-Net (depth 5, {sf} filters) train step, batch {args.batch} x 4x256x256 "
+                    "per GPU" + (", on-GPU add_noise/flip augment" if args.gpu_augment else ""))
+        if world > 1:
+            workload += f", data-parallel over {world} GPUs (RCCL gradient exchange overlapped with backward)"
         out = {
             "metric": "echogram patches/sec (4ch 256x256), training step (fwd+weighted CE+bwd+SGD)",
-            "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_LABEL[args.precision],
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, "
-                                   "batch 32 x 4x256x256 per GPU" + (
-                                       f", data-parallel over {world} GPUs (RCCL all-reduce)" if world > 1 else ""),
-                       "global_batch": world * B, "patch": [4, 256, 256], "precision": args.precision,
-                       "parallelism": f"dp{world}"},
-            "train_tflops": value * TRAIN_GFLOP_PER_PATCH / 1e3,
-            "infer_patches_per_s": infer,
-            "infer_tflops": infer * FWD_GFLOP_PER_PATCH / 1e3 if infer else None,
-            "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "kernel": "crimac_conv3x3: conv3x3_wch_kernel + conv3x3_p64_kernel + conv3x3_glds_w4_kernel + conv3x3_c16_kernel "
-                                                           "(halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": "HBM (L2-miss) bytes per launch, rocprofv3 PMC, profiles/r01_pmc_traffic.json",
-                         "algorithmic_flops_per_launch": (achieved * 1e12) * (ms * 1e-3) / max(n_launch, 1),
-                         "launches": n_launch, "avg_launch_us": 1e3 * ms / max(n_launch, 1),
-                         "measured": ("serialized pass after the timed region (weight-gradient side stream off); "
-                                      "in the timed region these launches overlap the weight gradients"
-                                      if serialized else "timed region"),
-                         "avg_launch_us_timed_region_overlapped": (lambda r: 1e3 * r[1] / max(r[2], 1))(
-                             kernel_rate("crimac_conv3x3", prof_timed))},
-            "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_kernel (weight gradient, all shapes)",
-                               "achieved": wg_achieved, "peak": peak, "unit": "TFLOP/s",
-                               "frac": wg_achieved / peak, "traffic": None, "launches": wg_n,
-                               "avg_launch_us": 1e3 * wg_ms / max(wg_n, 1),
-                               "avg_launch_us_timed_region_overlapped": (lambda r: 1e3 * r[1] / max(r[2], 1))(
-                                   kernel_rate("crimac_wgrad", prof_timed))},
+            "value": main["train_patches_per_s"], "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": main["dtype"], "data": "synthetic",
+            "config": {"workload": workload, "global_batch": world * args.batch, "patch": [4, 256, 256],
+                       "precision": args.precision, "start_filts": sf, "parallelism": f"dp{world}",
+                       "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+                       "launcher": "self-spawned" if os.environ.get("CRIMAC_SELF_LAUNCHED") == "1" else
+                                   ("torchrun" if world > 1 else "single process")},
+            "per_gpu_patches_per_s": main["train_patches_per_s"] / world,
+            "train_tflops": main["train_tflops"],
+            "infer_patches_per_s": main.get("infer_patches_per_s"),
+            "infer_tflops": main.get("infer_tflops"),
+            "final_loss": main["final_loss"],
+            "roofline": rl, "roofline_wgrad": main["roofline_wgrad"],
         }
+        if parity is not None:
+            out["parity_mode"] = parity
+        if tiled is not None:
+            out["tiled"] = tiled
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    from crimac_classifiers_unet_amd import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # parent: no GPU call in this process -- spawn one rank per GPU and relay rank 0's line
+        print(f"[bench] no torchrun environment: spawning {args.gpus} ranks (one per GPU)", file=sys.stderr, flush=True)
+        rc, out0 = launch.spawn_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        sys.exit(rc)
+    run_rank(args)
 
 
 if __name__ == "__main__":

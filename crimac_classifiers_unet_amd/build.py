@@ -15,8 +15,11 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libcrimac_unet_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 SOURCES = ["conv3x3.hip", "conv3x3_glds.hip", "igemm.hip", "upconv.hip", "wgrad.hip", "elementwise.hip", "pack.hip", "tiling.hip", "augment.hip", "labels.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"),
-           os.path.join(os.path.dirname(PKG_DIR), "include", "crimac_unet_hip.h")]
+def _headers():
+    """Every header a source may include: csrc/*.h plus the public C-ABI header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
+        os.path.join(os.path.dirname(PKG_DIR), "include", "crimac_unet_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
          "-Wno-unused-value"] + os.environ.get("CRIMAC_HIPCC_EXTRA", "").split()
 
@@ -32,7 +35,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 

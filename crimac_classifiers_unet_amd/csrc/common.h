@@ -135,4 +135,26 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// One-time per-DEVICE setup (hipFuncSetAttribute applies to the current device only): true the first time the
+// calling site runs with device d current.  `mask` is a static of the call site, bit d = done on device d.
+static inline bool crimac_first_use_on_device(unsigned long long* mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const unsigned long long bit = 1ull << dev;
+  return (__atomic_fetch_or(mask, bit, __ATOMIC_ACQ_REL) & bit) == 0;
+}
+// Compute units of the current device (cached per device).
+static inline int crimac_cu_count() {
+  static int ncu[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = __atomic_load_n(&ncu[dev], __ATOMIC_RELAXED);
+  if (n <= 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    __atomic_store_n(&ncu[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

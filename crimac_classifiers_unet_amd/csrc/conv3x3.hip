@@ -282,11 +282,10 @@ int launch(ConvParams p, hipStream_t st) {
   size_t lds = (size_t)2 * NPL * (HALO_ROWS * BK * 2 + BN * BK * 2);
   const size_t stage = (size_t)BM * (BN * sizeof(TA) + 16) + 2 * BN * sizeof(float);
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, NPL, BN, BK, TR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv3x3_kernel<TA, NPL, BN, BK, TR>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();

@@ -243,11 +243,10 @@ int launch_w4(ConvParams p, hipStream_t st) {
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   const size_t lds = (size_t)A_BYTES + (BN == 64 ? 3 : 2) * BN * RB;
   static_assert(BM * (BN * 2 + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB, "epilogue staging must fit");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
@@ -445,11 +444,10 @@ int launch_wch(ConvParams p, hipStream_t st) {
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;
   const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(conv3x3_wch_kernel, dim3((unsigned)ntiles, p.n_count / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
@@ -893,23 +891,16 @@ int launch_p64(ConvParams p, hipStream_t st) {
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4;     // 157184 B
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
+  const int ncu = crimac_cu_count();
   long grid = (ntiles + 1) / 2;
   if (grid > ncu) grid = ncu;
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;

@@ -272,11 +272,10 @@ int launch(const IgemmParams& p, hipStream_t st) {
   size_t lds = (size_t)(BM + BN) * BK * 2 * NPL;
   const size_t stage = (size_t)BM * (BN * sizeof(TA) + 16);
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<TA, NPL, BN, BK, OUT_MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((igemm_kernel<TA, NPL, BN, BK, OUT_MODE>), dim3(tilesM * tilesN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();

@@ -133,11 +133,10 @@ extern "C" int crimac_refine_labels(const void* labels_in, int label_bytes, cons
   CRIMAC_REQUIRE(aux_mask || (C > 0 && thr_channel >= 0 && thr_channel < C), "refine_labels: bad channel %d of %d",
                  thr_channel, C);
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "refine_labels: bad mode %d", mode);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_labels_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   const size_t lds = (size_t)(((2 * BAND + 18) * W + 15) & ~15) + 16;
   hipLaunchKernelGGL(refine_labels_kernel, dim3(B, cdiv(H, BAND)), dim3(kThreads), lds, (hipStream_t)stream, labels_in,

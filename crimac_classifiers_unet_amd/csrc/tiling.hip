@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256) void pr_histogram_kernel(const float* __restri
       prob = z[1] / den;
     }
     const _Float16 h = (_Float16)prob;       // round-to-nearest-even, as numpy .astype(float16)
-    const unsigned short bits = *reinterpret_cast<const unsigned short*>(&h);
+    unsigned short bits = *reinterpret_cast<const unsigned short*>(&h);
+    // a probability is in [0, 1] = bit patterns 0 .. 0x3C00; a NaN (diverged network: 0x7E00 / 0xFE00) must not
+    // index past the 16384 bins -> counted in the last bin, which no probability reaches (the host raises on it,
+    // as sklearn's precision_recall_curve does on a NaN score)
+    if (bits > 0x3C00) bits = CRIMAC_PR_NAN_BIN;
     atomicAdd((!seabed && l == 1) ? &hist_pos[bits] : &hist_neg[bits], 1u);
   }
 }

@@ -242,11 +242,10 @@ int launch(UpParams p, hipStream_t st) {
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;
   const size_t lds = stage > 2 * (size_t)A_BYTES ? stage : 2 * (size_t)A_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((upconv_wch_kernel<SCATTER>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();

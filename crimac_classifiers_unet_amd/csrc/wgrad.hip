@@ -525,11 +525,10 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   p.nsplits = splits;
   // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of NPL planes
   const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 : NPL);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
+  if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, NPL, MODE, NARROW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE, NARROW>), dim3(ch_tiles * splits), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();

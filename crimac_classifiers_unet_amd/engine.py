@@ -113,6 +113,7 @@ class UNetEngine:
         self._eval_pack_dirty = True
         self._versions = None
         self.saved = None          # activations of the last train-mode forward
+        self.forward_generation = 0   # bumped by every train-mode forward (unet._UNetFunction checks it in backward)
         self.accumulate_grads = False   # True: backward() adds to the flat gradient (torch semantics
         #                                 when .grad is not zeroed between backward calls)
 
@@ -305,6 +306,7 @@ class UNetEngine:
     exchange_on_side = os.environ.get("CRIMAC_EXCHANGE_SIDE", "0") != "0"
     _side = None
     _side_events = None
+    _eval_side = None
 
     @staticmethod
     def _gloo_ranks():
@@ -569,18 +571,20 @@ class UNetEngine:
     eval_two_streams = os.environ.get("CRIMAC_EVAL_STREAMS", "1") != "0"
 
     def _forward_eval_two_streams(self, x, softmax):
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device)]
-            self._side_events = [torch.cuda.Event() for _ in range(32)]
-            self._side_i = 0
-        side = self._side[0]
+        # (a stream of its own: the backward pass's side-stream logic keys on self._side, which must stay None when
+        # CRIMAC_WGRAD_STREAM=0 asks for a serialized backward pass or under gloo rehearsals)
+        if self._eval_side is None:
+            self._eval_side = torch.cuda.Stream(device=self.device)
+            self._eval_events = [torch.cuda.Event() for _ in range(8)]
+            self._eval_i = 0
+        side = self._eval_side
         B, _, H, W = x.shape
         h = B // 2
         self._check_versions()
         self._pack_eval()                              # (on the caller's stream, before either half starts)
         logits = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=self.device)
-        ev = self._side_events[self._side_i % len(self._side_events)]
-        self._side_i += 1
+        ev = self._eval_events[self._eval_i % len(self._eval_events)]
+        self._eval_i += 1
         ev.record()
         try:
             self._buf_prefix = "h0."
@@ -690,6 +694,8 @@ class UNetEngine:
              ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
         saved["head_in"] = cur if head_bn is None else None
         self.saved = saved if training else None
+        if training:
+            self.forward_generation += 1
         return logits
 
     # ------------------------------------------------------------------------------------------

@@ -257,6 +257,8 @@ class SegPipe:
                 call("crimac_pr_histogram", ptr(logits), nc, ptr(labels), labels.element_size(), B, H, W,
                      ptr(hist[0]), ptr(hist[1]))
         h = hist.cpu().numpy().astype(np.int64)
+        if h[:, self.PR_BINS - 1].any():      # CRIMAC_PR_NAN_BIN: sklearn raises on NaN scores as well
+            raise ValueError("Input contains NaN (sandeel probabilities of the validation set)")
         mean_loss = (float(sum_loss) if sum_loss is not None else 0.0) / len(dataloader)
         return h[0], h[1], mean_loss
 

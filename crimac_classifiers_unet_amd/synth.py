@@ -137,3 +137,56 @@ def synth_labels(batch, height=256, width=256, seed=2, p=(0.90, 0.04, 0.04, 0.02
     vals = np.array([0, 1, 2, LABEL_IGNORE_VAL], dtype=np.int16)
     idx = rng.choice(4, size=(batch, height, width), p=np.asarray(p))
     return vals[idx]
+
+
+class SyntheticSurveyReader:
+    """In-memory survey with the five reader members the tiled-inference path uses (the reference's zarr reader,
+    crimac_unet/data/data_reader.py:510-1120: ``shape``, ``get_data_slice`` -> [freq, ping, range] linear sv,
+    ``get_label_slice`` -> [ping, range], ``get_seabed``, ``get_seabed_mask`` = 1 below the seabed).
+
+    BASELINE configs[3]: sv [4, n_pings, 1024] fp32 linear, 10^U(-7.5, 0), flat seabed index 900.
+    One ``block``-ping random block is tiled along the ping axis (generating 268 M random floats would dominate
+    the benchmark's start-up); every chunk still moves and transforms its own bytes."""
+    data_format = "zarr"
+
+    class _Val:
+        def __init__(self, v):
+            self.values = v
+
+        def max(self):
+            return SyntheticSurveyReader._Val(np.max(self.values))
+
+    def __init__(self, n_pings=65536, n_range=1024, channels=4, seabed_index=900, block=4096, seed=1):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        blk = np.power(10.0, rng.uniform(-7.5, 0.0, size=(channels, min(block, n_pings), n_range))).astype(np.float32)
+        reps = -(-n_pings // blk.shape[1])
+        self.sv = np.ascontiguousarray(np.tile(blk, (1, reps, 1))[:, :n_pings])
+        self.labels = np.zeros((n_pings, n_range), dtype=np.int16)
+        self.seabed = np.full(n_pings, seabed_index, dtype=np.int64)
+        self.shape = (n_pings, n_range)
+        self.time_vector = np.arange(n_pings)
+        self.range_vector = np.arange(n_range) * 0.19
+        self.name = "synthetic_survey"
+
+    def get_data_slice(self, idx_ping, n_pings, idx_range=None, n_range=None, frequencies=None, drop_na=False,
+                       return_numpy=True):
+        return self.sv[:, idx_ping:idx_ping + n_pings]
+
+    def get_label_slice(self, idx_ping, n_pings, idx_range=None, n_range=None, drop_na=False, categories=None,
+                        return_numpy=True, correct_transducer_offset=False, mask=True):
+        return self.labels[idx_ping:idx_ping + n_pings]
+
+    def get_seabed(self, idx_ping, n_pings=1, idx_range=None, n_range=None, return_numpy=True):
+        v = self.seabed[idx_ping:idx_ping + n_pings]
+        return v.copy() if return_numpy else SyntheticSurveyReader._Val(v)
+
+    def get_seabed_mask(self, idx_ping, n_pings, idx_range=None, n_range=None, return_numpy=False, seabed_pad=0):
+        idx_range = 0 if idx_range is None else idx_range
+        hi = self.shape[1] if n_range is None else idx_range + n_range
+        r = np.arange(idx_range, min(hi, self.shape[1]))
+        m = (r[None, :] >= self.seabed[idx_ping:idx_ping + n_pings, None]).astype(np.float64)
+        if seabed_pad != 0:
+            out = np.zeros_like(m)
+            out[:, seabed_pad:] = m[:, :-seabed_pad]
+            return out
+        return m

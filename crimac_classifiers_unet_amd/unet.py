@@ -45,26 +45,54 @@ class _DecoderStage(nn.Module):
 
 
 class _UNetFunction(torch.autograd.Function):
-    """One autograd node for the whole network: forward and backward are HIP kernel chains."""
+    """One autograd node for the whole network: forward and backward are HIP kernel chains.
+
+    The activations a backward pass needs live in the ENGINE (one set of buffers, overwritten by every
+    train-mode forward), not in the autograd graph.  Each forward is therefore stamped with a generation
+    number; a backward through a node whose activations have since been overwritten raises instead of silently
+    differentiating the wrong forward (torch keeps one set of activations per node; the reference loop,
+    pipeline.py:167-178, only ever has one forward in flight).  Gradients ACCUMULATE into ``.grad`` like torch's:
+    whatever ``.grad`` holds when backward starts is added to the new gradient, so backward-twice-then-step
+    (micro-batching) works and ``zero_grad`` (either form) starts afresh.
+    """
 
     @staticmethod
     def forward(ctx, x, engine, *params):
         ctx.engine = engine
         ctx.nparams = len(params)
-        return engine.forward(x, training=True)
+        out = engine.forward(x, training=True)
+        ctx.generation = engine.forward_generation
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.engine
-        # keep whatever an un-zeroed .grad held (torch accumulates across backward calls)
-        carry = {}
+        if ctx.generation != eng.forward_generation or eng.saved is None:
+            raise RuntimeError(
+                "UNet_Baseline (MI355X build): backward() of a forward pass whose activations were overwritten by a "
+                "later train-mode forward (or already consumed by an earlier backward).  The HIP engine keeps the "
+                "activations of the LAST train-mode forward only: run forward -> loss -> backward per micro-batch "
+                "(gradients accumulate in .grad across backward calls until zero_grad).")
+        # torch semantics: backward ADDS to whatever .grad holds.  Gradients that alias the flat buffer are
+        # carried through one clone of it; foreign .grad tensors (assigned by the user) are added per parameter.
+        carry, aliased = {}, 0
         for name, p in eng.P.items():
             g = p.grad
-            if g is not None and g.data_ptr() != eng.G[name].data_ptr():
+            if g is None:
+                continue
+            if g.data_ptr() == eng.G[name].data_ptr():
+                aliased += 1
+            else:
                 carry[name] = g
-        prev = eng.flat_g.clone() if eng.accumulate_grads else None
+        none_grad = [name for name, p in eng.P.items() if p.grad is None]
+        prev = eng.flat_g.clone() if (aliased or eng.accumulate_grads) else None
         eng.backward(dlogits)
+        eng.saved = None                  # consumed: a second backward through this node must not run on stale buffers
         if prev is not None:
+            if none_grad and not eng.accumulate_grads:        # set_to_none on some parameters: those start afresh
+                for name in none_grad:
+                    o, n, _ = eng.layout[name]
+                    prev[o:o + n].zero_()
             eng.flat_g.add_(prev)
         for name, p in eng.P.items():
             if name in carry:

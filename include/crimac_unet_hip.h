@@ -10,7 +10,14 @@
  *
  * Conventions
  *   - every pointer is a raw DEVICE pointer owned by the caller (workspaces included); the library
- *     allocates nothing and keeps no mutable global state; one process per GPU, re-entrant per stream
+ *     allocates nothing; one process per GPU, re-entrant per stream.  Process state it does keep: the
+ *     thread-local last-error text; one-time per-DEVICE kernel attribute setup (dynamic-LDS limits, CU count;
+ *     keyed on hipGetDevice, so several GPUs in one process work); and A/B tuning switches read ONCE from the
+ *     environment at first use and constant afterwards (CRIMAC_CONV_W4, CRIMAC_CONV_P64, CRIMAC_CONV_TR,
+ *     CRIMAC_CONV_BK, CRIMAC_CONV_GLDS, CRIMAC_UPCONV_WCH, CRIMAC_WGRAD_BLOCKS -- kernel-selection experiments
+ *     only; results do not depend on them beyond summation order).  Reductions that use floating-point
+ *     atomics (BatchNorm sums, bias gradients) are not bit-reproducible run to run; everything on the
+ *     inference path is
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is asynchronous
  *   - return value: 0 (CRIMAC_OK) or a negative code; crimac_last_error() gives the thread-local text
  *   - activations are NHWC; `ld` arguments are the pixel stride in ELEMENTS (>= channels), so a
@@ -258,7 +265,11 @@ int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int
  * histograms (16384 bins, indexed by the float16 bit pattern of softmax(logits)[SANDEEL]) of the valid
  * pixels with raw label == SANDEEL (hist_pos) and the others (hist_neg); labels are RAW batch labels:
  * {-70,-30,-100,-10} are skipped, -50 (below seabed) counts as background with probability 0
- * (pipeline.py:222-239, :317).  Accumulates (caller zeroes). */
+ * (pipeline.py:222-239, :317).  Accumulates (caller zeroes).  A probability that is not in [0, 1] (NaN logits
+ * of a diverged network) is counted in bin CRIMAC_PR_NAN_BIN, which no valid probability reaches (1.0 = 0x3C00);
+ * sklearn's precision_recall_curve raises on such input and so does the host wrapper. */
+#define CRIMAC_PR_BINS 16384
+#define CRIMAC_PR_NAN_BIN (CRIMAC_PR_BINS - 1)
 int crimac_pr_histogram(const float* logits, int ncls, const void* labels, int label_bytes, int B, int H,
                         int W, unsigned int* hist_pos, unsigned int* hist_neg, void* stream);
 

@@ -169,17 +169,107 @@ def test_train_step_matches_reference_golden_f32x3(full_case):
     print("worst grad L2-rel / tolerance:", worst)
 
 
-def test_train_step_bf16_envelope(full_case):
+def _check_lowp_train_step(precision, x, lab, seed=0):
+    """The 16-bit-storage HIP path against the oracle that rounds at the same storage points
+    (oracle/unet_lowp_oracle.py): deterministic up to fp32 summation order, so EVERY gradient is compared."""
+    from oracle import unet_lowp_oracle as lowp
+    sd = synth.synth_state_dict(seed=seed)
+    ref_loss, ref_logits, ref_grads, ref_stats = lowp.loss_and_grads(sd, x, lab, storage=precision)
+    m, loss, logits, grads, stats = _train_once(precision, x, lab, fused=False)
+    r = rel(logits.detach(), ref_logits)
+    print(f"{precision} vs storage-rounding oracle: logits rel {r:.2e}, loss {loss:.6f} vs {float(ref_loss):.6f}")
+    assert r < 5e-3
+    assert abs(loss - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
+    for k, v in ref_stats.items():
+        assert rel(stats[k].float(), v) < 1e-3, k
+    worst = (0.0, None)
+    for k, g in grads.items():
+        if PRE_BN_BIAS.fullmatch(k):
+            # exactly zero in exact arithmetic (a bias in front of train-mode BatchNorm); the engine leaves the
+            # zero fill, autograd holds rounding noise: both must be negligible next to the weight gradient
+            wk = k[:-4] + "weight"
+            assert float(g.abs().max()) <= 1e-3 * float(ref_grads[wk].abs().max()), k
+            continue
+        e = l2rel(g, ref_grads[k])
+        if e > worst[0]:
+            worst = (e, k)
+        assert e < 2e-2, (k, e)
+    print(f"{precision}: worst gradient L2-rel vs storage-rounding oracle: {worst[0]:.2e} ({worst[1]})")
+
+
+def test_train_step_bf16_matches_storage_rounding_oracle_all_gradients(full_case):
+    """Replaces the envelope check (which accepted 0.8 relative error on early layers): the benched precision's
+    whole-network gradients, all 64 tensors, against an oracle with bf16 rounding at the engine's storage points."""
+    _, x, lab = full_case
+    _check_lowp_train_step("bf16", x, lab)
+
+
+def test_eval_bf16_matches_storage_rounding_oracle(full_case):
+    from oracle import unet_lowp_oracle as lowp
+    _, x, _ = full_case
+    sd = synth.synth_state_dict(seed=0)
+    ref = lowp.predict(sd, x, storage="bf16")
+    m = make_model("bf16").eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    r = rel(out, ref)
+    frac = float((out.argmax(1).cpu() != ref.argmax(1)).float().mean())
+    print(f"eval bf16 vs storage-rounding oracle: rel={r:.3e} argmax flip fraction={frac:.5%}")
+    assert r < 5e-3 and frac < 1e-3
+
+
+def test_train_step_bf16_envelope_vs_fp32_reference(full_case):
+    """Distance of the bf16 mode from the fp32 REFERENCE golden (the envelope BASELINE.md quotes for
+    torch.autocast(bf16) of the reference itself); the exactness proof is the storage-rounding test above."""
     fix, x, lab = full_case
     m, loss, logits, grads, _ = _train_once("bf16", x, lab, fused=False)
     assert rel(logits.detach(), fix["logits_train"]) < 6e-2
     assert abs(loss - float(fix["losses"][0])) < 2e-2 * abs(float(fix["losses"][0]))
-    # bf16 rounding (2^-9) flips ~1e3x more ReLU / max-pool decisions than fp32 rounding does, so
-    # single-batch gradients of the early layers carry O(0.5) relative noise (SGD-noise-like); the
-    # layers next to the loss stay tight
     assert l2rel(grads["conv_final.weight"], fix["grad/conv_final.weight"]) < 0.2
-    for k in ("down_convs.0.main.0.weight", "up_convs.3.upconv.weight"):
-        assert l2rel(grads[k], fix["grad/" + k]) < 0.8, k
+
+
+def test_batch32_full_size_f32x6_matches_oracle():
+    """BASELINE configs[1] at its real size (B = 32, 4 x 256 x 256) in the parity precision against the CPU
+    oracle run on the same box (~30 s of host time): eval logits <= 1e-3 rel with bit-exact argmax, and one
+    train step (loss, logits, BatchNorm buffers, all gradients)."""
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    sd = synth.synth_state_dict(seed=0)
+    x = torch.from_numpy(synth.synth_echogram_batch(32, 4, 256, 256, seed=31))
+    lab = torch.from_numpy(synth.synth_labels(32, 256, 256, seed=32))
+    ref = orc.predict(sd, x)
+    m = make_model("f32x6").eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    r = rel(out, ref)
+    diff = out.argmax(1).cpu() != ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[diff]
+    print(f"B=32 eval f32x6: rel={r:.3e} argmax flips={int(diff.sum())}/{ref[:, 0].numel()} margins={margin.tolist()}")
+    assert r < 1e-5
+    # identical masks except where the reference's own two top logits tie to fp32 round-off
+    assert int(diff.sum()) <= 2 and bool((margin < 2e-6).all())
+    ref_loss, ref_logits, ref_grads, ref_stats = orc.loss_and_grads(sd, x, lab)
+    m.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    logits = m(x.cuda())
+    loss = crit(logits, lab.long().cuda())
+    loss.backward()
+    assert rel(logits.detach(), ref_logits) < 2e-5
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+    sdm = m.state_dict()
+    for k, v in ref_stats.items():
+        assert rel(sdm[k].float(), v.float()) < 1e-5, k
+    worst = (0.0, None)
+    for k, p in m.named_parameters():
+        if PRE_BN_BIAS.fullmatch(k):
+            continue
+        e = l2rel(p.grad, ref_grads[k])
+        if e > worst[0]:
+            worst = (e, k)
+        # two fp32-accurate evaluations of a chaotic net (ReLU / max-pool decisions flip on 1e-7 perturbations):
+        # the reference's own fp32-vs-fp64 distance is 3-4e-3 on the golden crops (tests/golden, gnoise/*)
+        assert e < 2e-2, (k, e)
+    print(f"B=32 train f32x6: worst gradient L2-rel vs oracle {worst[0]:.2e} ({worst[1]})")
 
 
 def test_fused_step_equals_autograd_path(full_case):
@@ -554,3 +644,57 @@ def test_syncbn_two_ranks_equal_one_rank_on_the_concatenated_batch(full_case):
         worst = max(worst, r)
         assert r < 1e-2, (k, r)          # fp32-equivalent path vs fp64 oracle: the net's own chaos floor (3e-3)
     print("SyncBN worst grad L2-rel vs fp64 oracle:", worst)
+
+
+def test_autograd_node_refuses_stale_activations_and_accumulates_like_torch():
+    """the engine keeps ONE set of activations.  (1) backward of an older forward raises instead of
+    differentiating the newer one; (2) backward twice without zero_grad accumulates (torch semantics);
+    (3) zero_grad in either form starts afresh."""
+    m = make_model("f32x3").train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    x1 = torch.from_numpy(synth.synth_echogram_batch(1, 4, 32, 32, seed=41)).cuda()
+    x2 = torch.from_numpy(synth.synth_echogram_batch(1, 4, 32, 32, seed=42)).cuda()
+    l1 = torch.from_numpy(synth.synth_labels(1, 32, 32, seed=43)).long().cuda()
+    l2 = torch.from_numpy(synth.synth_labels(1, 32, 32, seed=44)).long().cuda()
+    loss_a = crit(m(x1), l1)
+    loss_b = crit(m(x2), l2)
+    with pytest.raises(RuntimeError, match="activations were overwritten"):
+        (loss_a + loss_b).backward()
+    # micro-batching: forward/backward per micro-batch, gradients add up
+    m.zero_grad(set_to_none=False)
+    crit(m(x1), l1).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    crit(m(x2), l2).backward()
+    g12 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    crit(m(x2), l2).backward()
+    g2 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k in g1:
+        if PRE_BN_BIAS.fullmatch(k):
+            continue
+        assert l2rel(g12[k], g1[k] + g2[k]) < 1e-4, k
+    # a second backward through the same node has no activations left
+    out = m(x1)
+    loss = crit(out, l1)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="activations were overwritten|already consumed"):
+        loss.backward()
+
+
+def test_pr_histogram_counts_nan_probabilities_in_the_guard_bin():
+    """NaN logits (diverged training) must not index outside the 2 x 16384 histogram."""
+    from crimac_classifiers_unet_amd.hip import call, ptr
+    B, H, W = 2, 16, 16
+    logits = torch.randn(B, 3, H, W, device="cuda")
+    logits[0, :, 3, 4] = float("nan")
+    logits[1, 1, 7, 7] = float("inf")
+    labels = torch.zeros(B, H, W, dtype=torch.int16, device="cuda")
+    labels[0, 3, 4] = 1
+    hist = torch.zeros(2, 16384 + 64, dtype=torch.int32, device="cuda")       # guard words behind each histogram
+    view = hist[:, :16384]
+    call("crimac_pr_histogram", ptr(logits), 3, ptr(labels), 2, B, H, W, ptr(hist[0]), ptr(hist[1]))
+    torch.cuda.synchronize()
+    h = hist.cpu()
+    assert int(h[:, 16384:].sum()) == 0
+    assert int(h[0, 16383]) == 1 and int(h[1, 16383]) == 1
+    assert int(view.sum()) == B * H * W

@@ -98,3 +98,30 @@ def test_state_shapes_match_reference_layout():
     assert shapes["up_convs.0.upconv.weight"] == (1024, 512, 2, 2)
     assert shapes["up_convs.0.conv1.weight"] == (512, 1024, 3, 3)
     assert shapes["conv_final.weight"] == (3, 64, 1, 1)
+
+
+def test_storage_rounding_oracle_is_the_fp32_oracle_up_to_the_16bit_envelope():
+    """oracle/unet_lowp_oracle.py (bf16 / fp16 storage points of the HIP engine) stays within the 16-bit envelope
+    of the fp32 oracle on a small case, rounds exactly where it says, and leaves fp32 weights untouched."""
+    import torch
+    from crimac_classifiers_unet_amd import synth
+    from oracle import unet_lowp_oracle as lowp
+    from oracle import unet_oracle as orc
+    sd = synth.synth_state_dict(seed=3)
+    x = torch.from_numpy(synth.synth_echogram_batch(1, 4, 32, 32, seed=5))
+    lab = torch.from_numpy(synth.synth_labels(1, 32, 32, seed=6))
+    ref_loss, ref_logits, ref_grads, _ = orc.loss_and_grads(sd, x, lab)
+    for storage, tol in (("bf16", 8e-2), ("fp16", 1e-2)):
+        loss, logits, grads, stats = lowp.loss_and_grads(sd, x, lab, storage=storage)
+        assert float((logits - ref_logits).abs().max() / ref_logits.abs().max()) < tol
+        assert abs(float(loss) - float(ref_loss)) < tol * abs(float(ref_loss))
+        assert set(grads) == set(ref_grads) and all(torch.isfinite(g).all() for g in grads.values())
+        g, r = grads["conv_final.weight"], ref_grads["conv_final.weight"]
+        assert float((g - r).norm() / r.norm()) < 5 * tol
+        assert len(stats) == 36
+    v = torch.randn(1000)
+    q = lowp._st(v.clone().requires_grad_(True), torch.bfloat16)
+    assert torch.equal(q.detach(), v.to(torch.bfloat16).float())
+    w = torch.randn(8, requires_grad=True)
+    (lowp._wq(w, torch.bfloat16) * torch.arange(8.0)).sum().backward()
+    assert torch.equal(w.grad, torch.arange(8.0))
