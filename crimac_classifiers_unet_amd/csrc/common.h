@@ -157,4 +157,32 @@ static inline int crimac_cu_count() {
   return n;
 }
 
+// ---- in-kernel clock diagnostic (MI355X_MICROARCH.md, DVFS give-back (6)) ---------------------------------
+// -DCRIMAC_DIAG_CLOCK builds (tools/diag_clock.py, never the shipped library): a kernel stamps s_memtime (shader
+// cycles) and s_memrealtime (100 MHz) around its main loop and thread 0 of each workgroup stores the two
+// differences into a buffer of the translation unit that no other code reads; clock = d_memtime / d_memrealtime
+// x 100 MHz.  In the normal build the macros expand to nothing.
+#ifdef CRIMAC_DIAG_CLOCK
+#define CRIMAC_DIAG_SLOTS 4096
+#define CRIMAC_DIAG_DECLARE(name)                                                                   \
+  __device__ unsigned long long name##_buf[2 * CRIMAC_DIAG_SLOTS];                                  \
+  extern "C" int name##_read(unsigned long long* host_out) {                                        \
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name##_buf), sizeof(unsigned long long) * 2 * CRIMAC_DIAG_SLOTS); \
+  }
+#define CRIMAC_DIAG_STAMP(t, r)                                                                     \
+  unsigned long long t, r;                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0);
+#define CRIMAC_DIAG_STORE(name, t0, r0, t1, r1)                                                     \
+  if (threadIdx.x == 0) {                                                                           \
+    name##_buf[2 * (blockIdx.x % CRIMAC_DIAG_SLOTS)] = (t1) - (t0);                                 \
+    name##_buf[2 * (blockIdx.x % CRIMAC_DIAG_SLOTS) + 1] = (r1) - (r0);                             \
+  }
+#else
+#define CRIMAC_DIAG_DECLARE(name)
+#define CRIMAC_DIAG_STAMP(t, r)
+#define CRIMAC_DIAG_STORE(name, t0, r0, t1, r1)
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -23,6 +23,8 @@
 #include "common.h"
 #include "conv_epilogue.h"
 
+CRIMAC_DIAG_DECLARE(crimac_diag_clock_conv)
+
 namespace {
 
 struct ConvParams {
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   WchFrags f;
   wch_load_b(wrow, wrow + w_nb, f.b[1]);
   wch_land_b(f.b[1]);
+  CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
   for (int kc = 0; kc < kchunks; ++kc) {
     issue_halo(kc);
     wait_vmcnt<0>();
@@ -434,6 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
   }
+  CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
+  CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
   conv_epilogue<bf16_t, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
 }
 

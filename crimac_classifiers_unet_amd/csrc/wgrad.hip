@@ -21,6 +21,8 @@
 // combined with fp32 atomics whose wave shape is two 128-byte row segments (full atomic rate).
 #include "common.h"
 
+CRIMAC_DIAG_DECLARE(crimac_diag_clock_wgrad)
+
 namespace {
 
 struct WgradParams {
@@ -388,6 +390,7 @@ void wgrad_kernel(WgradParams p) {
       const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
       const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
       if (t_begin < t_end) issue_tile(t_begin, 0);
+      CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
       for (long tile = t_begin; tile < t_end; ++tile) {
         const int cur = (int)((tile - t_begin) & 1);
         __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
@@ -413,6 +416,8 @@ void wgrad_kernel(WgradParams p) {
         }
 #endif
       }
+      CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
+      CRIMAC_DIAG_STORE(crimac_diag_clock_wgrad, dg_t0, dg_r0, dg_t1, dg_r1)
       // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps
 #pragma unroll
       for (int sh = 0; sh < 2; ++sh) {

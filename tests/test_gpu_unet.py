@@ -176,13 +176,18 @@ def _check_lowp_train_step(precision, x, lab, seed=0):
     sd = synth.synth_state_dict(seed=seed)
     ref_loss, ref_logits, ref_grads, ref_stats = lowp.loss_and_grads(sd, x, lab, storage=precision)
     m, loss, logits, grads, stats = _train_once(precision, x, lab, fused=False)
-    r = rel(logits.detach(), ref_logits)
-    print(f"{precision} vs storage-rounding oracle: logits rel {r:.2e}, loss {loss:.6f} vs {float(ref_loss):.6f}")
-    assert r < 5e-3
+    r, r2 = rel(logits.detach(), ref_logits), l2rel(logits.detach(), ref_logits)
+    errs = {k: l2rel(g, ref_grads[k]) for k, g in grads.items() if not PRE_BN_BIAS.fullmatch(k)}
+    worst = max(errs, key=errs.get)
+    print(f"{precision} vs storage-rounding oracle: logits max-rel {r:.2e} L2-rel {r2:.2e}, loss {loss:.6f} vs "
+          f"{float(ref_loss):.6f}; gradients: worst L2-rel {errs[worst]:.2e} ({worst}), median "
+          f"{sorted(errs.values())[len(errs) // 2]:.2e}, {sum(e > 1e-2 for e in errs.values())} of {len(errs)} above 1e-2")
+    # a 16-bit value that lands on the other side of a rounding boundary (fp32 summation order) moves by one ulp
+    # = 2^-8 relative (bf16): the max-norm sees single flips, the L2 norm their density
+    assert r2 < 3e-3 and r < 3e-2
     assert abs(loss - float(ref_loss)) < 1e-3 * abs(float(ref_loss))
     for k, v in ref_stats.items():
         assert rel(stats[k].float(), v) < 1e-3, k
-    worst = (0.0, None)
     for k, g in grads.items():
         if PRE_BN_BIAS.fullmatch(k):
             # exactly zero in exact arithmetic (a bias in front of train-mode BatchNorm); the engine leaves the
@@ -190,11 +195,7 @@ def _check_lowp_train_step(precision, x, lab, seed=0):
             wk = k[:-4] + "weight"
             assert float(g.abs().max()) <= 1e-3 * float(ref_grads[wk].abs().max()), k
             continue
-        e = l2rel(g, ref_grads[k])
-        if e > worst[0]:
-            worst = (e, k)
-        assert e < 2e-2, (k, e)
-    print(f"{precision}: worst gradient L2-rel vs storage-rounding oracle: {worst[0]:.2e} ({worst[1]})")
+        assert errs[k] < 2e-2, (k, errs[k])
 
 
 def test_train_step_bf16_matches_storage_rounding_oracle_all_gradients(full_case):
@@ -212,10 +213,10 @@ def test_eval_bf16_matches_storage_rounding_oracle(full_case):
     m = make_model("bf16").eval()
     with torch.no_grad():
         out = m(x.cuda())
-    r = rel(out, ref)
+    r, r2 = rel(out, ref), l2rel(out, ref)
     frac = float((out.argmax(1).cpu() != ref.argmax(1)).float().mean())
-    print(f"eval bf16 vs storage-rounding oracle: rel={r:.3e} argmax flip fraction={frac:.5%}")
-    assert r < 5e-3 and frac < 1e-3
+    print(f"eval bf16 vs storage-rounding oracle: max-rel={r:.3e} L2-rel={r2:.3e} argmax flip fraction={frac:.5%}")
+    assert r2 < 3e-3 and r < 3e-2 and frac < 2e-3
 
 
 def test_train_step_bf16_envelope_vs_fp32_reference(full_case):
