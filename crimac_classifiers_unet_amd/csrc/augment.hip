@@ -93,7 +93,7 @@ extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* l
                                       void* out, short* labels_out, unsigned char* aux_mask, int thr_channel,
                                       float thr_lo, float thr_hi, int B, int C, int H, int W, long ld,
                                       unsigned long long seed, int do_noise, int do_flip, void* stream) {
-  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "augment_db_nhwc: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "augment_db_nhwc: bad precision %d", prec);
   CRIMAC_REQUIRE(data && out && B > 0 && C > 0 && C <= 16 && H > 0 && W > 0 && ld >= C && ld <= 16 && ld % 8 == 0,
                  "augment_db_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
   CRIMAC_REQUIRE(!labels_in || label_bytes == 2 || label_bytes == 4 || label_bytes == 8,
@@ -106,14 +106,10 @@ extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* l
   if (blocks > 4096) blocks = 4096;
   const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
   hipStream_t st = (hipStream_t)stream;
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL(augment_db_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, data, labels_in,
-                       label_bytes, (bf16_t*)out, labels_out, aux_mask, thr_channel, thr_lo, thr_hi, B, C, H, W, (int)ld,
-                       lo, hi, do_noise, do_flip, 0.5f, 0.05f);
-  else
-    hipLaunchKernelGGL(augment_db_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, data, labels_in,
-                       label_bytes, (float*)out, labels_out, aux_mask, thr_channel, thr_lo, thr_hi, B, C, H, W, (int)ld,
-                       lo, hi, do_noise, do_flip, 0.5f, 0.05f);
+  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(augment_db_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, data,
+                                                 labels_in, label_bytes, (T*)out, labels_out, aux_mask, thr_channel,
+                                                 thr_lo, thr_hi, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
+                                                 0.05f));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

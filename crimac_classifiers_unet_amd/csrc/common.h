@@ -8,6 +8,8 @@
 #include "../../include/crimac_unet_hip.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
@@ -55,9 +57,42 @@ __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned
   lo = f2bfbits(x - bfbits2f(hi));
 }
 
+// ---- 16-bit element traits: the two storage / MFMA operand types of the 16-bit modes -------------------------
+// Fragments travel as raw 128-bit registers (typed bf16x8 for historical reasons: LDS reads, DMAs and inline-asm
+// loads do not care what the 16 bits mean); only the conversion to / from fp32 and the MFMA opcode depend on T16.
+template <typename T16> struct E16;
+template <> struct E16<bf16_t> {
+  __device__ static __forceinline__ unsigned short bits(float x) { return f2bfbits(x); }
+  __device__ static __forceinline__ float val(unsigned short b) { return bfbits2f(b); }
+  __device__ static __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct E16<half_t> {
+  __device__ static __forceinline__ unsigned short bits(float x) {
+    const half_t h = (half_t)x;                   // round-to-nearest-even (v_cvt_f16_f32); overflow -> inf
+    return *reinterpret_cast<const unsigned short*>(&h);
+  }
+  __device__ static __forceinline__ float val(unsigned short b) { return (float)*reinterpret_cast<const half_t*>(&b); }
+  __device__ static __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+  }
+};
+
+// Runtime-selected element type (weight packing): `fp16` != 0 -> IEEE half, else bf16.  The `planes` argument of the
+// pack entry points carries it in bit 4 (CRIMAC_PLANES_FP16).
+__device__ __forceinline__ unsigned short f2bits16(float x, int fp16) { return fp16 ? E16<half_t>::bits(x) : f2bfbits(x); }
+__device__ __forceinline__ float bits162f(unsigned short b, int fp16) { return fp16 ? E16<half_t>::val(b) : bfbits2f(b); }
+
 // Split 8 fp32 values (two 16-byte registers) into NPL bf16 planes of 8 values each:
 // x = p0 + p1 (+ p2) up to 2^-17 (2^-25) relative.  Each subtraction is exact in fp32.
-template <int NPL>
+template <int NPL, typename P16 = bf16_t>
 __device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4 (&pl)[NPL]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -65,33 +100,51 @@ __device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4 (
                   __uint_as_float(j < 2 ? r0[2 * j + 1] : r1[2 * j - 3])};
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
-      const unsigned short b0 = f2bfbits(f[0]), b1 = f2bfbits(f[1]);
+      const unsigned short b0 = E16<P16>::bits(f[0]), b1 = E16<P16>::bits(f[1]);
       pl[k][j] = (unsigned)b0 | ((unsigned)b1 << 16);
-      f[0] -= bfbits2f(b0);
-      f[1] -= bfbits2f(b1);
+      f[0] -= E16<P16>::val(b0);
+      f[1] -= E16<P16>::val(b1);
     }
   }
 }
 
 // D += A * B with A, B given as NPL bf16 planes: all plane products of total order < NPL, smallest
 // terms first (NPL 1: 1 MFMA, 2: 3 MFMAs, 3: 6 MFMAs).
-template <int NPL>
+template <int NPL, typename P16 = bf16_t>
 __device__ __forceinline__ void mfma_planes(const bf16x8 (&a)[NPL], const bf16x8 (&b)[NPL], f32x16& acc) {
 #pragma unroll
   for (int s = NPL - 1; s >= 0; --s)
 #pragma unroll
     for (int i = 0; i <= s; ++i)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[s - i], acc, 0, 0, 0);
+      acc = E16<P16>::mfma32(a[i], b[s - i], acc);
 }
 
+// MFMA operand (plane) element type of an activation storage type: 16-bit storage is its own plane; fp32 storage
+// is split into bf16 planes.
+template <typename TA> struct PlaneOf { using type = TA; };
+template <> struct PlaneOf<float> { using type = bf16_t; };
+
 // Number of operand planes of a precision mode.
-__host__ __device__ constexpr int planes_of(int prec) { return prec == 0 ? 1 : (prec == 1 ? 2 : 3); }
+__host__ __device__ constexpr int planes_of(int prec) { return (prec == 0 || prec == 3) ? 1 : (prec == 1 ? 2 : 3); }
+
+// Storage-type dispatch of an entry point: `T` is bf16_t (CRIMAC_PREC_BF16), half_t (CRIMAC_PREC_FP16) or float
+// (the fp32-storage modes) inside the statement.
+#define CRIMAC_FOR_STORAGE(prec, T, ...)                                  \
+  do {                                                                    \
+    if ((prec) == CRIMAC_PREC_BF16) { using T = bf16_t; __VA_ARGS__; }    \
+    else if ((prec) == CRIMAC_PREC_FP16) { using T = half_t; __VA_ARGS__; } \
+    else { using T = float; __VA_ARGS__; }                                \
+  } while (0)
 
 // Activation element traits: T = bf16_t (16-bit storage) or float (fp32 storage).
 template <typename T> struct ActT;
 template <> struct ActT<bf16_t> {
   static constexpr int kBytes = 2;
   static constexpr int kVec = 8;  // elements per 16-byte access
+};
+template <> struct ActT<half_t> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
 };
 template <> struct ActT<float> {
   static constexpr int kBytes = 4;
@@ -104,6 +157,11 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = bfbits2f(r[i]);
 }
+__device__ __forceinline__ void load8(const half_t* p, float (&v)[8]) {
+  half8 r = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+}
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
   f32x4 a = *reinterpret_cast<const f32x4*>(p);
   f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -115,6 +173,12 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) r[i] = f2bfbits(v[i]);
   *reinterpret_cast<u16x8*>(p) = r;
+}
+__device__ __forceinline__ void store8(half_t* p, const float (&v)[8]) {
+  half8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (half_t)v[i];
+  *reinterpret_cast<half8*>(p) = r;
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   f32x4 a, b;

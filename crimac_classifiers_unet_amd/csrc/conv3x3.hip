@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mfma_planes<NPL>(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) mfma_planes<NPL, typename PlaneOf<TA>::type>(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -294,24 +294,39 @@ int launch(ConvParams p, hipStream_t st) {
 
 }  // namespace
 
-// conv3x3_glds.hip: bf16 direct-to-LDS variant
-int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                             const void* w_hi, const EpiParams& epi, hipStream_t st, int n_first, int n_count);
-int crimac_conv3x3_c16_bf16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
-                            const EpiParams& epi, hipStream_t st);
+// conv3x3_glds.hip: 16-bit-storage direct-to-LDS variants (fp16 != 0: IEEE half, else bf16)
+int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16);
+int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
+                          const EpiParams& epi, hipStream_t st, int fp16);
+
+// register-staged kernel for one 16-bit storage type (odd channel counts, A/B runs)
+template <typename T16>
+static int conv3x3_staged16(const ConvParams& p, hipStream_t st, int Cin, bool n128, bool big, int force_bk) {
+  // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
+  // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128
+  if (Cin % 64 == 0 && force_bk != 32 && (n128 || force_bk == 64)) {
+    if (big) return n128 ? launch<T16, 1, 128, 64, 16>(p, st) : launch<T16, 1, 64, 64, 16>(p, st);
+    return n128 ? launch<T16, 1, 128, 64, 8>(p, st) : launch<T16, 1, 64, 64, 8>(p, st);
+  }
+  if (Cin % 32 == 0) return n128 ? launch<T16, 1, 128, 32, 8>(p, st) : launch<T16, 1, 64, 32, 8>(p, st);
+  return n128 ? launch<T16, 1, 128, 16, 8>(p, st) : launch<T16, 1, 64, 16, 8>(p, st);
+}
 
 static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
                        const void* w_hi, const void* w_lo, const float* bias, void* out,
                        long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
                        int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
                        long bnb_stride, int n_first, int n_count, void* stream) {
-  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "conv3x3: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
   CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0,
                  "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
   CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && in && w_hi && out, "conv3x3: bad arguments");
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "conv3x3: split precisions need the low weight plane(s)");
+  const bool is16 = prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16;
+  const int fp16 = prec == CRIMAC_PREC_FP16;
+  CRIMAC_REQUIRE(is16 || w_lo, "conv3x3: split precisions need the low weight plane(s)");
   CRIMAC_REQUIRE(stat_mode >= 0 && stat_mode <= 2, "conv3x3: stat_mode=%d", stat_mode);
   CRIMAC_REQUIRE(stat_mode == 0 || (stat_sum && stat_sumsq && stat_replicas >= 1),
                  "conv3x3: stat_mode %d needs both accumulators and replicas >= 1", stat_mode);
@@ -338,24 +353,17 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   // the N = 64 layers (4-wave kernel, two workgroups per CU).
   static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
   const bool ranged = n_first != 0 || n_count != N;
-  CRIMAC_REQUIRE(!ranged || (n_first >= 0 && n_count > 0 && n_first + n_count <= N && prec == CRIMAC_PREC_BF16 &&
+  CRIMAC_REQUIRE(!ranged || (n_first >= 0 && n_count > 0 && n_first + n_count <= N && is16 &&
                              Cin % 64 == 0 && use_glds),
-                 "conv3x3_cols: a channel range needs the bf16 LDS-DMA kernels (Cin %% 64 == 0)");
-  if (prec == CRIMAC_PREC_BF16 && Cin % 64 == 0 && use_glds)
-    return crimac_conv3x3_glds_bf16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count);
-  // first layer (4 input channels padded to 16): one-barrier kernel, 181 -> see DESIGN.md us at B = 32
-  if (prec == CRIMAC_PREC_BF16 && Cin == 16 && N == 64 && use_glds)
-    return crimac_conv3x3_c16_bf16(in, in_ld, B, H, W, N, w_hi, e, st);
-  if (prec == CRIMAC_PREC_BF16) {
-    // N = 64 layers (level 0 / decoder 3, also the HBM-heaviest): the 32-deep chunk halves the LDS
-    // footprint -> 3-4 workgroups per CU, measured 10-16 % faster there; 64-deep wins for N >= 128
-    if (Cin % 64 == 0 && force_bk != 32 && (n128 || force_bk == 64)) {
-      if (big) return n128 ? launch<bf16_t, 1, 128, 64, 16>(p, st) : launch<bf16_t, 1, 64, 64, 16>(p, st);
-      return n128 ? launch<bf16_t, 1, 128, 64, 8>(p, st) : launch<bf16_t, 1, 64, 64, 8>(p, st);
-    }
-    if (Cin % 32 == 0) return n128 ? launch<bf16_t, 1, 128, 32, 8>(p, st) : launch<bf16_t, 1, 64, 32, 8>(p, st);
-    return n128 ? launch<bf16_t, 1, 128, 16, 8>(p, st) : launch<bf16_t, 1, 64, 16, 8>(p, st);
-  }
+                 "conv3x3_cols: a channel range needs the 16-bit LDS-DMA kernels (Cin %% 64 == 0)");
+  if (is16 && Cin % 64 == 0 && use_glds)
+    return crimac_conv3x3_glds_16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, fp16);
+  // first layer (4 input channels padded to 16): persistent one-barrier kernel
+  if (is16 && Cin == 16 && N == 64 && use_glds)
+    return crimac_conv3x3_c16_16(in, in_ld, B, H, W, N, w_hi, e, st, fp16);
+  if (is16)
+    return fp16 ? conv3x3_staged16<half_t>(p, st, Cin, n128, big, force_bk)
+                : conv3x3_staged16<bf16_t>(p, st, Cin, n128, big, force_bk);
   // split-bf16 keeps 2-3 planes per operand: 32-deep chunks keep the LDS footprint in bounds
   if (prec == CRIMAC_PREC_F32X3) {
     if (Cin % 32 == 0) return n128 ? launch<float, 2, 128, 32, 8>(p, st) : launch<float, 2, 64, 32, 8>(p, st);

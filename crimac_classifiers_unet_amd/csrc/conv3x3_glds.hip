@@ -97,7 +97,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // drains the DMA queue: 470-610 us).
 // (BN = 128 instantiates too -- 64 x 128 per wave, 2-slot ring, 74 KB -- and was the default for N >= 128 until
 // the channel-split kernel below beat it by 12 %; CRIMAC_CONV_W4=1 selects it for A/B runs.)
-template <int BN>
+template <int BN, typename T16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void conv3x3_glds_w4_kernel(ConvParams p) {
   constexpr int NW = 4, NT = BN / 16;
@@ -124,7 +124,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
   const int b = tile_m / p.tiles_y;
   const int y0 = tyi * TR, x0 = txi * TC;
   const int n0 = blockIdx.y * BN;
-  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
+  const T16* inp = reinterpret_cast<const T16*>(p.in);
 
   long h_src[NH];
 #pragma unroll
@@ -189,7 +189,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = E16<T16>::mfma16(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -234,11 +234,11 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
       for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
   if (sum == 12345.678f) reinterpret_cast<float*>(p.epi.out)[tid] = sum;
 #else
-  conv_epilogue<bf16_t, BN, BM, 256, 4, NT, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
+  conv_epilogue<T16, BN, BM, 256, 4, NT, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
 #endif
 }
 
-template <int BN>
+template <int BN, typename T16>
 int launch_w4(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
@@ -247,10 +247,10 @@ int launch_w4(ConvParams p, hipStream_t st) {
   static_assert(BM * (BN * 2 + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB, "epilogue staging must fit");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -320,7 +320,7 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
       : "v"(s0), "v"(s1)
       : "memory");
 }
-template <int H, typename ACC>
+template <typename T16, int H, typename ACC>
 __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsigned short* wtap, long w_tap, long w_nb,
                                            const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
   constexpr int t = H / 8, ks2 = (H / 4) % 2, q = H % 4, NH = 72;
@@ -349,11 +349,12 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
-      acc[4 * q + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[H & 1][j], f.b[t & 1][ks2 * 2 + nb],
-                                                                    acc[4 * q + j][nb], 0, 0, 0);
-  if constexpr (H + 1 < NH) wch_step<H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
+      acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][ks2 * 2 + nb],
+                                                                    acc[4 * q + j][nb]);
+  if constexpr (H + 1 < NH) wch_step<T16, H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
+template <typename T16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel(ConvParams p) {
   constexpr int BN = 128, NW = 4;
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
@@ -433,15 +434,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned short* wtap = wrow + kc * BK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
     wch_issue<0>(av, f);
-    wch_step<0>(av, wtap, w_tap, w_nb, wnext, f, acc);
+    wch_step<T16, 0>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
   }
   CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
   CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
-  conv_epilogue<bf16_t, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
+  conv_epilogue<T16, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
 }
 
+template <typename T16>
 int launch_wch(ConvParams p, hipStream_t st) {
   constexpr int BN = 128;
   p.tiles_y = cdiv(p.H, TR);
@@ -451,10 +453,10 @@ int launch_wch(ConvParams p, hipStream_t st) {
   const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL(conv3x3_wch_kernel, dim3((unsigned)ntiles, p.n_count / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(conv3x3_wch_kernel<T16>, dim3((unsigned)ntiles, p.n_count / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -473,6 +475,7 @@ int launch_wch(ConvParams p, hipStream_t st) {
 //   * wave w owns image rows 4w .. 4w+3 x all 64 channels and writes them through a private LDS slab, one
 //     16-pixel row (2 KB contiguous in HBM) at a time -- no workgroup barrier in the epilogue;
 //   * the statistics stay in registers across tiles and are flushed once per workgroup.
+template <typename T16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 registers: 4 workgroups/CU
 void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   constexpr int BN = 64, CB = 32;                 // bytes per halo pixel
@@ -485,8 +488,8 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   float* sstat = reinterpret_cast<float*>(smem + HALO_ROWS * CB + 4 * SLAB);      // [2][64]
   unsigned char* wlds = smem + HALO_ROWS * CB + 4 * SLAB + 2 * BN * 4;
   const EpiParams& e = p.epi;
-  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
-  bf16_t* outp = reinterpret_cast<bf16_t*>(e.out);
+  const T16* inp = reinterpret_cast<const T16*>(p.in);
+  T16* outp = reinterpret_cast<T16*>(e.out);
   const bool stats = e.stat_sum != nullptr && e.stat_mode == 1;
   if (tid < 2 * BN) sstat[tid] = 0.f;
 
@@ -581,7 +584,7 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bw[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = E16<T16>::mfma16(af[i], bw[j], acc[i][j]);
       }
       // output: image row y0 + 4*wave + 2*ih + i = M tile i; accumulator element r of N tile j is pixel
       // (lane >> 4)*4 + r, channel j*16 + fr
@@ -595,8 +598,8 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
             const int px = (lane >> 4) * 4 + r;
             float v = acc[i][j][r] + bv[j];
             if (e.relu) v = fmaxf(v, 0.f);
-            const bf16_t q = (bf16_t)v;
-            *reinterpret_cast<bf16_t*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
+            const T16 q = (T16)v;
+            *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
             const float vs = (float)q;            // statistics of the value as STORED
             const bool ok = y < p.H && x0 + px < p.W;
             cs1[j] += ok ? vs : 0.f;
@@ -633,13 +636,14 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   }
 }
 
+template <typename T16>
 int launch_c16(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   constexpr size_t lds = (size_t)HALO_ROWS * 32 + 4 * 16 * (64 * 2 + 16) + 2 * 64 * 4 + 9 * 64 * 32;   // 38.6 KB
   const long grid = ntiles < 1024 ? ntiles : 1024;          // 4 workgroups per CU
-  hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)grid), dim3(256), lds, st, p, (int)ntiles);
+  hipLaunchKernelGGL(conv3x3_c16_kernel<T16>, dim3((unsigned)grid), dim3(256), lds, st, p, (int)ntiles);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -673,7 +677,7 @@ __device__ __forceinline__ void wg_barrier_lds() {
   asm volatile("" ::: "memory");
 }
 
-template <int MODE>        // statistics mode of the epilogue (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+template <int MODE, typename T16>   // statistics mode of the epilogue (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   constexpr int BN = 64, NT = 4;
@@ -688,8 +692,8 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   unsigned char* slab = halo + wave * SLAB;
   float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);          // [2][64]
   const EpiParams& e = p.epi;
-  const bf16_t* inp = reinterpret_cast<const bf16_t*>(p.in);
-  bf16_t* outp = reinterpret_cast<bf16_t*>(e.out);
+  const T16* inp = reinterpret_cast<const T16*>(p.in);
+  T16* outp = reinterpret_cast<T16*>(e.out);
   constexpr int mode = MODE;
   if (tid < 2 * BN) sstat[tid] = 0.f;
 
@@ -801,7 +805,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = E16<T16>::mfma16(af[i], bfr[j], acc[i][j]);
         }
       }
     }
@@ -820,8 +824,8 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
             const int px = (lane >> 4) * 4 + r;
             float v = acc[i][j][r] + bv[j];
             if (e.relu) v = fmaxf(v, 0.f);
-            const bf16_t q = (bf16_t)v;
-            *reinterpret_cast<bf16_t*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
+            const T16 q = (T16)v;
+            *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
             if (mode == 1) {
               const float vs = (float)q;        // statistics of the value as STORED
               const float vm = vs * okm[r];     // (0 for pixels outside the image: partial tiles)
@@ -833,14 +837,14 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int px = (lane >> 3) + 8 * k;
-          const bf16_t* sp = reinterpret_cast<const bf16_t*>(slab + px * SLAB_PITCH) + c8 * 8;
+          const T16* sp = reinterpret_cast<const T16*>(slab + px * SLAB_PITCH) + c8 * 8;
           if (y < p.H && x0 + px < p.W) {
             const long pix = ((long)b * p.H + y) * p.W + x0 + px;
             *reinterpret_cast<u32x4*>(outp + pix * e.out_ld + p.n_first + c8 * 8) = *reinterpret_cast<const u32x4*>(sp);
             if (mode == 2) {
               float g[8], yv[8];
               load8(sp, g);
-              load8(reinterpret_cast<const bf16_t*>(e.bnb_y) + pix * e.bnb_y_ld + p.n_first + c8 * 8, yv);
+              load8(reinterpret_cast<const T16*>(e.bnb_y) + pix * e.bnb_y_ld + p.n_first + c8 * 8, yv);
 #pragma unroll
               for (int kk = 0; kk < 8; ++kk) {
                 const float dz = (yv[kk] * sc[kk] + sh[kk]) > 0.f ? g[kk] : 0.f;
@@ -891,6 +895,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   }
 }
 
+template <typename T16>
 int launch_p64(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
@@ -898,55 +903,52 @@ int launch_p64(ConvParams p, hipStream_t st) {
   constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4;     // 157184 B
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<1, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<2, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int ncu = crimac_cu_count();
   long grid = (ntiles + 1) / 2;
   if (grid > ncu) grid = ncu;
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
-  if (mode == 0) hipLaunchKernelGGL(conv3x3_p64_kernel<0>, dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
-  else if (mode == 1) hipLaunchKernelGGL(conv3x3_p64_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
-  else hipLaunchKernelGGL(conv3x3_p64_kernel<2>, dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  if (mode == 0) hipLaunchKernelGGL((conv3x3_p64_kernel<0, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_p64_kernel<1, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else hipLaunchKernelGGL((conv3x3_p64_kernel<2, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
 
 }  // namespace
 
-// first layer: bf16, Cin == 16 (4 real channels), N == 64
-int crimac_conv3x3_c16_bf16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
-                            const EpiParams& epi, hipStream_t st) {
+// first layer: 16-bit storage (fp16 != 0: IEEE half, else bf16), Cin == 16 (4 real channels), N == 64
+int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
+                          const EpiParams& epi, hipStream_t st, int fp16) {
   ConvParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = 16; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
   p.n_first = 0; p.n_count = N;
-  return launch_c16(p, st);
+  return fp16 ? launch_c16<half_t>(p, st) : launch_c16<bf16_t>(p, st);
 }
 
-// bf16, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
-int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, int Cin, int N,
-                             const void* w_hi, const EpiParams& epi, hipStream_t st, int n_first, int n_count) {
-  ConvParams p;
-  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
-  p.w_hi = (const unsigned short*)w_hi;
-  p.epi = epi;
-  p.n_first = n_first; p.n_count = n_count;
+namespace {
+template <typename T16>
+int glds_dispatch(ConvParams p, hipStream_t st) {
+  const int B = p.B, H = p.H, W = p.W, Cin = p.Cin, N = p.N, n_first = p.n_first, n_count = p.n_count;
+  const long in_ld = p.in_ld;
   if (n_first != 0 || n_count != N) {
     // a range of output channels (crimac_conv3x3_cols): 64 of them with the persistent 64-channel kernel,
     // multiples of 128 with the channel-split kernel
     const long nt = (long)B * cdiv(H, TR) * cdiv(W, TC);
-    if (n_count == 64 && Cin == 64 && nt >= 512) return launch_p64(p, st);
+    if (n_count == 64 && Cin == 64 && nt >= 512) return launch_p64<T16>(p, st);
     const bool small_t = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
     CRIMAC_REQUIRE(n_first % 128 == 0 && n_count % 128 == 0 && small_t,
                    "conv3x3_cols: channel range [%d, +%d) of %d not supported (multiples of 128, or 64 of a "
                    "64-input-channel convolution with >= 512 tiles)", n_first, n_count, N);
-    return launch_wch(p, st);
+    return launch_wch<T16>(p, st);
   }
   // N % 128 == 0: channel-split kernel; N = 64 (or 192, ...): pixel-split kernel with the LDS weight ring.
   // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.6 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
@@ -954,8 +956,20 @@ int crimac_conv3x3_glds_bf16(const void* in, long in_ld, int B, int H, int W, in
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
   // 64 -> 64 with many tiles: persistent kernel with LDS-resident weights (CRIMAC_CONV_P64=0: W4 for A/B runs)
   static const int p64 = getenv("CRIMAC_CONV_P64") ? atoi(getenv("CRIMAC_CONV_P64")) : 1;
-  if (p64 && N == 64 && Cin == 64 && (long)B * cdiv(H, TR) * cdiv(W, TC) >= 512) return launch_p64(p, st);
-  if (N % 128 != 0) return launch_w4<64>(p, st);
+  if (p64 && N == 64 && Cin == 64 && (long)B * cdiv(H, TR) * cdiv(W, TC) >= 512) return launch_p64<T16>(p, st);
+  if (N % 128 != 0) return launch_w4<64, T16>(p, st);
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
-  return (w4 == 1 || !small) ? launch_w4<128>(p, st) : launch_wch(p, st);
+  return (w4 == 1 || !small) ? launch_w4<128, T16>(p, st) : launch_wch<T16>(p, st);
+}
+}  // namespace
+
+// 16-bit storage, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
+int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16) {
+  ConvParams p;
+  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
+  p.w_hi = (const unsigned short*)w_hi;
+  p.epi = epi;
+  p.n_first = n_first; p.n_count = n_count;
+  return fp16 ? glds_dispatch<half_t>(p, st) : glds_dispatch<bf16_t>(p, st);
 }

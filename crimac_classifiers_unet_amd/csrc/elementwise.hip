@@ -64,13 +64,14 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 
 // ---- weight packing -----------------------------------------------------------------------------
 // value -> plane 0 in `hi`, planes 1..npl-1 in `lo` (plane stride `n`)
-__device__ __forceinline__ void put_planes(float v, int npl, unsigned short* hi, unsigned short* lo,
+__device__ __forceinline__ void put_planes(float v, int planes_arg, unsigned short* hi, unsigned short* lo,
                                            long i, long n) {
-  unsigned short b = f2bfbits(v);
+  const int npl = planes_arg & 15, fp16 = planes_arg >> 4;      // (bit 4: IEEE half instead of bf16)
+  unsigned short b = f2bits16(v, fp16);
   hi[i] = b;
   for (int k = 1; k < npl; ++k) {
-    v -= bfbits2f(b);
-    b = f2bfbits(v);
+    v -= bits162f(b, fp16);
+    b = f2bits16(v, fp16);
     lo[(long)(k - 1) * n + i] = b;
   }
 }
@@ -788,9 +789,28 @@ __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ 
 }
 
 // ---- SGD with momentum over a flat parameter buffer -------------------------------------------------------------
+// Loss-scaled training (fp16 storage): state[0] = 1 if any gradient is not finite (this step), state[1] counts
+// the steps skipped because of it.  The check is a pass of its own over the flat gradient (31 M floats, ~25 us).
+__global__ __launch_bounds__(256) void grad_overflow_kernel(const float* __restrict__ g, long n4, long n, int* state) {
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    // |x| <= FLT_MAX is false for inf and NaN
+    bad |= !(fabsf(v[0]) <= 3.402823466e38f) | !(fabsf(v[1]) <= 3.402823466e38f) | !(fabsf(v[2]) <= 3.402823466e38f) |
+           !(fabsf(v[3]) <= 3.402823466e38f);
+  }
+  const long t = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t < n) bad |= !(fabsf(g[t]) <= 3.402823466e38f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&state[0], 1);
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ v, long n4, long n, float lr,
-                                                  float mom, float gscale, int zero_grad) {
+                                                  float mom, float gscale, int zero_grad, int* guard) {
+  if (guard && guard[0]) {       // non-finite gradients: skip the update (all threads see the same flag)
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard[1] += 1;
+    return;
+  }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
        i += (long)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
@@ -823,7 +843,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 // =================================================================================================
 #define ST ((hipStream_t)stream)
 #define PREC_OK(name) \
-  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, name ": bad precision %d", prec)
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, name ": bad precision %d", prec)
 
 extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, int C, int H, int W,
                                    long ld, void* stream) {
@@ -832,12 +852,8 @@ extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, 
                  "nchw_to_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
   const long npix = (long)B * H * W;
   const int grid = grid_for(npix, 256);
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST, in, (bf16_t*)out, C,
-                       (long)H * W, npix, ld);
-  else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, ST, in, (float*)out, C,
-                       (long)H * W, npix, ld);
+  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid), dim3(256), 0, ST, in, (T*)out, C,
+                                                 (long)H * W, npix, ld));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -846,7 +862,8 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
                                    int planes, void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo,
                                    void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0 && Ci_pad >= Ci, "pack_conv3x3: bad arguments");
-  CRIMAC_REQUIRE(planes >= 1 && planes <= 3 && (planes == 1 || fwd_lo) && (planes == 1 || !dg_hi || dg_lo),
+  CRIMAC_REQUIRE((planes == CRIMAC_PLANES_FP16 || (planes >= 1 && planes <= 3)) &&
+                     ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
                  "pack_conv3x3: planes=%d needs the lo plane buffers", planes);
   CRIMAC_REQUIRE(!dg_hi || Ci_pad == Ci, "pack_conv3x3: dgrad planes need Ci_pad == Ci");
   const int grid = grid_for(9L * Co * Ci_pad, 256);
@@ -860,7 +877,8 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
 extern "C" int crimac_pack_upconv2x2(const float* w, int Ci, int Co, int planes, void* fwd_hi,
                                      void* fwd_lo, void* dg_hi, void* dg_lo, void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0, "pack_upconv2x2: bad arguments");
-  CRIMAC_REQUIRE(planes >= 1 && planes <= 3 && (planes == 1 || fwd_lo) && (planes == 1 || !dg_hi || dg_lo),
+  CRIMAC_REQUIRE((planes == CRIMAC_PLANES_FP16 || (planes >= 1 && planes <= 3)) &&
+                     ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
                  "pack_upconv2x2: planes=%d needs the lo plane buffers", planes);
   const int grid = grid_for(4L * Co * Ci, 256);
   hipLaunchKernelGGL(pack_upconv_kernel, dim3(grid), dim3(256), 0, ST, w, Ci, Co, planes,
@@ -901,21 +919,12 @@ extern "C" int crimac_colstats(int prec, const void* y, long ld, long M, int C, 
                  "colstats: bad arguments (C=%d ld=%ld)", C, ld);
   const int grid = colreduce_grid(M, C);
   const size_t lds = 2 * C * sizeof(float);
-  if (prec == CRIMAC_PREC_BF16) {
-    if (sumsq)
-      hipLaunchKernelGGL((colstats_kernel<bf16_t, double, 2>), dim3(grid), dim3(256), lds, ST,
-                         (const bf16_t*)y, ld, M, C, sum, sumsq);
-    else
-      hipLaunchKernelGGL((colstats_kernel<bf16_t, double, 1>), dim3(grid), dim3(256), lds, ST,
-                         (const bf16_t*)y, ld, M, C, sum, sumsq);
-  } else {
-    if (sumsq)
-      hipLaunchKernelGGL((colstats_kernel<float, double, 2>), dim3(grid), dim3(256), lds, ST,
-                         (const float*)y, ld, M, C, sum, sumsq);
-    else
-      hipLaunchKernelGGL((colstats_kernel<float, double, 1>), dim3(grid), dim3(256), lds, ST,
-                         (const float*)y, ld, M, C, sum, sumsq);
-  }
+  if (sumsq)
+    CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL((colstats_kernel<T, double, 2>), dim3(grid), dim3(256), lds, ST,
+                                                   (const T*)y, ld, M, C, sum, sumsq));
+  else
+    CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL((colstats_kernel<T, double, 1>), dim3(grid), dim3(256), lds, ST,
+                                                   (const T*)y, ld, M, C, sum, sumsq));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -927,12 +936,8 @@ extern "C" int crimac_colsum_f32(int prec, const void* y, long ld, long M, int C
                  "colsum_f32: bad arguments (C=%d ld=%ld)", C, ld);
   const int grid = colreduce_grid(M, C);
   const size_t lds = 2 * C * sizeof(float);
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL((colstats_kernel<bf16_t, float, 1>), dim3(grid), dim3(256), lds, ST,
-                       (const bf16_t*)y, ld, M, C, sum, (float*)nullptr);
-  else
-    hipLaunchKernelGGL((colstats_kernel<float, float, 1>), dim3(grid), dim3(256), lds, ST,
-                       (const float*)y, ld, M, C, sum, (float*)nullptr);
+  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL((colstats_kernel<T, float, 1>), dim3(grid), dim3(256), lds, ST,
+                                                 (const T*)y, ld, M, C, sum, (float*)nullptr));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -995,11 +1000,8 @@ extern "C" int crimac_bn_act_pool(int prec, const void* y, long y_ld, const floa
                      (!pool_out || (pool_ld >= C && pool_ld % 8 == 0)),
                  "bn_act_pool: bad pixel strides");
   CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0), "bn_act_pool: pooling needs even H, W");
-  return prec == CRIMAC_PREC_BF16
-             ? bn_act_pool_launch<bf16_t>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld, B,
-                                          H, W, C, ST)
-             : bn_act_pool_launch<float>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld, B,
-                                         H, W, C, ST);
+  CRIMAC_FOR_STORAGE(prec, T, return bn_act_pool_launch<T>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld,
+                                                           B, H, W, C, ST));
 }
 
 static bool bnb_args_ok(const void* y, long y_ld, const float* vec, long stride, double* s0, double* s1, int replicas,
@@ -1028,11 +1030,8 @@ extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const voi
   hipLaunchKernelGGL((unpool_add_kernel<T, BNB>), dim3(grid), dim3(256), LDS, ST, (const T*)dp, dp_ld,     \
                      (const T*)a, a_ld, (const T*)ds, ds_ld, (T*)da, da_ld, B, H, W, C, bnb)
   const size_t lds = 2 * (size_t)C * sizeof(float);
-  if (prec == CRIMAC_PREC_BF16) {
-    if (stat_sum) UA(bf16_t, true, lds); else UA(bf16_t, false, 0);
-  } else {
-    if (stat_sum) UA(float, true, lds); else UA(float, false, 0);
-  }
+  if (stat_sum) CRIMAC_FOR_STORAGE(prec, T, UA(T, true, lds));
+  else CRIMAC_FOR_STORAGE(prec, T, UA(T, false, 0));
 #undef UA
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1049,14 +1048,9 @@ extern "C" int crimac_bn_bwd_reduce(int prec, const void* da, long da_ld, const 
                  "bn_bwd_reduce: bad arguments");
   const int grid = colreduce_grid(M, C);
   const size_t lds = 2 * C * sizeof(float);
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), lds, ST, (const bf16_t*)da,
-                       da_ld, (const bf16_t*)y, y_ld, scale, shift, mean, invstd, M, C, sum_dz,
-                       sum_dz_xhat);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), lds, ST, (const float*)da,
-                       da_ld, (const float*)y, y_ld, scale, shift, mean, invstd, M, C, sum_dz,
-                       sum_dz_xhat);
+  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(grid), dim3(256), lds, ST, (const T*)da,
+                                                 da_ld, (const T*)y, y_ld, scale, shift, mean, invstd, M, C, sum_dz,
+                                                 sum_dz_xhat));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -1076,14 +1070,9 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
                  "bn_bwd_apply: bad pixel strides");
   const int grid = colreduce_grid(M, C);
   const size_t lds = 2 * C * sizeof(float);
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, ST, (const bf16_t*)da,
-                       da_ld, (const bf16_t*)y, y_ld, scale, shift, mean, invstd, sum_dz, sum_dz_xhat, M,
-                       count, C, (bf16_t*)dy, dy_ld, dgamma, dbeta, dbias);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), lds, ST, (const float*)da,
-                       da_ld, (const float*)y, y_ld, scale, shift, mean, invstd, sum_dz, sum_dz_xhat, M,
-                       count, C, (float*)dy, dy_ld, dgamma, dbeta, dbias);
+  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), lds, ST, (const T*)da,
+                                                 da_ld, (const T*)y, y_ld, scale, shift, mean, invstd, sum_dz,
+                                                 sum_dz_xhat, M, count, C, (T*)dy, dy_ld, dgamma, dbeta, dbias));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -1118,9 +1107,8 @@ extern "C" int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, cons
                  "head_fwd: Cin=%d must be 8*2^k <= 512", Cin);
   CRIMAC_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "head_fwd: bn_scale and bn_shift go together");
   const long HW = (long)H * W;
-  return prec == CRIMAC_PREC_BF16
-             ? head_fwd_launch<bf16_t>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale, bn_shift, ST)
-             : head_fwd_launch<float>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale, bn_shift, ST);
+  CRIMAC_FOR_STORAGE(prec, T, return head_fwd_launch<T>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale,
+                                                        bn_shift, ST));
 }
 
 template <typename T>
@@ -1159,9 +1147,8 @@ extern "C" int crimac_head_bwd(int prec, const float* dlogits, const void* x, lo
                  "head_bwd: bad arguments of the fused BatchNorm-backward sums");
   const long HW = (long)H * W;
   const BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
-  return prec == CRIMAC_PREC_BF16
-             ? head_bwd_launch<bf16_t>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, bnb, ST)
-             : head_bwd_launch<float>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls, bnb, ST);
+  CRIMAC_FOR_STORAGE(prec, T, return head_bwd_launch<T>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls,
+                                                        bnb, ST));
 }
 
 extern "C" int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes,
@@ -1207,7 +1194,28 @@ extern "C" int crimac_sgd_momentum(float* p, float* g, float* v, long n, float l
   const long n4 = n / 4;
   const int grid = grid_for(n4 > 0 ? n4 : 1, 256 * 4);
   hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
-                     zero_grad);
+                     zero_grad, (int*)nullptr);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_grad_overflow_flag(const float* g, long n, int* state, void* stream) {
+  CRIMAC_REQUIRE(g && state && n > 0 && ((uintptr_t)g % 16 == 0), "grad_overflow_flag: bad arguments");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(grad_overflow_kernel, dim3(grid_for(n4 > 0 ? n4 : 1, 256 * 8)), dim3(256), 0, ST, g, n4, n, state);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_sgd_momentum_guarded(float* p, float* g, float* v, long n, float lr, float momentum,
+                                           float grad_scale, int zero_grad, int* state, void* stream) {
+  CRIMAC_REQUIRE(p && g && v && state && n > 0, "sgd_momentum_guarded: bad arguments");
+  CRIMAC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                 "sgd_momentum_guarded: buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  const int grid = grid_for(n4 > 0 ? n4 : 1, 256 * 4);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
+                     zero_grad, state);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

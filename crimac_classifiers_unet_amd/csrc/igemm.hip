@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mfma_planes<NPL>(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) mfma_planes<NPL, typename PlaneOf<TA>::type>(af[i], bfr[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -298,22 +298,23 @@ int dispatch(const IgemmParams& p, hipStream_t st) {
 
 // upconv.hip: channel-split LDS-DMA kernel for the two bf16 transposed-convolution contractions
 bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, long out_ld);
-int crimac_upconv_wch_bf16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N,
-                           const void* w, const float* bias, int cout_up, void* out, long out_ld, hipStream_t st);
+int crimac_upconv_wch_16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
+                         const float* bias, int cout_up, void* out, long out_ld, hipStream_t st, int fp16);
 
 extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int Wi, int Ho,
                                  int Wo, int Cin, int N, int ntaps, int tw, int pad, int stride,
                                  const void* w_hi, const void* w_lo, const float* bias, int bias_mod,
                                  void* out, long out_ld, int relu, int out_mode, int cout_up,
                                  void* stream) {
-  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "igemm: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "igemm: bad precision %d", prec);
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "igemm: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "igemm: N=%d must be a positive multiple of 64", N);
   CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0, "igemm: in_ld=%ld must be >= Cin and a multiple of 8", in_ld);
   CRIMAC_REQUIRE(ntaps >= 1 && tw >= 1 && ntaps % tw == 0 && stride >= 1, "igemm: bad tap geometry");
   CRIMAC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "igemm: bad grid");
   CRIMAC_REQUIRE(in && w_hi && out, "igemm: null pointer");
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || w_lo, "igemm: split precisions need the low weight plane(s)");
+  const bool is16 = prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16;
+  CRIMAC_REQUIRE(is16 || w_lo, "igemm: split precisions need the low weight plane(s)");
   CRIMAC_REQUIRE(out_mode == 0 || (out_mode == 1 && cout_up > 0 && N == 4 * cout_up),
                  "igemm: bad output mode / cout_up");
   CRIMAC_REQUIRE(out_mode == 1 ? out_ld >= cout_up : out_ld >= N, "igemm: out_ld too small");
@@ -327,7 +328,7 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   p.out = out; p.out_ld = out_ld; p.relu = relu; p.cout_up = cout_up;
   p.M = (long)B * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
-  if (prec == CRIMAC_PREC_BF16 && !relu) {
+  if (is16 && !relu) {
     // ConvTranspose2d(k2, s2): forward (1 tap, scatter) and input gradient (4 taps, stride 2) go to upconv.hip
     static const int use_wch = getenv("CRIMAC_UPCONV_WCH") ? atoi(getenv("CRIMAC_UPCONV_WCH")) : 1;
     const long in_bytes = (((long)B * Hi * Wi - 1) * in_ld + Cin) * 2;
@@ -336,10 +337,13 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
     const bool dgr = out_mode == 0 && ntaps == 4 && tw == 2 && stride == 2 && pad == 0 && Hi == 2 * Ho &&
                      Wi == 2 * Wo && !bias;
     if (use_wch && (fwd || dgr) && crimac_upconv_wch_ok(ntaps, in_bytes, Cin, N, cout_up, out_ld))
-      return crimac_upconv_wch_bf16(ntaps, in, in_ld, B, Ho, Wo, Cin, N, w_hi, bias, cout_up, out, out_ld, st);
+      return crimac_upconv_wch_16(ntaps, in, in_ld, B, Ho, Wo, Cin, N, w_hi, bias, cout_up, out, out_ld, st,
+                                  prec == CRIMAC_PREC_FP16);
   }
   if (prec == CRIMAC_PREC_BF16)
     return out_mode == 0 ? dispatch<bf16_t, 1, 0>(p, st) : dispatch<bf16_t, 1, 1>(p, st);
+  if (prec == CRIMAC_PREC_FP16)
+    return out_mode == 0 ? dispatch<half_t, 1, 0>(p, st) : dispatch<half_t, 1, 1>(p, st);
   if (prec == CRIMAC_PREC_F32X3)
     return out_mode == 0 ? dispatch<float, 2, 0>(p, st) : dispatch<float, 2, 1>(p, st);
   return out_mode == 0 ? dispatch<float, 3, 0>(p, st) : dispatch<float, 3, 1>(p, st);

@@ -53,28 +53,28 @@ __device__ __forceinline__ int find_layer(const Table& tb, int block) {
 
 // two adjacent values -> plane words; plane 0 -> hi[i/2], planes 1.. -> lo[(k-1)*n/2 + i/2]
 __device__ __forceinline__ void put_planes2(float v0, float v1, int npl, unsigned short* hi, unsigned short* lo,
-                                            long i, long n) {
-  unsigned short b0 = f2bfbits(v0), b1 = f2bfbits(v1);
+                                            long i, long n, int fp16) {
+  unsigned short b0 = f2bits16(v0, fp16), b1 = f2bits16(v1, fp16);
   *reinterpret_cast<unsigned int*>(hi + i) = (unsigned int)b0 | ((unsigned int)b1 << 16);
   for (int k = 1; k < npl; ++k) {
-    v0 -= bfbits2f(b0);
-    v1 -= bfbits2f(b1);
-    b0 = f2bfbits(v0);
-    b1 = f2bfbits(v1);
+    v0 -= bits162f(b0, fp16);
+    v1 -= bits162f(b1, fp16);
+    b0 = f2bits16(v0, fp16);
+    b1 = f2bits16(v1, fp16);
     *reinterpret_cast<unsigned int*>(lo + (long)(k - 1) * n + i) = (unsigned int)b0 | ((unsigned int)b1 << 16);
   }
 }
 
 // eight adjacent values -> one 16-byte store per plane (4-byte stores cost the pack kernel 2.5x its traffic time)
 __device__ __forceinline__ void put_planes8(float (&v)[8], int npl, unsigned short* hi, unsigned short* lo, long i,
-                                            long n) {
+                                            long n, int fp16) {
   unsigned short b[8];
   for (int k = 0; k < npl; ++k) {
     u32x4 w;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      b[q] = f2bfbits(v[q]);
-      v[q] -= bfbits2f(b[q]);
+      b[q] = f2bits16(v[q], fp16);
+      v[q] -= bits162f(b[q], fp16);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = (unsigned int)b[2 * q] | ((unsigned int)b[2 * q + 1] << 16);
@@ -82,8 +82,9 @@ __device__ __forceinline__ void put_planes8(float (&v)[8], int npl, unsigned sho
   }
 }
 
-__global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int npl) {
+__global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_arg) {
   __shared__ float tile[TILE][TILE * 9 + 1];
+  const int npl = planes_arg & 15, fp16 = planes_arg >> 4;
   const int l = find_layer(tb, blockIdx.x);
   const LayerDesc& d = tb.d[l];
   const Geo g = geo_of(d.kind, d.Co, d.Ci, d.Ci_pad);
@@ -109,14 +110,14 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int npl) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol][(il + q) * T + t];
-      put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n);
+      put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, fp16);
     }
   } else if (a_hi) {
     for (int idx = threadIdx.x; idx < T * TILE * (TILE / 2); idx += 256) {
       const int il = (idx % (TILE / 2)) * 2, ol = (idx / (TILE / 2)) % TILE, t = idx / (TILE * TILE / 2);
       if (i0 + il >= g.inner_pad) continue;
       put_planes2(tile[ol][il * T + t], tile[ol][(il + 1) * T + t], npl, a_hi, a_lo,
-                  ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n);
+                  ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, fp16);
     }
   }
   // pass B, outer index fastest: conv3x3 dgrad panel [8-t][ci][co] / upconv forward panel [ab][co][ci]
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int npl) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol + q][il * T + t];
-      put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n);
+      put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, fp16);
     }
   }
 }
@@ -166,7 +167,8 @@ struct HostDesc {              // == crimac_layer_desc
 };
 
 // mode 0: pack, 1: unpack
-int run_layers(const HostDesc* descs, int n, int mode, int planes, hipStream_t st) {
+int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream_t st) {
+  const int planes = planes_arg & 15;
   for (int base = 0; base < n; base += kMaxLayers) {
     Table tb;
     tb.n = n - base < kMaxLayers ? n - base : kMaxLayers;
@@ -196,7 +198,7 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes, hipStream_t s
     }
     tb.first[tb.n] = total;
     if (total == 0) continue;
-    if (mode == 0) hipLaunchKernelGGL(pack_layers_kernel, dim3(total), dim3(256), 0, st, tb, planes);
+    if (mode == 0) hipLaunchKernelGGL(pack_layers_kernel, dim3(total), dim3(256), 0, st, tb, planes_arg);
     else hipLaunchKernelGGL(unpack_layers_kernel, dim3(total), dim3(256), 0, st, tb);
     CRIMAC_LAUNCH_CHECK();
   }
@@ -206,7 +208,9 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes, hipStream_t s
 }  // namespace
 
 extern "C" int crimac_pack_layers(const crimac_layer_desc* descs, int n_layers, int planes, void* stream) {
-  CRIMAC_REQUIRE(descs && n_layers > 0 && planes >= 1 && planes <= 3, "pack_layers: bad arguments");
+  CRIMAC_REQUIRE(descs && n_layers > 0 && (planes & 15) >= 1 && (planes & 15) <= 3 && (planes >> 4) <= 1 &&
+                     (planes < 16 || planes == CRIMAC_PLANES_FP16),
+                 "pack_layers: bad arguments (planes=%d)", planes);
   return run_layers(reinterpret_cast<const HostDesc*>(descs), n_layers, 0, planes, (hipStream_t)stream);
 }
 

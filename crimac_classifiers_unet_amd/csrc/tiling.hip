@@ -156,7 +156,7 @@ extern "C" int crimac_pr_histogram(const float* logits, int ncls, const void* la
 
 extern "C" int crimac_gather_patches(int prec, const float* data, int C, int Wd, int H, const int* centres,
                                      int P, int ph, int pw, void* out, long ld, void* stream) {
-  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "gather_patches: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "gather_patches: bad precision %d", prec);
   CRIMAC_REQUIRE(data && centres && out && C > 0 && C <= 16 && Wd > 0 && H > 0 && P > 0 && ph > 0 && pw > 0,
                  "gather_patches: bad arguments (C=%d must be <= 16)", C);
   CRIMAC_REQUIRE(ld >= C && ld % 8 == 0 && ld <= 16, "gather_patches: ld=%ld must be 8 or 16 and >= C", ld);
@@ -164,12 +164,8 @@ extern "C" int crimac_gather_patches(int prec, const float* data, int C, int Wd,
   dim3 grid((pw + TS - 1) / TS, (ph + TS - 1) / TS, P);
   const size_t lds = (size_t)C * TS * (TS + 1) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (prec == CRIMAC_PREC_BF16)
-    hipLaunchKernelGGL(gather_patches_kernel<bf16_t>, grid, dim3(256), lds, st, data, C, Wd, H, centres, ph,
-                       pw, (bf16_t*)out, (int)ld);
-  else
-    hipLaunchKernelGGL(gather_patches_kernel<float>, grid, dim3(256), lds, st, data, C, Wd, H, centres, ph,
-                       pw, (float*)out, (int)ld);
+  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(gather_patches_kernel<T>, grid, dim3(256), lds, st, data, C, Wd, H,
+                                                 centres, ph, pw, (T*)out, (int)ld));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

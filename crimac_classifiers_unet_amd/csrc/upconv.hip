@@ -69,7 +69,7 @@ __device__ __forceinline__ void release_half(Frags& f, int set) {
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
                  :: "memory");
 }
-template <int H, typename ACC>
+template <typename T16, int H, typename ACC>
 __device__ __forceinline__ void half(const unsigned (&av)[2], Frags& f, ACC& acc) {
   constexpr int ks = H / 4, q = H % 4;
   if constexpr (H + 1 < 8) {
@@ -82,9 +82,8 @@ __device__ __forceinline__ void half(const unsigned (&av)[2], Frags& f, ACC& acc
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
-      acc[q * 4 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[H & 1][j], f.b[0][ks * 2 + nb], acc[q * 4 + j][nb],
-                                                                    0, 0, 0);
-  if constexpr (H + 1 < 8) half<H + 1>(av, f, acc);
+      acc[q * 4 + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[0][ks * 2 + nb], acc[q * 4 + j][nb]);
+  if constexpr (H + 1 < 8) half<T16, H + 1>(av, f, acc);
 }
 // s0: row of the wave's first 16 columns, s1: of the second 16; fragments [ks * 2 + nb]
 __device__ __forceinline__ void load_b(const unsigned short* s0, const unsigned short* s1, bf16x8 (&bf)[4]) {
@@ -99,7 +98,7 @@ __device__ __forceinline__ void load_b(const unsigned short* s0, const unsigned 
 }
 
 // SCATTER: forward (output on the fine grid, column group (a,b) -> pixel (2y+a, 2x+b)); else dense dgrad tile
-template <bool SCATTER>
+template <bool SCATTER, typename T16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void upconv_wch_kernel(UpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -193,14 +192,14 @@ void upconv_wch_kernel(UpParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) av[ks] = av0[ks] + buf * A_BYTES;
     issue_half<0>(av, f);
-    half<0>(av, f, acc);
+    half<T16, 0>(av, f, acc);
     // chunk c+1's A tile and weight fragments were requested 64 MFMAs ago
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[1][2]), "+v"(f.b[1][3]) :: "memory");
   }
   __syncthreads();                       // staging below reuses the A buffers
 
   if constexpr (!SCATTER) {
-    conv_epilogue<bf16_t, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
+    conv_epilogue<T16, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
   } else {
     // bias, then the tile through LDS: [256 rows][128 cols + pad] bf16, then 16-byte stores scattered to the
     // fine grid: column n = (a*2 + bb) * cout + co -> pixel (2y + a, 2x + bb), channel co
@@ -214,11 +213,11 @@ void upconv_wch_kernel(UpParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = i * 16 + (lane >> 4) * 4 + r;
-          *reinterpret_cast<bf16_t*>(smem + row * PITCH + col * 2) = (bf16_t)(acc[i][nb][r] + bv);
+          *reinterpret_cast<T16*>(smem + row * PITCH + col * 2) = (T16)(acc[i][nb][r] + bv);
         }
     }
     __syncthreads();
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+    T16* outp = reinterpret_cast<T16*>(p.out);
     const int c8 = tid & 15, r0 = tid >> 4;          // 16 chunks of 8 columns per row, 16 rows per pass
     const int n = n0 + c8 * 8;
     const int ab = n / p.cout, co = n - ab * p.cout;
@@ -235,7 +234,7 @@ void upconv_wch_kernel(UpParams p) {
   }
 }
 
-template <bool SCATTER>
+template <bool SCATTER, typename T16>
 int launch(UpParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TP);
   p.tiles_x = cdiv(p.W, TP);
@@ -244,10 +243,10 @@ int launch(UpParams p, hipStream_t st) {
   const size_t lds = stage > 2 * (size_t)A_BYTES ? stage : 2 * (size_t)A_BYTES;
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER, T16>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -264,7 +263,8 @@ bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, l
 }
 
 static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
-                      const float* bias, int cout_up, void* out, long out_ld, const EpiParams* bnb, hipStream_t st) {
+                      const float* bias, int cout_up, void* out, long out_ld, const EpiParams* bnb, hipStream_t st,
+                      int fp16) {
   UpParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.ntaps = ntaps;
   p.w = (const unsigned short*)w; p.bias = bias; p.cout = cout_up; p.out = out; p.out_ld = out_ld;
@@ -276,21 +276,23 @@ static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W
     p.epi.stat_replicas = bnb->stat_replicas; p.epi.bnb_y = bnb->bnb_y; p.epi.bnb_y_ld = bnb->bnb_y_ld;
     p.epi.bnb_vec = bnb->bnb_vec; p.epi.bnb_stride = bnb->bnb_stride;
   }
-  return ntaps == 1 ? launch<true>(p, st) : launch<false>(p, st);
+  if (fp16) return ntaps == 1 ? launch<true, half_t>(p, st) : launch<false, half_t>(p, st);
+  return ntaps == 1 ? launch<true, bf16_t>(p, st) : launch<false, bf16_t>(p, st);
 }
 
-int crimac_upconv_wch_bf16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N,
-                           const void* w, const float* bias, int cout_up, void* out, long out_ld, hipStream_t st) {
-  return upconv_run(ntaps, in, in_ld, B, H, W, K, N, w, bias, cout_up, out, out_ld, nullptr, st);
+int crimac_upconv_wch_16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
+                         const float* bias, int cout_up, void* out, long out_ld, hipStream_t st, int fp16) {
+  return upconv_run(ntaps, in, in_ld, B, H, W, K, N, w, bias, cout_up, out, out_ld, nullptr, st, fp16);
 }
 
 // Input gradient of the transposed convolution whose result is the `da` of a BatchNorm+ReLU block: that
 // block's backward sums (sum dz, sum dz*xhat; conv_epilogue.h stat_mode 2) are taken in the epilogue, which
 // removes a bn_bwd_reduce pass over (da, y) -- 4 launches, 0.21 ms per step at B = 32.
-extern "C" int crimac_upconv2x2_dgrad_bnb(const void* dy, long dy_ld, int B, int H, int W, int Cout, int Cin,
+extern "C" int crimac_upconv2x2_dgrad_bnb_prec(int prec, const void* dy, long dy_ld, int B, int H, int W, int Cout, int Cin,
                                           const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y,
                                           long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
                                           double* stat_sumsq, int stat_replicas, void* stream) {
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16, "upconv2x2_dgrad_bnb: 16-bit storage modes only (prec=%d)", prec);
   CRIMAC_REQUIRE(dy && w_dg_hi && dx && B > 0 && H > 0 && W > 0, "upconv2x2_dgrad_bnb: bad arguments");
   CRIMAC_REQUIRE(dy_ld >= Cout && dy_ld % 8 == 0 && dx_ld >= Cin && dx_ld % 8 == 0,
                  "upconv2x2_dgrad_bnb: bad pixel strides (dy_ld=%ld dx_ld=%ld)", dy_ld, dx_ld);
@@ -304,5 +306,15 @@ extern "C" int crimac_upconv2x2_dgrad_bnb(const void* dy, long dy_ld, int B, int
   EpiParams e{};
   e.stat_sum = stat_sum; e.stat_sumsq = stat_sumsq; e.stat_replicas = stat_replicas;
   e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
-  return upconv_run(4, dy, dy_ld, B, H, W, Cout, Cin, w_dg_hi, nullptr, 0, dx, dx_ld, &e, (hipStream_t)stream);
+  return upconv_run(4, dy, dy_ld, B, H, W, Cout, Cin, w_dg_hi, nullptr, 0, dx, dx_ld, &e, (hipStream_t)stream,
+                    prec == CRIMAC_PREC_FP16);
+}
+
+// bf16 form (kept for existing callers)
+extern "C" int crimac_upconv2x2_dgrad_bnb(const void* dy, long dy_ld, int B, int H, int W, int Cout, int Cin,
+                                          const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y,
+                                          long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
+                                          double* stat_sumsq, int stat_replicas, void* stream) {
+  return crimac_upconv2x2_dgrad_bnb_prec(CRIMAC_PREC_BF16, dy, dy_ld, B, H, W, Cout, Cin, w_dg_hi, dx, dx_ld, bnb_y,
+                                         bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas, stream);
 }

@@ -121,7 +121,7 @@ __device__ __forceinline__ void wg_rd_b(const unsigned (&sv)[4], WgFrags& f) {
 }
 // F fragment FH of step S: wait for it (first step of a row pair), 2 MFMAs, then (last step of a row pair)
 // request the same fragment of the next row pair into the registers just consumed
-template <int MODE, int TG, int S, int FH, bool NARROW, typename ACC>
+template <typename T16, int MODE, int TG, int S, int FH, bool NARROW, typename ACC>
 __device__ __forceinline__ void wg_fh(unsigned fv0, WgFrags& f, ACC& acc) {
   using G = WgTaps<MODE, TG>;
   constexpr int NSTEP = G::NRP * G::N, rp = S / G::N, L = S % G::N;
@@ -147,18 +147,18 @@ __device__ __forceinline__ void wg_fh(unsigned fv0, WgFrags& f, ACC& acc) {
 #pragma unroll
   for (int sh = 0; sh < NSH; ++sh) {
     const bf16x8 bfr = __builtin_shufflevector(f.b[S & 1][sh][0], f.b[S & 1][sh][1], 0, 1, 2, 3, 4, 5, 6, 7);
-    acc[L][FH][sh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[L][FH][sh], 0, 0, 0);
+    acc[L][FH][sh] = E16<T16>::mfma16(af, bfr, acc[L][FH][sh]);
   }
   if constexpr (L == G::N - 1 && rp + 1 < G::NRP) wg_rd_a<rp + 1, FH>(fv0, f);
-  if constexpr (FH + 1 < 4) wg_fh<MODE, TG, S, FH + 1, NARROW>(fv0, f, acc);
+  if constexpr (FH + 1 < 4) wg_fh<T16, MODE, TG, S, FH + 1, NARROW>(fv0, f, acc);
 }
-template <int MODE, int TG, int S, bool NARROW, typename ACC>
+template <typename T16, int MODE, int TG, int S, bool NARROW, typename ACC>
 __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], WgFrags& f, ACC& acc) {
   using G = WgTaps<MODE, TG>;
   constexpr int NSTEP = G::NRP * G::N;
   if constexpr (S + 1 < NSTEP) wg_rd_b<MODE, TG, S + 1, NARROW>(sv, f);
-  wg_fh<MODE, TG, S, 0, NARROW>(fv0, f, acc);
-  if constexpr (S + 1 < NSTEP) wg_step<MODE, TG, S + 1, NARROW>(fv0, sv, f, acc);
+  wg_fh<T16, MODE, TG, S, 0, NARROW>(fv0, f, acc);
+  if constexpr (S + 1 < NSTEP) wg_step<T16, MODE, TG, S + 1, NARROW>(fv0, sv, f, acc);
 }
 
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
@@ -268,7 +268,7 @@ void wgrad_kernel(WgradParams p) {
           bf16x4 x0v = lds_tr16(sS + k * S_BYTES + o0), x1v = lds_tr16(sS + k * S_BYTES + o1);
           bfr[k] = __builtin_shufflevector(x0v, x1v, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        mfma_planes<NPL>(af, bfr, acc[t]);
+        mfma_planes<NPL, typename PlaneOf<TA>::type>(af, bfr, acc[t]);
       }
     }
   };
@@ -346,7 +346,7 @@ void wgrad_kernel(WgradParams p) {
       tile_origin(tile, b, y0, x0);
       unsigned char* base = smem + buf * BUF_BYTES;
       const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<bf16_t*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+          const_cast<TA*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         int ry, rx;
@@ -358,7 +358,7 @@ void wgrad_kernel(WgradParams p) {
       unsigned char* sbase = base + F_BYTES;
       const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0, sx0 = MODE == 0 ? x0 - 1 : 2 * x0;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<bf16_t*>(sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+          const_cast<TA*>(sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int k = wave + 4 * i;
@@ -412,7 +412,7 @@ void wgrad_kernel(WgradParams p) {
           wg_rd_a<0, 2>(fv0, f);
           wg_rd_a<0, 3>(fv0, f);
           wg_rd_b<MODE, TG, 0, NARROW>(sv, f);
-          wg_step<MODE, TG, 0, NARROW>(fv0, sv, f, acc2);
+          wg_step<typename PlaneOf<TA>::type, MODE, TG, 0, NARROW>(fv0, sv, f, acc2);
         }
 #endif
       }
@@ -545,7 +545,7 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
 extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
                             long s_ld, int CS, int B, int Hf, int Wf, float* dw, int target_blocks,
                             void* stream) {
-  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_F32X6, "wgrad: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "wgrad: bad precision %d", prec);
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "wgrad: bad mode %d", mode);
   CRIMAC_REQUIRE(CF > 0 && CF % 8 == 0 && CS > 0 && CS % 8 == 0, "wgrad: channels must be multiples of 8");
   CRIMAC_REQUIRE(f_ld >= CF && s_ld >= CS && f_ld % 8 == 0 && s_ld % 8 == 0, "wgrad: bad pixel strides");
@@ -557,6 +557,10 @@ extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF
   if (prec == CRIMAC_PREC_BF16) {
     if (mode == 0 && CS <= 16) return launch<bf16_t, 1, 0, true>(p, target_blocks, st);     // first layer
     return mode == 0 ? launch<bf16_t, 1, 0>(p, target_blocks, st) : launch<bf16_t, 1, 1>(p, target_blocks, st);
+  }
+  if (prec == CRIMAC_PREC_FP16) {
+    if (mode == 0 && CS <= 16) return launch<half_t, 1, 0, true>(p, target_blocks, st);
+    return mode == 0 ? launch<half_t, 1, 0>(p, target_blocks, st) : launch<half_t, 1, 1>(p, target_blocks, st);
   }
   if (prec == CRIMAC_PREC_F32X3)
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);

@@ -76,8 +76,18 @@ class UNetEngine:
         self.module = module
         self.precision = precision
         self.prec = hip.PREC_NAMES[precision]
-        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.act_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision, torch.float32)
         self.planes = hip.PREC_PLANES[self.prec]
+        self.planes_arg = hip.PREC_PLANES_ARG[self.prec]     # what the packing entry points take
+        self.is16 = self.prec in hip.PREC_16BIT
+        # fp16 storage: the loss gradient is scaled by `loss_scale` (crimac_wce_bwd upstream) so that activation
+        # gradients (1e-5 .. 1e-8 unscaled) sit in fp16's normal range; SGD divides it out again and skips the
+        # step when a gradient overflowed (crimac_grad_overflow_flag / crimac_sgd_momentum_guarded)
+        self.loss_scale = 2.0 ** 16 if precision == "fp16" else 1.0
+        self.dynamic_loss_scale = precision == "fp16"
+        self._scale_state = None            # int32[2] on the GPU: [overflow this step, steps skipped]
+        self._skipped_seen = 0
+        self._good_checks = 0
         self.depth = module.depth
         self.sf = module.start_filts
         self.in_channels = module.in_channels
@@ -277,7 +287,7 @@ class UNetEngine:
         arr, bounds = self._layer_table()
         first, n = bounds[gi]
         if n:
-            call("crimac_pack_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n, self.planes)
+            call("crimac_pack_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n, self.planes_arg)
 
     def _pack_train(self):
         if not self._train_pack_dirty:
@@ -289,7 +299,7 @@ class UNetEngine:
                 if gi not in done:
                     self._pack_group(gi)
         else:
-            call("crimac_pack_layers", C.byref(arr), len(arr), self.planes)
+            call("crimac_pack_layers", C.byref(arr), len(arr), self.planes_arg)
         self._packed_groups = set()
         self._train_pack_dirty = False
 
@@ -374,7 +384,7 @@ class UNetEngine:
     def _pack_ups(self):
         for u in self.ups:
             pk = self.pk[u.key]
-            call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout, self.planes,
+            call("crimac_pack_upconv2x2", ptr(self.P[u.key + ".weight"]), u.cin, u.cout, self.planes_arg,
                  ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(pk["dg_hi"]), ptr(pk["dg_lo"]))
 
     def _pack_eval(self):
@@ -389,7 +399,7 @@ class UNetEngine:
                 pk = self.pk_eval[b.conv_key]
                 pk["bias"].copy_((self.P[b.conv_key + ".bias"] - rm) * s + be)
                 call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin,
-                     b.cin_pad, ptr(s.contiguous()), self.planes, ptr(pk["fwd_hi"]),
+                     b.cin_pad, ptr(s.contiguous()), self.planes_arg, ptr(pk["fwd_hi"]),
                      ptr(pk["fwd_lo"]), None, None)
                 # s must stay alive until the kernel ran: same stream, freed memory is stream-ordered
         # up-conv planes are shared with the train pack (no BN behind them)
@@ -479,10 +489,11 @@ class UNetEngine:
         next_bn=(block, y): dx is the ``da`` of that BatchNorm block -> take its backward sums in the epilogue
         (bf16 kernel shapes only).  Returns whether they were taken."""
         pk = self.pk[u.key]
-        if (next_bn is not None and self.fuse_bn_bwd and self.fuse_up_bnb and self.prec == hip.PREC_NAMES["bf16"]
+        if (next_bn is not None and self.fuse_bn_bwd and self.fuse_up_bnb and self.is16
                 and u.cout % 64 == 0 and u.cin % 128 == 0 and 8 * B * H * W * dy.ld < (1 << 31)):
             blk, y = next_bn
-            call("crimac_upconv2x2_dgrad_bnb", dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]), out.p, out.ld,
+            call("crimac_upconv2x2_dgrad_bnb_prec", self.prec, dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]),
+                 out.p, out.ld,
                  *self._bnb_args(blk, y), flops=2.0 * 4 * u.cin * u.cout * B * H * W)
             return True
         self._upconv_dgrad_plain(dy, u, out, B, H, W)
@@ -749,7 +760,7 @@ class UNetEngine:
             C_up = bias_from_stats[1] if bias_from_stats is not None else 0
             side = self._side[0] if (self._side is not None and len(self._side) == 1) else None
             if (stats is not None and side is not None and self.split_skip_dgrad and not self._gloo_ranks()
-                    and b.cin == 2 * C_up and b.cout % 64 == 0 and self.prec == hip.PREC_NAMES["bf16"]
+                    and b.cin == 2 * C_up and b.cout % 64 == 0 and self.is16
                     and (C_up % 128 == 0 or (C_up == 64 and b.cout == 64 and B * ((h + 15) // 16) * ((w + 15) // 16) >= 512))):
                 # decoder conv1: dx_out = d(concat [up | skip]).  The up half (and its column sums = the transposed
                 # convolution's bias gradient) is needed at once; the skip half only when the encoder level is
@@ -945,10 +956,42 @@ class UNetEngine:
         return dl
 
     @_on_device
-    def sgd_step(self, lr, momentum, grad_scale=1.0, zero_grad=False):
-        call("crimac_sgd_momentum", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
-             float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0)
+    def sgd_step(self, lr, momentum, grad_scale=1.0, zero_grad=False, guarded=False):
+        """guarded: check the flat gradient for inf / NaN first and skip the update if there is one (loss-scaled
+        fp16 training); the skip is counted on the device, see ``update_loss_scale``."""
+        if guarded:
+            if self._scale_state is None:
+                self._scale_state = torch.zeros(2, dtype=torch.int32, device=self.device)
+            st = self._scale_state
+            st[0:1].zero_()
+            call("crimac_grad_overflow_flag", ptr(self.flat_g), self.n_flat, ptr(st))
+            call("crimac_sgd_momentum_guarded", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
+                 float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0, ptr(st))
+        else:
+            call("crimac_sgd_momentum", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
+                 float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0)
         self.mark_dirty()
+
+    def skipped_steps(self):
+        """Steps whose update was skipped because a scaled gradient overflowed (host sync)."""
+        return 0 if self._scale_state is None else int(self._scale_state[1])
+
+    def update_loss_scale(self, growth_interval=4):
+        """Dynamic loss scale, evaluated only where the caller synchronises anyway (the pipeline's loss flush):
+        halve the scale if a step was skipped since the last call, double it after ``growth_interval`` clean
+        calls (up to 2^24).  Returns the scale now in force."""
+        if not self.dynamic_loss_scale or self.loss_scale == 1.0:
+            return self.loss_scale
+        n = self.skipped_steps()
+        if n > self._skipped_seen:
+            self._skipped_seen, self._good_checks = n, 0
+            self.loss_scale = max(self.loss_scale / 2.0, 1.0)
+        else:
+            self._good_checks += 1
+            if self._good_checks >= growth_interval and self.loss_scale < 2.0 ** 24:
+                self.loss_scale *= 2.0
+                self._good_checks = 0
+        return self.loss_scale
 
     @_on_device
     def train_step(self, x, labels, class_w, lr, momentum, grad_sync=None, ignore_index=-100):
@@ -964,9 +1007,22 @@ class UNetEngine:
     def _loss_backward_update(self, logits, labels, class_w, lr, momentum, grad_sync, ignore_index):
         sums = self.stat[0:2]
         sums, labels = self.ce_forward(logits, labels, class_w, ignore_index, sums=sums)
-        dl = self.ce_backward(logits, labels, class_w, sums, 1.0, ignore_index)
+        ls = float(self.loss_scale)
+        dl = self.ce_backward(logits, labels, class_w, sums, ls, ignore_index)
         scale = 1.0
         single = grad_sync is None or (hasattr(grad_sync, "world") and grad_sync.world() == 1)
+        if ls != 1.0:
+            # loss-scaled step: all ranges are applied together behind ONE overflow check (a step is applied
+            # whole or not at all), so the per-range early updates of the unscaled path are not used
+            if grad_sync is not None and hasattr(grad_sync, "launch"):
+                self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
+                scale = grad_sync.finish()
+            else:
+                self.backward(dl)
+                if grad_sync is not None:
+                    scale = grad_sync(self.flat_g)
+            self.sgd_step(lr, momentum, grad_scale=scale / ls, guarded=True)
+            return (sums[0] / sums[1]).float()
         if single and self.early_sgd and self._side is not None and len(self._side) == 1 and self.unpack_on_side:
             self._sgd_left = None
             self.mark_dirty()                         # (before the early re-packs register themselves)

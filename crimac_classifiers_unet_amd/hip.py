@@ -16,8 +16,12 @@ from . import build as _build
 PREC_BF16 = 0
 PREC_F32X3 = 1
 PREC_F32X6 = 2
-PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6}
-PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3}     # bf16 planes per MFMA operand
+PREC_FP16 = 3
+PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16}
+PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1}     # 16-bit planes per MFMA operand
+# `planes` argument of the packing entry points (CRIMAC_PLANES_FP16 = one IEEE-half plane)
+PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 17}
+PREC_16BIT = (PREC_BF16, PREC_FP16)
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -30,6 +34,8 @@ SIGNATURES = {
     "crimac_conv3x3_cols": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i,
                             _vp, _l, _vp, _l, _i, _i, _vp],
     "crimac_upconv2x2_dgrad_bnb": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _vp],
+    "crimac_upconv2x2_dgrad_bnb_prec": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i,
+                                        _vp],
     "crimac_sum_replicas": [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
@@ -54,6 +60,8 @@ SIGNATURES = {
     "crimac_wce_fwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "crimac_wce_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp],
     "crimac_sgd_momentum": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp],
+    "crimac_grad_overflow_flag": [_vp, _l, _vp, _vp],
+    "crimac_sgd_momentum_guarded": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _vp],
     "crimac_gather_patches": [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _l, _vp],
     "crimac_augment_db_nhwc": [_i, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _l, C.c_ulonglong,
                                _i, _i, _vp],

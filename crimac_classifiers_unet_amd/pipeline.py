@@ -9,7 +9,7 @@ the same ``state_dict`` checkpoints (``best.pt`` / ``last.pt``).
 The compute behind ``train_model`` / ``predict_batch`` is the HIP engine; with ``torch.distributed``
 initialised (one process per GPU) ``train_model`` all-reduces gradients over RCCL.
 New optional keywords (all defaulted, so the baseline yaml still works): ``precision``
-('bf16' | 'f32x3'), ``loss_flush`` (how often queued train losses are handed to the logger).
+('bf16' | 'fp16' | 'f32x3' | 'f32x6'), ``loss_flush`` (how often queued train losses are handed to the logger).
 """
 from __future__ import annotations
 
@@ -143,6 +143,7 @@ class SegPipe:
         pending = []
 
         def flush():
+            engine.update_loss_scale()          # (fp16 precision only; this is where the loop synchronises anyway)
             if logger is not None and pending:
                 vals = torch.stack([v for _, v in pending]).cpu().tolist()
                 for (step, _), v in zip(pending, vals):

@@ -85,7 +85,8 @@ class SGDMomentum:
         eng = self.engine
         eng.bind()
         g = self.param_groups[0]
-        eng.sgd_step(g["lr"], g["momentum"])
+        # loss-scaled precision (fp16): a step whose gradients overflowed is skipped, as torch.cuda.amp.GradScaler does
+        eng.sgd_step(g["lr"], g["momentum"], guarded=eng.loss_scale != 1.0)
 
     def state_dict(self):
         g = self.param_groups[0]

@@ -86,7 +86,10 @@ class _UNetFunction(torch.autograd.Function):
                 carry[name] = g
         none_grad = [name for name, p in eng.P.items() if p.grad is None]
         prev = eng.flat_g.clone() if (aliased or eng.accumulate_grads) else None
-        eng.backward(dlogits)
+        ls = float(eng.loss_scale)        # fp16 storage: activation gradients travel scaled, .grad holds true values
+        eng.backward(dlogits * ls if ls != 1.0 else dlogits)
+        if ls != 1.0:
+            eng.flat_g.mul_(1.0 / ls)     # (an overflowed gradient stays inf: SGDMomentum.step skips that step)
         eng.saved = None                  # consumed: a second backward through this node must not run on stale buffers
         if prev is not None:
             if none_grad and not eng.accumulate_grads:        # set_to_none on some parameters: those start afresh
@@ -111,6 +114,8 @@ class UNet_Baseline(nn.Module):
                  'f32x3' -- fp32 activations, 2-plane split-bf16 MFMA (~2^-16 per product)
                  'f32x6' -- fp32 activations, 3-plane split, 6 MFMAs per product (fp32-equivalent:
                             the parity mode, <=1e-3 on logits with bit-exact argmax masks)
+                 'fp16'  -- fp16 activations / MFMA, fp32 accumulate, loss-scaled gradients with overflow skip
+                            (BASELINE configs[4]); same kernels and rate as 'bf16'
     """
 
     def __init__(self, n_classes, in_channels, meta_in_channels=0, late_meta_inject=False, depth=5,

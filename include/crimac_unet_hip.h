@@ -29,6 +29,9 @@
  *                           accumulate (~2^-16 per product: meets 1e-3 relative on logits)
  *       CRIMAC_PREC_F32X6 : fp32 activations, 3-plane split, 6 MFMAs per product (~2^-24 per product,
  *                           i.e. fp32-equivalent: the parity mode for bit-exact argmax masks)
+ *       CRIMAC_PREC_FP16  : fp16 activations, fp16 MFMA (v_mfma_f32_16x16x32_f16), fp32 accumulate; same
+ *                           kernels and rate as BF16, 3 more mantissa bits, 5-bit exponent -> the caller
+ *                           scales the loss gradient (loss scaling)
  *     weight operands: `w_hi` is plane 0; `w_lo` holds the remaining (planes-1) planes back to back
  *     (unused for BF16)
  *     parameters, gradients of parameters, statistics and the loss are always fp32 / fp64
@@ -47,6 +50,13 @@ extern "C" {
 #define CRIMAC_PREC_BF16 0
 #define CRIMAC_PREC_F32X3 1
 #define CRIMAC_PREC_F32X6 2
+#define CRIMAC_PREC_FP16 3  /* fp16 activations / gradients, fp16 MFMA, fp32 accumulate (BASELINE configs[4]);
+                             * gradients need loss scaling: crimac_wce_bwd's `upstream`, undone by
+                             * crimac_sgd_momentum's `grad_scale`, overflow guard crimac_grad_overflow_flag */
+#define CRIMAC_PREC_MAX 3
+/* `planes` argument of the weight-packing entry points: 1..3 bf16 planes (BF16 / F32X3 / F32X6), or
+ * CRIMAC_PLANES_FP16 = one IEEE-half plane (FP16). */
+#define CRIMAC_PLANES_FP16 17
 
 /* Library identity / error text. */
 int crimac_version(void);
@@ -80,6 +90,12 @@ int crimac_upconv2x2_dgrad_bnb(const void* dy, long dy_ld, int B, int H, int W, 
                                const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y, long bnb_y_ld,
                                const float* bnb_vec, long bnb_stride, double* stat_sum, double* stat_sumsq,
                                int stat_replicas, void* stream);
+/* The same for either 16-bit storage mode (prec = CRIMAC_PREC_BF16 or CRIMAC_PREC_FP16). */
+int crimac_upconv2x2_dgrad_bnb_prec(int prec, const void* dy, long dy_ld, int B, int H, int W, int Cout, int Cin,
+                                    const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y, long bnb_y_ld,
+                                    const float* bnb_vec, long bnb_stride, double* stat_sum, double* stat_sumsq,
+                                    int stat_replicas, void* stream);
+
 
 /* 3x3 convolution, stride 1, pad 1 (nn.Conv2d forward, unet.py:35-44; with the dgrad weight planes
  * of crimac_pack_conv3x3 it is the input gradient): halo tile staged once per channel chunk in LDS,
@@ -236,6 +252,15 @@ int crimac_wce_bwd(const float* logits, const void* labels, int label_bytes, con
  * g' = g*grad_scale; v = momentum*v + g'; p -= lr*v; g = 0 if zero_grad. */
 int crimac_sgd_momentum(float* p, float* g, float* v, long n, float lr, float momentum,
                         float grad_scale, int zero_grad, void* stream);
+/* Loss-scaled training (CRIMAC_PREC_FP16; the reference trains in fp32 and needs none): state[0] |= 1 if any of
+ * the n gradients is inf / NaN (caller zeroes state[0] before every step); crimac_sgd_momentum_guarded then leaves
+ * p and v untouched for that step and counts it in state[1].  No host synchronisation is involved: the caller
+ * reads state[1] whenever it flushes its loss log and adapts the scale it passes as crimac_wce_bwd's `upstream`
+ * (and divides out again through `grad_scale`). */
+int crimac_grad_overflow_flag(const float* g, long n, int* state, void* stream);
+int crimac_sgd_momentum_guarded(float* p, float* g, float* v, long n, float lr, float momentum,
+                                float grad_scale, int zero_grad, int* state, void* stream);
+
 
 /* ---- tiled whole-survey inference (save_predict.py:160-209) ------------------------------------ */
 

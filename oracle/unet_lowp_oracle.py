@@ -96,15 +96,21 @@ def unet_forward_train(state, x, storage="bf16"):
     return logits, new_stats
 
 
-def loss_and_grads(state, x, labels, storage="bf16"):
-    """Train-mode forward + weighted CE + backward with 16-bit storage rounding: (loss, logits, grads, stats)."""
+def loss_and_grads(state, x, labels, storage="bf16", loss_scale=1.0):
+    """Train-mode forward + weighted CE + backward with 16-bit storage rounding: (loss, logits, grads, stats).
+
+    ``loss_scale``: the engine's fp16 mode multiplies the loss gradient by a power of two so that the stored
+    activation gradients sit in fp16's normal range, and divides the parameter gradients by it again
+    (engine._loss_backward_update); restated here by differentiating ``loss * loss_scale`` -- every stored
+    gradient is then rounded at the same scaled magnitude -- and unscaling the result."""
     work = OrderedDict((k, v.detach().clone()) for k, v in state.items())
     keys = trainable_keys(work)
     for k in keys:
         work[k].requires_grad_(True)
     logits, new_stats = unet_forward_train(work, x, storage)
     loss = weighted_cross_entropy(logits, labels)
-    gs = torch.autograd.grad(loss, [work[k] for k in keys])
+    gs = torch.autograd.grad(loss * float(loss_scale), [work[k] for k in keys])
+    gs = [g / float(loss_scale) for g in gs]
     return loss.detach(), logits.detach(), OrderedDict(zip(keys, gs)), new_stats
 
 

@@ -4,8 +4,8 @@ Each HIP kernel is compared with the torch CPU fp32 op the reference dispatches 
 (the oracle of a single op is that op itself, run on the host).  Tolerances:
   * 'f32x6' (parity mode): 2e-6 of max|ref| -- 3-plane split, ~2^-24 per product (fp32-equivalent);
   * 'f32x3': 1e-4 of max|ref| -- 2-plane split-bf16 products carry ~2^-16 relative error;
-  * 'bf16'  (throughput mode): inputs are pre-rounded to bf16 on the host, so what is left is the
-    bf16 rounding of the OUTPUT (2^-9 relative) and accumulation order: 1e-2 of max|ref|.
+  * 'bf16' / 'fp16' (16-bit storage modes): inputs are pre-rounded on the host, so what is left is the
+    rounding of the OUTPUT (2^-9 / 2^-11 relative) and accumulation order: 1e-2 / 2e-3 of max|ref|.
 """
 import numpy as np
 import pytest
@@ -17,18 +17,20 @@ from crimac_classifiers_unet_amd.hip import call, ptr
 
 pytestmark = pytest.mark.gpu
 
-PRECS = ["f32x6", "f32x3", "bf16"]
-TOL = {"f32x6": 5e-6, "f32x3": 1e-4, "bf16": 1e-2}
-NPL = {"f32x6": 3, "f32x3": 2, "bf16": 1}
+PRECS = ["f32x6", "f32x3", "bf16", "fp16"]
+LOWP = ("bf16", "fp16")                 # 16-bit storage modes: same kernels, instantiated per element type
+TOL = {"f32x6": 5e-6, "f32x3": 1e-4, "bf16": 1e-2, "fp16": 2e-3}      # fp16 output rounding is 2^-11
+NPL = {"f32x6": 3, "f32x3": 2, "bf16": 1, "fp16": 17}                 # `planes` argument (17 = CRIMAC_PLANES_FP16)
+_DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def _dt(prec):
-    return torch.bfloat16 if prec == "bf16" else torch.float32
+    return _DT.get(prec, torch.float32)
 
 
 def _round(x, prec):
     """Host-side rounding of kernel INPUTS to the activation storage type."""
-    return x.to(torch.bfloat16).float() if prec == "bf16" else x
+    return x.to(_DT[prec]).float() if prec in _DT else x
 
 
 def to_nhwc(x, prec, ld=None):
@@ -172,7 +174,7 @@ def test_upconv2x2_forward_dgrad_wgrad(prec, shape):
     grad = torch.empty(Ci, Co, 2, 2, dtype=torch.float32, device="cuda")
     call("crimac_unpack_wgrad_upconv2x2", ptr(dwp), Ci, Co, ptr(grad))
     torch.cuda.synchronize()
-    assert relerr(grad.cpu(), wg.grad) < (2e-3 if prec == "bf16" else TOL[prec])
+    assert relerr(grad.cpu(), wg.grad) < (2e-3 if prec in LOWP else TOL[prec])
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -200,13 +202,13 @@ def test_conv3x3_wgrad(prec, shape, target_blocks):
 @pytest.mark.parametrize("mode,shape", [(0, (2, 128, 128, 128, 64)), (0, (1, 256, 256, 64, 64)),
                                         (0, (2, 100, 120, 64, 128)), (1, (2, 64, 64, 128, 64)),
                                         (0, (2, 128, 128, 16, 64))])      # (the last: first-layer narrow-S kernel)
-def test_wgrad_many_workgroups_auto_split(mode, shape):
+@pytest.mark.parametrize("prec", LOWP)
+def test_wgrad_many_workgroups_auto_split(mode, shape, prec):
     """bf16 weight gradient with the library's own pixel split (target_blocks = 0): hundreds of workgroups in
     flight, several tiles per workgroup -- the hand-placed LDS-read pipeline (asm loads, counted waits) only
     shows ordering mistakes under this kind of load.  mode 0: conv3x3, mode 1: transposed conv."""
     B, H, W, Ci, Co = shape
     g = torch.Generator().manual_seed(17)
-    prec = "bf16"
     x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
     P = hip.PREC_NAMES[prec]
     if mode == 0:
@@ -293,15 +295,15 @@ def test_batchnorm_train_forward_backward_pool(prec, C):
     call("crimac_bn_bwd_apply", P, ptr(da), C, ptr(yn), C, ptr(st[2]), ptr(st[3]), ptr(st[0]), ptr(st[1]),
          ptr(s2[0]), ptr(s2[1]), M, 0, C, ptr(dy), C, ptr(dg), ptr(db), ptr(dbias))
     torch.cuda.synchronize()
-    if prec == "bf16":
+    if prec in LOWP:
         # bf16-rounded activations tie inside 2x2 windows far more often than fp32 ones; a tie routes
         # the pooled gradient to another pixel, so compare in L2 instead of max-norm
         d_out, d_ref = from_nhwc(dy, B, H, W).double(), yr.grad.double()
         assert float((d_out - d_ref).norm() / d_ref.norm()) < 0.1
     else:
         assert relerr(from_nhwc(dy, B, H, W), yr.grad) < 2e-4
-    assert relerr(dg.cpu(), gr.grad) < (2e-2 if prec == "bf16" else 2e-4)
-    assert relerr(db.cpu(), br.grad) < (2e-2 if prec == "bf16" else 2e-4)
+    assert relerr(dg.cpu(), gr.grad) < (2e-2 if prec in LOWP else 2e-4)
+    assert relerr(db.cpu(), br.grad) < (2e-2 if prec in LOWP else 2e-4)
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -414,9 +416,9 @@ def test_head_and_weighted_ce(prec, ncls):
          C, ptr(ref[0]), ptr(ref[1]))
     torch.cuda.synchronize()
     # (the two instantiations may contract the 3-term dot products differently: last-bit differences in dx)
-    assert relerr(dx2, dx) < (1e-2 if prec == "bf16" else 1e-6)
+    assert relerr(dx2, dx) < (1e-2 if prec in LOWP else 1e-6)
     assert relerr(rep[0].sum(0).cpu(), ref[0].cpu()) < 1e-5 and relerr(rep[1].sum(0).cpu(), ref[1].cpu()) < 1e-5
-    assert relerr(from_nhwc(dx, B, H, W), xr.grad) < (1e-2 if prec == "bf16" else 1e-4)
+    assert relerr(from_nhwc(dx, B, H, W), xr.grad) < (1e-2 if prec in LOWP else 1e-4)
     assert relerr(dw.cpu().reshape(ncls, C, 1, 1), wr.grad) < 1e-4
     assert relerr(dbv.cpu(), br.grad) < 1e-4
     # every pixel ignored -> 0/0 = NaN like torch
@@ -565,10 +567,10 @@ def test_conv3x3_dgrad_with_fused_bn_backward_sums(prec, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 12, 20, 256, 128), (2, 64, 64, 256, 128)])
-def test_upconv_dgrad_with_fused_bn_backward_sums(shape):
+@pytest.mark.parametrize("prec", LOWP)
+def test_upconv_dgrad_with_fused_bn_backward_sums(shape, prec):
     """crimac_upconv2x2_dgrad_bnb == crimac_igemm_conv (input gradient) + crimac_bn_bwd_reduce on its output."""
     B, H, W, Ci, Co = shape          # transposed conv Ci -> Co (coarse H x W -> fine 2H x 2W)
-    prec = "bf16"
     g = torch.Generator().manual_seed(23)
     w = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
     dy = _round(torch.randn(B, Co, 2 * H, 2 * W, generator=g), prec)
@@ -579,16 +581,20 @@ def test_upconv_dgrad_with_fused_bn_backward_sums(shape):
     n = 4 * Ci * Co
     fh, fl, dh, dl = (torch.empty(2 * n, **i16) for _ in range(4))
     wd = w.cuda()
-    call("crimac_pack_upconv2x2", ptr(wd), Ci, Co, 1, ptr(fh), ptr(fl), ptr(dh), ptr(dl))
+    call("crimac_pack_upconv2x2", ptr(wd), Ci, Co, NPL[prec], ptr(fh), ptr(fl), ptr(dh), ptr(dl))
     M, R = B * H * W, 6
     dyn, yn = to_nhwc(dy, prec), to_nhwc(y_prev, prec)
     vec = torch.stack([mean, invstd, scale, shift]).contiguous().cuda()
     acc = torch.zeros(2, R, Ci, dtype=torch.float64, device="cuda")
-    dx = torch.empty(M, Ci, dtype=torch.bfloat16, device="cuda")
-    call("crimac_upconv2x2_dgrad_bnb", ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dx), Ci, ptr(yn), Ci, ptr(vec), Ci,
-         ptr(acc[0]), ptr(acc[1]), R)
-    plain = torch.empty(M, Ci, dtype=torch.bfloat16, device="cuda")
+    dx = torch.empty(M, Ci, dtype=_dt(prec), device="cuda")
     P = hip.PREC_NAMES[prec]
+    if prec == "bf16":               # (the entry point without `prec` is the bf16 form)
+        call("crimac_upconv2x2_dgrad_bnb", ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dx), Ci, ptr(yn), Ci, ptr(vec),
+             Ci, ptr(acc[0]), ptr(acc[1]), R)
+    else:
+        call("crimac_upconv2x2_dgrad_bnb_prec", P, ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dx), Ci, ptr(yn), Ci,
+             ptr(vec), Ci, ptr(acc[0]), ptr(acc[1]), R)
+    plain = torch.empty(M, Ci, dtype=_dt(prec), device="cuda")
     call("crimac_igemm_conv", P, ptr(dyn), Co, B, 2 * H, 2 * W, H, W, Co, Ci, 4, 2, 0, 2, ptr(dh), ptr(dl),
          None, 0, ptr(plain), Ci, 0, 0, 0)
     ref = torch.zeros(2, Ci, dtype=torch.float64, device="cuda")
@@ -609,12 +615,12 @@ def test_upconv_dgrad_with_fused_bn_backward_sums(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 40, 128, 256), (3, 256, 256, 64, 128), (1, 16, 16, 64, 128)])
-def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape):
+@pytest.mark.parametrize("prec", LOWP)
+def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape, prec):
     """crimac_conv3x3_cols on [0, N/2) and [N/2, N) (weights / bias / out / accumulators of the FULL convolution)
     reproduces crimac_conv3x3 bit for bit, statistics included; unsupported ranges fail loudly.  The second shape
     takes the persistent 64-channel kernel for each half, the first the channel-split kernel."""
     B, H, W, Ci, Co = shape
-    prec = "bf16"
     P = hip.PREC_NAMES[prec]
     g = torch.Generator().manual_seed(41)
     x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
@@ -623,13 +629,13 @@ def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape):
     fh, fl, _, _ = pack_conv(w, prec, Ci, dgrad=False)
     xin = to_nhwc(x, prec)
     M = B * H * W
-    full = torch.empty(M, Co, dtype=torch.bfloat16, device="cuda")
+    full = torch.empty(M, Co, dtype=_dt(prec), device="cuda")
     st_full = torch.zeros(2, 4, Co, dtype=torch.float64, device="cuda")
     call("crimac_conv3x3", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(full), Co, 1, 1,
          ptr(st_full[0]), ptr(st_full[1]), 4, None, 0, None, 0)
     half = Co // 2
     supported = half % 128 == 0 or (half == 64 and Ci == 64 and B * ((H + 15) // 16) * ((W + 15) // 16) >= 512)
-    parts = torch.zeros(M, Co, dtype=torch.bfloat16, device="cuda")
+    parts = torch.zeros(M, Co, dtype=_dt(prec), device="cuda")
     st = torch.zeros(2, 4, Co, dtype=torch.float64, device="cuda")
     args = lambda n0: ("crimac_conv3x3_cols", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(parts), Co,
                        1, 1, ptr(st[0]), ptr(st[1]), 4, None, 0, None, 0, n0, half)
@@ -644,7 +650,7 @@ def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape):
     assert relerr(st.sum(1), st_full.sum(1)) < 1e-6       # (fp32 partial sums are grouped differently)
 
 
-@pytest.mark.parametrize("planes", [1, 2, 3])
+@pytest.mark.parametrize("planes", [1, 2, 3, 17])
 def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
     """crimac_pack_layers / crimac_unpack_wgrad_layers (one launch for all layers) are bit-identical to
     the per-layer kernels, incl. the padded first layer (Ci = 4 -> 16, no dgrad planes)."""
@@ -660,7 +666,7 @@ def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
         n = T * Co * Cp
         dw = torch.randn(n, generator=g).cuda()
         has_dg = Cp == Ci
-        nl = max(planes - 1, 1)
+        nl = max((planes & 15) - 1, 1)
         new = {k: torch.full((m,), -1, dtype=i16, device="cuda") for k, m in
                (("fwd_hi", n), ("fwd_lo", nl * n), ("dg_hi", n), ("dg_lo", nl * n))}
         old = {k: torch.full_like(v, -1) for k, v in new.items()}
@@ -685,7 +691,7 @@ def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
     torch.cuda.synchronize()
     for li, (w, dw, new, old, grad_new, grad_old, has_dg) in enumerate(keep):
         for k in new:
-            if planes == 1 and k.endswith("_lo"):
+            if (planes & 15) == 1 and k.endswith("_lo"):
                 continue
             assert torch.equal(new[k], old[k]), (li, k)
         assert torch.equal(grad_new, grad_old), li

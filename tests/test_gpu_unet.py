@@ -174,8 +174,9 @@ def _check_lowp_train_step(precision, x, lab, seed=0):
     (oracle/unet_lowp_oracle.py): deterministic up to fp32 summation order, so EVERY gradient is compared."""
     from oracle import unet_lowp_oracle as lowp
     sd = synth.synth_state_dict(seed=seed)
-    ref_loss, ref_logits, ref_grads, ref_stats = lowp.loss_and_grads(sd, x, lab, storage=precision)
     m, loss, logits, grads, stats = _train_once(precision, x, lab, fused=False)
+    ref_loss, ref_logits, ref_grads, ref_stats = lowp.loss_and_grads(sd, x, lab, storage=precision,
+                                                                     loss_scale=m.engine.loss_scale)
     r, r2 = rel(logits.detach(), ref_logits), l2rel(logits.detach(), ref_logits)
     errs = {k: l2rel(g, ref_grads[k]) for k, g in grads.items() if not PRE_BN_BIAS.fullmatch(k)}
     worst = max(errs, key=errs.get)
@@ -205,17 +206,25 @@ def test_train_step_bf16_matches_storage_rounding_oracle_all_gradients(full_case
     _check_lowp_train_step("bf16", x, lab)
 
 
-def test_eval_bf16_matches_storage_rounding_oracle(full_case):
+def test_train_step_fp16_matches_storage_rounding_oracle_all_gradients(full_case):
+    """BASELINE configs[4] precision: fp16 storage + fp16 MFMA + loss scaling, every gradient against the oracle
+    that rounds to fp16 at the engine's storage points with the same loss scale."""
+    _, x, lab = full_case
+    _check_lowp_train_step("fp16", x, lab)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_eval_lowp_matches_storage_rounding_oracle(full_case, precision):
     from oracle import unet_lowp_oracle as lowp
     _, x, _ = full_case
     sd = synth.synth_state_dict(seed=0)
-    ref = lowp.predict(sd, x, storage="bf16")
-    m = make_model("bf16").eval()
+    ref = lowp.predict(sd, x, storage=precision)
+    m = make_model(precision).eval()
     with torch.no_grad():
         out = m(x.cuda())
     r, r2 = rel(out, ref), l2rel(out, ref)
     frac = float((out.argmax(1).cpu() != ref.argmax(1)).float().mean())
-    print(f"eval bf16 vs storage-rounding oracle: max-rel={r:.3e} L2-rel={r2:.3e} argmax flip fraction={frac:.5%}")
+    print(f"eval {precision} vs storage-rounding oracle: max-rel={r:.3e} L2-rel={r2:.3e} argmax flip fraction={frac:.5%}")
     assert r2 < 3e-3 and r < 3e-2 and frac < 2e-3
 
 
@@ -699,3 +708,109 @@ def test_pr_histogram_counts_nan_probabilities_in_the_guard_bin():
     assert int(h[:, 16384:].sum()) == 0
     assert int(h[0, 16383]) == 1 and int(h[1, 16383]) == 1
     assert int(view.sum()) == B * H * W
+
+
+def test_fp16_eval_is_closer_to_the_fp32_reference_than_bf16(full_case):
+    """fp16 carries 3 more mantissa bits than bf16: against the fp32 reference golden it must land well inside the
+    bf16 envelope (~1e-2 / 0.5 % flips for 16-bit autocast)."""
+    fix, x, _ = full_case
+    ref = torch.from_numpy(fix["logits_eval"])
+    res = {}
+    for prec in ("bf16", "fp16"):
+        m = make_model(prec).eval()
+        with torch.no_grad():
+            out = m(x.cuda())
+        res[prec] = (rel(out, ref), float((out.argmax(1).cpu() != ref.argmax(1)).float().mean()))
+    print("eval vs fp32 reference golden (max-rel, argmax flip fraction):", res)
+    assert res["fp16"][0] < 5e-3 and res["fp16"][1] < 2e-3
+    assert res["fp16"][0] < res["bf16"][0]
+
+
+def test_fp16_loss_scale_overflow_skips_the_step_and_adapts():
+    """A scaled gradient that overflows fp16 storage must leave parameters and momentum untouched, be counted,
+    and halve the dynamic loss scale; a clean step at a sane scale updates the parameters."""
+    m = make_model("fp16").train()
+    eng = m.engine
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 64, 64, seed=51)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(2, 64, 64, seed=52)).cuda()
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    eng.bind()
+    eng.loss_scale = 2.0 ** 40                    # far beyond fp16's range: inf in the stored gradients
+    p0, v0 = eng.flat_p.clone(), eng.flat_v.clone()
+    loss = eng.train_step(x, lab, cw, lr=0.005, momentum=0.95)
+    assert bool(torch.isfinite(loss))             # the forward pass is unaffected
+    assert torch.equal(eng.flat_p, p0) and torch.equal(eng.flat_v, v0)
+    assert eng.skipped_steps() == 1
+    assert eng.update_loss_scale() == 2.0 ** 39
+    eng.loss_scale = 2.0 ** 16
+    loss2 = eng.train_step(x, lab, cw, lr=0.005, momentum=0.95)
+    assert eng.skipped_steps() == 1 and not torch.equal(eng.flat_p, p0)
+    assert bool(torch.isfinite(eng.flat_p).all()) and bool(torch.isfinite(loss2))
+    for _ in range(4):
+        eng.update_loss_scale()
+    assert eng.loss_scale == 2.0 ** 17            # grows again after clean intervals
+    # autograd path: .grad holds UNSCALED gradients, an overflowed step is skipped by SGDMomentum.step
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    opt = pkg.SGDMomentum(m, lr=0.005, momentum=0.95)
+    opt.zero_grad()
+    crit(m(x), lab.long()).backward()
+    g_auto = eng.flat_g.clone()
+    m2 = make_model("f32x6").train()
+    crit(m2(x), lab.long()).backward()
+    assert l2rel(g_auto, m2.engine.flat_g) < 0.2   # same gradient up to the 16-bit storage noise
+    eng.loss_scale = 2.0 ** 40
+    opt.zero_grad()
+    crit(m(x), lab.long()).backward()
+    p1 = eng.flat_p.clone()
+    opt.step()
+    assert torch.equal(eng.flat_p, p1) and eng.skipped_steps() == 2
+
+
+def test_wide_net_fp16_full_size_with_gpu_augment_properties():
+    """BASELINE configs[4] at size on one GPU: start_filts = 128 (2x channels, ~4x FLOPs, 124 M parameters),
+    B = 32 x 4 x 256 x 256, fp16 + loss scaling, add_noise / flip / dB on the GPU.  Size-independent properties:
+    patches are independent in eval mode, the augmented training step is finite, nothing overflows at the default
+    loss scale, and repeated steps on the same crops lower the loss."""
+    m = make_model("fp16", start_filts=128).eval()
+    eng = m.engine
+    x = torch.from_numpy(synth.synth_echogram_batch(32, 4, 256, 256, seed=61)).cuda()
+    with torch.no_grad():
+        full = m(x)
+        part = m(x[9:11].contiguous())
+    assert torch.equal(full[9:11], part) and bool(torch.isfinite(full).all())
+    lab = torch.from_numpy(synth.synth_labels(32, 256, 256, seed=62)).cuda()
+    x_lin = torch.pow(10.0, x / 10.0)
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    m.train()
+    losses = [float(eng.train_step_augmented(x_lin, lab, cw, 0.005, 0.95, seed=7, do_noise=False, do_flip=False))
+              for _ in range(3)]
+    print("wide fp16 losses", losses, "skipped", eng.skipped_steps())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert eng.skipped_steps() == 0
+    l_aug = float(eng.train_step_augmented(x_lin, lab, cw, 0.005, 0.95, seed=8))
+    assert np.isfinite(l_aug) and eng.skipped_steps() == 0
+    assert bool(torch.isfinite(eng.flat_p).all())
+
+
+def test_wide_net_gpu_augment_step_matches_oracle_on_the_augmented_crops():
+    """configs[4] at a size the oracle finishes in seconds: the wide net's training step on crops augmented on the
+    GPU (add_noise + flip + dB, crimac_augment_db_nhwc) equals the oracle's step on those same augmented crops."""
+    sd = synth.synth_state_dict(start_filts=128, seed=2)
+    m = pkg.UNet_Baseline(3, 4, start_filts=128, precision="f32x6")
+    m.load_state_dict(sd)
+    m.cuda().train()
+    eng = m.engine
+    B, H, W = 2, 32, 32
+    x = torch.from_numpy(synth.synth_echogram_batch(B, 4, H, W, seed=71))
+    lab = torch.from_numpy(synth.synth_labels(B, H, W, seed=72))
+    x_lin = torch.pow(10.0, x / 10.0).cuda()
+    xa, la = eng.augment_batch(x_lin, lab.cuda(), seed=99)
+    xa_nchw = xa.float().reshape(B, H, W, -1)[..., :4].permute(0, 3, 1, 2).contiguous().cpu()
+    la_cpu = la.cpu().clone()
+    assert not torch.equal(xa_nchw, x)            # the augmentation did something
+    ref_loss, _, ref_grads, _ = orc.loss_and_grads(sd, xa_nchw, la_cpu)
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    loss = eng.train_step_augmented(x_lin, lab.cuda(), cw, lr=0.0, momentum=0.0, seed=99)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    for k in ("conv_final.weight", "up_convs.3.conv2.weight", "down_convs.4.main.3.weight"):
+        assert l2rel(eng.G[k], ref_grads[k]) < 2e-2, k
