@@ -198,7 +198,7 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
         serialized = True
 
     def kernel_rate(kname, records):
-        sel = [(f, s.elapsed_time(e)) for n, f, s, e in records if n == kname]
+        sel = [(f, s.elapsed_time(e)) for n, f, s, e in records if n.startswith(kname)]   # (crimac_wgrad[_partials])
         fl, ms_ = sum(f for f, _ in sel), sum(m for _, m in sel)
         return (fl / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0), ms_, len(sel)
 

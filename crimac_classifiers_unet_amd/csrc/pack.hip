@@ -23,6 +23,8 @@ struct LayerDesc {             // mirrors crimac_layer_desc (include/crimac_unet
   unsigned short* dg_hi;
   unsigned short* dg_lo;
   int kind, Co, Ci, Ci_pad;
+  int dw_splits;             // partial slabs of dw to add up (crimac_wgrad_partials); <= 1: dw is the gradient
+  long dw_stride;            // floats between slabs
 };
 
 struct Table {
@@ -136,6 +138,41 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
   }
 }
 
+// Partial slabs of the weight gradients (crimac_wgrad_partials): layers whose pixel range was split many ways (the
+// 64-channel layers at 256 x 256: 512 slabs of 147 KB) are first folded to kFold slabs, slab j += slabs j + kFold,
+// j + 2 kFold, ... (in place, fixed order), by a grid that is parallel over elements AND over the kFold groups;
+// unpack_layers_kernel then adds up at most kFold slabs per element.  Without this stage the unpack tiles of such a
+// layer (4 workgroups) would each walk 512 slabs serially.
+constexpr int kFold = 16;
+struct FoldTable {
+  float* dw[kMaxLayers];
+  long stride[kMaxLayers];
+  int splits[kMaxLayers];
+  int n4[kMaxLayers];          // float4 elements per slab
+  int first[kMaxLayers + 1];   // first workgroup (x index) of each layer
+  int n;
+};
+__global__ __launch_bounds__(256) void fold_slabs_kernel(FoldTable tb) {
+  int l = 0;
+  while (l + 1 < tb.n && (int)blockIdx.x >= tb.first[l + 1]) ++l;
+  const int i = (blockIdx.x - tb.first[l]) * 256 + threadIdx.x;
+  const int j = blockIdx.y;                                   // group: slabs j, j + kFold, ...
+  if (i >= tb.n4[l] || j >= tb.splits[l]) return;
+  float* base = tb.dw[l] + 4L * i;
+  const long st = tb.stride[l];
+  f32x4 acc = *reinterpret_cast<const f32x4*>(base + j * st);
+  int k = j + kFold;
+  for (; k + 3 * kFold < tb.splits[l]; k += 4 * kFold) {      // four independent loads in flight
+    const f32x4 a = *reinterpret_cast<const f32x4*>(base + (long)k * st);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(base + (long)(k + kFold) * st);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(base + (long)(k + 2 * kFold) * st);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(base + (long)(k + 3 * kFold) * st);
+    acc += a; acc += b; acc += c; acc += d;
+  }
+  for (; k < tb.splits[l]; k += kFold) acc += *reinterpret_cast<const f32x4*>(base + (long)k * st);
+  *reinterpret_cast<f32x4*>(base + j * st) = acc;
+}
+
 __global__ __launch_bounds__(256) void unpack_layers_kernel(Table tb) {
   __shared__ float tile[TILE][TILE * 9 + 1];
   const int l = find_layer(tb, blockIdx.x);
@@ -148,7 +185,13 @@ __global__ __launch_bounds__(256) void unpack_layers_kernel(Table tb) {
   // packed side: dw[t][outer][inner_pad] (conv3x3: [t][co][ci_pad], upconv: [ab][ci][co]), inner fastest
   for (int idx = threadIdx.x; idx < T * TILE * TILE; idx += 256) {
     const int il = idx % TILE, ol = (idx / TILE) % TILE, t = idx / (TILE * TILE);
-    if (il < nin) tile[ol][il * T + t] = d.dw[((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il];
+    if (il < nin) {
+      const float* src = d.dw + ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il;
+      float v = src[0];
+      const int nsl = d.dw_splits < kFold ? d.dw_splits : kFold;                       // (folded by fold_slabs_kernel)
+      for (int sp = 1; sp < nsl; ++sp) v += src[(long)sp * d.dw_stride];              // fixed order: reproducible
+      tile[ol][il * T + t] = v;
+    }
   }
   __syncthreads();
   const int valid = nin * T;
@@ -164,6 +207,8 @@ struct HostDesc {              // == crimac_layer_desc
   const float* dw;
   void *fwd_hi, *fwd_lo, *dg_hi, *dg_lo;
   int kind, Co, Ci, Ci_pad;
+  int dw_splits;
+  long dw_stride;
 };
 
 // mode 0: pack, 1: unpack
@@ -192,12 +237,37 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream
       d.fwd_hi = (unsigned short*)h.fwd_hi; d.fwd_lo = (unsigned short*)h.fwd_lo;
       d.dg_hi = (unsigned short*)h.dg_hi; d.dg_lo = (unsigned short*)h.dg_lo;
       d.kind = h.kind; d.Co = h.Co; d.Ci = h.Ci; d.Ci_pad = h.kind == 0 ? h.Ci_pad : h.Ci;
+      d.dw_splits = h.dw_splits; d.dw_stride = h.dw_stride;
+      if (mode == 1)
+        CRIMAC_REQUIRE(h.dw_splits <= 1 || h.dw_stride >= (long)(h.kind == 0 ? 9L * h.Co * h.Ci_pad : 4L * h.Co * h.Ci),
+                       "layer %d: dw_stride smaller than one packed gradient", base + i);
       const Geo g = geo_of(d.kind, d.Co, d.Ci, d.Ci_pad);
       tb.first[i] = total;
       total += (g.outer / TILE) * g.tiles_inner;
     }
     tb.first[tb.n] = total;
     if (total == 0) continue;
+    if (mode == 1) {
+      FoldTable ft;
+      ft.n = 0;
+      int fb = 0;
+      for (int i = 0; i < tb.n; ++i) {
+        const LayerDesc& d = tb.d[i];
+        if (d.dw_splits <= kFold) continue;
+        const long nfl = (long)(d.kind == 0 ? 9 : 4) * d.Co * d.Ci_pad;
+        CRIMAC_REQUIRE(nfl % 4 == 0 && d.dw_stride % 4 == 0 && ((uintptr_t)d.dw % 16 == 0),
+                       "layer %d: partial slabs must be 16-byte aligned", base + i);
+        ft.dw[ft.n] = const_cast<float*>(d.dw); ft.stride[ft.n] = d.dw_stride; ft.splits[ft.n] = d.dw_splits;
+        ft.n4[ft.n] = (int)(nfl / 4); ft.first[ft.n] = fb;
+        fb += (int)((nfl / 4 + 255) / 256);
+        ++ft.n;
+      }
+      if (ft.n) {
+        ft.first[ft.n] = fb;
+        hipLaunchKernelGGL(fold_slabs_kernel, dim3(fb, kFold), dim3(256), 0, st, ft);
+        CRIMAC_LAUNCH_CHECK();
+      }
+    }
     if (mode == 0) hipLaunchKernelGGL(pack_layers_kernel, dim3(total), dim3(256), 0, st, tb, planes_arg);
     else hipLaunchKernelGGL(unpack_layers_kernel, dim3(total), dim3(256), 0, st, tb);
     CRIMAC_LAUNCH_CHECK();

@@ -34,6 +34,7 @@ struct WgradParams {
   long ntiles;
   int tiles_per_block;
   int nsplits;
+  long partial_stride;     // 0: dw += acc by fp32 atomics; > 0: plain stores into dw + split * partial_stride
 };
 
 __device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 6; }
@@ -418,7 +419,12 @@ void wgrad_kernel(WgradParams p) {
       }
       CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
       CRIMAC_DIAG_STORE(crimac_diag_clock_wgrad, dg_t0, dg_r0, dg_t1, dg_r1)
-      // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps
+      // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps.
+      // partial_stride > 0: every (channel tile, split) workgroup OWNS its tile of slab `split` -- plain stores, no
+      // zero fill, no atomics (each split used to cost an fp32-atomic pass over dW at the chip-wide atomic rate of
+      // ~1.3 TB/s, issued by all workgroups of the single resident round at once: an unoverlapped tail of ~50 us per
+      // launch); the slabs are added up, in a fixed order, by crimac_unpack_wgrad_layers.
+      float* dwp = p.dw + (p.partial_stride > 0 ? (long)split * p.partial_stride : 0);
 #pragma unroll
       for (int sh = 0; sh < 2; ++sh) {
         const int col = cs0 + ws * 32 + sh * 16 + (lane & 15);
@@ -434,7 +440,11 @@ void wgrad_kernel(WgradParams p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int row = cf0 + fh * 16 + (lane >> 4) * 4 + r;
-                if (row < p.CF) atomicAdd(p.dw + ((long)(G::T0 + t) * p.CF + row) * p.CS + col, acc2[t][fh][sh][r]);
+                if (row < p.CF) {
+                  float* dst = dwp + ((long)(G::T0 + t) * p.CF + row) * p.CS + col;
+                  if (p.partial_stride > 0) *dst = acc2[t][fh][sh][r];
+                  else atomicAdd(dst, acc2[t][fh][sh][r]);
+                }
               }
         }
       }
@@ -488,35 +498,38 @@ void wgrad_kernel(WgradParams p) {
 #else
   if (col < p.CS) {
 #endif
+    float* dwp = p.dw + (p.partial_stride > 0 ? (long)split * p.partial_stride : 0);
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = cf0 + wf * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < p.CF) atomicAdd(p.dw + ((long)t * p.CF + row) * p.CS + col, acc[t][r]);
+        if (row < p.CF) {
+          float* dst = dwp + ((long)t * p.CF + row) * p.CS + col;
+          if (p.partial_stride > 0) *dst = acc[t][r];
+          else atomicAdd(dst, acc[t][r]);
+        }
       }
     }
   }
 }
 
-template <typename TA, int NPL, int MODE, bool NARROW = false>
-int launch(WgradParams p, int target_blocks, hipStream_t st) {
-  constexpr int TR = MODE == 0 ? 8 : 4;
-  constexpr int F_ROWS = TR * 16;
-  constexpr int S_ROWS = ((MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32) + 7) / 8 * 8;   // padded to 8 rows
+// Pixel-range split of a shape: fills tiles_y/x, ntiles, tiles_per_block, nsplits (same for every precision).
+void plan_splits(WgradParams& p, int mode, int target_blocks) {
+  const int TR = mode == 0 ? 8 : 4;
   p.tiles_y = cdiv(p.Hf, TR);
   p.tiles_x = cdiv(p.Wf, 16);
   p.ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   const int ch_tiles = cdiv(p.CF, 64) * cdiv(p.CS, 64);
   const bool autosplit = target_blocks <= 0;
-  // one resident round: 2 workgroups per CU x 256 CUs.  More splits only add atomic volume (each workgroup
-  // ends with 147 KB of fp32 atomics) and a second, partially filled round: 512 measured 2 % faster than 1024.
+  // one resident round: 2 workgroups per CU x 256 CUs.  More splits only add partial-sum volume (each workgroup
+  // ends with 147 KB of fp32 output) and a second, partially filled round: 512 measured 2 % faster than 1024.
   static const int auto_blocks = getenv("CRIMAC_WGRAD_BLOCKS") ? atoi(getenv("CRIMAC_WGRAD_BLOCKS")) : 512;
   if (autosplit) target_blocks = auto_blocks;
   int splits = target_blocks / ch_tiles;
   if (autosplit) {
-    // every split adds one fp32-atomic pass over dW (chip-wide atomic rate ~1.3 TB/s): keep at
-    // least ~4096 contraction pixels per split so the atomics stay below the MFMA time
+    // every split adds one pass over dW (fp32 atomics at ~1.3 TB/s chip-wide, or a partial slab written and read
+    // back): keep at least ~4096 contraction pixels per split so that pass stays below the MFMA time
     long max_splits = ((long)p.B * p.Hf * p.Wf) / 4096;
     if (max_splits < 1) max_splits = 1;
     // ... unless that leaves fewer than two workgroups per CU: then parallelism is worth more
@@ -526,8 +539,17 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   if (splits < 1) splits = 1;
   if (splits > p.ntiles) splits = (int)p.ntiles;
   p.tiles_per_block = cdiv(p.ntiles, splits);
-  splits = cdiv(p.ntiles, p.tiles_per_block);
-  p.nsplits = splits;
+  p.nsplits = cdiv(p.ntiles, p.tiles_per_block);       // every split owns at least one tile
+}
+
+template <typename TA, int NPL, int MODE, bool NARROW = false>
+int launch(WgradParams p, int target_blocks, hipStream_t st) {
+  constexpr int TR = MODE == 0 ? 8 : 4;
+  constexpr int F_ROWS = TR * 16;
+  constexpr int S_ROWS = ((MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32) + 7) / 8 * 8;   // padded to 8 rows
+  plan_splits(p, MODE, target_blocks);
+  const int ch_tiles = cdiv(p.CF, 64) * cdiv(p.CS, 64);
+  const int splits = p.nsplits;
   // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of NPL planes
   const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 : NPL);
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
@@ -540,19 +562,19 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   return CRIMAC_OK;
 }
 
-}  // namespace
-
-extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
-                            long s_ld, int CS, int B, int Hf, int Wf, float* dw, int target_blocks,
-                            void* stream) {
+int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld, int CS, int B, int Hf,
+              int Wf, float* dw, long partial_stride, int target_blocks, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "wgrad: bad precision %d", prec);
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "wgrad: bad mode %d", mode);
   CRIMAC_REQUIRE(CF > 0 && CF % 8 == 0 && CS > 0 && CS % 8 == 0, "wgrad: channels must be multiples of 8");
   CRIMAC_REQUIRE(f_ld >= CF && s_ld >= CS && f_ld % 8 == 0 && s_ld % 8 == 0, "wgrad: bad pixel strides");
   CRIMAC_REQUIRE(B > 0 && Hf > 0 && Wf > 0 && f && s && dw, "wgrad: bad arguments");
+  CRIMAC_REQUIRE(partial_stride == 0 || partial_stride >= (long)(mode == 0 ? 9 : 4) * CF * CS,
+                 "wgrad: partial slab stride %ld smaller than one dW (%d taps x %d x %d)", partial_stride,
+                 mode == 0 ? 9 : 4, CF, CS);
   WgradParams p;
   p.f = f; p.f_ld = f_ld; p.CF = CF; p.s = s; p.s_ld = s_ld; p.CS = CS;
-  p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw;
+  p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw; p.partial_stride = partial_stride;
   hipStream_t st = (hipStream_t)stream;
   if (prec == CRIMAC_PREC_BF16) {
     if (mode == 0 && CS <= 16) return launch<bf16_t, 1, 0, true>(p, target_blocks, st);     // first layer
@@ -565,4 +587,27 @@ extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF
   if (prec == CRIMAC_PREC_F32X3)
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
   return mode == 0 ? launch<float, 3, 0>(p, target_blocks, st) : launch<float, 3, 1>(p, target_blocks, st);
+}
+
+}  // namespace
+
+extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
+                            long s_ld, int CS, int B, int Hf, int Wf, float* dw, int target_blocks,
+                            void* stream) {
+  return wgrad_run(prec, mode, f, f_ld, CF, s, s_ld, CS, B, Hf, Wf, dw, 0, target_blocks, stream);
+}
+
+extern "C" int crimac_wgrad_splits(int mode, int CF, int CS, int B, int Hf, int Wf, int target_blocks) {
+  if (!(mode == 0 || mode == 1) || CF <= 0 || CS <= 0 || B <= 0 || Hf <= 0 || Wf <= 0) return CRIMAC_ERR_INVALID;
+  WgradParams p;
+  p.CF = CF; p.CS = CS; p.B = B; p.Hf = Hf; p.Wf = Wf;
+  plan_splits(p, mode, target_blocks);
+  return p.nsplits;
+}
+
+extern "C" int crimac_wgrad_partials(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
+                                     long s_ld, int CS, int B, int Hf, int Wf, float* partials, long slab_stride,
+                                     int target_blocks, void* stream) {
+  CRIMAC_REQUIRE(slab_stride > 0, "wgrad_partials: slab_stride must be positive");
+  return wgrad_run(prec, mode, f, f_ld, CF, s, s_ld, CS, B, Hf, Wf, partials, slab_stride, target_blocks, stream);
 }

@@ -177,8 +177,9 @@ class UNetEngine:
         self._ltab = None
         self.pk = {}      # train-mode operand planes
         self.pk_eval = {}  # eval-mode (BN folded) forward planes + folded bias
-        tot_dw = 0
-        self.dw_off = {}
+        self.dw_plan = None       # (B, H, W) the partial-sum workspace of the weight gradients is laid out for
+        self.dw_off = {}          # layer key -> (first float, slabs, floats per slab) in self.dw_packed
+        self.dw_packed = None
         for b in self.blocks:
             n_f = 9 * b.cout * b.cin_pad
             n_lo = max(self.planes - 1, 1)        # the lo buffer holds planes 1..planes-1
@@ -194,8 +195,6 @@ class UNetEngine:
                 "fwd_lo": torch.empty(n_lo * n_f, dtype=i16, device=dev),
                 "bias": torch.empty(b.cout, dtype=torch.float32, device=dev),
             }
-            self.dw_off[b.conv_key] = tot_dw
-            tot_dw += _align(n_f)
         for u in self.ups:
             n = 4 * u.cin * u.cout
             n_lo = max(self.planes - 1, 1)
@@ -203,9 +202,6 @@ class UNetEngine:
                               "fwd_lo": torch.empty(n_lo * n, dtype=i16, device=dev),
                               "dg_hi": torch.empty(n, dtype=i16, device=dev),
                               "dg_lo": torch.empty(n_lo * n, dtype=i16, device=dev)}
-            self.dw_off[u.key] = tot_dw
-            tot_dw += _align(n)
-        self.dw_packed = torch.zeros(tot_dw, dtype=torch.float32, device=dev)
         cmax = self.sf * 2 ** (self.depth - 1)
         nb = len(self.blocks)
         # fp64 scratch: [0:2] loss sums, then per BN layer (2*R + 2) x cmax:
@@ -233,9 +229,55 @@ class UNetEngine:
         o = (b.idx * 4 + k) * self.cmax
         return self.bnf[o:o + b.cout]
 
-    def _dw(self, key, n):
-        o = self.dw_off[key]
-        return self.dw_packed[o:o + n]
+    # Reproducible weight gradients (opt-in): crimac_wgrad_partials writes one slab per pixel split by plain stores
+    # (no atomics, no zero fill) and crimac_unpack_wgrad_layers adds the slabs up in a fixed order, so the 31 M
+    # weight gradients are bit-identical run to run.  Measured at B = 32 (profiles/r02_wgrad_partials_ab.txt): the
+    # wgrad launches get 10 % faster (157 -> 142 us: the atomic tail is gone), but the step gets 3 % SLOWER (13.04 ->
+    # 13.43 ms): 1.44 GB of slabs per step (75 MB per layer whatever its size: 512 workgroups x 147 KB) have to be
+    # written and read back, against atomics that overlap with the other workgroups' MFMAs -- hence not the default.
+    # The number of splits depends on the batch geometry, so the workspace is planned per (B, H, W).
+    use_wgrad_partials = os.environ.get("CRIMAC_WGRAD_PARTIALS", "0") != "0"
+
+    def _plan_dw(self, B, H, W):
+        if self.dw_plan == (B, H, W, self.use_wgrad_partials):
+            return
+        lib = hip.load_library()
+        geo = self._geom(B, H, W)
+        D = self.depth
+        off, tot = {}, 0
+
+        def add(key, mode, cf, cs, n, h, w):
+            nonlocal tot
+            sp = 1
+            if self.use_wgrad_partials:
+                sp = lib.crimac_wgrad_splits(mode, cf, cs, B, h, w, self.wgrad_target_blocks)
+                if sp < 1:
+                    raise hip.HipLibraryError(f"crimac_wgrad_splits failed for {key}")
+            stride = _align(n)
+            off[key] = (tot, sp, stride)
+            tot += sp * stride
+
+        for i in range(D):
+            h, w, _ = geo[i]
+            for b in self.enc[i]:
+                add(b.conv_key, 0, b.cout, b.cin_pad, 9 * b.cout * b.cin_pad, h, w)
+        for j in range(D - 1):
+            L = D - 2 - j
+            h, w, _ = geo[L]
+            for b in self.dec[j]:
+                add(b.conv_key, 0, b.cout, b.cin_pad, 9 * b.cout * b.cin_pad, h, w)
+            u = self.ups[j]
+            hp, wp, _ = geo[L + 1]
+            add(u.key, 1, u.cin, u.cout, 4 * u.cin * u.cout, hp, wp)
+        self.dw_off = off
+        self.dw_packed = torch.zeros(tot, dtype=torch.float32, device=self.device)
+        self.dw_plan = (B, H, W, self.use_wgrad_partials)
+        self._ltab = None                             # the layer table carries the slab pointers
+
+    def _dw(self, key):
+        """(slab workspace of the layer, slabs, floats per slab)"""
+        o, sp, stride = self.dw_off[key]
+        return self.dw_packed[o:o + sp * stride], sp, stride
 
     def mark_dirty(self):
         self._train_pack_dirty = self._eval_pack_dirty = True
@@ -271,7 +313,11 @@ class UNetEngine:
             n = (4 if up else 9) * l.cout * cin_pad
             d.w = self.P[key + ".weight"].data_ptr()
             d.grad = self.G[key + ".weight"].data_ptr()
-            d.dw = self._dw(key, n).data_ptr()
+            if self.dw_off:
+                dwt, sp, stride = self._dw(key)
+                d.dw, d.dw_splits, d.dw_stride = dwt.data_ptr(), sp, stride
+            else:                                     # (packing before the first backward pass: no gradients yet)
+                d.dw, d.dw_splits, d.dw_stride = None, 1, 0
             d.fwd_hi, d.fwd_lo = pk["fwd_hi"].data_ptr(), pk["fwd_lo"].data_ptr()
             d.dg_hi = pk["dg_hi"].data_ptr() if pk["dg_hi"] is not None else None
             d.dg_lo = pk["dg_lo"].data_ptr() if pk["dg_lo"] is not None else None
@@ -328,9 +374,16 @@ class UNetEngine:
         return (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
                 and dist.get_backend() == "gloo")
 
-    def _wgrad(self, *args, flops=None):
+    def _wgrad(self, prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, key, flops=None):
+        dwt, sp, stride = self._dw(key)
+        if self.use_wgrad_partials:
+            name, args = "crimac_wgrad_partials", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt), stride,
+                                                   self.wgrad_target_blocks)
+        else:
+            name, args = "crimac_wgrad", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt),
+                                          self.wgrad_target_blocks)
         if self.wgrad_side_streams <= 0 or self._gloo_ranks():
-            call("crimac_wgrad", *args, flops=flops)
+            call(name, *args, flops=flops)
             return
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.wgrad_side_streams)]
@@ -342,7 +395,7 @@ class UNetEngine:
         ev.record()                                   # everything wgrad reads has been queued on this stream
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            call("crimac_wgrad", *args, flops=flops)
+            call(name, *args, flops=flops)
 
     def _join_wgrad(self):
         if self._side is not None:
@@ -745,10 +798,8 @@ class UNetEngine:
              ptr(self._stat(b, 3)), M, M * world, b.cout, dy.p, dy.ld, ptr(dgamma), ptr(dbeta),
              None)      # d(conv bias in front of train-mode BN) = sum dy == 0 exactly: left at the zero fill
              #            (the reference holds ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
-        n = 9 * b.cout * b.cin_pad
-        dw = self._dw(b.conv_key, n)
-        self._wgrad(self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w,
-             ptr(dw), self.wgrad_target_blocks, flops=2.0 * 9 * b.cin * b.cout * B * h * w)
+        self._wgrad(self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w, b.conv_key,
+                    flops=2.0 * 9 * b.cin * b.cout * B * h * w)
         fused = False
         if dx_out is not None:
             stats = None
@@ -845,8 +896,10 @@ class UNetEngine:
         D = self.depth
         self._skip_done = {}
         self._unpacked = {}
+        self._plan_dw(B, H, W)
         self.flat_g.zero_()
-        self.dw_packed.zero_()
+        if not self.use_wgrad_partials:
+            self.dw_packed.zero_()                    # (the atomic form accumulates; the slab form overwrites)
         # the fused BatchNorm-backward reductions accumulate into the replica slots the forward statistics used:
         # one fill for all layers (and one for the transposed-conv bias sums) instead of one per fused block
         self.stat[2:].zero_()
@@ -883,10 +936,8 @@ class UNetEngine:
             dup = dcat.slice(0, c)
             skip_grad[L] = dcat.slice(c, c)
             hp, wp, Mp = geo[L + 1]
-            n = 4 * u.cin * u.cout
-            dw = self._dw(u.key, n)
-            self._wgrad(self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp,
-                 wp, ptr(dw), self.wgrad_target_blocks, flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
+            self._wgrad(self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp, wp, u.key,
+                        flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
             d_prev = Act(self._buf(f"g.d{j}.xprev", (Mp, u.cin)), u.cin)
             # d_prev is the `da` of the next coarser block (decoder j-1, or the bottleneck encoder block)
             nxt = (self.dec[j - 1][1], s[f"d{j - 1}"][4]) if j > 0 else (self.enc[D - 1][1], s[f"e{D - 1}"][3])

@@ -38,6 +38,7 @@ SIGNATURES = {
                                         _vp],
     "crimac_sum_replicas": [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
+    "crimac_wgrad_partials": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp],
     "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_pack_upconv2x2": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_unpack_wgrad_conv3x3": [_vp, _i, _i, _i, _vp, _vp],
@@ -76,7 +77,8 @@ SIGNATURES = {
 class LayerDesc(C.Structure):
     """crimac_layer_desc (include/crimac_unet_hip.h): one Conv2d / ConvTranspose2d layer's buffers."""
     _fields_ = [("w", _vp), ("grad", _vp), ("dw", _vp), ("fwd_hi", _vp), ("fwd_lo", _vp), ("dg_hi", _vp),
-                ("dg_lo", _vp), ("kind", _i), ("Co", _i), ("Ci", _i), ("Ci_pad", _i)]
+                ("dg_lo", _vp), ("kind", _i), ("Co", _i), ("Ci", _i), ("Ci_pad", _i), ("dw_splits", _i),
+                ("dw_stride", _l)]
 
 
 _lib = None
@@ -105,6 +107,8 @@ def load_library():
     lib.crimac_version.argtypes = []
     lib.crimac_last_error.restype = C.c_char_p
     lib.crimac_last_error.argtypes = []
+    lib.crimac_wgrad_splits.restype = C.c_int          # (returns a count, not a status; no stream argument)
+    lib.crimac_wgrad_splits.argtypes = [_i, _i, _i, _i, _i, _i, _i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = C.c_int

@@ -137,6 +137,16 @@ int crimac_conv3x3_cols(int prec, const void* in, long in_ld, int B, int H, int 
  *   one atomic pass). */
 int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld,
                  int CS, int B, int Hf, int Wf, float* dw, int target_blocks, void* stream);
+/* The same contraction WITHOUT atomics: the pixel range is split into crimac_wgrad_splits(...) parts and the
+ * workgroups of part k store their finished 64 x 64 x taps tiles into slab k = partials + k * slab_stride (plain
+ * stores; every element of every slab is written, no zero fill needed).  crimac_unpack_wgrad_layers adds the slabs
+ * up in order, so the weight gradient is bit-reproducible run to run; it also removes the fp32-atomic tail of the
+ * single resident round (each split was one atomic pass over dW at ~1.3 TB/s chip-wide).  slab_stride in floats,
+ * >= taps * CF * CS.  crimac_wgrad_splits returns the number of slabs for a shape (> 0) or a negative error. */
+int crimac_wgrad_splits(int mode, int CF, int CS, int B, int Hf, int Wf, int target_blocks);
+int crimac_wgrad_partials(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld, int CS,
+                          int B, int Hf, int Wf, float* partials, long slab_stride, int target_blocks, void* stream);
+
 
 /* ---- weight layout (fp32 master weights <-> bf16 MFMA operand planes) ------------------------ */
 
@@ -166,6 +176,10 @@ typedef struct crimac_layer_desc {
   void* dg_lo;
   int kind;            /* 0: Conv2d 3x3, 1: ConvTranspose2d 2x2 stride 2 */
   int Co, Ci, Ci_pad;  /* Ci_pad: kind 0 only */
+  int dw_splits;       /* crimac_unpack_wgrad_layers: `dw` holds this many partial slabs (crimac_wgrad_partials),
+                        * added up in a fixed order (bit-reproducible; more than 16 slabs are first folded IN PLACE
+                        * into the first 16, so dw is scratch afterwards); 0 or 1: dw is the finished sum (crimac_wgrad) */
+  long dw_stride;      /* floats between two slabs */
 } crimac_layer_desc;
 int crimac_pack_layers(const crimac_layer_desc* descs, int n_layers, int planes, void* stream);
 int crimac_unpack_wgrad_layers(const crimac_layer_desc* descs, int n_layers, void* stream);

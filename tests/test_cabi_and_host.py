@@ -29,7 +29,12 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
     # and the binding table covers the header exactly (plus version / last_error)
-    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error"} == set(syms)
+    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error", "crimac_wgrad_splits"} == set(syms)
+    # the split planner is a host-only query (no GPU): the level-0 shape fills one resident round
+    lib2 = hip.load_library()
+    assert lib2.crimac_wgrad_splits(0, 64, 64, 32, 256, 256, 0) == 512
+    assert lib2.crimac_wgrad_splits(0, 1024, 1024, 32, 16, 16, 0) >= 1
+    assert lib2.crimac_wgrad_splits(2, 64, 64, 32, 256, 256, 0) < 0
     assert hip.load_library().crimac_version() >= 1
 
 

@@ -700,3 +700,59 @@ def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
     call("crimac_unpack_wgrad_layers", ctypes.byref(descs, 2 * ctypes.sizeof(hip.LayerDesc)), 1)
     torch.cuda.synchronize()
     assert torch.equal(keep[2][4], keep[2][5]) and float(keep[1][4].abs().max()) == 0
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "f32x3"])
+@pytest.mark.parametrize("mode,shape", [(0, (2, 64, 64, 64, 128)), (1, (2, 32, 32, 128, 64)), (0, (1, 40, 24, 16, 64))])
+def test_wgrad_partial_slabs_sum_to_the_atomic_result_and_are_reproducible(prec, mode, shape):
+    """crimac_wgrad_partials: one slab per pixel split by plain stores (no zero fill, no atomics);
+    crimac_unpack_wgrad_layers adds the slabs in order.  Equals crimac_wgrad (+ per-layer unpack) and the torch
+    reference, and two runs are bit-identical (the atomic form is not)."""
+    import ctypes
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(29)
+    P = hip.PREC_NAMES[prec]
+    lib = hip.load_library()
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    if mode == 0:
+        dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+        ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), dy, padding=1)
+        F_, S_, CF, CS, taps, shape_w, kind = to_nhwc(dy, prec), to_nhwc(x, prec), Co, Ci, 9, (Co, Ci, 3, 3), 0
+    else:
+        dy = _round(torch.randn(B, Co, 2 * H, 2 * W, generator=g), prec)
+        wg = torch.zeros(Ci, Co, 2, 2, requires_grad=True)
+        F.conv_transpose2d(x, wg, None, stride=2).backward(dy)
+        ref = wg.grad
+        F_, S_, CF, CS, taps, shape_w, kind = to_nhwc(x, prec), to_nhwc(dy, prec), Ci, Co, 4, (Ci, Co, 2, 2), 1
+    n = taps * CF * CS
+    for target in (0, 24):
+        sp = lib.crimac_wgrad_splits(mode, CF, CS, B, H, W, target)
+        assert sp >= 1
+        stride = n + 64
+        outs = []
+        for rep in range(2):
+            slabs = torch.full((sp * stride,), float("nan"), dtype=torch.float32, device="cuda")   # no zero fill needed
+            call("crimac_wgrad_partials", P, mode, ptr(F_), CF, CF, ptr(S_), CS, CS, B, H, W, ptr(slabs), stride, target)
+            grad = torch.zeros(*shape_w, dtype=torch.float32, device="cuda")
+            d = (hip.LayerDesc * 1)()
+            d[0].grad, d[0].dw, d[0].kind = grad.data_ptr(), slabs.data_ptr(), kind
+            d[0].Co, d[0].Ci, d[0].Ci_pad = Co, Ci, Ci
+            d[0].dw_splits, d[0].dw_stride = sp, stride
+            if Co % 32 == 0 and (kind == 0 or Ci % 32 == 0):
+                call("crimac_unpack_wgrad_layers", ctypes.byref(d), 1)
+                torch.cuda.synchronize()
+            else:
+                torch.cuda.synchronize()
+                summed = slabs.view(sp, stride)[:, :n].sum(0)
+                grad = (summed.view(9, Co, Ci).permute(1, 2, 0).reshape(Co, Ci, 3, 3) if kind == 0
+                        else summed.view(4, Ci, Co).permute(1, 2, 0).reshape(Ci, Co, 2, 2)).contiguous()
+            assert bool(torch.isfinite(slabs.view(sp, stride)[:, :n]).all())        # every slab element was written
+            outs.append(grad.clone())
+        assert torch.equal(outs[0], outs[1])
+        assert relerr(outs[0].cpu(), ref) < (2e-4 if prec in LOWP else 1e-4)
+        dwp = torch.zeros(n, dtype=torch.float32, device="cuda")
+        call("crimac_wgrad", P, mode, ptr(F_), CF, CF, ptr(S_), CS, CS, B, H, W, ptr(dwp), target)
+        torch.cuda.synchronize()
+        summed = (dwp.view(9, Co, Ci).permute(1, 2, 0).reshape(Co, Ci, 3, 3) if kind == 0
+                  else dwp.view(4, Ci, Co).permute(1, 2, 0).reshape(Ci, Co, 2, 2))
+        assert relerr(outs[0], summed) < 1e-5

@@ -1,0 +1,17 @@
+#!/bin/bash
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r2e
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_unet.py -m gpu -q -x -k "wgrad or pack or train or grad or step" > gpurun_out/r2e/tests.log 2>&1
+rc=$?
+tail -4 gpurun_out/r2e/tests.log
+if [ $rc -gt 1 ]; then echo "tests killed rc=$rc"; exit $rc; fi
+for v in p1 p0 q1 q0; do
+CRIMAC_WGRAD_PARTIALS=${v:1:1} timeout -k 10 200 python bench.py --no-cpu-baseline --no-tiled --no-parity-mode > gpurun_out/r2e/bench_$v.json 2> gpurun_out/r2e/bench_$v.err || { echo bench failed; tail -20 gpurun_out/r2e/bench_$v.err; exit 1; }
+done
+python - <<'PY'
+import json
+for n in ("p1","p0","q1","q0"):
+    d=json.load(open(f"gpurun_out/r2e/bench_{n}.json"))
+    print(n, round(d["value"],1), "patches/s", round(d["ms_per_step"],3), "ms", "wgrad frac", round(d["roofline_wgrad"]["frac"],3), "avg us", round(d["roofline_wgrad"]["avg_launch_us"],1), "conv", round(d["roofline"]["frac"],3))
+PY
