@@ -114,6 +114,12 @@ class UNetEngine:
             self.ups.append(_UpConv(p + "upconv", cprev, c))
             self.dec.append((_ConvBlock(p + "conv1", p + "bn1", 2 * c, c),
                              _ConvBlock(p + "conv2", p + "bn2", c, c)))
+        # UNet_LateMetInject (unet.py:346-391): per-pixel perceptron on the metadata planes, its output concatenated
+        # to the last decoder activation in front of conv_final (65 -> n_classes)
+        self.lmi = bool(getattr(module, "late_meta_inject", False))
+        self.meta_channels = int(getattr(module, "meta_in_channels", 0)) if self.lmi else 0
+        if self.lmi and not 1 <= self.meta_channels <= 8:
+            raise ValueError(f"late metadata injection supports 1..8 metadata channels, got {self.meta_channels}")
         self.blocks = [b for pair in self.enc for b in pair] + [b for pair in self.dec for b in pair]
         for k, b in enumerate(self.blocks):
             b.idx = k
@@ -620,14 +626,42 @@ class UNetEngine:
         return xin, B, H, W
 
     @_on_device
-    def forward(self, x, training, softmax=False):
-        """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs."""
+    def forward(self, x, training, softmax=False, meta=None):
+        """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs.
+        ``meta`` [B,Cm,H,W]: the metadata planes of UNet_LateMetInject.forward(x, meta_tensor) (unet.py:372)."""
         self.bind()
+        if self.lmi:
+            meta = self._meta(meta, x)
+        elif meta is not None:
+            raise ValueError("this model takes no metadata tensor (late_meta_inject=False)")
         if (not training and self.eval_two_streams and x.dim() == 4 and x.shape[0] >= 16 and x.shape[0] % 2 == 0
-                and x.is_cuda and not self._gloo_ranks()):
+                and x.is_cuda and not self._gloo_ranks() and not self.lmi):
             return self._forward_eval_two_streams(x, softmax)
         xin, B, H, W = self._input(x)
-        return self.forward_nhwc(xin, B, H, W, training, softmax)
+        return self.forward_nhwc(xin, B, H, W, training, softmax, meta=meta)
+
+    def _meta(self, meta, x):
+        if meta is None:
+            raise ValueError("UNet_LateMetInject.forward needs the metadata tensor")
+        if not meta.is_cuda:
+            raise hip.HipLibraryError("metadata tensor is not on a GPU: the HIP path has no CPU fallback")
+        if meta.dim() != 4 or meta.shape[1] != self.meta_channels or meta.shape[0] != x.shape[0] \
+                or tuple(meta.shape[2:]) != tuple(x.shape[2:]):
+            raise ValueError(f"expected metadata [B,{self.meta_channels},H,W] matching the data, got {tuple(meta.shape)}")
+        return meta.contiguous().float()
+
+    def _lmi_weights(self):
+        """conv_final.weight [nc, 65, 1, 1] -> (first 64 columns packed [nc, 64], metadata column [nc])"""
+        w = self.P["conv_final.weight"].detach().view(self.n_classes, self.sf + 1)
+        w64 = self._buf("lmi.w64", (self.n_classes, self.sf), torch.float32)
+        wm = self._buf("lmi.wm", (self.n_classes,), torch.float32)
+        w64.copy_(w[:, :self.sf])
+        wm.copy_(w[:, self.sf])
+        return w64, wm
+
+    def _mlp(self):
+        pre = "post_processing_weights.main."
+        return [ptr(self.P[pre + k]) for k in ("0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias")]
 
     # Inference: the two halves of a batch run on two streams (own activation buffers each).  The kernels of one
     # half fill the ragged last rounds and the launch gaps of the other -- the same effect the side stream has in
@@ -665,7 +699,7 @@ class UNetEngine:
         return logits
 
     @_on_device
-    def forward_nhwc(self, xin, B, H, W, training, softmax=False, out=None):
+    def forward_nhwc(self, xin, B, H, W, training, softmax=False, out=None, meta=None):
         """Same, from an NHWC activation matrix [B*H*W, 16] already in the engine's storage type
         (what ``crimac_gather_patches`` writes for the tiled-inference path)."""
         self.bind()
@@ -752,10 +786,23 @@ class UNetEngine:
             cur = a2
         logits = out if out is not None else torch.empty((B, self.n_classes, H, W), dtype=torch.float32,
                                                          device=self.device)
-        call("crimac_head_fwd", self.prec, cur.p, cur.ld, self.sf, ptr(self.P["conv_final.weight"]),
-             ptr(self.P["conv_final.bias"]), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0,
-             ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
-             ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
+        if self.lmi:
+            if meta is None:
+                raise ValueError("UNet_LateMetInject needs the metadata tensor")
+            w64, wm = self._lmi_weights()
+            call("crimac_head_fwd", self.prec, cur.p, cur.ld, self.sf, ptr(w64), ptr(self.P["conv_final.bias"]),
+                 ptr(logits), B, H, W, self.n_classes, 0,
+                 ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
+                 ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
+            m = self._buf("lmi.m", (B * H * W,), torch.float32)
+            call("crimac_meta_mlp_fwd", ptr(meta), self.meta_channels, B, H, W, *self._mlp(), ptr(m))
+            call("crimac_meta_inject_fwd", ptr(m), ptr(wm), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0)
+            saved["meta"] = meta
+        else:
+            call("crimac_head_fwd", self.prec, cur.p, cur.ld, self.sf, ptr(self.P["conv_final.weight"]),
+                 ptr(self.P["conv_final.bias"]), ptr(logits), B, H, W, self.n_classes, 1 if softmax else 0,
+                 ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
+                 ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
         saved["head_in"] = cur if head_bn is None else None
         self.saved = saved if training else None
         if training:
@@ -873,7 +920,7 @@ class UNetEngine:
         if [g for g, _ in bounds] != sorted(starts) or bounds[-1][1] != 0 or not bounds[0][1] < lo_dec:
             raise RuntimeError("unexpected parameter order in the flat buffer")
         for k, (o, _, _) in self.layout.items():
-            if (o >= lo_dec) != (k.startswith(dec) or k.startswith("conv_final")):
+            if (o >= lo_dec) != (k.startswith(dec) or k.startswith("conv_final") or k.startswith("post_processing_weights")):
                 raise RuntimeError(f"unexpected parameter order in the flat buffer at {k}")
         ranges, hi = [(lo_dec, self.n_flat)], lo_dec
         for _, lo in bounds:
@@ -912,11 +959,28 @@ class UNetEngine:
         head_fused = self.fuse_bn_bwd and D >= 2
         if head_in is None and not head_fused:
             raise RuntimeError("head input was not materialised (fuse_head_bn) but the fused BatchNorm sums are off")
+        w_head, g_head = ptr(self.P["conv_final.weight"]), self.G["conv_final.weight"]
+        if self.lmi:
+            # metadata column + perceptron first (they only need dlogits), then the 64-channel head on the packed columns
+            w64, wm = self._lmi_weights()
+            g64 = self._buf("lmi.g64", (self.n_classes, self.sf), torch.float32)
+            gwm = self._buf("lmi.gwm", (self.n_classes,), torch.float32)
+            g64.zero_()
+            gwm.zero_()
+            pre = "post_processing_weights.main."
+            call("crimac_meta_bwd", ptr(dlogits), ptr(s["meta"]), self.meta_channels, B, H, W, self.n_classes, ptr(wm),
+                 *self._mlp(), ptr(gwm), *[ptr(self.G[pre + k]) for k in
+                                          ("0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias")])
+            w_head, g_head = ptr(w64), g64
         call("crimac_head_bwd", self.prec, ptr(dlogits), head_in.p if head_in is not None else None,
              head_in.ld if head_in is not None else 0, self.sf,
-             ptr(self.P["conv_final.weight"]), d_cur.p, d_cur.ld, ptr(self.G["conv_final.weight"]),
+             w_head, d_cur.p, d_cur.ld, ptr(g_head),
              ptr(self.G["conv_final.bias"]), B, H, W, self.n_classes,
              *self._bnb_args(self.dec[D - 2][1], s[f"d{D - 2}"][4] if head_fused else None))
+        if self.lmi:
+            gw = self.G["conv_final.weight"].view(self.n_classes, self.sf + 1)
+            gw[:, :self.sf].copy_(g64)
+            gw[:, self.sf].copy_(gwm)
         skip_grad = {}
         cur_done = head_fused            # BatchNorm-backward sums of d_cur's block already taken by its producer
         for j in reversed(range(D - 1)):
@@ -1045,14 +1109,14 @@ class UNetEngine:
         return self.loss_scale
 
     @_on_device
-    def train_step(self, x, labels, class_w, lr, momentum, grad_sync=None, ignore_index=-100):
+    def train_step(self, x, labels, class_w, lr, momentum, grad_sync=None, ignore_index=-100, meta=None):
         """Fused step: forward + weighted CE + backward (+ gradient exchange) + SGD.
 
         Mirrors the loop body of SegPipe.train_model (pipeline.py:163-178) without autograd and
         without a host sync; returns the loss as a 0-d device tensor.
         ``grad_sync(flat_grad) -> scale`` may all-reduce the flat gradient in place.
         """
-        logits = self.forward(x, training=True)
+        logits = self.forward(x, training=True, meta=meta)
         return self._loss_backward_update(logits, labels, class_w, lr, momentum, grad_sync, ignore_index)
 
     def _loss_backward_update(self, logits, labels, class_w, lr, momentum, grad_sync, ignore_index):

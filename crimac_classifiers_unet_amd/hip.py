@@ -63,6 +63,10 @@ SIGNATURES = {
     "crimac_sgd_momentum": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp],
     "crimac_grad_overflow_flag": [_vp, _l, _vp, _vp],
     "crimac_sgd_momentum_guarded": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _vp],
+    "crimac_meta_mlp_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "crimac_meta_inject_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "crimac_meta_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                        _vp, _vp],
     "crimac_gather_patches": [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _l, _vp],
     "crimac_augment_db_nhwc": [_i, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _l, C.c_ulonglong,
                                _i, _i, _vp],

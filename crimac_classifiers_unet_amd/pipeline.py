@@ -20,7 +20,7 @@ import torch
 
 from . import parallel
 from .train_ops import ExponentialLR, SGDMomentum, WeightedCrossEntropy
-from .unet import UNet_Baseline
+from .unet import UNet_Baseline, UNet_LateMetInject
 
 # crimac_unet/constants.py:20-33
 BACKGROUND, SANDEEL, OTHER = 0, 1, 2
@@ -155,7 +155,14 @@ class SegPipe:
             inputs_train = batch["data"].float().to(self.device, non_blocking=True)
             labels_train = batch["labels"].to(self.device, non_blocking=True)
             self.model.train()
+            meta_train = None
+            if self.late_meta_inject:            # pipeline.py:170-174: data planes | metadata planes
+                nf = len(self.frequencies)
+                inputs_train, meta_train = inputs_train[:, :nf], inputs_train[:, nf:]
             if self.gpu_augment:
+                if self.late_meta_inject:
+                    raise NotImplementedError("gpu_augment with late metadata injection: the metadata planes follow the "
+                                              "flip of the reference's *_metadata augmentations, which run on the host")
                 rank = parallel.env_world()[1]
                 loss = engine.train_step_augmented(
                     inputs_train, labels_train, criterion.weight, optimizer.param_groups[0]["lr"],
@@ -164,7 +171,7 @@ class SegPipe:
             else:
                 loss = engine.train_step(inputs_train, labels_train, criterion.weight,
                                          optimizer.param_groups[0]["lr"], self.momentum,
-                                         grad_sync=grad_sync)
+                                         grad_sync=grad_sync, meta=meta_train)
             pending.append((i + 1, loss))
             if len(pending) >= self.loss_flush:
                 flush()
@@ -195,8 +202,10 @@ class SegPipe:
         self.model.eval()
         with torch.no_grad():
             inputs = batch["data"].float().to(self.device)
-            if self.late_meta_inject:
-                raise NotImplementedError("late metadata injection is not on the accelerated path")
+            if self.late_meta_inject:            # pipeline.py:210-216
+                nf = len(self.frequencies)
+                data, meta = inputs[:, :nf].contiguous(), inputs[:, nf:].contiguous()
+                return self.model.predict_softmax(data, meta) if return_softmax else self.model(data, meta)
             if return_softmax:
                 return self.model.predict_softmax(inputs)
             return self.model(inputs)
@@ -361,12 +370,16 @@ class SegPipeUNet(SegPipe):
 
     def __init__(self, checkpoint_dir=None, start_filts=64, depth=5, **kwargs):
         super().__init__(checkpoint_dir, **kwargs)
-        if self.late_meta_inject:
-            raise NotImplementedError("UNet_LateMetInject is not on the accelerated path")
-        # reference: depth 5, 64 filters (pipeline.py:390-398); start_filts=128 is BASELINE configs[4]
-        self.model = UNet_Baseline(n_classes=3, in_channels=4 + get_in_channels(self.meta_channels),
-                                   late_meta_inject=False, depth=depth, start_filts=start_filts,
-                                   up_mode="transpose", merge_mode="concat", precision=self.precision)
+        # reference: depth 5, 64 filters (pipeline.py:390-410); start_filts=128 is BASELINE configs[4]
+        if not self.late_meta_inject:
+            self.model = UNet_Baseline(n_classes=3, in_channels=4 + get_in_channels(self.meta_channels),
+                                       late_meta_inject=False, depth=depth, start_filts=start_filts,
+                                       up_mode="transpose", merge_mode="concat", precision=self.precision)
+        else:
+            self.model = UNet_LateMetInject(n_classes=3, in_channels=4,
+                                            meta_in_channels=get_in_channels(self.meta_channels),
+                                            late_meta_inject=True, depth=depth, start_filts=start_filts,
+                                            up_mode="transpose", merge_mode="concat", precision=self.precision)
 
 
 def get_in_channels(meta_channels):

@@ -21,7 +21,7 @@ import torch
 LABEL_IGNORE_VAL = -100  # crimac_unet/constants.py:25
 
 
-def unet_state_shapes(n_classes=3, in_channels=4, depth=5, start_filts=64):
+def unet_state_shapes(n_classes=3, in_channels=4, depth=5, start_filts=64, meta_in_channels=0):
     """Key -> shape of ``UNet_Baseline.state_dict()`` (crimac_unet/models/unet.py:200-289).
 
     Key order follows module registration order in the reference: down_convs, up_convs, conv_final.
@@ -58,8 +58,17 @@ def unet_state_shapes(n_classes=3, in_channels=4, depth=5, start_filts=64):
         shapes[p + "conv2.bias"] = (outs,)
         bn(p + "bn1", outs)
         bn(p + "bn2", outs)
-    shapes["conv_final.weight"] = (n_classes, outs, 1, 1)
-    shapes["conv_final.bias"] = (n_classes,)
+    if meta_in_channels == 0:
+        shapes["conv_final.weight"] = (n_classes, outs, 1, 1)
+        shapes["conv_final.bias"] = (n_classes,)
+    else:
+        # UNet_LateMetInject (unet.py:346-391): conv_final = conv1x1(65, 3), then the metadata perceptron
+        shapes["conv_final.weight"] = (3, 65, 1, 1)
+        shapes["conv_final.bias"] = (3,)
+        p = "post_processing_weights.main."
+        for idx, (o, i) in (("0", (32, meta_in_channels)), ("2", (32, 32)), ("4", (1, 32))):
+            shapes[p + idx + ".weight"] = (o, i)
+            shapes[p + idx + ".bias"] = (o,)
     return shapes
 
 
@@ -95,7 +104,9 @@ def synth_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
         raise KeyError(key)
     # convolution / transposed convolution
     if leaf == "weight":
-        if "upconv" in key:  # ConvTranspose2d weight [Cin, Cout, 2, 2]: torch fan_in = Cout*k*k
+        if len(shape) == 2:  # nn.Linear [out, in] (metadata perceptron)
+            fan_in = shape[1]
+        elif "upconv" in key:  # ConvTranspose2d weight [Cin, Cout, 2, 2]: torch fan_in = Cout*k*k
             fan_in = shape[1] * shape[2] * shape[3]
         else:
             fan_in = shape[1] * shape[2] * shape[3]
@@ -108,10 +119,11 @@ def synth_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
     raise KeyError(key)
 
 
-def synth_state_dict(n_classes=3, in_channels=4, depth=5, start_filts=64, seed=0):
-    """Full deterministic ``state_dict`` (torch CPU tensors) for ``UNet_Baseline``."""
+def synth_state_dict(n_classes=3, in_channels=4, depth=5, start_filts=64, seed=0, meta_in_channels=0):
+    """Full deterministic ``state_dict`` (torch CPU tensors) for ``UNet_Baseline`` (``meta_in_channels`` > 0:
+    for ``UNet_LateMetInject``)."""
     sd = OrderedDict()
-    for k, shp in unet_state_shapes(n_classes, in_channels, depth, start_filts).items():
+    for k, shp in unet_state_shapes(n_classes, in_channels, depth, start_filts, meta_in_channels).items():
         sd[k] = torch.from_numpy(np.ascontiguousarray(synth_tensor(k, shp, seed)))
     return sd
 
@@ -190,3 +202,28 @@ class SyntheticSurveyReader:
             out[:, seabed_pad:] = m[:, :-seabed_pad]
             return out
         return m
+
+
+def synth_metadata(batch, channels=7, height=256, width=256, seed=3):
+    """[B,Cm,H,W] float32 metadata planes in the ranges the reference Dataset produces (dataset.py:288-351):
+    portion of year (constant plane in [0,1]), sin / cos of the time of day, time difference along pings, relative
+    depth, depth below surface and above seabed along range (order of [0, 1])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.empty((batch, channels, height, width), dtype=np.float32)
+    r = (np.arange(height, dtype=np.float32) / height)[None, :, None]
+    for c in range(channels):
+        kind = c % 7
+        if kind == 0:
+            out[:, c] = rng.uniform(0, 1, size=(batch, 1, 1))
+        elif kind in (1, 2):
+            t = rng.uniform(0, 1, size=(batch, 1, 1))
+            out[:, c] = np.sin(2 * np.pi * t) if kind == 1 else np.cos(2 * np.pi * t)
+        elif kind == 3:
+            out[:, c] = rng.uniform(0.5, 1.5, size=(batch, 1, width))
+        elif kind == 4:
+            out[:, c] = r / rng.uniform(0.6, 1.0, size=(batch, 1, width))
+        elif kind == 5:
+            out[:, c] = r * np.ones((batch, 1, width), dtype=np.float32)
+        else:
+            out[:, c] = rng.uniform(0.6, 1.0, size=(batch, 1, width)) - r
+    return out

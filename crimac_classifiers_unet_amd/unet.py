@@ -57,10 +57,10 @@ class _UNetFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, engine, *params):
+    def forward(ctx, x, engine, meta, *params):
         ctx.engine = engine
         ctx.nparams = len(params)
-        out = engine.forward(x, training=True)
+        out = engine.forward(x, training=True, meta=meta)
         ctx.generation = engine.forward_generation
         return out
 
@@ -103,7 +103,7 @@ class _UNetFunction(torch.autograd.Function):
             p.grad = eng.G[name]     # .grad aliases the flat buffer (zero_grad(set_to_none) undoes it)
         # gradients were written straight into the flat buffer; return None so autograd does not
         # add them a second time
-        return (None, None) + (None,) * ctx.nparams
+        return (None, None, None) + (None,) * ctx.nparams
 
 
 class UNet_Baseline(nn.Module):
@@ -131,9 +131,9 @@ class UNet_Baseline(nn.Module):
             # the reference pipeline always passes transpose/concat (pipeline.py:396-397)
             raise NotImplementedError("the MI355X hot path implements up_mode='transpose', "
                                       "merge_mode='concat' (the only combination the pipeline uses)")
-        if late_meta_inject:
-            raise NotImplementedError("late metadata injection (UNet_LateMetInject) is not on the "
-                                      "accelerated path")
+        if late_meta_inject and type(self) is UNet_Baseline:
+            raise ValueError("late_meta_inject=True is the UNet_LateMetInject model (pipeline.py:400-410)")
+        self.late_meta_inject = bool(late_meta_inject)
         self.n_classes, self.in_channels = n_classes, in_channels
         self.meta_in_channels = meta_in_channels
         self.depth, self.start_filts = depth, start_filts
@@ -149,7 +149,12 @@ class UNet_Baseline(nn.Module):
             dec.append(_DecoderStage(ins, outs))
         self.down_convs = nn.Sequential(*enc)
         self.up_convs = nn.Sequential(*dec)
-        self.conv_final = nn.Conv2d(outs, n_classes, kernel_size=1)
+        if not self.late_meta_inject:
+            self.conv_final = nn.Conv2d(outs, n_classes, kernel_size=1)
+        else:
+            # registration order of the reference (unet.py:283-289): conv_final, then post_processing_weights
+            self.conv_final = nn.Conv2d(outs + meta_in_channels, n_classes, kernel_size=1)
+            self.post_processing_weights = _MetaPostProcessing(meta_in_channels, 1)
         self._precision = precision
         self._engine = None
 
@@ -191,9 +196,50 @@ class UNet_Baseline(nn.Module):
         eng = self.engine
         if self.training and torch.is_grad_enabled():
             eng.bind()
-            return _UNetFunction.apply(x, eng, *eng.P.values())
+            return _UNetFunction.apply(x, eng, None, *eng.P.values())
         return eng.forward(x, training=self.training)
 
     def predict_softmax(self, x):
         """Eval forward with F.softmax(dim=1) fused into the 1x1 head (pipeline.py:205-219)."""
         return self.engine.forward(x, training=False, softmax=True)
+
+
+class _MetaPostProcessing(nn.Module):
+    """Parameter container with the reference's key names ``main.{0,2,4}`` (MetaPostProcessing, unet.py:140-166):
+    Linear(Cm, 32) / ReLU / Linear(32, 32) / ReLU / Linear(32, out) applied over the channel axis of [N, C, H, W]."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.hidden_channels_1 = self.hidden_channels_2 = 32
+        self.main = nn.Sequential(nn.Linear(in_channels, 32), nn.ReLU(), nn.Linear(32, 32), nn.ReLU(),
+                                  nn.Linear(32, out_channels))
+
+
+class UNet_LateMetInject(UNet_Baseline):
+    """U-Net with late metadata injection (reference unet.py:346-391) on MI355X.
+
+    ``forward(x, meta_tensor)``: the U-Net body runs on ``x`` [B, in_channels, H, W]; ``meta_tensor`` [B, Cm, H, W]
+    goes through the per-pixel perceptron ``post_processing_weights`` (Cm -> 32 -> 32 -> 1) and its output plane is
+    concatenated behind the 64 decoder channels in front of ``conv_final`` -- which the reference hard-codes as
+    ``conv1x1(65, 3)`` (unet.py:370), so ``start_filts`` must be 64 and ``n_classes`` 3, whatever the constructor
+    arguments of the base class computed.  Same ``state_dict`` keys and shapes as the reference module."""
+
+    def __init__(self, n_classes, in_channels, meta_in_channels, late_meta_inject=True, depth=5, start_filts=64,
+                 up_mode="transpose", merge_mode="concat", precision="bf16"):
+        super().__init__(n_classes, in_channels, meta_in_channels, True, depth, start_filts, up_mode, merge_mode,
+                         precision)
+        if start_filts != 64 or n_classes != 3:
+            raise ValueError("UNet_LateMetInject hard-codes conv_final = conv1x1(65, 3) (reference unet.py:370): "
+                             "start_filts must be 64 and n_classes 3")
+        self.conv_final = nn.Conv2d(65, 3, kernel_size=1)
+
+    def forward(self, x, meta_tensor):
+        eng = self.engine
+        if self.training and torch.is_grad_enabled():
+            eng.bind()
+            return _UNetFunction.apply(x, eng, meta_tensor, *eng.P.values())
+        return eng.forward(x, training=self.training, meta=meta_tensor)
+
+    def predict_softmax(self, x, meta_tensor):
+        return self.engine.forward(x, training=False, softmax=True, meta=meta_tensor)

@@ -312,6 +312,25 @@ int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int
 int crimac_pr_histogram(const float* logits, int ncls, const void* labels, int label_bytes, int B, int H,
                         int W, unsigned int* hist_pos, unsigned int* hist_neg, void* stream);
 
+/* ---- late metadata injection (UNet_LateMetInject, unet.py:346-391; MetaPostProcessing, unet.py:140-166) ---- */
+
+/* m[b*H*W + p] = W3 . relu(W2 . relu(W1 . meta[b,:,p] + b1) + b2) + b3: the per-pixel 3-layer perceptron
+ * (Linear(Cm,32) / ReLU / Linear(32,32) / ReLU / Linear(32,1), applied over the channel axis, unet.py:151-166) on
+ * meta [B][Cm][H][W] fp32 NCHW; w1 [32][Cm], w2 [32][32], w3 [1][32] as torch.nn.Linear stores them.  Cm <= 8. */
+int crimac_meta_mlp_fwd(const float* meta, int Cm, int B, int H, int W, const float* w1, const float* b1,
+                        const float* w2, const float* b2, const float* w3, const float* b3, float* m, void* stream);
+/* conv_final on torch.cat((x, m), 1) (unet.py:386-388) = crimac_head_fwd on the first 64 weight columns, then
+ * logits[b][o][p] += wm[o] * m[b][p] (wm = conv_final.weight[:, 64]); softmax != 0: F.softmax over the classes
+ * afterwards (pipeline.py:218). */
+int crimac_meta_inject_fwd(const float* m, const float* wm, float* logits, int B, int H, int W, int ncls, int softmax,
+                           void* stream);
+/* Backward of both: dwm[o] += sum dlogits[o] * m, dm = sum_o dlogits[o] * wm[o] (recomputed per pixel, never
+ * stored), then the gradients of the three Linear layers (accumulated: caller zeroes). */
+int crimac_meta_bwd(const float* dlogits, const float* meta, int Cm, int B, int H, int W, int ncls, const float* wm,
+                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                    const float* b3, float* dwm, float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3,
+                    void* stream);
+
 /* ---- on-GPU training augmentation + data transform (BASELINE configs[4]) -------------------------- */
 
 /* add_noise + flip_x_axis (batch/data_augmentation/add_noise.py:21-41, flip_x_axis.py:21-25) fused

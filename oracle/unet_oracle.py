@@ -59,7 +59,18 @@ def _conv_bn_relu(x, state, conv_key, bn_key, training, new_stats):
     return torch.relu(z)
 
 
-def unet_forward(state, x, training=False, taps=None):
+def meta_post_processing(state, meta):
+    """MetaPostProcessing.forward (unet.py:160-166): Linear(Cm,32)/ReLU/Linear(32,32)/ReLU/Linear(32,1) over the
+    channel axis of [N, C, H, W]."""
+    p = "post_processing_weights.main."
+    h = meta.permute(0, 2, 3, 1)
+    h = torch.relu(F.linear(h, state[p + "0.weight"], state[p + "0.bias"]))
+    h = torch.relu(F.linear(h, state[p + "2.weight"], state[p + "2.bias"]))
+    h = F.linear(h, state[p + "4.weight"], state[p + "4.bias"])
+    return h.permute(0, 3, 1, 2)
+
+
+def unet_forward(state, x, training=False, taps=None, meta=None):
     """``UNet_Baseline.forward`` (unet.py:327-343) on a state dict.
 
     Returns ``(logits, new_stats)``; ``new_stats`` holds the BatchNorm buffers after the step when
@@ -89,6 +100,8 @@ def unet_forward(state, x, training=False, taps=None):
         x = _conv_bn_relu(x, state, p + "conv2", p + "bn2", training, new_stats)
         if taps is not None:
             taps[f"dec{i}"] = x
+    if meta is not None:      # UNet_LateMetInject.forward (unet.py:386-388): metadata plane behind the decoder output
+        x = torch.cat((x, meta_post_processing(state, meta)), dim=1)
     logits = F.conv2d(x, state["conv_final.weight"], state["conv_final.bias"])   # unet.py:342
     return logits, new_stats
 
@@ -117,7 +130,7 @@ def trainable_keys(state):
                     or k.endswith("num_batches_tracked"))]
 
 
-def loss_and_grads(state, x, labels):
+def loss_and_grads(state, x, labels, meta=None):
     """One forward + weighted CE + backward in train mode (pipeline.py:167-177).
 
     Returns ``(loss, logits, grads, new_stats)`` with ``grads`` keyed like ``state``.
@@ -127,7 +140,7 @@ def loss_and_grads(state, x, labels):
         work[k] = v.detach().clone()
     for k in trainable_keys(work):
         work[k].requires_grad_(True)
-    logits, new_stats = unet_forward(work, x, training=True)
+    logits, new_stats = unet_forward(work, x, training=True, meta=meta)
     loss = weighted_cross_entropy(logits, labels)
     keys = trainable_keys(work)
     gs = torch.autograd.grad(loss, [work[k] for k in keys])
@@ -160,10 +173,10 @@ def train_steps(state, batches, lr, momentum, lr_reduction=1.0, lr_step=10 ** 9)
     return state, losses
 
 
-def predict(state, x, return_softmax=False):
+def predict(state, x, return_softmax=False, meta=None):
     """``SegPipe.predict_batch`` (pipeline.py:205-219): eval-mode forward (+ softmax over classes)."""
     with torch.no_grad():
-        logits, _ = unet_forward(state, x.float(), training=False)
+        logits, _ = unet_forward(state, x.float(), training=False, meta=None if meta is None else meta.float())
         return F.softmax(logits, dim=1) if return_softmax else logits
 
 

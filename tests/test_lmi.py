@@ -1,0 +1,117 @@
+"""UNet_LateMetInject (reference crimac_unet/models/unet.py:346-391, MetaPostProcessing :140-166):
+golden fixture from the imported reference (tools/make_golden_lmi.py), oracle restatement, module surface, and the
+HIP path (crimac_meta_mlp_fwd / crimac_meta_inject_fwd / crimac_meta_bwd + the 64-channel head kernels)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import crimac_classifiers_unet_amd as pkg
+from crimac_classifiers_unet_amd import synth
+from oracle import unet_oracle as orc
+
+CM, HW = 7, 64
+
+
+@pytest.fixture(scope="module")
+def case(golden_dir):
+    fix = np.load(os.path.join(golden_dir, "lmi.npz"))
+    sd = synth.synth_state_dict(seed=0, meta_in_channels=CM)
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, HW, HW, seed=1))
+    meta = torch.from_numpy(synth.synth_metadata(2, CM, HW, HW, seed=3))
+    lab = torch.from_numpy(synth.synth_labels(2, HW, HW, seed=2))
+    return fix, sd, x, meta, lab
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def test_oracle_metadata_branch_matches_reference_golden(case):
+    fix, sd, x, meta, lab = case
+    assert rel(orc.predict(sd, x, meta=meta), fix["logits_eval"]) < 2e-6
+    loss, logits, grads, _ = orc.loss_and_grads(sd, x, lab, meta=meta)
+    assert rel(logits, fix["logits_train"]) < 1e-5
+    assert abs(float(loss) - float(fix["loss"])) < 1e-6 * abs(float(fix["loss"]))
+    for k in grads:
+        if "grad/" + k in fix.files:
+            assert rel(grads[k], fix["grad/" + k]) < 1e-3, k
+
+
+def test_module_surface_matches_reference_state_dict(case):
+    fix, sd, *_ = case
+    m = pkg.UNet_LateMetInject(n_classes=3, in_channels=4, meta_in_channels=CM)
+    assert list(m.state_dict().keys()) == [str(k) for k in fix["keys"]]      # key ORDER of the reference module
+    assert tuple(m.conv_final.weight.shape) == (3, 65, 1, 1)
+    m.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        pkg.UNet_LateMetInject(n_classes=3, in_channels=4, meta_in_channels=CM, start_filts=128)
+    with pytest.raises(ValueError):
+        pkg.UNet_Baseline(3, 4, late_meta_inject=True)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 32, 32), torch.zeros(1, CM, 32, 32))
+
+
+def test_pipeline_builds_the_late_injection_model():
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(save_model_params=False, late_meta_inject=True,
+               meta_channels={"portion_year": True, "portion_day": True, "depth_rel": True, "depth_abs_surface": True,
+                              "depth_abs_seabed": True, "time_diff": True})
+    pipe = pkg.SegPipeUNet(experiment_name="t", **{k: v for k, v in cfg.items() if k != "experiment_name"})
+    assert isinstance(pipe.model, pkg.UNet_LateMetInject) and pipe.model.meta_in_channels == 7
+    assert pkg.get_in_channels(cfg["meta_channels"]) == 7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("f32x6", 2e-5), ("bf16", 6e-2)])
+def test_late_injection_hip_path_matches_reference_golden(case, precision, tol):
+    fix, sd, x, meta, lab = case
+    m = pkg.UNet_LateMetInject(3, 4, CM, precision=precision)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    with torch.no_grad():
+        out = m(x.cuda(), meta.cuda())
+        sm = m.predict_softmax(x.cuda(), meta.cuda())
+    assert rel(out, fix["logits_eval"]) < tol
+    assert rel(sm, torch.softmax(out, dim=1)) < 1e-5
+    m.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    logits = m(x.cuda(), meta.cuda())
+    loss = crit(logits, lab.long().cuda())
+    loss.backward()
+    assert rel(logits.detach(), fix["logits_train"]) < tol
+    assert abs(float(loss) - float(fix["loss"])) < (1e-5 if precision == "f32x6" else 2e-2) * abs(float(fix["loss"]))
+    if precision != "f32x6":
+        return
+    for k, p in m.named_parameters():
+        if "grad/" + k in fix.files:
+            e = float((p.grad.double().cpu() - torch.from_numpy(fix["grad/" + k]).double()).norm()
+                      / torch.from_numpy(fix["grad/" + k]).double().norm())
+            assert e < 2e-3, (k, e)
+    # the fused step takes the metadata too and equals the autograd path
+    m2 = pkg.UNet_LateMetInject(3, 4, CM, precision=precision)
+    m2.load_state_dict(sd)
+    m2.cuda().train()
+    l2 = m2.engine.train_step(x.cuda(), lab.cuda(), crit.weight, lr=0.0, momentum=0.0, meta=meta.cuda())
+    assert abs(float(l2) - float(loss)) < 1e-6 * abs(float(loss))
+    g1, g2 = m.engine.G["post_processing_weights.main.2.weight"], m2.engine.G["post_processing_weights.main.2.weight"]
+    assert float((g1 - g2).norm() / g1.norm()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_pipeline_predict_batch_splits_data_and_metadata(case):
+    fix, sd, x, meta, lab = case
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(save_model_params=False, late_meta_inject=True, precision="f32x6",
+               meta_channels={"portion_year": True, "portion_day": True, "depth_rel": True, "depth_abs_surface": True,
+                              "depth_abs_seabed": True, "time_diff": True})
+    pipe = pkg.SegPipeUNet(experiment_name="t", **{k: v for k, v in cfg.items() if k != "experiment_name"})
+    pipe.model.load_state_dict(sd)
+    pipe.model.to(pipe.device)
+    batch = {"data": torch.cat((x, meta), dim=1).double(), "labels": lab}       # as the reference Dataset collates it
+    out = pipe.predict_batch(batch)
+    assert rel(out, fix["logits_eval"]) < 2e-5
