@@ -634,7 +634,7 @@ class UNetEngine:
             meta = self._meta(meta, x)
         elif meta is not None:
             raise ValueError("this model takes no metadata tensor (late_meta_inject=False)")
-        if (not training and self.eval_two_streams and x.dim() == 4 and x.shape[0] >= 16 and x.shape[0] % 2 == 0
+        if (not training and self.eval_two_streams and x.dim() == 4 and x.shape[0] >= 16
                 and x.is_cuda and not self._gloo_ranks() and not self.lmi):
             return self._forward_eval_two_streams(x, softmax)
         xin, B, H, W = self._input(x)
@@ -692,7 +692,38 @@ class UNetEngine:
             with torch.cuda.stream(side):
                 side.wait_event(ev)
                 xin, _, _, _ = self._input(x[h:])
-                self.forward_nhwc(xin, h, H, W, False, softmax, out=logits[h:])
+                self.forward_nhwc(xin, B - h, H, W, False, softmax, out=logits[h:])
+        finally:
+            self._buf_prefix = ""
+        torch.cuda.current_stream().wait_stream(side)
+        return logits
+
+    @_on_device
+    def forward_nhwc_eval_split(self, xin, B, H, W, softmax=False):
+        """Eval forward from an NHWC matrix (tiled inference), the batch split over two streams like
+        ``_forward_eval_two_streams`` (uneven halves allowed)."""
+        self.bind()
+        if not (self.eval_two_streams and B >= 16 and not self._gloo_ranks() and not self.lmi):
+            return self.forward_nhwc(xin, B, H, W, False, softmax)
+        if self._eval_side is None:
+            self._eval_side = torch.cuda.Stream(device=self.device)
+            self._eval_events = [torch.cuda.Event() for _ in range(8)]
+            self._eval_i = 0
+        side = self._eval_side
+        h = B // 2
+        self._check_versions()
+        self._pack_eval()
+        logits = torch.empty((B, self.n_classes, H, W), dtype=torch.float32, device=self.device)
+        ev = self._eval_events[self._eval_i % len(self._eval_events)]
+        self._eval_i += 1
+        ev.record()
+        try:
+            self._buf_prefix = "h0."
+            self.forward_nhwc(xin[:h * H * W], h, H, W, False, softmax, out=logits[:h])
+            self._buf_prefix = "h1."
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                self.forward_nhwc(xin[h * H * W:], B - h, H, W, False, softmax, out=logits[h:])
         finally:
             self._buf_prefix = ""
         torch.cuda.current_stream().wait_stream(side)
@@ -1123,6 +1154,8 @@ class UNetEngine:
         sums = self.stat[0:2]
         sums, labels = self.ce_forward(logits, labels, class_w, ignore_index, sums=sums)
         ls = float(self.loss_scale)
+        # (sum w*nll, sum w) of this rank's batch: the pipeline adds them up over ranks for the logged loss
+        self.last_loss_sums = sums.clone()
         dl = self.ce_backward(logits, labels, class_w, sums, ls, ignore_index)
         scale = 1.0
         single = grad_sync is None or (hasattr(grad_sync, "world") and grad_sync.world() == 1)

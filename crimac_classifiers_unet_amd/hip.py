@@ -68,6 +68,9 @@ SIGNATURES = {
     "crimac_meta_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                         _vp, _vp],
     "crimac_gather_patches": [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _l, _vp],
+    "crimac_gather_patches_memm": [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _l, _vp, _vp],
+    "crimac_scatter_patches_ex": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i,
+                                  _i, _i, _vp, _i, _vp],
     "crimac_augment_db_nhwc": [_i, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _l, C.c_ulonglong,
                                _i, _i, _vp],
     "crimac_refine_labels": [_vp, _i, _vp, _vp, _i, _f, _f, _i, _vp, _i, _i, _i, _i, _vp],

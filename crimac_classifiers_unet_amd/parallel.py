@@ -60,11 +60,19 @@ class GradSync:
     launched yet, waits for everything and returns the 1/world averaging scale (folded into SGD).
     """
 
-    def __init__(self, bucket_mb=32.0, group=None):
+    def __init__(self, bucket_mb=32.0, group=None, algo=None):
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.group = group
+        # 'all_reduce' (default): one RCCL all-reduce per bucket.  'rs_ag': the same sum spelled out as
+        # reduce-scatter + all-gather per bucket (SURVEY.md §8e) -- what RCCL's ring all-reduce does internally; the
+        # explicit form lets the two halves be scheduled as separate collectives on the process group's stream.
+        self.algo = algo or os.environ.get("CRIMAC_GRAD_EXCHANGE", "all_reduce")
+        if self.algo not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"GradSync: unknown algo {self.algo!r}")
         self._works = []
         self._done = []          # [(lo, hi)] ranges already in flight this step
+        self._shards = {}        # bucket -> reduce-scatter output buffer
+        self._gathers = []       # (reduce-scatter work, bucket, shard) whose all-gather is still to be issued
 
     def world(self):
         if not (dist.is_available() and dist.is_initialized()):
@@ -78,9 +86,22 @@ class GradSync:
             if lo < b and a < hi:
                 raise RuntimeError(f"GradSync: range [{lo},{hi}) overlaps [{a},{b}) already in flight")
         self._done.append((lo, hi))
+        world = self.world()
         for s, e in bucket_bounds(hi - lo, self.bucket_elems):
-            self._works.append(dist.all_reduce(flat_grad[lo + s:lo + e], op=dist.ReduceOp.SUM,
-                                               group=self.group, async_op=True))
+            buf = flat_grad[lo + s:lo + e]
+            n = e - s
+            if self.algo == "rs_ag" and n % world == 0 and n >= world:
+                key = (lo + s, n)        # one shard per bucket: several buckets are in flight at once
+                shard = self._shards.get(key)
+                if shard is None or shard.device != buf.device:
+                    shard = self._shards[key] = torch.empty(n // world, dtype=buf.dtype, device=buf.device)
+                # the reduce-scatter starts now (overlapped with the rest of the backward pass); its all-gather is
+                # issued from finish() once the reduce-scatter has completed -- a backend whose asynchronous
+                # collectives are not ordered among themselves (gloo) would otherwise gather a stale shard
+                w = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._gathers.append((w, buf, shard))
+            else:
+                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def pending_ranges(self, n):
         """Complement of the launched ranges in [0, n)."""
@@ -94,9 +115,12 @@ class GradSync:
         return out
 
     def finish(self):
+        for w, buf, shard in self._gathers:
+            w.wait()
+            self._works.append(dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True))
         for w in self._works:
             w.wait()
-        self._works, self._done = [], []
+        self._works, self._done, self._gathers = [], [], []
         return 1.0 / self.world()
 
     def __call__(self, flat_grad):

@@ -144,10 +144,14 @@ class SegPipe:
 
         def flush():
             engine.update_loss_scale()          # (fp16 precision only; this is where the loop synchronises anyway)
-            if logger is not None and pending:
-                vals = torch.stack([v for _, v in pending]).cpu().tolist()
-                for (step, _), v in zip(pending, vals):
-                    logger.add_scalar(tag="train/loss", scalar_value=v, global_step=step)
+            if pending:
+                # the logged loss is the loss of the GLOBAL batch: sum of (sum w*nll, sum w) over ranks -- one small
+                # all-reduce per flush, not per step
+                sums = parallel.all_reduce_scalars(torch.stack([s for _, s in pending]))
+                if logger is not None:
+                    vals = (sums[:, 0] / sums[:, 1]).float().cpu().tolist()
+                    for (step, _), v in zip(pending, vals):
+                        logger.add_scalar(tag="train/loss", scalar_value=v, global_step=step)
             pending.clear()
 
         for i, batch in _tqdm(enumerate(dataloader_train), desc="Training model",
@@ -172,7 +176,7 @@ class SegPipe:
                 loss = engine.train_step(inputs_train, labels_train, criterion.weight,
                                          optimizer.param_groups[0]["lr"], self.momentum,
                                          grad_sync=grad_sync, meta=meta_train)
-            pending.append((i + 1, loss))
+            pending.append((i + 1, engine.last_loss_sums))
             if len(pending) >= self.loss_flush:
                 flush()
 
@@ -252,9 +256,15 @@ class SegPipe:
         dev = self.device
         hist = torch.zeros(2, self.PR_BINS, dtype=torch.int32, device=dev)
         sum_loss = None
+        world, rank, _ = parallel.env_world()
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world, rank = 1, 0
         self.model.eval()
         with torch.no_grad():
-            for batch in _tqdm(dataloader, desc="Evaluating model", total=len(dataloader), disable=disable_tqdm):
+            for bi, batch in enumerate(_tqdm(dataloader, desc="Evaluating model", total=len(dataloader),
+                                             disable=disable_tqdm)):
+                if bi % world != rank:            # batches are dealt round-robin to the ranks
+                    continue
                 logits = self.predict_batch(batch, return_softmax=False)
                 labels = batch["labels"].to(dev)
                 if labels.dtype not in (torch.int16, torch.int32, torch.int64):
@@ -266,6 +276,11 @@ class SegPipe:
                 B, nc, H, W = logits.shape
                 call("crimac_pr_histogram", ptr(logits), nc, ptr(labels), labels.element_size(), B, H, W,
                      ptr(hist[0]), ptr(hist[1]))
+        if world > 1:                          # the histograms ARE the metric's sufficient statistic: 128 KB all-reduce
+            torch.distributed.all_reduce(hist)
+            sl = torch.zeros(1, dtype=torch.float64, device=dev) if sum_loss is None else sum_loss.double().reshape(1)
+            torch.distributed.all_reduce(sl)
+            sum_loss = sl[0]
         h = hist.cpu().numpy().astype(np.int64)
         if h[:, self.PR_BINS - 1].any():      # CRIMAC_PR_NAN_BIN: sklearn raises on NaN scores as well
             raise ValueError("Input contains NaN (sandeel probabilities of the validation set)")
@@ -306,7 +321,11 @@ class SegPipe:
 
     def validate_model_training(self, dataloader_test, criterion, logger, iteration_no):
         """Reference pipeline.py:305-341."""
-        if self.gpu_metrics:
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        if self.gpu_metrics or multi:
+            # N > 1: validation is sharded over the ranks; only the histogram form has a small sufficient statistic
+            # to exchange (the per-pixel vectors of the sklearn form would have to be gathered on one rank)
             hp, hn, loss_test = self.get_pr_histograms_dataloader(dataloader_test, criterion=criterion)
             metrics = self.compute_evaluation_metrics_from_histograms(hp, hn)
             labels = preds = None
@@ -336,33 +355,59 @@ class SegPipe:
         return metrics
 
     def validate_model_testing(self, dataloader, save_path_metrics, save_path_plot):
-        """Reference pipeline.py:343-376."""
+        """Test-set evaluation (reference pipeline.py:343-376): PR curve / F1 of the SANDEEL probability over the
+        valid pixels of ``dataloader``; the curve is written as csv (columns as the reference's DataFrame:
+        precision, recall, thresholds, F1; the last threshold is NaN) and, if asked for, drawn."""
         if not self.model_is_loaded:
             self.load_model_params()
-        labels, preds, _ = self.get_predictions_dataloader(dataloader, disable_tqdm=False)
-        preds[labels == LABEL_SEABED_MASK_VAL] = 0
-        labels, preds = self.select_valid_predictions(labels=labels, preds=preds)
-        metrics = self.compute_evaluation_metrics(labels=labels, preds=preds)
-        if save_path_metrics is not None:
-            import pandas as pd
-            metrics["thresholds"] = np.array(list(metrics["thresholds"]) + [np.nan])
-            pd.DataFrame(metrics).to_csv(save_path_metrics)
-        if save_path_plot is not None:
-            import matplotlib
-            matplotlib.use("Agg")
-            import matplotlib.pyplot as plt
-            fig, ax = plt.subplots(1, figsize=(8, 8))
-            ax.tick_params(labelsize=6)
-            ax.set_xlabel("Recall", fontsize=8)
-            ax.set_ylabel("Precision", fontsize=8)
-            ax.set_xticks([0, 0.2, 0.4, 0.6, 0.8, 1.0])
-            ax.scatter(metrics["recall"], metrics["precision"], s=2)
-            ax.set_xlim(-0.06, 1.06)
-            ax.set_ylim(-0.06, 1.06)
-            plt.savefig(save_path_plot)
+        if self.gpu_metrics:
+            hp, hn, _ = self.get_pr_histograms_dataloader(dataloader, disable_tqdm=False)
+            metrics = self.compute_evaluation_metrics_from_histograms(hp, hn)
+        else:
+            labels, preds, _ = self.get_predictions_dataloader(dataloader, disable_tqdm=False)
+            preds[labels == LABEL_SEABED_MASK_VAL] = 0
+            labels, preds = self.select_valid_predictions(labels=labels, preds=preds)
+            metrics = self.compute_evaluation_metrics(labels=labels, preds=preds)
+        metrics["thresholds"] = np.append(np.asarray(metrics["thresholds"], dtype=np.float64), np.nan)
+        if parallel.env_world()[1] == 0:
+            if save_path_metrics is not None:
+                write_pr_csv(metrics, save_path_metrics)
+            if save_path_plot is not None:
+                plot_pr_curve(metrics, save_path_plot)
         F1 = metrics["F1"]
         print(f"F1 score: {F1[np.argmax(F1)]}")
         return metrics
+
+
+def write_pr_csv(metrics, path):
+    """precision / recall / thresholds / F1 rows, index column first (what DataFrame(metrics).to_csv writes)."""
+    import csv
+    cols = ("precision", "recall", "thresholds", "F1")
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(("",) + cols)
+        for i in range(len(metrics["F1"])):
+            w.writerow([i] + ["" if np.isnan(metrics[c][i]) else repr(float(metrics[c][i])) for c in cols])
+
+
+def plot_pr_curve(metrics, path):
+    """Precision over recall, best-F1 point marked (needs matplotlib; skipped with a note when it is absent)."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        from matplotlib import pyplot
+    except Exception as e:  # pragma: no cover
+        print(f"PR plot skipped ({type(e).__name__}: matplotlib not usable)")
+        return
+    best = int(np.argmax(metrics["F1"]))
+    fig = pyplot.figure(figsize=(6, 6))
+    axes = fig.add_subplot(111, xlabel="recall", ylabel="precision", xlim=(-0.05, 1.05), ylim=(-0.05, 1.05))
+    axes.step(metrics["recall"], metrics["precision"], where="post", linewidth=1)
+    axes.plot([metrics["recall"][best]], [metrics["precision"][best]], marker="o",
+              label=f"max F1 = {metrics['F1'][best]:.3f}")
+    axes.legend(loc="lower left")
+    fig.savefig(path, dpi=120)
+    pyplot.close(fig)
 
 
 class SegPipeUNet(SegPipe):

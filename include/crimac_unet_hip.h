@@ -285,6 +285,13 @@ int crimac_sgd_momentum_guarded(float* p, float* g, float* v, long n, float lr, 
  * to [-75, 0]; written as NHWC activations [P*ph*pw][ld] (channels >= C zero) -- the first conv's input. */
 int crimac_gather_patches(int prec, const float* data, int C, int Wd, int H, const int* centres, int P,
                           int ph, int pw, void* out, long ld, void* stream);
+/* The memm flavour of the same crop (save_reader_predictions_memm, save_predict.py:222-265; get_crop_memmap,
+ * dataset.py:251-287; define_data_transform_test, transforms.py:57-64): border_labels [Wd][H] int16 raw annotation
+ * ids over the same extent as `data`; pixels outside it, and pixels whose raw id the test-time label transform
+ * maps to "ignore" (negative ids), are set to 0.0 after the dB transform (set_data_border_value). */
+int crimac_gather_patches_memm(int prec, const float* data, int C, int Wd, int H, const int* centres, int P, int ph,
+                               int pw, void* out, long ld, const short* border_labels, void* stream);
+
 /* fill_out_array (save_predict.py:41-65) for P patches: probs [P][ncls][ph][pw] fp32 softmax;
  * centres[p] = (range idx, GLOBAL ping idx); writes channels SANDEEL(1), OTHER(2) of every valid
  * interior pixel into out [2][H][n_chunk] fp32 (ping = global ping - start_ping).  A pixel is valid
@@ -299,6 +306,20 @@ int crimac_scatter_patches(const float* probs, int ncls, const int* centres, int
                            const unsigned char* seabed_mask, int mask_ping0, int mask_pings,
                            const float* data0, int data_ping0, int data_pings, int seabed_pad, float* out,
                            void* stream);
+/* The same with the rules of the other callers of fill_out_array made explicit:
+ *   seabed: seabed index per ping [seabed_pings] (global ping of entry 0 = seabed_ping0) -- the mask is then
+ *           evaluated in the kernel (range index - pad >= seabed[ping]) and no [pings][H] mask has to be built and
+ *           uploaded by the host; give seabed_mask OR seabed;
+ *   seabed_rule 0: zarr reader (data_reader.py:837-841: the pad shifts the mask down INSIDE the patch's own slice),
+ *               1: memm reader Echogram.get_seabed_mask (data_reader.py:407-431: absolute rows >= seabed + pad);
+ *   out_f16 != 0: `out` is float16 -- the reference stores the predictions as float16 (save_predict.py:212, :252),
+ *           so the rounding happens here and half the bytes travel back to the host. */
+int crimac_scatter_patches_ex(const float* probs, int ncls, const int* centres, int P, int ph, int pw, int overlap,
+                              int start_ping, int n_chunk, int H, const short* labels,
+                              const unsigned char* seabed_mask, int mask_ping0, int mask_pings, const int* seabed,
+                              int seabed_ping0, int seabed_pings, const float* data0, int data_ping0, int data_pings,
+                              int seabed_pad, int seabed_rule, void* out, int out_f16, void* stream);
+
 
 /* Validation metrics (get_predictions_dataloader + compute_evaluation_metrics, pipeline.py:242-295):
  * histograms (16384 bins, indexed by the float16 bit pattern of softmax(logits)[SANDEEL]) of the valid

@@ -85,7 +85,7 @@ def data_transform(data):
     return db, nonfinite0
 
 
-def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfinite0):
+def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfinite0, seabed_rule="zarr"):
     """Labels of one patch after the test-time transforms, as far as they decide validity.
 
     raw_labels: [n_range, chunk_pings] crop source (chunk-local ping axis, already offset);
@@ -114,7 +114,10 @@ def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfi
             continue
         ok_rows = (y_data >= 0) & (y_data < n_range)
         r = y_data - y_top
-        below[:, j] = ok_rows & (r >= SEABED_PAD) & ((y_data - SEABED_PAD) >= seabed[x])
+        if seabed_rule == "zarr":      # zarr reader: the 10-pixel pad shifts the mask down INSIDE the requested slice
+            below[:, j] = ok_rows & (r >= SEABED_PAD) & ((y_data - SEABED_PAD) >= seabed[x])
+        else:                          # Echogram.get_seabed_mask (data_reader.py:407-431): absolute rows >= seabed + pad
+            below[:, j] = ok_rows & ((y_data - SEABED_PAD) >= seabed[x])
     lab[below & (lab == 0)] = LABEL_SEABED_MASK_VAL
     # mask_label_overlap
     if patch_overlap > 0:
@@ -124,7 +127,8 @@ def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfi
         out[lab == LABEL_BOUNDARY_VAL] = LABEL_BOUNDARY_VAL
         lab = out
     # remove_nan_inf
-    lab[nonfinite0] = LABEL_IGNORE_VAL
+    if nonfinite0 is not None:
+        lab[nonfinite0] = LABEL_IGNORE_VAL
     return lab
 
 
@@ -164,3 +168,35 @@ def predict_chunk(sv, raw_labels, seabed, start_ping, end_ping, predict_fn, patc
         preds = predict_fn(d.astype(np.float32))
         fill_out_array(out, preds, lab, c, start_ping)
     return out, grid
+
+
+def predict_echogram_memm(sv_hw, raw_labels_hw, seabed, predict_fn, patch_size=(256, 256), patch_overlap=20):
+    """``save_reader_predictions_memm`` (save_predict.py:222-265) on in-memory arrays in the memm orientation:
+    sv_hw [C, n_range, n_pings] linear, raw_labels_hw [n_range, n_pings], seabed [n_pings].
+
+    Differences from the zarr-preload flavour (``predict_chunk``), each from the reference:
+      * the whole echogram is one grid, ping_start = 0 (save_predict.py:244-247, :258);
+      * ``get_crop_memmap`` (dataset.py:251-287): a water column not deeper than the patch puts every centre row at
+        n_range // 2; non-finite samples are zeroed in the crop itself, so ``remove_nan_inf`` never touches labels;
+      * ``define_data_transform_test`` (transforms.py:57-64) ends with ``set_data_border_value``
+        (set_data_border_value.py:20-23): data := 0.0 (after the dB transform) wherever the TRANSFORMED label is -100
+        -- outside the echogram, and at annotations that ``convert_label_indexing`` maps to ignore;
+      * the seabed mask comes from ``Echogram.get_seabed_mask`` (absolute rows >= seabed + 10);
+      * predictions are rounded to float16 before they are written (save_predict.py:252).
+    Returns out_array [2, n_range, n_pings] float64."""
+    n_range, n_pings = sv_hw.shape[1], sv_hw.shape[2]
+    grid = get_data_grid(n_range, int(np.max(seabed)), 0, n_pings, patch_size, patch_overlap)
+    out = np.zeros([2, n_range, n_pings])
+    for c in grid:
+        c = np.array(c)
+        if n_range <= patch_size[0]:
+            c[0] = n_range // 2
+        d = crop(sv_hw, c, patch_size, 0)
+        d = np.where(np.isfinite(d), d, d.dtype.type(0))
+        lab = patch_labels(raw_labels_hw, {"local": (c[0], c[1]), "global": (c[0], c[1])}, patch_size, seabed,
+                           n_range, patch_overlap, None, seabed_rule="memm")
+        db, _ = data_transform(d)
+        db[:, lab == LABEL_BOUNDARY_VAL] = 0.0
+        preds = predict_fn(db.astype(np.float32)).astype(np.float16)
+        fill_out_array(out, preds, lab, c, 0)
+    return out

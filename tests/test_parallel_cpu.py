@@ -41,6 +41,15 @@ def _worker(rank, world, port, results):
     scale = gs(flat)
     ok_grad = ok_grad and bool(torch.equal(flat, expect)) and abs(scale - 1.0 / world) < 1e-12 \
         and gs.pending_ranges(1000) == [(0, 1000)]
+    # reduce-scatter + all-gather spelling of the same exchange (even buckets take it, the ragged tail all-reduces)
+    try:
+        gs = parallel.GradSync(bucket_mb=0.001, algo="rs_ag")
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        scale = gs(flat)
+        ok_grad = ok_grad and bool(torch.equal(flat, expect)) and abs(scale - 1.0 / world) < 1e-12
+    except RuntimeError as e:            # a backend without reduce_scatter_tensor must say so, not corrupt data
+        ok_grad = ok_grad and ("reduce_scatter" in str(e).lower() or "not supported" in str(e).lower()
+                               or "unsupported" in str(e).lower())
     # SGD with grad_scale=1/world on the summed gradient == SGD on the mean gradient
     # inference: 7 "patches", each rank computes its shard, all-gather restores patch order
     n = 7

@@ -159,3 +159,135 @@ def test_predict_survey_with_unet_matches_oracle(survey):
     assert len(grid) == 6
     assert np.array_equal(got != 0, ref != 0)
     assert np.abs(got - ref).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# memm flavour (save_reader_predictions_memm, save_predict.py:222-265) -- fixture from the reference's own
+# DatasetGriddedReader / define_data_transform_test / define_label_transform_test / fill_out_array on a fake Echogram
+# (tools/make_golden_tiling_memm.py)
+# ---------------------------------------------------------------------------------------------------------------
+from tools.fake_reader import FakeEchogram  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fix_memm(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiling_memm.npz"))
+
+
+def _memm_case(fix_memm, tag):
+    n_pings, n_range, seed = (int(v) for v in fix_memm[tag + "/shape"])
+    sv, labels, seabed = synth_survey(n_pings=n_pings, n_range=n_range, seed=seed)
+    return np.ascontiguousarray(sv.swapaxes(1, 2)), np.ascontiguousarray(labels.T), seabed
+
+
+@pytest.mark.parametrize("tag", ["deep", "shallow"])
+def test_memm_oracle_matches_reference_golden(fix_memm, tag):
+    sv_hw, labels_hw, seabed = _memm_case(fix_memm, tag)
+    out = orc.predict_echogram_memm(sv_hw, labels_hw, seabed, linear_predictor)
+    assert np.array_equal(out.astype(np.float16), fix_memm[tag + "/out_f16"])
+    # one patch as the reference Dataset returned it: border rule (data = 0.0 where the transformed label is -100)
+    c = fix_memm[tag + "/patch_centre"]
+    d = orc.crop(sv_hw, c, (256, 256), 0)
+    d = np.where(np.isfinite(d), d, np.float32(0))
+    lab = orc.patch_labels(labels_hw, {"local": tuple(c), "global": tuple(c)}, (256, 256), seabed, sv_hw.shape[1], 20,
+                           None, seabed_rule="memm")
+    db, _ = orc.data_transform(d)
+    db[:, lab == -100] = 0.0
+    assert np.abs(db - fix_memm[tag + "/patch_data"]).max() < 1e-5
+    ref = fix_memm[tag + "/patch_labels"].astype(np.int64)
+    assert np.array_equal(lab[ref != -30], ref[ref != -30])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["deep", "shallow"])
+def test_memm_echogram_prediction_matches_reference_golden(fix_memm, tag):
+    """crimac_gather_patches_memm (border rule) -> stand-in predictor -> crimac_scatter_patches_ex (Echogram seabed
+    rule, seabed vector, float16 output) over a whole echogram == the array the reference would np.save."""
+    import crimac_classifiers_unet_amd as pkg
+    sv_hw, labels_hw, seabed = _memm_case(fix_memm, tag)
+    eg = FakeEchogram(sv_hw, labels_hw, seabed)
+
+    class Pipe:
+        frequencies = [18, 38, 120, 200]
+        device = torch.device("cuda")
+    pipe = Pipe()
+    pipe.model = pkg.UNet_Baseline(3, 4, precision="f32x6")
+    seen = {}
+
+    def predict_fn(x, P, H, W):
+        d = x.float().reshape(P, H, W, 16)[..., :4].permute(0, 3, 1, 2).cpu().numpy()
+        seen.setdefault("first", d[0].copy())
+        return torch.from_numpy(np.stack([linear_predictor(di) for di in d])).cuda().contiguous()
+
+    out = ti.predict_echogram_memm(eg, pipe, (256, 256), 20, 4, predict_fn=predict_fn)
+    ref = fix_memm[tag + "/out_f16"]
+    assert out.dtype == np.float64 and out.shape == ref.shape
+    assert np.array_equal(out != 0, ref != 0)
+    assert np.abs(out - ref.astype(np.float64)).max() < 1e-3            # (the stand-in net runs in fp32 here and there)
+    # the border rule, on the first patch of the grid (its top / left rim lies outside the echogram)
+    g = fix_memm[tag + "/centres"][0]
+    d = orc.crop(sv_hw, g, (256, 256), 0)
+    d = np.where(np.isfinite(d), d, np.float32(0))
+    lab = orc.patch_labels(labels_hw, {"local": tuple(g), "global": tuple(g)}, (256, 256), seabed, sv_hw.shape[1], 20,
+                           None, seabed_rule="memm")
+    db, _ = orc.data_transform(d)
+    db[:, lab == -100] = 0.0
+    assert np.abs(seen["first"] - db).max() < 2e-5
+    assert (db[0][lab == -100] == 0).all() and (lab == -100).any()
+
+
+@pytest.mark.gpu
+def test_chunk_loop_with_seabed_vector_and_f16_output_matches_reference_golden(fix, survey):
+    """The host-cheap form of the zarr flavour: the seabed VECTOR instead of a [pings, range] mask, float16 output."""
+    import crimac_classifiers_unet_amd as pkg
+    sv, labels, seabed = survey
+    reader = FakeZarrReader(sv, labels, seabed)
+    n_pings, n_range = reader.shape
+    model = pkg.UNet_Baseline(3, 4, precision="f32x6").cuda().eval()
+    cp = ti.ChunkPredictor(model, n_range, (256, 256), int(fix["overlap"]), batch_size=4, out_f16=True)
+
+    def predict_fn(x, P, H, W):
+        d = x.float().reshape(P, H, W, 16)[..., :4].permute(0, 3, 1, 2).cpu().numpy()
+        return torch.from_numpy(np.stack([linear_predictor(di) for di in d])).cuda().contiguous()
+
+    outs = []
+    for s, e in ti.plan_chunks(0, n_pings, int(fix["preload"])):
+        grid = ti.plan_grid(n_range, seabed[s:e].max(), s, e, (256, 256), int(fix["overlap"]))
+        lo, hi = max(0, grid[0, 1] - 128), min(n_pings, grid[-1, 1] + 128)
+        # the seabed vector must cover every ping a patch of the chunk touches: hand over the data slice's range
+        cp.load_chunk(reader.get_data_slice(lo, hi - lo), lo, reader.get_label_slice(s, e - s), None, s, e,
+                      seabed=reader.get_seabed(lo, hi - lo), seabed_ping0=lo)
+        o = cp.predict(grid, predict_fn)
+        assert o.dtype == torch.float16
+        outs.append(o.cpu().numpy())
+    full = np.concatenate(outs, axis=2)
+    ref = fix["out_f16"]
+    assert np.array_equal(full != 0, ref != 0)                   # exactly the same pixels written
+    # the reference's float16 store up to one float16 ulp (the stand-in net sees log10f of the GPU, not numpy's)
+    assert np.abs(full.astype(np.float32) - ref.astype(np.float32)).max() <= 2.0 ** -10
+
+
+@pytest.mark.gpu
+def test_configs3_chunk_of_4096_pings_covers_the_water_column():
+    """BASELINE configs[3] geometry at size: one chunk of 4096 pings x 1024 range, flat seabed 900
+    -> 95 patches; predict_survey (reader thread, pinned staging, copy stream, GPU mask from the seabed vector,
+    float16 result) writes 100 % of [0:910) x chunk and nothing below."""
+    import types
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    reader = synth.SyntheticSurveyReader(n_pings=8192, n_range=1024, seabed_index=900, block=4096)
+    model = pkg.UNet_Baseline(3, 4, precision="bf16")
+    model.load_state_dict(synth.synth_state_dict(seed=0))
+    pipe = types.SimpleNamespace(model=model, device=torch.device("cuda"), frequencies=[18, 38, 120, 200])
+    chunks = list(ti.predict_survey(reader, pipe, (256, 256), 20, 32, 4096, out_dtype=np.float16))
+    assert [c[:2] for c in chunks] == [(0, 4096), (4096, 8192)]
+    assert len(ti.plan_grid(1024, 900, 0, 4096)) == 95
+    for s, e, out in chunks:
+        assert out.dtype == np.float16 and out.shape == (2, 1024, 4096)
+        assert (out[0, :910] != 0).all() and (out[1, :910] != 0).all()          # softmax > 0: written everywhere
+        assert (out[:, 910:] == 0).all()
+        assert np.isfinite(out).all() and out.max() <= 1.0
+    # the two chunks see the same tiled block of data: same predictions in their interiors (patch grids are shifted
+    # by the chunk origin, so compare a column range both grids cover identically)
+    s32 = list(ti.predict_survey(reader, pipe, (256, 256), 20, 32, 4096, out_dtype=np.float32))
+    assert np.abs(s32[0][2].astype(np.float16).astype(np.float32) - chunks[0][2].astype(np.float32)).max() <= 1e-3

@@ -81,3 +81,44 @@ def linear_predictor(data):
     z = z - z.max(0, keepdims=True)
     e = np.exp(z)
     return (e / e.sum(0, keepdims=True)).astype(np.float32)
+
+
+class FakeEchogram:
+    """In-memory stand-in for the reference's memmap reader ``Echogram`` (crimac_unet/data/data_reader.py:44-508;
+    it needs a directory of .dat memory maps, pickled metadata and py<3.10 idioms, so it is replaced here).  Implements
+    the members the memm flavour of the hot path's callers use: ``data_format = 'memmap'``, ``shape = (range, pings)``,
+    ``data_memmaps(freqs)`` -> list of [range, pings] arrays, ``label_memmap()``, ``get_seabed(idx, n)`` and
+    ``get_seabed_mask`` with the Echogram semantics (data_reader.py:407-431: 1 where range index >= seabed + pad,
+    in ABSOLUTE range coordinates -- unlike the zarr reader, whose pad shifts the mask inside the requested slice)."""
+    data_format = "memmap"
+
+    def __init__(self, sv_hw, labels_hw, seabed, frequencies=(18, 38, 120, 200), name="fake_echogram"):
+        self.sv = sv_hw                 # [C, range, pings] linear sv
+        self.labels = labels_hw         # [range, pings] raw species labels
+        self._seabed = np.asarray(seabed).astype(np.int64)
+        self.shape = (sv_hw.shape[1], sv_hw.shape[2])
+        self.frequencies = list(frequencies)
+        self.name = name
+        self.objects = []
+
+    def data_memmaps(self, frequencies=None):
+        if frequencies is None:
+            frequencies = self.frequencies
+        if not isinstance(frequencies, (list, tuple, np.ndarray)):
+            frequencies = [frequencies]
+        return [self.sv[self.frequencies.index(f)] for f in frequencies]
+
+    def label_memmap(self, heave=True):
+        return self.labels
+
+    def get_seabed(self, idx_ping=None, n_pings=1, save_to_file=True, ignore_saved=False):
+        return self._seabed[idx_ping:idx_ping + n_pings].copy()
+
+    def get_seabed_mask(self, idx_ping=0, n_pings=None, idx_range=None, n_range=None, seabed_pad=0):
+        if n_pings is None:
+            n_pings = self.shape[1]
+        sb = self.get_seabed(idx_ping, n_pings) + seabed_pad
+        idx_range = 0 if idx_range is None else idx_range
+        n_range = self.shape[0] if n_range is None else n_range
+        sb = np.maximum(sb - idx_range, 0)
+        return (np.arange(n_range)[:, None] >= sb[None, :]).astype(np.float64)
