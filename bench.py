@@ -12,8 +12,9 @@ full training step of the reference loop (forward + weighted CE + backward + SGD
 per GPU (BASELINE.json configs[1]); for N > 1 the mini-batches shard over ranks and gradients are exchanged
 over RCCL every step (configs[2], weak scaling).  The JSON line also carries
   * ``infer_patches_per_s``   eval forward + softmax (pipeline.py:205-219) on the same batch;
-  * ``parity_mode``           the same two measurements in the precision that meets the north-star parity bar
-                              (f32x6: <= 1e-3 rel on logits, bit-exact argmax), with its own roofline;
+  * ``parity_mode``           the same two measurements in a precision that meets the north-star parity bar
+                              (f32h3: fp32 storage, forward products on two fp16 planes, ~2^-21: <= 1e-3 rel on logits
+                              and identical argmax masks; --parity-precision f32x6 for the 6-MFMA mode), with its roofline;
   * ``tiled``                 BASELINE configs[3]: tiled whole-survey inference (save_predict.py path), synthetic
                               survey 4 x 65536 pings x 1024 range, preload_n_pings 4096, host reader + H2D + crop/dB +
                               U-Net + softmax + scatter + D2H all inside the timed region;
@@ -37,8 +38,9 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_PATCH = 96.43      # SURVEY.md §8(a) a10, hook-counted on the reference module (start_filts 64)
 TRAIN_GFLOP_PER_PATCH = 288.98
 # dense 16-bit MFMA peak / MFMAs per product of the mode
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32x3": 2500.0 / 3.0, "f32x6": 2500.0 / 6.0}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32x3": 2500.0 / 3.0, "f32h3": 2500.0 / 3.0, "f32x6": 2500.0 / 6.0}
 DTYPE_LABEL = {"bf16": "bf16", "fp16": "fp16", "f32x3": "fp32 storage, 3x bf16 MFMA per product",
+               "f32h3": "fp32 storage, 3x MFMA per product (fp16 planes forward ~2^-21, bf16 planes backward)",
                "f32x6": "fp32 storage, 6x bf16 MFMA per product (fp32-equivalent)"}
 CONV_KERNELS = ("crimac_conv3x3: conv3x3_wch_kernel + conv3x3_p64_kernel + conv3x3_glds_w4_kernel + "
                 "conv3x3_c16_kernel (halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)")
@@ -54,7 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--start-filts", type=int, default=64, help="128 = BASELINE configs[4] (2x channels)")
     ap.add_argument("--gpu-augment", action="store_true",
                     help="train on raw linear sv with add_noise / flip / dB on the GPU (configs[4])")
-    ap.add_argument("--parity-precision", default="f32x6", choices=["f32x3", "f32x6"])
+    ap.add_argument("--parity-precision", default="f32h3", choices=["f32x3", "f32h3", "f32x6"],
+                    help="f32h3: fp16-plane forward (fp32-class logits, identical argmax masks) at 3 MFMAs per product; "
+                         "f32x6: 6 MFMAs, fp32-equivalent gradients too")
     ap.add_argument("--tiled-pings", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -322,7 +326,8 @@ def run_rank(args):
         parity, pm = measure_mode(args, args.parity_precision, max(3, args.steps // 2), 2, world, rank, dev,
                                   grad_sync, infer=not args.no_infer, log=log)
         del pm
-        parity["meets"] = "north-star parity bar: logits <= 1e-3 rel, bit-exact argmax (tests/test_gpu_unet.py)"
+        parity["meets"] = ("north-star parity bar: logits <= 1e-3 rel (measured 1e-6 class), identical argmax masks vs the "
+                           "reference golden and vs the oracle at B = 32 (tests/test_gpu_unet.py)")
 
     if rank == 0:
         sf = args.start_filts

@@ -125,7 +125,26 @@ template <typename TA> struct PlaneOf { using type = TA; };
 template <> struct PlaneOf<float> { using type = bf16_t; };
 
 // Number of operand planes of a precision mode.
-__host__ __device__ constexpr int planes_of(int prec) { return (prec == 0 || prec == 3) ? 1 : (prec == 1 ? 2 : 3); }
+__host__ __device__ constexpr int planes_of(int prec) {
+  return (prec == 0 || prec == 3) ? 1 : ((prec == 1 || prec == 4) ? 2 : 3);
+}
+// `planes` argument of the packing entry points (crimac_unet_hip.h, CRIMAC_PLANES_*)
+struct PlaneFmt {
+  int npl, fwd_fp16, dg_fp16;
+  float fwd_scale;
+};
+__host__ __device__ inline PlaneFmt plane_fmt(int planes_arg) {
+  PlaneFmt f;
+  f.npl = planes_arg & 15;
+  f.fwd_fp16 = (planes_arg >> 4) & 1;
+  f.dg_fp16 = (planes_arg >> 5) & 1;
+  f.fwd_scale = (float)(1 << ((planes_arg >> 8) & 255));
+  return f;
+}
+__host__ inline bool planes_arg_ok(int planes_arg) {
+  const int npl = planes_arg & 15, sh = (planes_arg >> 8) & 255;
+  return npl >= 1 && npl <= 3 && (planes_arg >> 16) == 0 && (planes_arg & 0xC0) == 0 && sh <= 16;
+}
 
 // Storage-type dispatch of an entry point: `T` is bf16_t (CRIMAC_PREC_BF16), half_t (CRIMAC_PREC_FP16) or float
 // (the fp32-storage modes) inside the statement.

@@ -64,7 +64,7 @@ template <int BK> struct Sw {
 
 // TR = tile rows: 8 (128-pixel tile, wave 64 x BN/2, 2 workgroups per CU) or 16 (256-pixel tile,
 // wave 128 x BN/2: 25 % fewer LDS fragment bytes per MFMA, 1 workgroup per CU).
-template <typename TA, int NPL, int BN, int BK, int TR>
+template <typename TA, int NPL, int BN, int BK, int TR, typename P16 = typename PlaneOf<TA>::type>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   constexpr int HALO_ROWS = (TR + 2) * HP;
   constexpr int BM = TR * TC;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
       if (h_lds[i] < 0) continue;
       if constexpr (X3) {
         u32x4 pl[NPL];
-        split8<NPL>(rh[i][0], rh[i][1], pl);
+        split8<NPL, P16>(rh[i][0], rh[i][1], pl);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(sA(buf, k) + h_lds[i]) = pl[k];
       } else {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mfma_planes<NPL, typename PlaneOf<TA>::type>(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) mfma_planes<NPL, P16>(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   conv_epilogue<TA, BN, BM, 256, MT, NT, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
 }
 
-template <typename TA, int NPL, int BN, int BK, int TR>
+template <typename TA, int NPL, int BN, int BK, int TR, typename P16 = typename PlaneOf<TA>::type>
 int launch(ConvParams p, hipStream_t st) {
   constexpr int HALO_ROWS = (TR + 2) * HP;
   constexpr int BM = TR * TC;
@@ -284,10 +284,10 @@ int launch(ConvParams p, hipStream_t st) {
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, NPL, BN, BK, TR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, NPL, BN, BK, TR, P16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((conv3x3_kernel<TA, NPL, BN, BK, TR>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_kernel<TA, NPL, BN, BK, TR, P16>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -340,6 +340,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   e.stat_mode = stat_mode; e.stat_sum = stat_mode ? stat_sum : nullptr; e.stat_sumsq = stat_sumsq;
   e.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
   e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
+  e.acc_scale = prec == CRIMAC_PREC_F32H3 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
   hipStream_t st = (hipStream_t)stream;
   const bool n128 = N % 128 == 0;
   // measured (tools/bench_conv.py): the 256-pixel tile of THIS kernel (4 waves, 1 workgroup/CU) loses
@@ -364,7 +365,11 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   if (is16)
     return fp16 ? conv3x3_staged16<half_t>(p, st, Cin, n128, big, force_bk)
                 : conv3x3_staged16<bf16_t>(p, st, Cin, n128, big, force_bk);
-  // split-bf16 keeps 2-3 planes per operand: 32-deep chunks keep the LDS footprint in bounds
+  // split planes keep 2-3 planes per operand: 32-deep chunks keep the LDS footprint in bounds
+  if (prec == CRIMAC_PREC_F32H3) {       // two fp16 planes (forward operands only: see the header)
+    if (Cin % 32 == 0) return n128 ? launch<float, 2, 128, 32, 8, half_t>(p, st) : launch<float, 2, 64, 32, 8, half_t>(p, st);
+    return n128 ? launch<float, 2, 128, 16, 8, half_t>(p, st) : launch<float, 2, 64, 16, 8, half_t>(p, st);
+  }
   if (prec == CRIMAC_PREC_F32X3) {
     if (Cin % 32 == 0) return n128 ? launch<float, 2, 128, 32, 8>(p, st) : launch<float, 2, 64, 32, 8>(p, st);
     return n128 ? launch<float, 2, 128, 16, 8>(p, st) : launch<float, 2, 64, 16, 8>(p, st);

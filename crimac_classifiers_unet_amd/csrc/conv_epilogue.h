@@ -24,6 +24,7 @@ struct EpiParams {
   long bnb_y_ld;
   const float* bnb_vec;   // rows: mean, invstd, scale, shift; row stride bnb_stride
   long bnb_stride;
+  float acc_scale;        // the accumulators are multiplied by this before the bias (F32H3: 2^-WSHIFT; else 1)
 };
 
 // Accumulator access for the two MFMA shapes (C/D layouts: cdna_hip_programming.md §3):
@@ -69,7 +70,7 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
 #pragma unroll
       for (int r = 0; r < L::NR; ++r) {
         const int row = wr * (MT * L::TS) + i * L::TS + L::row(r, lane);
-        float v = acc[i][j][r] + bv;
+        float v = acc[i][j][r] * e.acc_scale + bv;
         if (e.relu) v = fmaxf(v, 0.f);
         const TA q = (TA)v;
         *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = q;

@@ -64,9 +64,8 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 
 // ---- weight packing -----------------------------------------------------------------------------
 // value -> plane 0 in `hi`, planes 1..npl-1 in `lo` (plane stride `n`)
-__device__ __forceinline__ void put_planes(float v, int planes_arg, unsigned short* hi, unsigned short* lo,
+__device__ __forceinline__ void put_planes(float v, int npl, int fp16, unsigned short* hi, unsigned short* lo,
                                            long i, long n) {
-  const int npl = planes_arg & 15, fp16 = planes_arg >> 4;      // (bit 4: IEEE half instead of bf16)
   unsigned short b = f2bits16(v, fp16);
   hi[i] = b;
   for (int k = 1; k < npl; ++k) {
@@ -80,6 +79,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
                                     const float* __restrict__ scale, int npl, unsigned short* fwd_hi,
                                     unsigned short* fwd_lo, unsigned short* dg_hi,
                                     unsigned short* dg_lo) {
+  const PlaneFmt pf = plane_fmt(npl);
   const long n_fwd = 9L * Co * Ci_pad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_fwd;
        i += (long)gridDim.x * blockDim.x) {
@@ -91,7 +91,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       v = w[((long)co * Ci + ci) * 9 + t];
       if (scale) v *= scale[co];
     }
-    put_planes(v, npl, fwd_hi, fwd_lo, i, n_fwd);
+    put_planes(v * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n_fwd);
   }
   if (dg_hi) {
     const long n_dg = 9L * Ci * Co;
@@ -100,7 +100,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       const int co = (int)(i % Co);
       const long r = i / Co;
       const int ci = (int)(r % Ci), t = (int)(r / Ci);
-      put_planes(w[((long)co * Ci + ci) * 9 + (8 - t)], npl, dg_hi, dg_lo, i, n_dg);
+      put_planes(w[((long)co * Ci + ci) * 9 + (8 - t)], pf.npl, pf.dg_fp16, dg_hi, dg_lo, i, n_dg);
     }
   }
 }
@@ -109,6 +109,7 @@ __global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, 
                                    unsigned short* fwd_hi, unsigned short* fwd_lo,
                                    unsigned short* dg_hi, unsigned short* dg_lo) {
   // w[ci][co][a][b]; fwd[(ab*Co + co)][ci]; dgrad[ab][ci][co]
+  const PlaneFmt pf = plane_fmt(npl);
   const long n = 4L * Ci * Co;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
@@ -116,13 +117,13 @@ __global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, 
       const int ci = (int)(i % Ci);
       const long r = i / Ci;
       const int co = (int)(r % Co), ab = (int)(r / Co);
-      put_planes(w[((long)ci * Co + co) * 4 + ab], npl, fwd_hi, fwd_lo, i, n);
+      put_planes(w[((long)ci * Co + co) * 4 + ab] * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n);
     }
     if (dg_hi) {
       const int co = (int)(i % Co);
       const long r = i / Co;
       const int ci = (int)(r % Ci), ab = (int)(r / Ci);
-      put_planes(w[((long)ci * Co + co) * 4 + ab], npl, dg_hi, dg_lo, i, n);
+      put_planes(w[((long)ci * Co + co) * 4 + ab], pf.npl, pf.dg_fp16, dg_hi, dg_lo, i, n);
     }
   }
 }
@@ -862,8 +863,7 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
                                    int planes, void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo,
                                    void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0 && Ci_pad >= Ci, "pack_conv3x3: bad arguments");
-  CRIMAC_REQUIRE((planes == CRIMAC_PLANES_FP16 || (planes >= 1 && planes <= 3)) &&
-                     ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
+  CRIMAC_REQUIRE(planes_arg_ok(planes) && ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
                  "pack_conv3x3: planes=%d needs the lo plane buffers", planes);
   CRIMAC_REQUIRE(!dg_hi || Ci_pad == Ci, "pack_conv3x3: dgrad planes need Ci_pad == Ci");
   const int grid = grid_for(9L * Co * Ci_pad, 256);
@@ -877,8 +877,7 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
 extern "C" int crimac_pack_upconv2x2(const float* w, int Ci, int Co, int planes, void* fwd_hi,
                                      void* fwd_lo, void* dg_hi, void* dg_lo, void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0, "pack_upconv2x2: bad arguments");
-  CRIMAC_REQUIRE((planes == CRIMAC_PLANES_FP16 || (planes >= 1 && planes <= 3)) &&
-                     ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
+  CRIMAC_REQUIRE(planes_arg_ok(planes) && ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
                  "pack_upconv2x2: planes=%d needs the lo plane buffers", planes);
   const int grid = grid_for(4L * Co * Ci, 256);
   hipLaunchKernelGGL(pack_upconv_kernel, dim3(grid), dim3(256), 0, ST, w, Ci, Co, planes,

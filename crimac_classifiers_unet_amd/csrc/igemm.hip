@@ -43,6 +43,7 @@ struct IgemmParams {
   int relu;
   int cout_up;  // UPSCATTER: columns per (a,b) group
   long M;
+  float acc_scale;   // F32H3: 2^-WSHIFT (forward planes hold w * 2^WSHIFT); else 1
 };
 
 constexpr int BM = 128;
@@ -56,7 +57,7 @@ template <int BK> struct Swz {
   }
 };
 
-template <typename TA, int NPL, int BN, int BK, int OUT_MODE>
+template <typename TA, int NPL, int BN, int BK, int OUT_MODE, typename P16 = typename PlaneOf<TA>::type>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
   static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int o = Swz<BK>::off(a_row[i], a_u[i]);
       if constexpr (X3) {
         u32x4 pl[NPL];
-        split8<NPL>(ra[i][0], ra[i][1], pl);
+        split8<NPL, P16>(ra[i][0], ra[i][1], pl);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(sA(k) + o) = pl[k];
       } else {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mfma_planes<NPL, typename PlaneOf<TA>::type>(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) mfma_planes<NPL, P16>(af[i], bfr[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        float v = acc[i][j][r] + bv;
+        float v = acc[i][j][r] * p.acc_scale + bv;
         if (p.relu) v = fmaxf(v, 0.f);
         *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = (TA)v;
       }
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   }
 }
 
-template <typename TA, int NPL, int BN, int BK, int OUT_MODE>
+template <typename TA, int NPL, int BN, int BK, int OUT_MODE, typename P16 = typename PlaneOf<TA>::type>
 int launch(const IgemmParams& p, hipStream_t st) {
   const int tilesM = cdiv(p.M, BM), tilesN = p.N / BN;
   size_t lds = (size_t)(BM + BN) * BK * 2 * NPL;
@@ -274,23 +275,23 @@ int launch(const IgemmParams& p, hipStream_t st) {
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<TA, NPL, BN, BK, OUT_MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<TA, NPL, BN, BK, OUT_MODE, P16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((igemm_kernel<TA, NPL, BN, BK, OUT_MODE>), dim3(tilesM * tilesN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_kernel<TA, NPL, BN, BK, OUT_MODE, P16>), dim3(tilesM * tilesN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
 
-template <typename TA, int NPL, int OUT_MODE>
+template <typename TA, int NPL, int OUT_MODE, typename P16 = typename PlaneOf<TA>::type>
 int dispatch(const IgemmParams& p, hipStream_t st) {
   const bool n128 = (p.N % 128) == 0;
   if (p.Cin % 64 == 0 && NPL < 3) {
-    return n128 ? launch<TA, NPL, 128, 64, OUT_MODE>(p, st) : launch<TA, NPL, 64, 64, OUT_MODE>(p, st);
+    return n128 ? launch<TA, NPL, 128, 64, OUT_MODE, P16>(p, st) : launch<TA, NPL, 64, 64, OUT_MODE, P16>(p, st);
   } else if (p.Cin % 32 == 0) {
-    return n128 ? launch<TA, NPL, 128, 32, OUT_MODE>(p, st) : launch<TA, NPL, 64, 32, OUT_MODE>(p, st);
+    return n128 ? launch<TA, NPL, 128, 32, OUT_MODE, P16>(p, st) : launch<TA, NPL, 64, 32, OUT_MODE, P16>(p, st);
   } else {
-    return n128 ? launch<TA, NPL, 128, 16, OUT_MODE>(p, st) : launch<TA, NPL, 64, 16, OUT_MODE>(p, st);
+    return n128 ? launch<TA, NPL, 128, 16, OUT_MODE, P16>(p, st) : launch<TA, NPL, 64, 16, OUT_MODE, P16>(p, st);
   }
 }
 
@@ -327,6 +328,7 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   p.bias = bias; p.bias_mod = bias_mod > 0 ? bias_mod : N;
   p.out = out; p.out_ld = out_ld; p.relu = relu; p.cout_up = cout_up;
   p.M = (long)B * Ho * Wo;
+  p.acc_scale = prec == CRIMAC_PREC_F32H3 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
   hipStream_t st = (hipStream_t)stream;
   if (is16 && !relu) {
     // ConvTranspose2d(k2, s2): forward (1 tap, scatter) and input gradient (4 taps, stride 2) go to upconv.hip
@@ -344,6 +346,8 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
     return out_mode == 0 ? dispatch<bf16_t, 1, 0>(p, st) : dispatch<bf16_t, 1, 1>(p, st);
   if (prec == CRIMAC_PREC_FP16)
     return out_mode == 0 ? dispatch<half_t, 1, 0>(p, st) : dispatch<half_t, 1, 1>(p, st);
+  if (prec == CRIMAC_PREC_F32H3)
+    return out_mode == 0 ? dispatch<float, 2, 0, half_t>(p, st) : dispatch<float, 2, 1, half_t>(p, st);
   if (prec == CRIMAC_PREC_F32X3)
     return out_mode == 0 ? dispatch<float, 2, 0>(p, st) : dispatch<float, 2, 1>(p, st);
   return out_mode == 0 ? dispatch<float, 3, 0>(p, st) : dispatch<float, 3, 1>(p, st);

@@ -86,7 +86,8 @@ __device__ __forceinline__ void put_planes8(float (&v)[8], int npl, unsigned sho
 
 __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_arg) {
   __shared__ float tile[TILE][TILE * 9 + 1];
-  const int npl = planes_arg & 15, fp16 = planes_arg >> 4;
+  const PlaneFmt pf = plane_fmt(planes_arg);
+  const int npl = pf.npl;
   const int l = find_layer(tb, blockIdx.x);
   const LayerDesc& d = tb.d[l];
   const Geo g = geo_of(d.kind, d.Co, d.Ci, d.Ci_pad);
@@ -105,21 +106,23 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
   // pass A, inner index fastest: conv3x3 forward panel [t][co][ci_pad] / upconv dgrad panel [ab][ci][co]
   unsigned short* a_hi = d.kind == 0 ? d.fwd_hi : d.dg_hi;
   unsigned short* a_lo = d.kind == 0 ? d.fwd_lo : d.dg_lo;
+  const int a_fp16 = d.kind == 0 ? pf.fwd_fp16 : pf.dg_fp16, b_fp16 = d.kind == 0 ? pf.dg_fp16 : pf.fwd_fp16;
+  const float a_sc = d.kind == 0 ? pf.fwd_scale : 1.f, b_sc = d.kind == 0 ? 1.f : pf.fwd_scale;
   if (a_hi && g.inner_pad % 8 == 0) {
     for (int idx = threadIdx.x; idx < T * TILE * (TILE / 8); idx += 256) {
       const int il = (idx % (TILE / 8)) * 8, ol = (idx / (TILE / 8)) % TILE, t = idx / (TILE * TILE / 8);
       if (i0 + il >= g.inner_pad) continue;
       float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = tile[ol][(il + q) * T + t];
-      put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, fp16);
+      for (int q = 0; q < 8; ++q) v[q] = tile[ol][(il + q) * T + t] * a_sc;
+      put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, a_fp16);
     }
   } else if (a_hi) {
     for (int idx = threadIdx.x; idx < T * TILE * (TILE / 2); idx += 256) {
       const int il = (idx % (TILE / 2)) * 2, ol = (idx / (TILE / 2)) % TILE, t = idx / (TILE * TILE / 2);
       if (i0 + il >= g.inner_pad) continue;
-      put_planes2(tile[ol][il * T + t], tile[ol][(il + 1) * T + t], npl, a_hi, a_lo,
-                  ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, fp16);
+      put_planes2(tile[ol][il * T + t] * a_sc, tile[ol][(il + 1) * T + t] * a_sc, npl, a_hi, a_lo,
+                  ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, a_fp16);
     }
   }
   // pass B, outer index fastest: conv3x3 dgrad panel [8-t][ci][co] / upconv forward panel [ab][co][ci]
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
       const int tt = d.kind == 0 ? T - 1 - t : t;
       float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = tile[ol + q][il * T + t];
-      put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, fp16);
+      for (int q = 0; q < 8; ++q) v[q] = tile[ol + q][il * T + t] * b_sc;
+      put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, b_fp16);
     }
   }
 }
@@ -278,9 +281,7 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream
 }  // namespace
 
 extern "C" int crimac_pack_layers(const crimac_layer_desc* descs, int n_layers, int planes, void* stream) {
-  CRIMAC_REQUIRE(descs && n_layers > 0 && (planes & 15) >= 1 && (planes & 15) <= 3 && (planes >> 4) <= 1 &&
-                     (planes < 16 || planes == CRIMAC_PLANES_FP16),
-                 "pack_layers: bad arguments (planes=%d)", planes);
+  CRIMAC_REQUIRE(descs && n_layers > 0 && planes_arg_ok(planes), "pack_layers: bad arguments (planes=%d)", planes);
   return run_layers(reinterpret_cast<const HostDesc*>(descs), n_layers, 0, planes, (hipStream_t)stream);
 }
 

@@ -565,6 +565,8 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
 int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld, int CS, int B, int Hf,
               int Wf, float* dw, long partial_stride, int target_blocks, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "wgrad: bad precision %d", prec);
+  CRIMAC_REQUIRE(prec != CRIMAC_PREC_F32H3, "wgrad: F32H3 is a forward-operand mode (fp16 planes have no range for "
+                 "gradients); call the backward kernels with CRIMAC_PREC_F32X3");
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "wgrad: bad mode %d", mode);
   CRIMAC_REQUIRE(CF > 0 && CF % 8 == 0 && CS > 0 && CS % 8 == 0, "wgrad: channels must be multiples of 8");
   CRIMAC_REQUIRE(f_ld >= CF && s_ld >= CS && f_ld % 8 == 0 && s_ld % 8 == 0, "wgrad: bad pixel strides");

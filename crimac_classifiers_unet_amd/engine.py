@@ -80,6 +80,7 @@ class UNetEngine:
         self.planes = hip.PREC_PLANES[self.prec]
         self.planes_arg = hip.PREC_PLANES_ARG[self.prec]     # what the packing entry points take
         self.is16 = self.prec in hip.PREC_16BIT
+        self.prec_bwd = hip.PREC_BACKWARD.get(self.prec, self.prec)      # (f32h3: backward on the bf16 2-plane split)
         # fp16 storage: the loss gradient is scaled by `loss_scale` (crimac_wce_bwd upstream) so that activation
         # gradients (1e-5 .. 1e-8 unscaled) sit in fp16's normal range; SGD divides it out again and skips the
         # step when a gradient overflowed (crimac_grad_overflow_flag / crimac_sgd_momentum_guarded)
@@ -504,6 +505,7 @@ class UNetEngine:
         accumulators).  Returns True if the requested fusion ran inside the conv kernel."""
         flops = 2.0 * 9 * (cin_real or cin) * cout * B * H * W
         w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
+        prec = self.prec_bwd if dgrad else self.prec
         if self.conv_impl == "halo":
             mode, s0, s1, by, by_ld, bvec = 0, None, None, None, 0, None
             if stats is not None:
@@ -513,15 +515,15 @@ class UNetEngine:
                 mode, s0, s1 = 2, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1))
                 by, by_ld, bvec = y.p, y.ld, ptr(self._bnf(blk, 0))
             if cols is not None:                      # a range of the output channels (crimac_conv3x3_cols)
-                call("crimac_conv3x3_cols", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
+                call("crimac_conv3x3_cols", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
                      out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
                      cols[0], cols[1], flops=flops * cols[1] / cout)
                 return mode != 0
-            call("crimac_conv3x3", self.prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
+            call("crimac_conv3x3", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
                  out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
                  flops=flops)
             return mode != 0
-        call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1, w_hi, w_lo,
+        call("crimac_igemm_conv", prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1, w_hi, w_lo,
              ptr(bias), cout, out.p, out.ld, 1 if relu else 0, 0, 0, flops=flops)
         if stats:
             call("crimac_colstats", self.prec, out.p, out.ld, B * H * W, cout, ptr(stats[0]), ptr(stats[1]))
@@ -560,7 +562,7 @@ class UNetEngine:
 
     def _upconv_dgrad_plain(self, dy: Act, u, out: Act, B, H, W):
         pk = self.pk[u.key]
-        call("crimac_igemm_conv", self.prec, dy.p, dy.ld, B, 2 * H, 2 * W, H, W, u.cout, u.cin, 4, 2, 0,
+        call("crimac_igemm_conv", self.prec_bwd, dy.p, dy.ld, B, 2 * H, 2 * W, H, W, u.cout, u.cin, 4, 2, 0,
              2, ptr(pk["dg_hi"]), ptr(pk["dg_lo"]), None, 0, out.p, out.ld, 0, 0, 0,
              flops=2.0 * 4 * u.cin * u.cout * B * H * W)
 
@@ -876,7 +878,7 @@ class UNetEngine:
              ptr(self._stat(b, 3)), M, M * world, b.cout, dy.p, dy.ld, ptr(dgamma), ptr(dbeta),
              None)      # d(conv bias in front of train-mode BN) = sum dy == 0 exactly: left at the zero fill
              #            (the reference holds ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
-        self._wgrad(self.prec, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w, b.conv_key,
+        self._wgrad(self.prec_bwd, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w, b.conv_key,
                     flops=2.0 * 9 * b.cin * b.cout * B * h * w)
         fused = False
         if dx_out is not None:
@@ -1031,7 +1033,7 @@ class UNetEngine:
             dup = dcat.slice(0, c)
             skip_grad[L] = dcat.slice(c, c)
             hp, wp, Mp = geo[L + 1]
-            self._wgrad(self.prec, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp, wp, u.key,
+            self._wgrad(self.prec_bwd, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp, wp, u.key,
                         flops=2.0 * 4 * u.cin * u.cout * B * hp * wp)
             d_prev = Act(self._buf(f"g.d{j}.xprev", (Mp, u.cin)), u.cin)
             # d_prev is the `da` of the next coarser block (decoder j-1, or the bottleneck encoder block)

@@ -17,10 +17,17 @@ PREC_BF16 = 0
 PREC_F32X3 = 1
 PREC_F32X6 = 2
 PREC_FP16 = 3
-PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16}
-PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1}     # 16-bit planes per MFMA operand
-# `planes` argument of the packing entry points (CRIMAC_PLANES_FP16 = one IEEE-half plane)
-PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 17}
+PREC_F32H3 = 4
+PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16, "f32h3": PREC_F32H3}
+PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1, PREC_F32H3: 2}   # 16-bit planes per operand
+# `planes` argument of the packing entry points (CRIMAC_PLANES_* of the header): bits 0-3 planes, bit 4 / 5 forward /
+# input-gradient planes in IEEE half, bits 8-15 log2 of the scale on the forward planes
+PLANES_FP16 = 1 | 16 | 32
+PLANES_F32H3 = 2 | 16 | (8 << 8)
+PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: PLANES_FP16, PREC_F32H3: PLANES_F32H3}
+# precision the BACKWARD kernels (input gradients, weight gradients) are called with: F32H3 is a forward-operand
+# mode (fp16 planes have no range for gradients), its backward pass runs on the 2-plane bf16 split
+PREC_BACKWARD = {PREC_F32H3: PREC_F32X3}
 PREC_16BIT = (PREC_BF16, PREC_FP16)
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float

@@ -114,6 +114,8 @@ class UNet_Baseline(nn.Module):
                  'f32x3' -- fp32 activations, 2-plane split-bf16 MFMA (~2^-16 per product)
                  'f32x6' -- fp32 activations, 3-plane split, 6 MFMAs per product (fp32-equivalent:
                             the parity mode, <=1e-3 on logits with bit-exact argmax masks)
+                 'f32h3' -- fp32 activations; forward products on a 2-plane fp16 split (~2^-21 per product, 3 MFMAs:
+                            fp32-class logits at half the MFMAs of 'f32x6'), backward on the 2-plane bf16 split
                  'fp16'  -- fp16 activations / MFMA, fp32 accumulate, loss-scaled gradients with overflow skip
                             (BASELINE configs[4]); same kernels and rate as 'bf16'
     """

@@ -53,10 +53,23 @@ extern "C" {
 #define CRIMAC_PREC_FP16 3  /* fp16 activations / gradients, fp16 MFMA, fp32 accumulate (BASELINE configs[4]);
                              * gradients need loss scaling: crimac_wce_bwd's `upstream`, undone by
                              * crimac_sgd_momentum's `grad_scale`, overflow guard crimac_grad_overflow_flag */
-#define CRIMAC_PREC_MAX 3
+#define CRIMAC_PREC_F32H3 4 /* fp32 activations, FORWARD products on a 2-plane fp16 split (hi*hi + hi*lo + lo*hi, 11 + 11
+                             * mantissa bits: ~2^-21 per product, fp32-class) at 3 MFMAs per product -- half the MFMAs
+                             * of F32X6.  fp16 planes only have the range for forward operands (activations O(1..100),
+                             * weights pre-scaled by 2^CRIMAC_F32H3_WSHIFT when packed, undone in the conv epilogue);
+                             * gradients span too many decades, so the backward kernels of this mode are called with
+                             * CRIMAC_PREC_F32X3 (entry points that only exist for the backward pass reject F32H3). */
+#define CRIMAC_PREC_MAX 4
+#define CRIMAC_F32H3_WSHIFT 8
 /* `planes` argument of the weight-packing entry points: 1..3 bf16 planes (BF16 / F32X3 / F32X6), or
- * CRIMAC_PLANES_FP16 = one IEEE-half plane (FP16). */
-#define CRIMAC_PLANES_FP16 17
+ * CRIMAC_PLANES_FP16 = one IEEE-half plane each way (FP16), or CRIMAC_PLANES_F32H3.  Layout of the argument: bits
+ * 0-3 number of planes, bit 4 / bit 5 forward / input-gradient planes in IEEE half, bits 8-15 log2 of the scale
+ * applied to the forward planes. */
+#define CRIMAC_PLANES_FWD_FP16 16   /* forward planes are IEEE half instead of bf16 */
+#define CRIMAC_PLANES_DG_FP16 32    /* input-gradient planes are IEEE half instead of bf16 */
+#define CRIMAC_PLANES_FP16 (1 | CRIMAC_PLANES_FWD_FP16 | CRIMAC_PLANES_DG_FP16)                /* FP16 storage mode */
+/* F32H3: two fp16 forward planes of w * 2^CRIMAC_F32H3_WSHIFT (bits 8-15 carry the shift), two bf16 dgrad planes */
+#define CRIMAC_PLANES_F32H3 (2 | CRIMAC_PLANES_FWD_FP16 | (CRIMAC_F32H3_WSHIFT << 8))
 
 /* Library identity / error text. */
 int crimac_version(void);

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 PRECS = ["f32x6", "f32x3", "bf16", "fp16"]
 LOWP = ("bf16", "fp16")                 # 16-bit storage modes: same kernels, instantiated per element type
 TOL = {"f32x6": 5e-6, "f32x3": 1e-4, "bf16": 1e-2, "fp16": 2e-3}      # fp16 output rounding is 2^-11
-NPL = {"f32x6": 3, "f32x3": 2, "bf16": 1, "fp16": 17}                 # `planes` argument (17 = CRIMAC_PLANES_FP16)
+NPL = {"f32x6": 3, "f32x3": 2, "bf16": 1, "fp16": hip.PLANES_FP16, "f32h3": hip.PLANES_F32H3}     # `planes` argument
 _DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
 
@@ -650,7 +650,7 @@ def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape, prec):
     assert relerr(st.sum(1), st_full.sum(1)) < 1e-6       # (fp32 partial sums are grouped differently)
 
 
-@pytest.mark.parametrize("planes", [1, 2, 3, 17])
+@pytest.mark.parametrize("planes", [1, 2, 3, hip.PLANES_FP16, hip.PLANES_F32H3])
 def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
     """crimac_pack_layers / crimac_unpack_wgrad_layers (one launch for all layers) are bit-identical to
     the per-layer kernels, incl. the padded first layer (Ci = 4 -> 16, no dgrad planes)."""
@@ -756,3 +756,31 @@ def test_wgrad_partial_slabs_sum_to_the_atomic_result_and_are_reproducible(prec,
         summed = (dwp.view(9, Co, Ci).permute(1, 2, 0).reshape(Co, Ci, 3, 3) if kind == 0
                   else dwp.view(4, Ci, Co).permute(1, 2, 0).reshape(Ci, Co, 2, 2))
         assert relerr(outs[0], summed) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 16, 32, 128, 128), (2, 16, 16, 4, 64), (1, 24, 40, 64, 192)])
+def test_conv3x3_forward_f32h3_fp16_planes(shape):
+    """CRIMAC_PREC_F32H3: fp32 storage, two fp16 planes per operand (weights packed x 2^8, undone in the epilogue),
+    3 MFMAs per product: ~2^-21 per product -- fp32-class, 30x tighter than the bf16 2-plane split (f32x3)."""
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Ci, H, W, generator=g) * 3.0
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    cin_pad = 16 if Ci < 16 else Ci
+    fh, fl, _, _ = pack_conv(w, "f32h3", cin_pad, dgrad=False)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    xin = to_nhwc(x, "f32h3", ld=cin_pad)
+    out = torch.empty(B * H * W, Co, dtype=torch.float32, device="cuda")
+    bd = b.cuda()
+    call("crimac_conv3x3", hip.PREC_NAMES["f32h3"], ptr(xin), cin_pad, B, H, W, cin_pad, Co, ptr(fh), ptr(fl), ptr(bd),
+         ptr(out), Co, 1, 0, None, None, 1, None, 0, None, 0)
+    torch.cuda.synchronize()
+    e = relerr(from_nhwc(out, B, H, W), torch.relu(ref))
+    assert e < 2e-6, e
+    out2 = conv3x3("f32h3", xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, bd)          # gather implementation
+    assert relerr(from_nhwc(out2, B, H, W), ref) < 2e-6
+    # the backward-only entry point refuses the forward-operand mode
+    dwp = torch.zeros(9 * Co * cin_pad, dtype=torch.float32, device="cuda")
+    with pytest.raises(hip.HipLibraryError, match="forward-operand"):
+        call("crimac_wgrad", hip.PREC_NAMES["f32h3"], 0, ptr(out), Co, Co, ptr(xin), cin_pad, cin_pad, B, H, W, ptr(dwp), 0)

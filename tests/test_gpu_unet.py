@@ -268,6 +268,16 @@ def test_batch32_full_size_f32x6_matches_oracle():
     assert r < 1e-5
     # identical masks except where the reference's own two top logits tie to fp32 round-off
     assert int(diff.sum()) <= 2 and bool((margin < 2e-6).all())
+    # the 3-MFMA parity mode (fp16 planes forward) at the same size: same bar
+    mh = make_model("f32h3").eval()
+    with torch.no_grad():
+        outh = mh(x.cuda())
+    rh = rel(outh, ref)
+    diffh = outh.argmax(1).cpu() != ref.argmax(1)
+    marginh = (top2[:, 0] - top2[:, 1])[diffh]
+    print(f"B=32 eval f32h3: rel={rh:.3e} argmax flips={int(diffh.sum())}/{ref[:, 0].numel()} margins={marginh.tolist()}")
+    assert rh < 1e-5 and int(diffh.sum()) <= 2 and bool((marginh < 2e-5).all())
+    del mh
     ref_loss, ref_logits, ref_grads, ref_stats = orc.loss_and_grads(sd, x, lab)
     m.train()
     crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
@@ -946,3 +956,30 @@ def test_evaluate_flow_writes_the_pr_report(tmp_path):
                                              data_transform_factory=lambda use_meta: "DT",
                                              label_transform_factory=lambda **kw: "LT")
     assert abs(m2["F1"].max() - m["F1"].max()) < 1e-9
+
+
+def test_f32h3_eval_is_fp32_class_and_train_step_matches_golden(full_case):
+    """'f32h3': forward on two fp16 planes (3 MFMAs per product, ~2^-21), backward on the bf16 2-plane split.
+    Forward parity like the 6-MFMA mode (<= 1e-3 bar, identical argmax masks); gradients like f32x3."""
+    fix, x, lab = full_case
+    m = make_model("f32h3").eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    ref = torch.from_numpy(fix["logits_eval"])
+    r = rel(out, ref)
+    flips = int((out.argmax(1).cpu() != ref.argmax(1)).sum())
+    print(f"eval f32h3: rel={r:.3e} argmax flips={flips}/{ref[:, 0].numel()}")
+    assert r < 1e-5 and flips == 0
+    m, loss, logits, grads, stats = _train_once("f32h3", x, lab, fused=False)
+    assert rel(logits.detach(), fix["logits_train"]) < 1e-4
+    assert abs(loss - float(fix["losses"][0])) < 1e-5 * abs(float(fix["losses"][0]))
+    for k, v in stats.items():
+        assert rel(v.float(), fix["stat1/" + k]) < 1e-4, k
+    for k, g in grads.items():
+        if PRE_BN_BIAS.fullmatch(k):
+            continue
+        gn, noise = float(fix["gnorm/" + k]), float(fix["gnoise/" + k])
+        tol = max(20 * noise, 2e-2)              # the backward pass is the f32x3 arithmetic
+        assert abs(float(g.double().norm()) - gn) <= tol * gn, (k, float(g.double().norm()), gn)
+        if "grad/" + k in fix.files:
+            assert l2rel(g, fix["grad/" + k]) < tol, k
