@@ -387,7 +387,9 @@ def main():
         # parent: no GPU call in this process -- spawn one rank per GPU and relay rank 0's line
         print(f"[bench] no torchrun environment: spawning {args.gpus} ranks (one per GPU)", file=sys.stderr, flush=True)
         rc, out0 = launch.spawn_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus)
-        sys.stdout.write(out0)
+        # rank 0's stdout: the result line (a backend may chat on stdout too -- gloo does -- that goes to stderr)
+        for line in out0.splitlines():
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
         sys.stdout.flush()
         sys.exit(rc)
     run_rank(args)
