@@ -255,8 +255,8 @@ def measure_tiled(model, args, log):
     pipe = types.SimpleNamespace(model=model, device=next(model.parameters()).device, frequencies=[18, 38, 120, 200])
     import numpy as np
     f16 = dict(out_dtype=np.float16)                     # what the reference stores (save_predict.py:212)
-    for _ in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, start_ping=n_pings - 2 * preload, **f16):
-        pass                                             # warm-up on the last two chunks
+    for _ in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, **f16):
+        pass                                             # warm-up: one untimed pass over the survey
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n_patches, written = 0, 0

@@ -258,13 +258,18 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                 m_d = dev_misc[slot][:sb.numel()]
                 m_d.copy_(sb, non_blocking=True)                        # (sb: seabed | centres, pinned)
                 uploaded[i % NS].record()
+            note("enq_upload_s", t0)
+            t1 = tick()
             main.wait_stream(copy_stream)
             P = len(grid)
             if stats is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             cp.load_chunk(d_d, lo, l_d, None, s, e, seabed=m_d[:hi - lo], seabed_ping0=lo)
+            note("enq_load_s", t1)
+            t1 = tick()
             out = cp.predict(grid, centres_dev=m_d[hi - lo:].view(2, P, 2))
+            note("enq_predict_s", t1)
             if stats is not None:
                 ev1.record()
                 stats.setdefault("gpu_events", []).append((ev0, ev1))
