@@ -547,6 +547,59 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
                          dbias, (float*)nullptr);
 }
 
+// The same without the (never used) pre-BatchNorm bias gradient: a pure streaming kernel like bn_act_kernel --
+// thread-fixed channel chunk, constants in registers, U rows in flight, no LDS, no reduction tail.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
+    const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, long M, long count, int C,
+    T* __restrict__ dy, long dy_ld, float* dgamma, float* dbeta) {
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dgamma[c] = (float)sum_dzx[c];
+      dbeta[c] = (float)sum_dz[c];
+    }
+  }
+  const int cpr = C / 8;
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  if (rl >= rpi) return;
+  const int c0 = chunk * 8;
+  const double invM = 1.0 / (double)count;
+  float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
+    k1[j] = (float)(sum_dz[c0 + j] * invM);
+    k2[j] = (float)(sum_dzx[c0 + j] * invM);
+  }
+  const long stride = (long)gridDim.x * rpi;
+  constexpr int U = 4;
+  for (long m = (long)blockIdx.x * rpi + rl; m < M; m += U * stride) {
+    float g[U][8], yv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (m + u * stride < M) {
+        load8(da + (m + u * stride) * da_ld + c0, g[u]);
+        load8(y + (m + u * stride) * y_ld + c0, yv[u]);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (m + u * stride >= M) continue;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float act = yv[u][j] * sc[j] + sh[j];
+        const float dz = act > 0.f ? g[u][j] : 0.f;
+        const float xh = (yv[u][j] - mu[j]) * is[j];
+        o[j] = sc[j] * (dz - k1[j] - xh * k2[j]);
+      }
+      store8(dy + (m + u * stride) * dy_ld + c0, o);
+    }
+  }
+}
+
 // ---- 1x1 head --------------------------------------------------------------------------------------------
 template <typename T, int NC>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long x_ld, int Cin,
@@ -1069,9 +1122,15 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
                  "bn_bwd_apply: bad pixel strides");
   const int grid = colreduce_grid(M, C);
   const size_t lds = 2 * C * sizeof(float);
-  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), lds, ST, (const T*)da,
-                                                 da_ld, (const T*)y, y_ld, scale, shift, mean, invstd, sum_dz,
-                                                 sum_dz_xhat, M, count, C, (T*)dy, dy_ld, dgamma, dbeta, dbias));
+  static const int stream_form = getenv("CRIMAC_BNB_STREAM") ? atoi(getenv("CRIMAC_BNB_STREAM")) : 1;
+  if (!dbias && stream_form && C <= 2048)
+    CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_apply_stream_kernel<T>, dim3(grid), dim3(256), 0, ST,
+                                                   (const T*)da, da_ld, (const T*)y, y_ld, scale, shift, mean, invstd,
+                                                   sum_dz, sum_dz_xhat, M, count, C, (T*)dy, dy_ld, dgamma, dbeta));
+  else
+    CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), lds, ST, (const T*)da,
+                                                   da_ld, (const T*)y, y_ld, scale, shift, mean, invstd, sum_dz,
+                                                   sum_dz_xhat, M, count, C, (T*)dy, dy_ld, dgamma, dbeta, dbias));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

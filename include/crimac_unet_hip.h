@@ -14,7 +14,7 @@
  *     thread-local last-error text; one-time per-DEVICE kernel attribute setup (dynamic-LDS limits, CU count;
  *     keyed on hipGetDevice, so several GPUs in one process work); and A/B tuning switches read ONCE from the
  *     environment at first use and constant afterwards (CRIMAC_CONV_W4, CRIMAC_CONV_P64, CRIMAC_CONV_TR,
- *     CRIMAC_CONV_BK, CRIMAC_CONV_GLDS, CRIMAC_UPCONV_WCH, CRIMAC_WGRAD_BLOCKS -- kernel-selection experiments
+ *     CRIMAC_CONV_BK, CRIMAC_CONV_GLDS, CRIMAC_UPCONV_WCH, CRIMAC_WGRAD_BLOCKS, CRIMAC_BNB_STREAM -- kernel-selection experiments
  *     only; results do not depend on them beyond summation order).  Reductions that use floating-point
  *     atomics (BatchNorm sums, bias gradients) are not bit-reproducible run to run; everything on the
  *     inference path is

@@ -356,7 +356,7 @@ def test_head_with_batchnorm_relu_applied_on_the_fly(prec):
         outs.append((dx, dw, db, rep.sum(1)))
     assert torch.equal(outs[0][0], outs[1][0])
     assert relerr(outs[1][1], outs[0][1]) < 1e-5 and relerr(outs[1][2], outs[0][2]) < 1e-5
-    assert relerr(outs[1][3], outs[0][3]) < 1e-9
+    assert relerr(outs[1][3], outs[0][3]) < 1e-5          # (fp32 partials meet in a run-dependent atomic order)
     with pytest.raises(hip.HipLibraryError):     # x == NULL without the fused sums
         call("crimac_head_bwd", P, ptr(dl), None, 0, C, ptr(wd), ptr(dx), C, ptr(dw), ptr(db), B, H, W, ncls,
              None, 0, None, 0, None, None, 1)
