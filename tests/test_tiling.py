@@ -291,3 +291,56 @@ def test_configs3_chunk_of_4096_pings_covers_the_water_column():
     # by the chunk origin, so compare a column range both grids cover identically)
     s32 = list(ti.predict_survey(reader, pipe, (256, 256), 20, 32, 4096, out_dtype=np.float32))
     assert np.abs(s32[0][2].astype(np.float16).astype(np.float32) - chunks[0][2].astype(np.float32)).max() <= 1e-3
+
+
+def _tiled_rank_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", CRIMAC_DIST_BACKEND="gloo")
+    import types
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import parallel, synth
+    parallel.init_distributed(backend="gloo")          # two ranks share the one GPU of the box: gloo, not RCCL
+    sv, labels, seabed = synth_survey()
+    sv, labels, seabed = sv[:, :700, :300], labels[:700, :300], np.clip(seabed[:700], 0, 230)
+    reader = FakeZarrReader(sv, labels, seabed)
+    model = pkg.UNet_Baseline(3, 4, precision="f32x6")
+    model.load_state_dict(synth.synth_state_dict(seed=0))
+    pipe = types.SimpleNamespace(model=model, device=torch.device("cuda"), frequencies=[18, 38, 120, 200])
+    chunks = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16))
+    if rank == 0:
+        out["chunks"] = [(s, e, o.copy()) for s, e, o in chunks]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_patches_of_a_chunk_and_merge_exactly():
+    """SURVEY.md §8e inference partition: patch p of a chunk -> rank p % 2; the per-rank float16 outputs are summed
+    (disjoint interiors): bit-identical to the single-process result."""
+    import socket
+    import types
+    import torch.multiprocessing as mp
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    sv, labels, seabed = synth_survey()
+    sv, labels, seabed = sv[:, :700, :300], labels[:700, :300], np.clip(seabed[:700], 0, 230)
+    reader = FakeZarrReader(sv, labels, seabed)
+    model = pkg.UNet_Baseline(3, 4, precision="f32x6")
+    model.load_state_dict(synth.synth_state_dict(seed=0))
+    pipe = types.SimpleNamespace(model=model, device=torch.device("cuda"), frequencies=[18, 38, 120, 200])
+    single = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16))
+    assert len(single) == 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_tiled_rank_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        multi = out["chunks"]
+    for (s0, e0, o0), (s1, e1, o1) in zip(single, multi):
+        assert (s0, e0) == (s1, e1) and np.array_equal(o0, o1) and (o0 != 0).any()
