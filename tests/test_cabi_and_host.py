@@ -119,3 +119,57 @@ def test_bucket_and_shard_plans():
     assert parallel.shard_indices(10, 1, 4) == [1, 5, 9]
     allidx = sorted(i for r in range(8) for i in parallel.shard_indices(95, r, 8))
     assert allidx == list(range(95))             # 95 patches of one 4096-ping chunk
+
+
+def test_pr_report_csv_has_the_reference_dataframe_layout(tmp_path):
+    """validate_model_testing's csv (reference pipeline.py:358-361 writes DataFrame(metrics).to_csv): index column,
+    precision / recall / thresholds / F1, NaN threshold in the last row."""
+    import csv
+    import numpy as np
+    from crimac_classifiers_unet_amd.pipeline import SegPipe, write_pr_csv
+    hp = np.zeros(16384, dtype=np.int64)
+    hn = np.zeros(16384, dtype=np.int64)
+    bits = lambda v: int(np.float16(v).view(np.uint16))
+    hp[bits(0.9)], hp[bits(0.6)], hn[bits(0.7)], hn[bits(0.1)] = 3, 1, 2, 10
+    m = SegPipe.compute_evaluation_metrics_from_histograms(hp, hn)
+    # same numbers as sklearn on the expanded vectors
+    from sklearn.metrics import precision_recall_curve
+    y = np.r_[np.ones(4), np.zeros(12)]
+    sc = np.r_[[0.9] * 3, [0.6], [0.7] * 2, [0.1] * 10].astype(np.float16)
+    p, r, t = precision_recall_curve(y, sc, pos_label=1)
+    assert np.allclose(m["precision"], p) and np.allclose(m["recall"], r) and np.allclose(m["thresholds"], t)
+    m["thresholds"] = np.append(m["thresholds"], np.nan)
+    write_pr_csv(m, tmp_path / "pr.csv")
+    rows = list(csv.reader(open(tmp_path / "pr.csv")))
+    assert rows[0] == ["", "precision", "recall", "thresholds", "F1"]
+    assert len(rows) == len(p) + 1 and rows[-1][3] == "" and rows[1][0] == "0"
+    assert abs(float(rows[1][1]) - p[0]) < 1e-15
+
+
+def test_evaluate_flow_needs_the_reference_data_stack_or_injected_factories():
+    from crimac_classifiers_unet_amd import evaluate
+    with pytest.raises(ImportError, match="dataset_cls"):
+        evaluate.validate_model_survey_memm([], None, [], [256, 256], 20, "all", 4, 0, "/tmp", "/tmp")
+
+
+def test_spawned_ranks_time_out_and_are_reaped():
+    import sys
+    from crimac_classifiers_unet_amd import launch
+    rc, _ = launch.spawn_ranks([sys.executable, "-c", "import time; time.sleep(60)"], 2, timeout=2)
+    assert rc != 0
+
+
+def test_planes_argument_layout_matches_the_header():
+    text = open(os.path.join(ROOT, "include", "crimac_unet_hip.h")).read()
+    assert "#define CRIMAC_PLANES_FWD_FP16 16" in text and "#define CRIMAC_PLANES_DG_FP16 32" in text
+    assert "#define CRIMAC_F32H3_WSHIFT 8" in text
+    assert hip.PLANES_FP16 == 1 | 16 | 32 and hip.PLANES_F32H3 == 2 | 16 | (8 << 8)
+    assert hip.PREC_NAMES == {"bf16": 0, "f32x3": 1, "f32x6": 2, "fp16": 3, "f32h3": 4}
+    assert hip.PREC_BACKWARD[hip.PREC_F32H3] == hip.PREC_F32X3
+    lib = hip.load_library()
+    # argument checks of the packers run without a GPU: a plane count of 0 or stray bits are refused
+    assert lib.crimac_pack_layers(None, 1, 1, None) < 0
+    import ctypes
+    d = (hip.LayerDesc * 1)()
+    assert lib.crimac_pack_layers(ctypes.byref(d), 1, 0, None) < 0
+    assert lib.crimac_pack_layers(ctypes.byref(d), 1, 2 | 64, None) < 0
