@@ -232,8 +232,8 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
         note("fetch_s", t0)
         return grid, lo, hi, d_t, l_t, stage_misc[k][:hi - lo + 4 * P]
 
-    pinned = [torch.empty((2, n_range, widest), dtype=torch.float16 if f16 else torch.float32).pin_memory()
-              for _ in range(2)]
+    pinned = [torch.empty(2 * n_range * widest, dtype=torch.float16 if f16 else torch.float32).pin_memory()
+              for _ in range(2)]                 # flat: every chunk's [2, range, e - s] view of it is contiguous
     events = [torch.cuda.Event() for _ in range(2)]
     pending = None                      # (s, e, slot) of the chunk whose D2H copy is in flight
     main = torch.cuda.current_stream()
@@ -274,7 +274,7 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                 ev1.record()
                 stats.setdefault("gpu_events", []).append((ev0, ev1))
             computed[slot].record()
-            pinned[slot][:, :, :e - s].copy_(out, non_blocking=True)
+            pinned[slot][:out.numel()].view(out.shape).copy_(out, non_blocking=True)
             events[slot].record()
             note("enqueue_s", t0)
             if pending is not None:
@@ -283,13 +283,13 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                 events[pslot].synchronize()
                 note("wait_gpu_s", t0)
                 t0 = tick()
-                res = pinned[pslot][:, :, :pe - ps].numpy().copy()
+                res = pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
                 note("copy_out_s", t0)
                 yield ps, pe, res
             pending = (s, e, slot)
         ps, pe, pslot = pending
         events[pslot].synchronize()
-        yield ps, pe, pinned[pslot][:, :, :pe - ps].numpy().copy()
+        yield ps, pe, pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
 
 
 def predict_echogram_memm(echogram, segpipe, patch_size, patch_overlap, batch_size, predict_fn=None, **kwargs):

@@ -983,3 +983,41 @@ def test_f32h3_eval_is_fp32_class_and_train_step_matches_golden(full_case):
         assert abs(float(g.double().norm()) - gn) <= tol * gn, (k, float(g.double().norm()), gn)
         if "grad/" + k in fix.files:
             assert l2rel(g, fix["grad/" + k]) < tol, k
+
+
+@pytest.mark.parametrize("cfg", [dict(in_channels=11), dict(depth=3), dict(depth=4, in_channels=6, start_filts=128),
+                                 dict(batch=1, hw=(16, 48)), dict(batch=5, hw=(80, 32))])
+def test_other_architectures_and_ragged_shapes_match_oracle(cfg):
+    """Parity away from the benchmark shape: metadata planes as extra INPUT channels (pipeline.py:392: 4 + 7 = 11),
+    shallower nets, odd batch sizes, the smallest legal crop (16 px for depth 5) and non-square crops -- eval logits
+    and one training step (loss, head / first-layer / deepest-layer gradients) against the oracle."""
+    depth, cin, sf = cfg.get("depth", 5), cfg.get("in_channels", 4), cfg.get("start_filts", 64)
+    B = cfg.get("batch", 2)
+    H, W = cfg.get("hw", (32, 48))
+    sd = synth.synth_state_dict(in_channels=cin, depth=depth, start_filts=sf, seed=9)
+    x = torch.from_numpy(synth.synth_echogram_batch(B, cin, H, W, seed=91))
+    lab = torch.from_numpy(synth.synth_labels(B, H, W, seed=92))
+    m = pkg.UNet_Baseline(3, cin, depth=depth, start_filts=sf, precision="f32x6")
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    ref = orc.predict(sd, x)
+    assert rel(out, ref) < 1e-5
+    ref_loss, ref_logits, ref_grads, ref_stats = orc.loss_and_grads(sd, x, lab)
+    m.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    logits = m(x.cuda())
+    loss = crit(logits, lab.long().cuda())
+    loss.backward()
+    assert rel(logits.detach(), ref_logits) < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    g = {k: p.grad for k, p in m.named_parameters()}
+    deep = f"down_convs.{depth - 1}.main.3.weight"
+    for k in ("conv_final.weight", "down_convs.0.main.0.weight", deep, "up_convs.0.upconv.weight"):
+        # tiny crops leave few pixels per BatchNorm channel at the deepest level: gradients there are ill-conditioned
+        assert l2rel(g[k], ref_grads[k]) < (5e-2 if min(H, W) >> (depth - 1) <= 2 else 2e-2), k
+    sdm = m.state_dict()
+    for k, v in ref_stats.items():
+        if "running" in k:
+            assert rel(sdm[k].float(), v.float()) < 1e-3, k
