@@ -441,13 +441,22 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
       const long t = r / Wp;
       const int yp = (int)(t % Hp);
       const long b = t / Hp;
-      float g[8], av[4][8];
+      float g[8], av[4][8], yv[4][8];
       load8(dp + r * dp_ld + c0, g);
       long pix[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         pix[d] = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
-        load8(a + pix[d] * a_ld + c0, av[d]);
+        if constexpr (BNB) {
+          // the block's conv output y is read for the fused sums anyway: the pooled activation is rebuilt from it,
+          // a = round(relu(y * scale + shift)) exactly as bn_act_pool stored it (same fma, same rounding, so the same
+          // ties and the same first maximum) -- `a` is not read at all (one tensor less: 0.5 GB per step)
+          load8(reinterpret_cast<const T*>(bnb.y) + pix[d] * bnb.y_ld + c0, yv[d]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) av[d][j] = (float)(T)fmaxf(yv[d][j] * k.sc[j] + k.sh[j], 0.f);
+        } else {
+          load8(a + pix[d] * a_ld + c0, av[d]);
+        }
       }
       int arg[8];
 #pragma unroll
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
           if constexpr (BNB) o[j] = (float)(T)o[j];          // the sums see da as it is stored
         }
         store8(da + pix[d] * da_ld + c0, o);
-        if constexpr (BNB) bnb_accum<T>(bnb, k, pix[d], c0, o, d1, d2);
+        if constexpr (BNB) bnb_accum_v(k, yv[d], o, d1, d2);
       }
     }
   }

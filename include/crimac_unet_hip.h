@@ -231,7 +231,9 @@ int crimac_bn_act_pool(int prec, const void* y, long y_ld, const float* scale, c
  * aten::max_pool2d; `a` is the forward activation that was pooled.  ds may be NULL.
  * stat_sum != NULL: `da` feeds a BatchNorm+ReLU block; its backward sums (as crimac_conv3x3 stat_mode 2:
  * y = bnb_y, rows of bnb_vec = mean, invstd, scale, shift) are accumulated into [stat_replicas][C] while
- * da is produced (crimac_bn_bwd_reduce fused away; finish with crimac_sum_replicas).  crimac_head_bwd
+ * da is produced (crimac_bn_bwd_reduce fused away; finish with crimac_sum_replicas).  In that form `a` MUST be
+ * that block's stored activation round(relu(bnb_y * scale + shift)): the kernel rebuilds it from bnb_y (which it
+ * reads for the sums anyway) instead of reading `a` -- bit-identical, one tensor less.  crimac_head_bwd
  * takes the same seven arguments for its dx. */
 int crimac_unpool_add(int prec, const void* dp, long dp_ld, const void* a, long a_ld, const void* ds,
                       long ds_ld, void* da, long da_ld, int B, int H, int W, int C, const void* bnb_y,
