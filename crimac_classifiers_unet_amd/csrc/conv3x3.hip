@@ -317,8 +317,13 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
                        const void* w_hi, const void* w_lo, const float* bias, void* out,
                        long out_ld, int relu, int stat_mode, double* stat_sum, double* stat_sumsq,
                        int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
-                       long bnb_stride, int n_first, int n_count, void* stream) {
+                       long bnb_stride, int n_first, int n_count, void* stream, void* pool_out = nullptr,
+                       long pool_ld = 0) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "conv3x3: bad precision %d", prec);
+  CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0 && pool_ld >= N && pool_ld % 8 == 0 && stat_mode == 0 &&
+                               n_first == 0 && n_count == N && !(Cin == 16 && N == 64)),
+                 "conv3x3_pool: needs even H, W, pool_ld >= N (multiple of 8), no fused reduction, the whole channel "
+                 "range, and not the first-layer kernel");
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
   CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0,
@@ -341,6 +346,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   e.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
   e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
   e.acc_scale = prec == CRIMAC_PREC_F32H3 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
+  e.pool_out = pool_out; e.pool_ld = pool_ld;
   hipStream_t st = (hipStream_t)stream;
   const bool n128 = N % 128 == 0;
   // measured (tools/bench_conv.py): the 256-pixel tile of THIS kernel (4 waves, 1 workgroup/CU) loses
@@ -398,4 +404,15 @@ extern "C" int crimac_conv3x3_cols(int prec, const void* in, long in_ld, int B, 
                                    long bnb_stride, int n_first, int n_count, void* stream) {
   return conv3x3_run(prec, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld, relu, stat_mode, stat_sum,
                      stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, n_first, n_count, stream);
+}
+
+// Eval-mode encoder block tail (conv3x3 + folded BatchNorm + ReLU, then nn.MaxPool2d(2, 2), unet.py:85-92): the same
+// convolution that ALSO writes the 2x2/2 max-pool of its stored output -- the pooled tensor comes out of the conv
+// epilogue (the tile is still in LDS) instead of a second pass over the skip tensor.
+extern "C" int crimac_conv3x3_pool(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                                   const void* w_hi, const void* w_lo, const float* bias, void* out, long out_ld,
+                                   int relu, void* pool_out, long pool_ld, void* stream) {
+  CRIMAC_REQUIRE(pool_out, "conv3x3_pool: pool_out is NULL (use crimac_conv3x3)");
+  return conv3x3_run(prec, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld, relu, 0, nullptr, nullptr, 1,
+                     nullptr, 0, nullptr, 0, 0, N, stream, pool_out, pool_ld);
 }

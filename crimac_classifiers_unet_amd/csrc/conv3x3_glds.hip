@@ -689,9 +689,10 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   unsigned char* wl = smem;
   const int tid = threadIdx.x, team = tid >> 8, tt = tid & 255, lane = tid & 63, wave = tt >> 6;
   unsigned char* halo = smem + W_BYTES + team * H_BYTES;
-  unsigned char* slab = halo + wave * SLAB;
-  float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);          // [2][64]
   const EpiParams& e = p.epi;
+  unsigned char* slab0 = halo + wave * 2 * SLAB;           // two wave-private slabs (image rows 2k, 2k + 1): with a
+  const bool do_pool = e.pool_out != nullptr;              // fused max-pool both rows of a window must be at hand
+  float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);          // [2][64]
   const T16* inp = reinterpret_cast<const T16*>(p.in);
   T16* outp = reinterpret_cast<T16*>(e.out);
   constexpr int mode = MODE;
@@ -814,6 +815,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = y0 + wave * 4 + i;
+        unsigned char* slab = slab0 + (i & 1) * SLAB;
         float okm[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) okm[r] = (y < p.H && x0 + (lane >> 4) * 4 + r < p.W) ? 1.f : 0.f;
@@ -852,6 +854,22 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
                 d2[kk] += dz * (yv[kk] - mu[kk]);
               }
             }
+          }
+        }
+        if (do_pool && (i & 1)) {
+          // rows y - 1 and y are in the two slabs: pooled row (y >> 1), 8 pooled pixels x 8 channel chunks = 64 lanes
+          const int pxl = lane >> 3, yp = y >> 1, xp = (x0 >> 1) + pxl;
+          if (y < p.H && xp < (p.W >> 1)) {
+            float m[8], v[8];
+            load8(reinterpret_cast<const T16*>(slab0 + (2 * pxl) * SLAB_PITCH) + c8 * 8, m);
+#pragma unroll
+            for (int d = 1; d < 4; ++d) {
+              load8(reinterpret_cast<const T16*>(slab0 + (d >> 1) * SLAB + (2 * pxl + (d & 1)) * SLAB_PITCH) + c8 * 8, v);
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) m[kk] = fmaxf(m[kk], v[kk]);
+            }
+            store8(reinterpret_cast<T16*>(e.pool_out) + (((long)b * (p.H >> 1) + yp) * (p.W >> 1) + xp) * e.pool_ld +
+                       p.n_first + c8 * 8, m);
           }
         }
       }

@@ -25,6 +25,8 @@ struct EpiParams {
   const float* bnb_vec;   // rows: mean, invstd, scale, shift; row stride bnb_stride
   long bnb_stride;
   float acc_scale;        // the accumulators are multiplied by this before the bias (F32H3: 2^-WSHIFT; else 1)
+  void* pool_out;         // != NULL: also the 2x2/2 max-pool of the stored tile, [B][H/2][W/2][pool_ld] (eval path:
+  long pool_ld;           //          nn.MaxPool2d behind the block, unet.py:85-86 -- no second pass over the output)
 };
 
 // Accumulator access for the two MFMA shapes (C/D layouts: cdna_hip_programming.md §3):
@@ -161,6 +163,29 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
           atomicAdd(&sstat[BN + c8 * 8 + k], d2[k]);
         }
       }
+    }
+  }
+  if (e.pool_out) {
+    // the staged tile still holds the values as stored: 2x2 windows never straddle tiles (y0, x0 are even)
+    constexpr int CPR = BN / 8;
+    constexpr int PROWS = BM / 32;                      // pooled rows of the tile (tile rows / 2), 8 pooled columns
+    TA* pool = reinterpret_cast<TA*>(e.pool_out);
+    const int Hp = e.H >> 1, Wp = e.W >> 1;
+    for (int i = tid; i < PROWS * 8 * CPR; i += NTHREADS) {
+      const int c8 = i % CPR, pp = i / CPR;
+      const int pyl = pp >> 3, pxl = pp & 7;
+      const int yp = (y0 >> 1) + pyl, xp = (x0 >> 1) + pxl;
+      if (yp >= Hp || xp >= Wp) continue;
+      const int r00 = (2 * pyl) * 16 + 2 * pxl;
+      float m[8], v[8];
+      load8(reinterpret_cast<const TA*>(stage + r00 * STAGE_PITCH) + c8 * 8, m);
+#pragma unroll
+      for (int d = 1; d < 4; ++d) {
+        load8(reinterpret_cast<const TA*>(stage + (r00 + (d >> 1) * 16 + (d & 1)) * STAGE_PITCH) + c8 * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
+      }
+      store8(pool + (((long)b * Hp + yp) * Wp + xp) * e.pool_ld + n0 + c8 * 8, m);
     }
   }
   if (mode) {

@@ -492,6 +492,7 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
     fuse_bn_bwd = os.environ.get("CRIMAC_FUSE_BNB", "1") != "0"   # BN-backward sums inside the dgrad conv
+    fuse_eval_pool = os.environ.get("CRIMAC_FUSE_EVAL_POOL", "1") != "0"   # eval: max-pool in the conv epilogue
     fuse_up_bnb = os.environ.get("CRIMAC_FUSE_UPBNB", "1") != "0"  # ... and inside the transposed-conv dgrad
     # BatchNorm+ReLU of the last decoder block applied inside the 1x1 head (needs fuse_bn_bwd: the head's backward
     # rebuilds its input from the y it reads for the fused sums)
@@ -777,9 +778,15 @@ class UNetEngine:
             else:
                 pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
                 self._conv3x3(cur, pe1, pe1["bias"], a1, B, h, w, b1.cin_pad, c, relu=True, cin_real=b1.cin)
-                self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
-                if pool is not None:
-                    self._act(b2, a2, None, pool, B, h, w, train=False)
+                if pool is not None and self.fuse_eval_pool and self.conv_impl == "halo":
+                    # the max-pool comes out of the conv epilogue (the tile is still in LDS)
+                    call("crimac_conv3x3_pool", self.prec, a1.p, a1.ld, B, h, w, c, c, ptr(pe2["fwd_hi"]),
+                         ptr(pe2["fwd_lo"]), ptr(pe2["bias"]), a2.p, a2.ld, 1, pool.p, pool.ld,
+                         flops=2.0 * 9 * c * c * B * h * w)
+                else:
+                    self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
+                    if pool is not None:
+                        self._act(b2, a2, None, pool, B, h, w, train=False)
             cur = pool if pool is not None else a2
         for j in range(D - 1):
             L = D - 2 - j

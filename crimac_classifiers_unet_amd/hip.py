@@ -38,6 +38,7 @@ SIGNATURES = {
                           _vp, _l, _i, _i, _i, _vp],
     "crimac_conv3x3": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i,
                        _vp, _l, _vp, _l, _vp],
+    "crimac_conv3x3_pool": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp],
     "crimac_conv3x3_cols": [_i, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i,
                             _vp, _l, _vp, _l, _i, _i, _vp],
     "crimac_upconv2x2_dgrad_bnb": [_vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _vp],

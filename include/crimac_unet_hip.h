@@ -141,6 +141,13 @@ int crimac_conv3x3_cols(int prec, const void* in, long in_ld, int B, int H, int 
                    int relu, int stat_mode, double* stat_sum, double* stat_sumsq, int stat_replicas,
                    const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, int n_first, int n_count, void* stream);
 
+/* Eval-mode encoder block tail: crimac_conv3x3 (bias / folded BatchNorm / ReLU) that ALSO writes
+ * pool_out [B][H/2][W/2][pool_ld] = nn.MaxPool2d(2, 2) (unet.py:85-86) of its stored output from the epilogue's
+ * staged tile -- no second pass over the skip tensor.  H, W even; not for the first-layer shape (Cin 16 -> 64). */
+int crimac_conv3x3_pool(int prec, const void* in, long in_ld, int B, int H, int W, int Cin, int N,
+                        const void* w_hi, const void* w_lo, const float* bias, void* out, long out_ld, int relu,
+                        void* pool_out, long pool_ld, void* stream);
+
 /* Weight gradient (aten::convolution_backward weight half, pipeline.py:177):
  *   dw[t][f][s] += sum_pixels F[p][f] * S[shift_t(p)][s]   (fp32 atomics; caller zeroes dw)
  *   mode 0 (conv3x3): F=dY [B][Hf][Wf][CF=Cout], S=X same grid [CS=Cin], 9 taps

@@ -784,3 +784,38 @@ def test_conv3x3_forward_f32h3_fp16_planes(shape):
     dwp = torch.zeros(9 * Co * cin_pad, dtype=torch.float32, device="cuda")
     with pytest.raises(hip.HipLibraryError, match="forward-operand"):
         call("crimac_wgrad", hip.PREC_NAMES["f32h3"], 0, ptr(out), Co, Co, ptr(xin), cin_pad, cin_pad, B, H, W, ptr(dwp), 0)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "f32x3"])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 128, 128), (3, 256, 256, 64, 64), (1, 24, 40, 64, 64), (2, 16, 48, 256, 128)])
+def test_conv3x3_with_fused_maxpool_equals_conv_then_pool(prec, shape):
+    """crimac_conv3x3_pool (eval encoder tail): the output equals crimac_conv3x3 bit for bit and pool_out equals
+    crimac_bn_act_pool (identity + 2x2 max-pool) of it -- channel-split kernel, persistent 64-channel kernel
+    (3 x 256 x 256: 768 tiles), pixel-split kernel with partial tiles, and the fp32 register-staged kernel."""
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(51)
+    P = hip.PREC_NAMES[prec]
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    bd = torch.randn(Co, generator=g).cuda()
+    fh, fl, _, _ = pack_conv(w, prec, Ci, dgrad=False)
+    xin = to_nhwc(x, prec)
+    M = B * H * W
+    ld_o, ld_p = Co + 8, Co + 16                       # channel slices of wider buffers
+    ref = torch.zeros(M, ld_o, dtype=_dt(prec), device="cuda")
+    call("crimac_conv3x3", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(ref), ld_o, 1, 0,
+         None, None, 1, None, 0, None, 0)
+    pool_ref = torch.zeros(M // 4, ld_p, dtype=_dt(prec), device="cuda")
+    call("crimac_bn_act_pool", P, ptr(ref), ld_o, None, None, 0, None, 0, ptr(pool_ref), ld_p, B, H, W, Co)
+    out = torch.zeros(M, ld_o, dtype=_dt(prec), device="cuda")
+    pool = torch.zeros(M // 4, ld_p, dtype=_dt(prec), device="cuda")
+    call("crimac_conv3x3_pool", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(out), ld_o, 1,
+         ptr(pool), ld_p)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(pool, pool_ref) and float(pool[:, :Co].float().abs().max()) > 0
+    pr = F.max_pool2d(torch.relu(F.conv2d(x, _round(w, prec), bd.cpu(), padding=1)), 2, 2)
+    assert relerr(from_nhwc(pool, B, H // 2, W // 2, Co), pr) < TOL[prec]
+    with pytest.raises(hip.HipLibraryError):           # odd size: refused, not silently wrong
+        call("crimac_conv3x3_pool", P, ptr(xin), Ci, B, H - 1, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(out), ld_o, 1,
+             ptr(pool), ld_p)
