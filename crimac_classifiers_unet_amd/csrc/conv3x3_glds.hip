@@ -677,22 +677,35 @@ __device__ __forceinline__ void wg_barrier_lds() {
   asm volatile("" ::: "memory");
 }
 
-template <int MODE, typename T16>   // statistics mode of the epilogue (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+// Every global access of the tile loop is a BUFFER load / store whose per-lane offset is out of range where the
+// pixel is outside the image (loads return zeros, stores are dropped): no branch around any of them, so every wave
+// issues the same number of vector-memory operations per tile and hipcc's wait-count pass can count them -- the
+// wait in front of the halo's register -> LDS move becomes `s_waitcnt vmcnt(<stores of the previous tile>)`.  With
+// the loads and stores under `if (pixel inside)` branches (the first form of this kernel) that wait was vmcnt(0):
+// every tile waited for the previous tile's output stores to be ACKNOWLEDGED before its MFMA phase began, which is
+// why the MFMA phase (83 us) and the memory phase (110 us) added up to the 195 us measured.  The prologue issues one
+// all-out-of-range epilogue so that the loop entry and the back edge carry the same operation count (the pass
+// merges the two states conservatively).
+template <int MODE, bool POOL, typename T16>   // epilogue statistics (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums); fused 2x2 max-pool
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_p64_kernel(ConvParams p, int ntiles) {
+  static_assert(!POOL || MODE == 0, "the fused max-pool is an inference epilogue");
   constexpr int BN = 64, NT = 4;
   constexpr int W_BYTES = 9 * BN * RB;               // 73728
   constexpr int H_BYTES = HALO_ROWS * RB;            // 41472
   constexpr int NHU = (HALO_ROWS * 8 + 255) / 256;   // 16-byte halo units per thread: 11
   constexpr int SLAB_PITCH = BN * 2 + 16, SLAB = 16 * SLAB_PITCH;
+  constexpr unsigned OOB = 0x80000000u;              // >= num_records of the rebased buffer resources
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wl = smem;
-  const int tid = threadIdx.x, team = tid >> 8, tt = tid & 255, lane = tid & 63, wave = tt >> 6;
+  const int tid = threadIdx.x, tt = tid & 255, lane = tid & 63;
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane(tt >> 6);
   unsigned char* halo = smem + W_BYTES + team * H_BYTES;
   const EpiParams& e = p.epi;
-  unsigned char* slab0 = halo + wave * 2 * SLAB;           // two wave-private slabs (image rows 2k, 2k + 1): with a
-  const bool do_pool = e.pool_out != nullptr;              // fused max-pool both rows of a window must be at hand
-  float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);          // [2][64]
+  constexpr int NSL = 2;                                   // wave-private slabs: image rows 2k, 2k + 1 (the fused max-pool
+  unsigned char* slab0 = halo + wave * NSL * SLAB;         // needs both rows of a window)
+  static_assert(4 * NSL * SLAB <= H_BYTES, "the slabs live in the team's (dead) halo buffer");
+  float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);
   const T16* inp = reinterpret_cast<const T16*>(p.in);
   T16* outp = reinterpret_cast<T16*>(e.out);
   constexpr int mode = MODE;
@@ -738,42 +751,179 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
     y0 = (q % p.tiles_y) * TR;
     x0 = txi * TC;
   };
-  u32x4 hreg[NHU];
-  auto fetch_halo = [&](int tile) {
-    int b, y0, x0;
-    tile_geo(tile, b, y0, x0);
+  // this lane's halo units: byte offset from the halo's first pixel (y0 - 1, x0 - 1) and its (row, column) there
+  // (H and W are multiples of the tile size here -- launch_p64 -- so a halo pixel is outside the image only on the
+  // tile's first / last row or column facing an image border: four flag bits, kept in the idle low bits of the offset)
+  unsigned h_rel[NHU];
 #pragma unroll
-    for (int i = 0; i < NHU; ++i) {
-      const int u = tt + i * 256;
-      const int row = u >> 3, c = u & 7;
-      const int hy = row / HP, hx = row - hy * HP;
-      const int y = y0 + hy - 1, x = x0 + hx - 1;
-      hreg[i] = u32x4{0, 0, 0, 0};
-      if (u < HALO_ROWS * 8 && y >= 0 && y < p.H && x >= 0 && x < p.W)
-        hreg[i] = *reinterpret_cast<const u32x4*>(inp + (((long)b * p.H + y) * p.W + x) * p.in_ld +
-                                                  ((c ^ halo_swz(hx)) * 8));
+  for (int i = 0; i < NHU; ++i) {
+    const int u = tt + i * 256;
+    const int row = u >> 3, c = u & 7;
+    const int hy = row / HP, hx = row - hy * HP;
+    const unsigned off = (unsigned)((((long)hy * p.W + hx) * p.in_ld + ((c ^ halo_swz(hx)) * 8)) * 2);     // % 16 == 0
+    const unsigned edge = (hy == 0 ? 1u : 0u) | (hx == 0 ? 2u : 0u) | (hy == TR + 1 ? 4u : 0u) | (hx == TC + 1 ? 8u : 0u);
+    h_rel[i] = u < HALO_ROWS * 8 ? (off | edge) : (OOB | 15u);
+  }
+  u32x4 hreg[NHU];
+  auto fetch_halo = [&](int tile, bool valid) {      // always NHU loads per lane
+    int b, y0, x0;
+    tile_geo(valid ? tile : 0, b, y0, x0);
+    // image borders this tile touches (no tile: all four, and the out-of-range bit of every offset)
+    const unsigned border = valid ? ((y0 == 0 ? 1u : 0u) | (x0 == 0 ? 2u : 0u) | (y0 + TR >= p.H ? 4u : 0u) |
+                                     (x0 + TC >= p.W ? 8u : 0u)) : 15u;
+    const unsigned kill = valid ? 0u : OOB;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T16*>(inp + (((long)b * p.H + y0 - 1) * p.W + x0 - 1) * p.in_ld), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NHU; ++i)
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs, (int)((h_rel[i] & border) ? OOB : ((h_rel[i] & ~15u) | kill)), 0, 0);
+  };
+
+  // this lane's output units: rows wave * 4 + i, pixels (lane >> 3) + 8 k, channel chunk c8
+  const long out_row = (long)p.W * e.out_ld * 2, y_row = mode == 2 ? (long)p.W * e.bnb_y_ld * 2 : 0;
+  const unsigned o_rel = (unsigned)((wave * 4) * out_row + (lane >> 3) * e.out_ld * 2 + c8 * 16);
+  const unsigned y_rel = mode == 2 ? (unsigned)((wave * 4) * y_row + (lane >> 3) * e.bnb_y_ld * 2 + c8 * 16) : 0u;
+  const int Hp = p.H >> 1, Wp = p.W >> 1;
+  const unsigned q_rel = POOL ? (unsigned)(((long)(wave * 2) * Wp + (lane >> 3)) * e.pool_ld * 2 + c8 * 16) : 0u;
+
+  // writes one tile (accumulators -> bias / ReLU -> wave-private slabs -> 16-byte stores) and folds the statistics;
+  // valid == false: the same instruction stream with every store and load out of range
+  auto epilogue = [&](const f32x4 (&acc)[4][NT], bool valid, int b, int y0, int x0) {
+    const int Hl = valid ? p.H : 0;                      // (as in fetch_halo)
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        outp + (((long)b * p.H + y0) * p.W + x0) * e.out_ld + p.n_first, 0, 0x7FFFFFFF, 0x00020000);
+    // mode 2: the saved forward outputs of image row i, requested one row ahead and BEFORE that row's stores, so
+    // that their wait leaves the youngest stores in flight.  (All four rows up front -- 32 registers -- would leave
+    // the whole tile's stores in flight, but hipcc then spills the prefetched halo into scratch, i.e. into vmcnt.)
+    u32x4 yreg[2][2];
+    auto load_y = [&](int i) {
+      if constexpr (mode == 2) {
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T16*>(reinterpret_cast<const T16*>(e.bnb_y) + (((long)b * p.H + y0) * p.W + x0) * e.bnb_y_ld +
+                             p.n_first), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool ok = (y0 + wave * 4 + i < Hl) & (x0 + (lane >> 3) + 8 * k < p.W);
+          yreg[i & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(
+              ry, (int)(ok ? y_rel + (unsigned)(i * y_row + 8 * k * e.bnb_y_ld * 2) : OOB), 0, 0);
+        }
+      }
+    };
+    auto to_slab = [&](int i) {                  // bias / ReLU / rounding, one image row -> its slab (+ statistics)
+      const int y = y0 + wave * 4 + i;
+      unsigned char* slab = slab0 + (i % NSL) * SLAB;
+      bool okm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) okm[r] = (y < Hl) & (x0 + (lane >> 4) * 4 + r < p.W);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = (lane >> 4) * 4 + r;
+          float v = acc[i][j][r] + bv[j];
+          if (e.relu) v = fmaxf(v, 0.f);
+          const T16 q = (T16)v;
+          *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
+          if (mode == 1) {
+            const float vs = (float)q;        // statistics of the value as STORED (pixels outside the image: 0)
+            cs1[j] += okm[r] ? vs : 0.f;
+            cs2[j] += okm[r] ? vs * vs : 0.f;
+          }
+        }
+    };
+    auto from_slab = [&](int i) {                // (wave-private slab: the LDS operations of one wave execute in order)
+      const int y = y0 + wave * 4 + i;
+      unsigned char* slab = slab0 + (i % NSL) * SLAB;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int px = (lane >> 3) + 8 * k;
+        const T16* sp = reinterpret_cast<const T16*>(slab + px * SLAB_PITCH) + c8 * 8;
+        const bool ok = (y < Hl) & (x0 + px < p.W);
+        const u32x4 val = *reinterpret_cast<const u32x4*>(sp);
+        __builtin_amdgcn_raw_buffer_store_b128(val, ro, (int)(ok ? o_rel + (unsigned)(i * out_row + 8 * k * e.out_ld * 2) : OOB), 0, 0);
+        if constexpr (mode == 2) {
+          float g[8], yv[8];
+          load8(sp, g);
+          load8(reinterpret_cast<const T16*>(&yreg[i & 1][k]), yv);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const float dz = (ok && (yv[kk] * sc[kk] + sh[kk]) > 0.f) ? g[kk] : 0.f;
+            d1[kk] += dz;
+            d2[kk] += dz * (yv[kk] - mu[kk]);
+          }
+        }
+      }
+      if constexpr (POOL) {
+        if (i & 1) {
+          // rows y - 1 and y are in the two slabs: pooled row (y >> 1), 8 pooled pixels x 8 channel chunks = 64 lanes
+          const int pxl = lane >> 3;
+          const bool ok = (y < Hl) & ((x0 >> 1) + pxl < Wp);
+          float m[8], v[8];
+          load8(reinterpret_cast<const T16*>(slab0 + (2 * pxl) * SLAB_PITCH) + c8 * 8, m);
+#pragma unroll
+          for (int d = 1; d < 4; ++d) {
+            load8(reinterpret_cast<const T16*>(slab0 + (d >> 1) * SLAB + (2 * pxl + (d & 1)) * SLAB_PITCH) + c8 * 8, v);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) m[kk] = fmaxf(m[kk], v[kk]);
+          }
+          u32x4 pv;
+          store8(reinterpret_cast<T16*>(&pv), m);
+          const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+              reinterpret_cast<T16*>(e.pool_out) + (((long)b * Hp + (y0 >> 1)) * Wp + (x0 >> 1)) * e.pool_ld + p.n_first,
+              0, 0x7FFFFFFF, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b128(pv, rq, (int)(ok ? q_rel + (unsigned)((long)(i >> 1) * Wp * e.pool_ld * 2) : OOB), 0, 0);
+        }
+      }
+    };
+    load_y(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      to_slab(i);
+      if (i + 1 < 4) load_y(i + 1);
+      from_slab(i);
     }
   };
 
   const int stride = 2 * gridDim.x;
   int tile = 2 * blockIdx.x + team;
-  if (tile < ntiles) fetch_halo(tile);
+  fetch_halo(tile, tile < ntiles);
+  {
+    f32x4 zacc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zacc[i][j][r] = 0.f;
+    epilogue(zacc, false, 0, 0, 0);             // (see above: equal operation counts on both edges into the loop)
+  }
   // both teams run the same number of iterations (the barriers are workgroup-wide); a team without a tile idles
   const int niter = (ntiles - 2 * (int)blockIdx.x + stride - 1) / stride;
+  CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
+#ifdef CRIMAC_DIAG_PHASES
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, ph_t = dg_t0;
+#define CRIMAC_PH(k) { unsigned long long tn; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[k] += tn - ph_t; ph_t = tn; }
+#else
+#define CRIMAC_PH(k)
+#endif
   for (int it = 0; it < niter; ++it, tile += stride) {
     const bool active = tile < ntiles;
-    int b = 0, y0 = 0, x0 = 0;
-    if (active) tile_geo(tile, b, y0, x0);
+    int b, y0, x0;
+    tile_geo(active ? tile : 0, b, y0, x0);
     wg_barrier_lds();                           // slabs of the previous tile consumed (and weights in place)
-    if (active) {
+    CRIMAC_PH(0)
 #pragma unroll
-      for (int i = 0; i < NHU; ++i) {
-        const int u = tt + i * 256;
-        if (u < HALO_ROWS * 8) *reinterpret_cast<u32x4*>(halo + u * 16) = hreg[i];
-      }
+    for (int i = 0; i < NHU; ++i) {
+      const int u = tt + i * 256;
+      if (u < HALO_ROWS * 8) *reinterpret_cast<u32x4*>(halo + u * 16) = hreg[i];
     }
     wg_barrier_lds();                           // halo in place
-    if (tile + stride < ntiles) fetch_halo(tile + stride);
+    CRIMAC_PH(1)
+    fetch_halo(tile + stride, tile + stride < ntiles);
+    CRIMAC_PH(4)
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -782,7 +932,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    if (active) {
+    if (active) {                               // (no vector-memory operation inside this branch)
       // (tap rows not unrolled: a fully unrolled 9-tap body lets the compiler hoist fragment reads until the
       // long-lived statistics registers spill)
 #pragma unroll 1
@@ -811,70 +961,22 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
       }
     }
     wg_barrier_lds();                           // halo consumed: its buffer now holds the output slabs
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int y = y0 + wave * 4 + i;
-        unsigned char* slab = slab0 + (i & 1) * SLAB;
-        float okm[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) okm[r] = (y < p.H && x0 + (lane >> 4) * 4 + r < p.W) ? 1.f : 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int px = (lane >> 4) * 4 + r;
-            float v = acc[i][j][r] + bv[j];
-            if (e.relu) v = fmaxf(v, 0.f);
-            const T16 q = (T16)v;
-            *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
-            if (mode == 1) {
-              const float vs = (float)q;        // statistics of the value as STORED
-              const float vm = vs * okm[r];     // (0 for pixels outside the image: partial tiles)
-              cs1[j] += vm;
-              cs2[j] += vm * vs;
-            }
-          }
-        // (wave-private slab: the LDS operations of one wave execute in order)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int px = (lane >> 3) + 8 * k;
-          const T16* sp = reinterpret_cast<const T16*>(slab + px * SLAB_PITCH) + c8 * 8;
-          if (y < p.H && x0 + px < p.W) {
-            const long pix = ((long)b * p.H + y) * p.W + x0 + px;
-            *reinterpret_cast<u32x4*>(outp + pix * e.out_ld + p.n_first + c8 * 8) = *reinterpret_cast<const u32x4*>(sp);
-            if (mode == 2) {
-              float g[8], yv[8];
-              load8(sp, g);
-              load8(reinterpret_cast<const T16*>(e.bnb_y) + pix * e.bnb_y_ld + p.n_first + c8 * 8, yv);
-#pragma unroll
-              for (int kk = 0; kk < 8; ++kk) {
-                const float dz = (yv[kk] * sc[kk] + sh[kk]) > 0.f ? g[kk] : 0.f;
-                d1[kk] += dz;
-                d2[kk] += dz * (yv[kk] - mu[kk]);
-              }
-            }
-          }
-        }
-        if (do_pool && (i & 1)) {
-          // rows y - 1 and y are in the two slabs: pooled row (y >> 1), 8 pooled pixels x 8 channel chunks = 64 lanes
-          const int pxl = lane >> 3, yp = y >> 1, xp = (x0 >> 1) + pxl;
-          if (y < p.H && xp < (p.W >> 1)) {
-            float m[8], v[8];
-            load8(reinterpret_cast<const T16*>(slab0 + (2 * pxl) * SLAB_PITCH) + c8 * 8, m);
-#pragma unroll
-            for (int d = 1; d < 4; ++d) {
-              load8(reinterpret_cast<const T16*>(slab0 + (d >> 1) * SLAB + (2 * pxl + (d & 1)) * SLAB_PITCH) + c8 * 8, v);
-#pragma unroll
-              for (int kk = 0; kk < 8; ++kk) m[kk] = fmaxf(m[kk], v[kk]);
-            }
-            store8(reinterpret_cast<T16*>(e.pool_out) + (((long)b * (p.H >> 1) + yp) * (p.W >> 1) + xp) * e.pool_ld +
-                       p.n_first + c8 * 8, m);
-          }
-        }
-      }
-    }
+    CRIMAC_PH(2)
+    epilogue(acc, active, b, y0, x0);
+    CRIMAC_PH(3)
   }
+  CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
+#ifdef CRIMAC_DIAG_PHASES
+  // cycles of wave 0 of each team per phase: wait for the slabs | halo registers -> LDS (incl. the wait for the
+  // prefetch) | prefetch issue + MFMA phase | epilogue
+  if (lane == 0 && wave == 0)
+    for (int k = 0; k < 5; ++k) {
+      crimac_diag_clock_conv_buf[2 * ((blockIdx.x * 2 + team) * 5 + k)] = ph[k];
+      crimac_diag_clock_conv_buf[2 * ((blockIdx.x * 2 + team) * 5 + k) + 1] = (unsigned long long)niter;
+    }
+#else
+  CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
+#endif
   if (mode == 1) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -921,20 +1023,28 @@ int launch_p64(ConvParams p, hipStream_t st) {
   constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4;     // 157184 B
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0, T16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0, false, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<1, T16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0, true, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<2, T16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<1, false, T16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<2, false, T16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
+  CRIMAC_REQUIRE(p.H % TR == 0 && p.W % TC == 0, "conv3x3 (64 -> 64 persistent kernel): H, W must be multiples of 16");
   const int ncu = crimac_cu_count();
   long grid = (ntiles + 1) / 2;
   if (grid > ncu) grid = ncu;
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
-  if (mode == 0) hipLaunchKernelGGL((conv3x3_p64_kernel<0, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
-  else if (mode == 1) hipLaunchKernelGGL((conv3x3_p64_kernel<1, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
-  else hipLaunchKernelGGL((conv3x3_p64_kernel<2, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  if (mode == 0 && p.epi.pool_out)
+    hipLaunchKernelGGL((conv3x3_p64_kernel<0, true, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else if (mode == 0)
+    hipLaunchKernelGGL((conv3x3_p64_kernel<0, false, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else if (mode == 1)
+    hipLaunchKernelGGL((conv3x3_p64_kernel<1, false, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
+  else
+    hipLaunchKernelGGL((conv3x3_p64_kernel<2, false, T16>), dim3((unsigned)grid), dim3(512), lds, st, p, (int)ntiles);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -961,7 +1071,7 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
     // a range of output channels (crimac_conv3x3_cols): 64 of them with the persistent 64-channel kernel,
     // multiples of 128 with the channel-split kernel
     const long nt = (long)B * cdiv(H, TR) * cdiv(W, TC);
-    if (n_count == 64 && Cin == 64 && nt >= 512) return launch_p64<T16>(p, st);
+    if (n_count == 64 && Cin == 64 && nt >= 512 && H % TR == 0 && W % TC == 0) return launch_p64<T16>(p, st);
     const bool small_t = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
     CRIMAC_REQUIRE(n_first % 128 == 0 && n_count % 128 == 0 && small_t,
                    "conv3x3_cols: channel range [%d, +%d) of %d not supported (multiples of 128, or 64 of a "
@@ -974,7 +1084,8 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
   // 64 -> 64 with many tiles: persistent kernel with LDS-resident weights (CRIMAC_CONV_P64=0: W4 for A/B runs)
   static const int p64 = getenv("CRIMAC_CONV_P64") ? atoi(getenv("CRIMAC_CONV_P64")) : 1;
-  if (p64 && N == 64 && Cin == 64 && (long)B * cdiv(H, TR) * cdiv(W, TC) >= 512) return launch_p64<T16>(p, st);
+  if (p64 && N == 64 && Cin == 64 && H % TR == 0 && W % TC == 0 && (long)B * (H / TR) * (W / TC) >= 512)
+    return launch_p64<T16>(p, st);
   if (N % 128 != 0) return launch_w4<64, T16>(p, st);
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
   return (w4 == 1 || !small) ? launch_w4<128, T16>(p, st) : launch_wch<T16>(p, st);
