@@ -686,10 +686,30 @@ __device__ __forceinline__ void wg_barrier_lds() {
 // why the MFMA phase (83 us) and the memory phase (110 us) added up to the 195 us measured.  The prologue issues one
 // all-out-of-range epilogue so that the loop entry and the back edge carry the same operation count (the pass
 // merges the two states conservatively).
+// Barrier of ONE team (4 of the workgroup's 8 waves): s_barrier counts all 8 waves, which keeps the two teams in the
+// same phase -- both in their MFMA phase, then both writing out, the SIMDs idle meanwhile.  A counter in LDS instead:
+// each wave adds 1 and polls until all four have (LDS executes one wave's operations in order, so a wave that sees
+// the count has the others' earlier LDS writes and they have finished their reads).  The teams then run half a tile
+// apart: one team's MFMA phase fills the SIMDs while the other moves data.
+__device__ __forceinline__ void team_barrier(unsigned* cnt, unsigned& target, int lane) {
+  target += 4;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
 template <int MODE, bool POOL, typename T16>   // epilogue statistics (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums); fused 2x2 max-pool
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   static_assert(!POOL || MODE == 0, "the fused max-pool is an inference epilogue");
+#ifdef CRIMAC_DIAG_PHASES
+  unsigned long long rt[4];
+#define CRIMAC_RT(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+  CRIMAC_RT(0)
+#else
+#define CRIMAC_RT(k)
+#endif
   constexpr int BN = 64, NT = 4;
   constexpr int W_BYTES = 9 * BN * RB;               // 73728
   constexpr int H_BYTES = HALO_ROWS * RB;            // 41472
@@ -712,11 +732,18 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   if (tid < 2 * BN) sstat[tid] = 0.f;
 
   // weights: LDS unit c of row (t, n) holds source unit c ^ swizzle(n) (as the W4 weight slots)
-  for (int u = tid; u < 9 * BN * 8; u += 512) {
-    const int row = u >> 3, c = u & 7, n = row & (BN - 1);
-    const int t = row >> 6;                      // (rows of a range: tap stride N * Cin, first row n_first)
-    *reinterpret_cast<u32x4*>(wl + u * 16) = *reinterpret_cast<const u32x4*>(
-        p.w_hi + ((long)t * p.N + p.n_first + n) * BN + ((c ^ ((n >> 1) & 7)) * 8));
+  {
+    static_assert(9 * BN * 8 == 9 * 512, "nine 16-byte units per thread");
+    u32x4 wreg[9];                               // (all nine requests in flight, one wait: the prologue is latency)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int u = tid + k * 512;
+      const int row = u >> 3, c = u & 7, n = row & (BN - 1);
+      const int t = row >> 6;                    // (rows of a range: tap stride N * Cin, first row n_first)
+      wreg[k] = *reinterpret_cast<const u32x4*>(p.w_hi + ((long)t * p.N + p.n_first + n) * BN + ((c ^ ((n >> 1) & 7)) * 8));
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) *reinterpret_cast<u32x4*>(wl + (tid + k * 512) * 16) = wreg[k];
   }
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -765,7 +792,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
     h_rel[i] = u < HALO_ROWS * 8 ? (off | edge) : (OOB | 15u);
   }
   u32x4 hreg[NHU];
-  auto fetch_halo = [&](int tile, bool valid) {      // always NHU loads per lane
+  auto fetch_halo = [&](int tile, bool valid, int i0 = 0, int i1 = NHU) {      // always the same loads per lane
     int b, y0, x0;
     tile_geo(valid ? tile : 0, b, y0, x0);
     // image borders this tile touches (no tile: all four, and the out-of-range bit of every offset)
@@ -776,8 +803,9 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         const_cast<T16*>(inp + (((long)b * p.H + y0 - 1) * p.W + x0 - 1) * p.in_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NHU; ++i)
-      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs, (int)((h_rel[i] & border) ? OOB : ((h_rel[i] & ~15u) | kill)), 0, 0);
+      if (i >= i0 && i < i1)
+        hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (int)((h_rel[i] & border) ? OOB : ((h_rel[i] & ~15u) | kill)), 0, 0);
   };
 
   // this lane's output units: rows wave * 4 + i, pixels (lane >> 3) + 8 k, channel chunk c8
@@ -885,8 +913,10 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
     }
   };
 
-  const int stride = 2 * gridDim.x;
-  int tile = 2 * blockIdx.x + team;
+  // tiles of this workgroup: blockIdx.x + j * gridDim.x; the teams take the next j from a queue counter in LDS (the
+  // team whose waves are older on their SIMDs runs ~20 % faster: with a fixed half each it idled through the tail)
+  const int stride = gridDim.x;
+  int tile = blockIdx.x + team * stride;
   fetch_halo(tile, tile < ntiles);
   {
     f32x4 zacc[4][NT];
@@ -898,32 +928,40 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         for (int r = 0; r < 4; ++r) zacc[i][j][r] = 0.f;
     epilogue(zacc, false, 0, 0, 0);             // (see above: equal operation counts on both edges into the loop)
   }
-  // both teams run the same number of iterations (the barriers are workgroup-wide); a team without a tile idles
-  const int niter = (ntiles - 2 * (int)blockIdx.x + stride - 1) / stride;
+  // the teams loop independently (team barriers); team 1 starts half a tile late
+  unsigned* tq = reinterpret_cast<unsigned*>(sstat + 2 * BN);      // [0..1] team barriers, [2] tile queue, [4..5] next j
+  unsigned* tcnt = tq + team;
+  unsigned ttarget = 0;
+  if (tid < 3) tq[tid] = tid == 2 ? 2u : 0u;
+  wg_barrier_lds();                             // weights, statistics and counters in place
+  if (team == 1) {
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) __builtin_amdgcn_s_sleep(32);
+  }
   CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
+  CRIMAC_RT(1)
 #ifdef CRIMAC_DIAG_PHASES
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, ph_t = dg_t0;
 #define CRIMAC_PH(k) { unsigned long long tn; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     ph[k] += tn - ph_t; ph_t = tn; }
+  int niter = 0;
 #else
 #define CRIMAC_PH(k)
 #endif
-  for (int it = 0; it < niter; ++it, tile += stride) {
-    const bool active = tile < ntiles;
+  while (tile < ntiles) {
     int b, y0, x0;
-    tile_geo(active ? tile : 0, b, y0, x0);
-    wg_barrier_lds();                           // slabs of the previous tile consumed (and weights in place)
+    tile_geo(tile, b, y0, x0);
+    team_barrier(tcnt, ttarget, lane);          // slabs of the previous tile consumed
     CRIMAC_PH(0)
+    if (tt == 0) tq[4 + team] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int i = 0; i < NHU; ++i) {
       const int u = tt + i * 256;
       if (u < HALO_ROWS * 8) *reinterpret_cast<u32x4*>(halo + u * 16) = hreg[i];
     }
-    wg_barrier_lds();                           // halo in place
+    team_barrier(tcnt, ttarget, lane);          // halo in place
     CRIMAC_PH(1)
-    fetch_halo(tile + stride, tile + stride < ntiles);
-    CRIMAC_PH(4)
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -932,11 +970,10 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    if (active) {                               // (no vector-memory operation inside this branch)
-      // (tap rows not unrolled: a fully unrolled 9-tap body lets the compiler hoist fragment reads until the
-      // long-lived statistics registers spill)
-#pragma unroll 1
-      for (int ky = 0; ky < 3; ++ky)
+    // the next tile's halo is requested in three parts, one in front of each tap row: a load that has to wait for
+    // room behind the previous tile's stores then stalls this wave while the other team's wave on the SIMD computes
+    // (tap rows not unrolled into one body: the compiler then hoists fragment reads until registers spill)
+    auto tap_row = [&](int ky) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int t = ky * 3 + kx;
@@ -959,16 +996,36 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
               acc[i][j] = E16<T16>::mfma16(af[i], bfr[j], acc[i][j]);
         }
       }
-    }
-    wg_barrier_lds();                           // halo consumed: its buffer now holds the output slabs
+    };
+    // (written by the team's first wave in front of the barrier above)
+    const int next = (int)blockIdx.x + __builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(tq + 4 + team)) * stride;
+    const bool more = next < ntiles;
+    fetch_halo(next, more, 0, 4);
+    tap_row(0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_halo(next, more, 4, 8);
+    tap_row(1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_halo(next, more, 8, NHU);
+    tap_row(2);
+    team_barrier(tcnt, ttarget, lane);          // halo consumed: its buffer now holds the output slabs
     CRIMAC_PH(2)
-    epilogue(acc, active, b, y0, x0);
+    epilogue(acc, true, b, y0, x0);
     CRIMAC_PH(3)
+#ifdef CRIMAC_DIAG_PHASES
+    ++niter;
+#endif
+    tile = next;
   }
   CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
 #ifdef CRIMAC_DIAG_PHASES
   // cycles of wave 0 of each team per phase: wait for the slabs | halo registers -> LDS (incl. the wait for the
   // prefetch) | prefetch issue + MFMA phase | epilogue
+  CRIMAC_RT(2)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last stores acknowledged)
+  CRIMAC_RT(3)
+  if (lane == 0 && wave == 0)
+    for (int k = 0; k < 4; ++k) crimac_diag_clock_conv_buf[5120 + (blockIdx.x * 2 + team) * 4 + k] = rt[k];
   if (lane == 0 && wave == 0)
     for (int k = 0; k < 5; ++k) {
       crimac_diag_clock_conv_buf[2 * ((blockIdx.x * 2 + team) * 5 + k)] = ph[k];
@@ -1020,7 +1077,7 @@ int launch_p64(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4;     // 157184 B
+  constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4 + 32;     // 157216 B
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0, false, T16>),

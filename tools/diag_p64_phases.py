@@ -25,4 +25,11 @@ for name, fn in forms.items():
     a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 2).astype(np.float64)[:2560].reshape(512, 5, 2)
     per = a[:, :, 0] / a[:, :, 1]
     med = np.median(per, axis=0)
+    raw = np.frombuffer(buf, dtype=np.uint64)[5120:5120 + 2048].astype(np.int64).reshape(256, 2, 4)
+    t0 = raw[:, :, 0].min()
+    r = (raw - t0) / 100.0                                    # us since the first workgroup entered the kernel
+    for tm in (0, 1):
+        q = r[:, tm]
+        print(f"   team {tm}: entry {np.median(q[:, 0]):6.1f} (max {q[:, 0].max():6.1f}) | loop start {np.median(q[:, 1]):6.1f} | "
+              f"loop end {np.median(q[:, 2]):6.1f} (min {q[:, 2].min():6.1f} max {q[:, 2].max():6.1f}) | stores done {np.median(q[:, 3]):6.1f} (max {q[:, 3].max():6.1f}) us")
     print(f"{name:6s} cycles per tile: slab-wait {med[0]:7.0f} | halo->LDS {med[1]:7.0f} | prefetch issue {med[4]:7.0f} | MFMA {med[2]:7.0f} | epilogue {med[3]:7.0f} | sum {med.sum():7.0f}", flush=True)
