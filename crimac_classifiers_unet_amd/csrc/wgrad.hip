@@ -179,9 +179,18 @@ __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], W
 // LDS budget allows only one tile in flight per workgroup and the level-0 shapes wait for their tiles at
 // 3.9 TB/s): every shape got 8-15 % SLOWER (2.49 vs 2.25 ms over the 13 conv shapes).
 // fp32 (split-bf16) path: register staging with the hi/lo split, single buffer.
-template <typename TA, int NPL, int MODE, bool NARROW = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
+//
+// TEAMS = 2 (16-bit storage, conv3x3): ONE workgroup of 8 waves per CU instead of two of 4.  Two workgroups of a CU are
+// not equals -- the SIMD arbiter serves the older wave first: of 512 workgroups with 32 tiles each, the 256 dispatched
+// first left their tile loop after 82 us and the others after 123 us (diag_wgrad_phases.py) -- and each ends with its
+// own 147 KB of fp32 atomics.  Here the two teams of 4 waves work on the SAME output tile and pixel range: they take
+// tiles from a queue in LDS (whoever is faster takes more; both leave the loop together), run on team barriers (LDS
+// counters; s_barrier would put both in the same phase), and team 1's accumulators are added to team 0's through
+// LDS before the atomics: half the splits, half the atomic volume per launch.
+template <typename TA, int NPL, int MODE, bool NARROW = false, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 8 waves per CU
 void wgrad_kernel(WgradParams p) {
+  static_assert(TEAMS == 1 || (sizeof(TA) == 2 && MODE == 0), "two teams: 16-bit conv3x3 only (LDS: 4 tile buffers)");
   constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
   static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
   constexpr int TR = MODE == 0 ? 8 : 4;
@@ -194,8 +203,17 @@ void wgrad_kernel(WgradParams p) {
   constexpr int BUF_BYTES = F_BYTES + S_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef CRIMAC_DIAG_PHASES
+  unsigned long long rt[4];
+#define CRIMAC_WRT(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+  CRIMAC_WRT(0)
+#else
+#define CRIMAC_WRT(k)
+#endif
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int team = TEAMS == 2 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;       // (wave: index inside the team)
+  const int wave = TEAMS == 2 ? __builtin_amdgcn_readfirstlane((tid >> 6) & 3) : tid >> 6;
   const int wf = wave >> 1, ws = wave & 1;
   // Workgroup -> (channel-tile pair q, pixel split).  Workgroups with equal id % 8 share an XCD (and
   // its 4 MiB L2): give each XCD a contiguous block of channel-tile pairs (same F channels, a run of
@@ -345,7 +363,7 @@ void wgrad_kernel(WgradParams p) {
     auto issue_tile = [&](long tile, int buf) {
       long b; int y0, x0;
       tile_origin(tile, b, y0, x0);
-      unsigned char* base = smem + buf * BUF_BYTES;
+      unsigned char* base = smem + (team * 2 + buf) * BUF_BYTES;
       const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<TA*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
@@ -389,15 +407,8 @@ void wgrad_kernel(WgradParams p) {
       // lane's k block g = lane / 16: tile row (g >> 1) of the row pair, x = 4 * (g & 1) + q (+ 8: second read)
       const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
       const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
-      const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
-      if (t_begin < t_end) issue_tile(t_begin, 0);
-      CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
-      for (long tile = t_begin; tile < t_end; ++tile) {
-        const int cur = (int)((tile - t_begin) & 1);
-        __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
-#ifndef CRIMAC_EXP_NOLOAD
-        if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
-#endif
+      const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem)) + team * 2 * BUF_BYTES;
+      auto contract_tile = [&](int cur) {
 #ifndef CRIMAC_EXP_NOCOMPUTE
         const unsigned aF = lds0 + cur * BUF_BYTES, aS = aF + F_BYTES;
         const unsigned fv0 = aF + RF * 128 + 8 * pp + swz16(RF);
@@ -416,9 +427,116 @@ void wgrad_kernel(WgradParams p) {
           wg_step<typename PlaneOf<TA>::type, MODE, TG, 0, NARROW>(fv0, sv, f, acc2);
         }
 #endif
+      };
+#ifdef CRIMAC_DIAG_PHASES
+      unsigned long long ph[3] = {0, 0, 0}, ph_t;
+#define CRIMAC_WPH(k) { unsigned long long tn; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[k] += tn - ph_t; ph_t = tn; }
+#else
+#define CRIMAC_WPH(k)
+#endif
+      long ntaken = 0;                           // (diagnostics: tiles this team contracted)
+      if constexpr (TEAMS == 2) {
+        // tile queue of the workgroup: tq[2] = next tile (relative to t_begin); tq[4 + 2 * team + parity] = the tile the
+        // team requests in its NEXT iteration, taken by its first lane one iteration ahead
+        unsigned* tq = reinterpret_cast<unsigned*>(smem + 4 * BUF_BYTES);
+        if (tid < 3) tq[tid] = tid == 2 ? 2u : 0u;
+        __syncthreads();
+        const int tt = tid & 255;
+        unsigned* tcnt = tq + team;
+        unsigned ttarget = 0;
+        long cur_tile = t_begin + team;
+        bool have = cur_tile < t_end;
+        if (have) issue_tile(cur_tile, 0);
+        if (tt == 0) tq[4 + 2 * team] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
+        CRIMAC_WRT(1)
+#ifdef CRIMAC_DIAG_PHASES
+        ph_t = dg_t0;
+#endif
+        int cur = 0, par = 0;
+        while (have) {
+          // this wave's share of the tile has landed; then the team: all of it has, and the other buffer is free
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          ttarget += 4;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(tcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          while (__hip_atomic_load(tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ttarget) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+          CRIMAC_WPH(0)
+          const long nxt = t_begin + __builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(tq + 4 + 2 * team + par));
+          par ^= 1;
+          if (tt == 0) tq[4 + 2 * team + par] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const bool has_next = nxt < t_end;
+#ifndef CRIMAC_EXP_NOLOAD
+          if (has_next) issue_tile(nxt, cur ^ 1);
+#endif
+          CRIMAC_WPH(1)
+          contract_tile(cur);
+          CRIMAC_WPH(2)
+          cur ^= 1;
+          cur_tile = nxt;
+          have = has_next;
+          ++ntaken;
+        }
+      } else {
+        if (t_begin < t_end) issue_tile(t_begin, 0);
+        CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
+        CRIMAC_WRT(1)
+#ifdef CRIMAC_DIAG_PHASES
+        ph_t = dg_t0;
+#endif
+        for (long tile = t_begin; tile < t_end; ++tile) {
+          const int cur = (int)((tile - t_begin) & 1);
+          __syncthreads();     // vmcnt(0)+barrier: tile landed for everyone; the other buffer is free
+          CRIMAC_WPH(0)
+#ifndef CRIMAC_EXP_NOLOAD
+          if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+#endif
+          CRIMAC_WPH(1)
+          contract_tile(cur);
+          CRIMAC_WPH(2)
+          ++ntaken;
+        }
       }
-      CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
-      CRIMAC_DIAG_STORE(crimac_diag_clock_wgrad, dg_t0, dg_r0, dg_t1, dg_r1)
+      CRIMAC_WRT(2)
+#ifdef CRIMAC_DIAG_PHASES
+      // cycles per phase of waves 0 (tap group 0) and 2 (tap group 1) of each team: wait for the tile | DMA issue |
+      // contraction; slot = (workgroup, team, tap group)
+      if (lane == 0 && (wave & 1) == 0 && blockIdx.x < 256)
+        for (int k = 0; k < 3; ++k) {
+          crimac_diag_clock_wgrad_buf[2 * (((blockIdx.x * 2 + team) * 2 + (wave >> 1)) * 3 + k)] = ph[k];
+          crimac_diag_clock_wgrad_buf[2 * (((blockIdx.x * 2 + team) * 2 + (wave >> 1)) * 3 + k) + 1] = (unsigned long long)ntaken;
+        }
+#endif
+      if constexpr (TEAMS == 2) {
+        // team 1's accumulators -> LDS (the tile buffers are dead once every wave has left its loop) -> added to team 0's
+        constexpr int N0 = WgTaps<MODE, 0>::N, N1 = WgTaps<MODE, 1>::N;
+        static_assert((2 * N0 + 2 * N1) * 8192 <= 4 * BUF_BYTES, "accumulator exchange area");
+        unsigned char* xa = smem + (TG == 0 ? ws * N0 : 2 * N0 + ws * N1) * 8192 + lane * 16;
+        __syncthreads();
+        if (team == 1) {
+#pragma unroll
+          for (int t = 0; t < G::N; ++t)
+#pragma unroll
+            for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+              for (int sh = 0; sh < 2; ++sh) *reinterpret_cast<f32x4*>(xa + ((t * 4 + fh) * 2 + sh) * 1024) = acc2[t][fh][sh];
+        }
+        __syncthreads();
+        if (team == 1) return;
+#pragma unroll
+        for (int t = 0; t < G::N; ++t)
+#pragma unroll
+          for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(xa + ((t * 4 + fh) * 2 + sh) * 1024);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc2[t][fh][sh][r] += o[r];
+            }
+      }
       // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps.
       // partial_stride > 0: every (channel tile, split) workgroup OWNS its tile of slab `split` -- plain stores, no
       // zero fill, no atomics (each split used to cost an fp32-atomic pass over dW at the chip-wide atomic rate of
@@ -451,6 +569,12 @@ void wgrad_kernel(WgradParams p) {
     };
     if (tg == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
+#ifdef CRIMAC_DIAG_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the atomics issued -- not their completion)
+    CRIMAC_WRT(3)
+    if (lane == 0 && wave == 0 && team == 0 && blockIdx.x < 512)
+      for (int k = 0; k < 4; ++k) crimac_diag_clock_wgrad_buf[6144 + blockIdx.x * 4 + k] = rt[k];
+#endif
     return;
   } else {
     // ---- fp32 activations: register staging with the plane split ------------------------------------
@@ -515,7 +639,8 @@ void wgrad_kernel(WgradParams p) {
 }
 
 // Pixel-range split of a shape: fills tiles_y/x, ntiles, tiles_per_block, nsplits (same for every precision).
-void plan_splits(WgradParams& p, int mode, int target_blocks) {
+// teams: 2 for the 8-wave kernel (one workgroup per CU), 1 for the 4-wave kernel (two per CU).
+void plan_splits(WgradParams& p, int mode, int target_blocks, int teams) {
   const int TR = mode == 0 ? 8 : 4;
   p.tiles_y = cdiv(p.Hf, TR);
   p.tiles_x = cdiv(p.Wf, 16);
@@ -525,7 +650,8 @@ void plan_splits(WgradParams& p, int mode, int target_blocks) {
   // one resident round: 2 workgroups per CU x 256 CUs.  More splits only add partial-sum volume (each workgroup
   // ends with 147 KB of fp32 output) and a second, partially filled round: 512 measured 2 % faster than 1024.
   static const int auto_blocks = getenv("CRIMAC_WGRAD_BLOCKS") ? atoi(getenv("CRIMAC_WGRAD_BLOCKS")) : 512;
-  if (autosplit) target_blocks = auto_blocks;
+  if (autosplit) target_blocks = auto_blocks / teams;
+  const int round = 512 / teams;               // workgroups of one resident round
   int splits = target_blocks / ch_tiles;
   if (autosplit) {
     // every split adds one pass over dW (fp32 atomics at ~1.3 TB/s chip-wide, or a partial slab written and read
@@ -533,7 +659,7 @@ void plan_splits(WgradParams& p, int mode, int target_blocks) {
     long max_splits = ((long)p.B * p.Hf * p.Wf) / 4096;
     if (max_splits < 1) max_splits = 1;
     // ... unless that leaves fewer than two workgroups per CU: then parallelism is worth more
-    while (max_splits * ch_tiles < 512 && max_splits * 2 <= ((long)p.B * p.Hf * p.Wf) / 1024) max_splits *= 2;
+    while (max_splits * ch_tiles < round && max_splits * 2 <= ((long)p.B * p.Hf * p.Wf) / 1024) max_splits *= 2;
     if (splits > max_splits) splits = (int)max_splits;
   }
   if (splits < 1) splits = 1;
@@ -542,24 +668,31 @@ void plan_splits(WgradParams& p, int mode, int target_blocks) {
   p.nsplits = cdiv(p.ntiles, p.tiles_per_block);       // every split owns at least one tile
 }
 
-template <typename TA, int NPL, int MODE, bool NARROW = false>
+template <typename TA, int NPL, int MODE, bool NARROW = false, int TEAMS = 1>
 int launch(WgradParams p, int target_blocks, hipStream_t st) {
   constexpr int TR = MODE == 0 ? 8 : 4;
   constexpr int F_ROWS = TR * 16;
   constexpr int S_ROWS = ((MODE == 0 ? (TR + 2) * 18 : (2 * TR) * 32) + 7) / 8 * 8;   // padded to 8 rows
-  plan_splits(p, MODE, target_blocks);
+  plan_splits(p, MODE, target_blocks, TEAMS);
   const int ch_tiles = cdiv(p.CF, 64) * cdiv(p.CS, 64);
   const int splits = p.nsplits;
-  // bf16: two buffers (double-buffered direct-to-LDS tiles); fp32: one buffer of NPL planes
-  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 : NPL);
+  // bf16: two buffers per team (double-buffered direct-to-LDS tiles, + the tile queue); fp32: one buffer of NPL planes
+  const size_t lds = (size_t)(F_ROWS + S_ROWS) * 128 * (NPL == 1 ? 2 * TEAMS : NPL) + (TEAMS == 2 ? 64 : 0);
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, NPL, MODE, NARROW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TA, NPL, MODE, NARROW, TEAMS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE, NARROW>), dim3(ch_tiles * splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((wgrad_kernel<TA, NPL, MODE, NARROW, TEAMS>), dim3(ch_tiles * splits), dim3(256 * TEAMS), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
+}
+
+// 16-bit storage, conv3x3: the two-team kernel (CRIMAC_WGRAD_TEAMS=1 selects the 4-wave kernel for A/B runs)
+int teams_of(int prec, int mode) {
+  static const int forced = getenv("CRIMAC_WGRAD_TEAMS") ? atoi(getenv("CRIMAC_WGRAD_TEAMS")) : 0;
+  if (forced == 1) return 1;
+  return (prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16) && mode == 0 ? 2 : 1;
 }
 
 int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld, int CS, int B, int Hf,
@@ -578,13 +711,18 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
   p.f = f; p.f_ld = f_ld; p.CF = CF; p.s = s; p.s_ld = s_ld; p.CS = CS;
   p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw; p.partial_stride = partial_stride;
   hipStream_t st = (hipStream_t)stream;
+  const bool two = teams_of(prec, mode) == 2;
   if (prec == CRIMAC_PREC_BF16) {
-    if (mode == 0 && CS <= 16) return launch<bf16_t, 1, 0, true>(p, target_blocks, st);     // first layer
-    return mode == 0 ? launch<bf16_t, 1, 0>(p, target_blocks, st) : launch<bf16_t, 1, 1>(p, target_blocks, st);
+    if (mode == 0 && CS <= 16)                                                              // first layer
+      return two ? launch<bf16_t, 1, 0, true, 2>(p, target_blocks, st) : launch<bf16_t, 1, 0, true>(p, target_blocks, st);
+    if (mode == 0) return two ? launch<bf16_t, 1, 0, false, 2>(p, target_blocks, st) : launch<bf16_t, 1, 0>(p, target_blocks, st);
+    return launch<bf16_t, 1, 1>(p, target_blocks, st);
   }
   if (prec == CRIMAC_PREC_FP16) {
-    if (mode == 0 && CS <= 16) return launch<half_t, 1, 0, true>(p, target_blocks, st);
-    return mode == 0 ? launch<half_t, 1, 0>(p, target_blocks, st) : launch<half_t, 1, 1>(p, target_blocks, st);
+    if (mode == 0 && CS <= 16)
+      return two ? launch<half_t, 1, 0, true, 2>(p, target_blocks, st) : launch<half_t, 1, 0, true>(p, target_blocks, st);
+    if (mode == 0) return two ? launch<half_t, 1, 0, false, 2>(p, target_blocks, st) : launch<half_t, 1, 0>(p, target_blocks, st);
+    return launch<half_t, 1, 1>(p, target_blocks, st);
   }
   if (prec == CRIMAC_PREC_F32X3)
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
@@ -599,11 +737,13 @@ extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF
   return wgrad_run(prec, mode, f, f_ld, CF, s, s_ld, CS, B, Hf, Wf, dw, 0, target_blocks, stream);
 }
 
-extern "C" int crimac_wgrad_splits(int mode, int CF, int CS, int B, int Hf, int Wf, int target_blocks) {
-  if (!(mode == 0 || mode == 1) || CF <= 0 || CS <= 0 || B <= 0 || Hf <= 0 || Wf <= 0) return CRIMAC_ERR_INVALID;
+extern "C" int crimac_wgrad_splits(int prec, int mode, int CF, int CS, int B, int Hf, int Wf, int target_blocks) {
+  if (prec < CRIMAC_PREC_BF16 || prec > CRIMAC_PREC_MAX || !(mode == 0 || mode == 1) || CF <= 0 || CS <= 0 || B <= 0 ||
+      Hf <= 0 || Wf <= 0)
+    return CRIMAC_ERR_INVALID;
   WgradParams p;
   p.CF = CF; p.CS = CS; p.B = B; p.Hf = Hf; p.Wf = Wf;
-  plan_splits(p, mode, target_blocks);
+  plan_splits(p, mode, target_blocks, teams_of(prec, mode));
   return p.nsplits;
 }
 

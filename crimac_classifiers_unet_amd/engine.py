@@ -257,7 +257,7 @@ class UNetEngine:
             nonlocal tot
             sp = 1
             if self.use_wgrad_partials:
-                sp = lib.crimac_wgrad_splits(mode, cf, cs, B, h, w, self.wgrad_target_blocks)
+                sp = lib.crimac_wgrad_splits(self.prec_bwd, mode, cf, cs, B, h, w, self.wgrad_target_blocks)
                 if sp < 1:
                     raise hip.HipLibraryError(f"crimac_wgrad_splits failed for {key}")
             stride = _align(n)

@@ -123,7 +123,7 @@ def load_library():
     lib.crimac_last_error.restype = C.c_char_p
     lib.crimac_last_error.argtypes = []
     lib.crimac_wgrad_splits.restype = C.c_int          # (returns a count, not a status; no stream argument)
-    lib.crimac_wgrad_splits.argtypes = [_i, _i, _i, _i, _i, _i, _i]
+    lib.crimac_wgrad_splits.argtypes = [_i, _i, _i, _i, _i, _i, _i, _i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = C.c_int

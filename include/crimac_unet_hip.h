@@ -163,7 +163,7 @@ int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const voi
  * up in order, so the weight gradient is bit-reproducible run to run; it also removes the fp32-atomic tail of the
  * single resident round (each split was one atomic pass over dW at ~1.3 TB/s chip-wide).  slab_stride in floats,
  * >= taps * CF * CS.  crimac_wgrad_splits returns the number of slabs for a shape (> 0) or a negative error. */
-int crimac_wgrad_splits(int mode, int CF, int CS, int B, int Hf, int Wf, int target_blocks);
+int crimac_wgrad_splits(int prec, int mode, int CF, int CS, int B, int Hf, int Wf, int target_blocks);
 int crimac_wgrad_partials(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld, int CS,
                           int B, int Hf, int Wf, float* partials, long slab_stride, int target_blocks, void* stream);
 

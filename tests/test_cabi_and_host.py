@@ -32,9 +32,11 @@ def test_library_exports_every_declared_symbol():
     assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error", "crimac_wgrad_splits"} == set(syms)
     # the split planner is a host-only query (no GPU): the level-0 shape fills one resident round
     lib2 = hip.load_library()
-    assert lib2.crimac_wgrad_splits(0, 64, 64, 32, 256, 256, 0) == 512
-    assert lib2.crimac_wgrad_splits(0, 1024, 1024, 32, 16, 16, 0) >= 1
-    assert lib2.crimac_wgrad_splits(2, 64, 64, 32, 256, 256, 0) < 0
+    assert lib2.crimac_wgrad_splits(0, 0, 64, 64, 32, 256, 256, 0) == 256        # bf16: one 8-wave workgroup per CU
+    assert lib2.crimac_wgrad_splits(1, 0, 64, 64, 32, 256, 256, 0) == 512        # fp32 planes: two 4-wave workgroups
+    assert lib2.crimac_wgrad_splits(0, 0, 1024, 1024, 32, 16, 16, 0) >= 1
+    assert lib2.crimac_wgrad_splits(0, 2, 64, 64, 32, 256, 256, 0) < 0          # bad mode
+    assert lib2.crimac_wgrad_splits(9, 0, 64, 64, 32, 256, 256, 0) < 0          # bad precision
     assert hip.load_library().crimac_version() >= 1
 
 

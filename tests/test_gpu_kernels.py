@@ -726,7 +726,7 @@ def test_wgrad_partial_slabs_sum_to_the_atomic_result_and_are_reproducible(prec,
         F_, S_, CF, CS, taps, shape_w, kind = to_nhwc(x, prec), to_nhwc(dy, prec), Ci, Co, 4, (Ci, Co, 2, 2), 1
     n = taps * CF * CS
     for target in (0, 24):
-        sp = lib.crimac_wgrad_splits(mode, CF, CS, B, H, W, target)
+        sp = lib.crimac_wgrad_splits(P, mode, CF, CS, B, H, W, target)
         assert sp >= 1
         stride = n + 64
         outs = []
