@@ -354,11 +354,20 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
   if constexpr (H + 1 < NH) wch_step<T16, H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
-template <typename T16>
+template <typename T16, int MODE>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel(ConvParams p) {
   constexpr int BN = 128, NW = 4;
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef CRIMAC_DIAG_PHASES
+  unsigned long long wph[4] = {0, 0, 0, 0}, wph_t;
+  { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wph_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define CRIMAC_CPH(k) { unsigned long long tn; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    wph[k] += tn - wph_t; wph_t = tn; }
+#else
+#define CRIMAC_CPH(k)
+#endif
   unsigned char* sA = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane >> 3, c8 = lane & 7;
@@ -426,21 +435,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   wch_load_b(wrow, wrow + w_nb, f.b[1]);
   wch_land_b(f.b[1]);
   CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
+  CRIMAC_CPH(0)
   for (int kc = 0; kc < kchunks; ++kc) {
     issue_halo(kc);
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    CRIMAC_CPH(1)
     const unsigned short* wtap = wrow + kc * BK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
     wch_issue<0>(av, f);
     wch_step<T16, 0>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
+    CRIMAC_CPH(2)
   }
   CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
+#ifndef CRIMAC_DIAG_PHASES
   CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
-  conv_epilogue<T16, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
+#endif
+  conv_epilogue<T16, BN, BM, 256, 16, 2, f32x4, MODE>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
+#ifdef CRIMAC_DIAG_PHASES
+  // cycles of wave 0: prologue | waiting for the halo chunks | MFMA steps | epilogue (stores issued)
+  CRIMAC_CPH(3)
+  const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) % 1024;
+  if (tid == 0)
+    for (int k = 0; k < 4; ++k) crimac_diag_clock_conv_buf[slot * 4 + k] = wph[k];
+#endif
 }
 
 template <typename T16>
@@ -453,10 +474,18 @@ int launch_wch(ConvParams p, hipStream_t st) {
   const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL(conv3x3_wch_kernel<T16>, dim3((unsigned)ntiles, p.n_count / BN), dim3(256), lds, st, p);
+  const dim3 grid((unsigned)ntiles, p.n_count / BN);
+  const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
+  if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0>), grid, dim3(256), lds, st, p);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2>), grid, dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

@@ -45,19 +45,25 @@ template <> struct AccLayout<f32x4> {
 };
 
 // acc[MT][NT]: wave (wr, wc) holds rows wr*MT*TS + i*TS + ..., cols wc*NT*TS + j*TS + ... .
-template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC>
-__device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
-                                              unsigned char* smem, int b, int y0, int x0, int n0,
-                                              int tile_rows, int wr, int wc) {
+//
+// MODE (compile time: 0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums) and FULL (the tile lies inside the
+// image: no per-element tests) are template parameters of the body -- the first form of this epilogue carried the
+// three modes and the border tests through one runtime path: 2 800 vector instructions, 155 spilled SGPRs, ~19 k
+// cycles per workgroup of the channel-split kernel (two 64-channel chunks of MFMAs take 18 k), phase stamps of
+// tools/diag_wch_phases.py.  Stores (and the mode-2 loads) are buffer operations on a resource rebased at the tile's
+// first pixel: 32-bit offsets, `row * pitch` instead of 64-bit pixel arithmetic per row, out of range = dropped.
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, bool FULL, typename ACC>
+__device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], const EpiParams& e,
+                                                   unsigned char* smem, int b, int y0, int x0, int n0,
+                                                   int wr, int wc) {
   using L = AccLayout<ACC>;
-  constexpr int TCOLS = 16;
   constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;
   constexpr bool F32 = sizeof(TA) == 4;
+  constexpr unsigned OOB = 0x80000000u;
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned char* stage = smem;                                           // [BM][STAGE_PITCH]
   float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);     // [2][BN]
-  const int mode = e.stat_sum ? e.stat_mode : 0;
-  const bool full_tile = (y0 + tile_rows <= e.H) && (x0 + TCOLS <= e.W);
+  constexpr int mode = MODE;
   if (mode)
     for (int i = tid; i < 2 * BN; i += NTHREADS) sstat[i] = 0.f;
   float cs1[NT], cs2[NT];
@@ -76,10 +82,12 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
         if (e.relu) v = fmaxf(v, 0.f);
         const TA q = (TA)v;
         *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = q;
-        const float vs = (float)q;       // statistics of the value as STORED
-        const bool ok = full_tile || ((y0 + (row >> 4) < e.H) && (x0 + (row & 15) < e.W));
-        cs1[j] += ok ? vs : 0.f;
-        cs2[j] += ok ? vs * vs : 0.f;
+        if (mode == 1) {
+          const float vs = (float)q;       // statistics of the value as STORED
+          const bool ok = FULL || ((y0 + (row >> 4) < e.H) && (x0 + (row & 15) < e.W));
+          cs1[j] += ok ? vs : 0.f;
+          cs2[j] += ok ? vs * vs : 0.f;
+        }
       }
   }
   __syncthreads();
@@ -104,8 +112,23 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
   {
     constexpr int CPR = BN / 8;                 // 8-channel chunks per row
     constexpr int RPP = NTHREADS / CPR;         // rows per pass
+    static_assert(RPP % 16 == 0 || 16 % RPP == 0, "a pass covers whole image rows or a fraction of one");
     const int c8 = tid % CPR, r0 = tid / CPR;
     TA* outp = reinterpret_cast<TA*>(e.out);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        outp + (((long)b * e.H + y0) * e.W + x0) * e.out_ld + n0, 0, 0x7FFFFFFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t ry = ro;
+    if (mode == 2)
+      ry = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<TA*>(reinterpret_cast<const TA*>(e.bnb_y) + (((long)b * e.H + y0) * e.W + x0) * e.bnb_y_ld + n0), 0,
+          0x7FFFFFFF, 0x00020000);
+    // this thread's rows: r0 + rr * RPP -> (image row, column) of the tile; byte offsets from the tile's first pixel
+    const int ty0 = r0 >> 4, tx = r0 & 15;
+    const unsigned o0 = (unsigned)((((long)ty0 * e.W + tx) * e.out_ld + c8 * 8) * (int)sizeof(TA));
+    const unsigned o_step = (unsigned)(((long)(RPP >> 4) * e.W * e.out_ld + (RPP & 15) * e.out_ld) * (int)sizeof(TA));
+    const unsigned q0 = mode == 2 ? (unsigned)((((long)ty0 * e.W + tx) * e.bnb_y_ld + c8 * 8) * (int)sizeof(TA)) : 0u;
+    const unsigned q_step = mode == 2 ? (unsigned)(((long)(RPP >> 4) * e.W * e.bnb_y_ld + (RPP & 15) * e.bnb_y_ld) * (int)sizeof(TA)) : 0u;
+    static_assert(RPP >= 16, "rows of one thread differ by whole image rows");
     float sc[8], sh[8], mu[8], is[8], d1[8], d2[8];
     if (mode == 2) {
 #pragma unroll
@@ -122,27 +145,33 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
 #pragma unroll
     for (int rr = 0; rr < BM / RPP; ++rr) {
       const int row = r0 + rr * RPP;
-      const int y = y0 + (row >> 4), x = x0 + (row & 15);
-      if (full_tile || (y < e.H && x < e.W)) {
-        const long pix = ((long)b * e.H + y) * e.W + x;
-        const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
-        TA* dst = outp + pix * e.out_ld + n0 + c8 * 8;
+      const bool ok = FULL || ((y0 + (row >> 4) < e.H) && (x0 + tx < e.W));
+      const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
+      const int off = (int)(ok ? o0 + rr * o_step : OOB);
+      if constexpr (F32) {
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp), ro, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp + 4), ro, off, 16, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp), ro, off, 0, 0);
+      }
+      if (mode == 2) {
+        float g[8], yv[8];
+        load8(sp, g);
+        const int yoff = (int)(ok ? q0 + rr * q_step : OOB);
         if constexpr (F32) {
-          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
-          *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+          u32x4 t[2];
+          t[0] = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 0, 0);
+          t[1] = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 16, 0);
+          load8(reinterpret_cast<const TA*>(t), yv);
         } else {
-          *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sp);
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 0, 0);
+          load8(reinterpret_cast<const TA*>(&t), yv);
         }
-        if (mode == 2) {
-          float g[8], yv[8];
-          load8(sp, g);
-          load8(reinterpret_cast<const TA*>(e.bnb_y) + pix * e.bnb_y_ld + n0 + c8 * 8, yv);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float dz = (yv[k] * sc[k] + sh[k]) > 0.f ? g[k] : 0.f;
-            d1[k] += dz;
-            d2[k] += dz * (yv[k] - mu[k]) * is[k];
-          }
+        for (int k = 0; k < 8; ++k) {
+          const float dz = (ok && (yv[k] * sc[k] + sh[k]) > 0.f) ? g[k] : 0.f;
+          d1[k] += dz;
+          d2[k] += dz * (yv[k] - mu[k]) * is[k];
         }
       }
     }
@@ -198,4 +227,26 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
       atomicAdd(&e.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
     }
   }
+}
+
+// Dispatch on the (workgroup-uniform) tile position and, when MODE < 0, on the runtime statistics mode.
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC, int MODE = -1>
+__device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
+                                              unsigned char* smem, int b, int y0, int x0, int n0,
+                                              int tile_rows, int wr, int wc) {
+  const bool full = (y0 + tile_rows <= e.H) && (x0 + 16 <= e.W);
+  const int mode = MODE >= 0 ? MODE : (e.stat_sum ? e.stat_mode : 0);
+#define CRIMAC_EPI(M)                                                                                      \
+  do {                                                                                                     \
+    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC>(acc, e, smem, b, y0, x0, n0, wr, wc);   \
+    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC>(acc, e, smem, b, y0, x0, n0, wr, wc);       \
+  } while (0)
+  if constexpr (MODE >= 0) {
+    CRIMAC_EPI(MODE);
+  } else {
+    if (mode == 0) CRIMAC_EPI(0);
+    else if (mode == 1) CRIMAC_EPI(1);
+    else CRIMAC_EPI(2);
+  }
+#undef CRIMAC_EPI
 }

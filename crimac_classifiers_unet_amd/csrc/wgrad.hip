@@ -449,7 +449,14 @@ void wgrad_kernel(WgradParams p) {
         long cur_tile = t_begin + team;
         bool have = cur_tile < t_end;
         if (have) issue_tile(cur_tile, 0);
-        if (tt == 0) tq[4 + 2 * team] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (partial slabs promise bit-reproducible sums: there the teams take alternate tiles, whoever is faster)
+        const bool fixed_order = p.partial_stride > 0;
+        unsigned my_next = 2u + team;
+        auto take = [&]() -> unsigned {
+          if (fixed_order) { const unsigned v = my_next; my_next += 2; return v; }
+          return __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (tt == 0) tq[4 + 2 * team] = take();
         CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
         CRIMAC_WRT(1)
 #ifdef CRIMAC_DIAG_PHASES
@@ -467,7 +474,7 @@ void wgrad_kernel(WgradParams p) {
           CRIMAC_WPH(0)
           const long nxt = t_begin + __builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)(tq + 4 + 2 * team + par));
           par ^= 1;
-          if (tt == 0) tq[4 + 2 * team + par] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (tt == 0) tq[4 + 2 * team + par] = take();
           const bool has_next = nxt < t_end;
 #ifndef CRIMAC_EXP_NOLOAD
           if (has_next) issue_tile(nxt, cur ^ 1);
