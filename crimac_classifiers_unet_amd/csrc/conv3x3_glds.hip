@@ -97,7 +97,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // drains the DMA queue: 470-610 us).
 // (BN = 128 instantiates too -- 64 x 128 per wave, 2-slot ring, 74 KB -- and was the default for N >= 128 until
 // the channel-split kernel below beat it by 12 %; CRIMAC_CONV_W4=1 selects it for A/B runs.)
-template <int BN, typename T16>
+template <int BN, typename T16, int MODE>     // MODE: the epilogue's fused reduction (0 none, 1 statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void conv3x3_glds_w4_kernel(ConvParams p) {
   constexpr int NW = 4, NT = BN / 16;
@@ -234,7 +234,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
       for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
   if (sum == 12345.678f) reinterpret_cast<float*>(p.epi.out)[tid] = sum;
 #else
-  conv_epilogue<T16, BN, BM, 256, 4, NT, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
+  conv_epilogue<T16, BN, BM, 256, 4, NT, f32x4, MODE>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
 #endif
 }
 
@@ -247,10 +247,18 @@ int launch_w4(ConvParams p, hipStream_t st) {
   static_assert(BM * (BN * 2 + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB, "epilogue staging must fit");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  const dim3 grid((unsigned)ntiles, p.N / BN);
+  const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
+  if (mode == 0) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0>), grid, dim3(256), lds, st, p);
+  else if (mode == 1) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 1>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 2>), grid, dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -432,13 +440,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int kchunks = p.Cin / BK;
   WchFrags f;
+  issue_halo(0);                         // (in flight together with the first weight fragments: one latency, not two)
   wch_load_b(wrow, wrow + w_nb, f.b[1]);
-  wch_land_b(f.b[1]);
+  wch_land_b(f.b[1]);                    // vmcnt(0): the fragments and the first halo chunk
   CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
   CRIMAC_CPH(0)
   for (int kc = 0; kc < kchunks; ++kc) {
-    issue_halo(kc);
-    wait_vmcnt<0>();
+    if (kc > 0) {
+      issue_halo(kc);
+      wait_vmcnt<0>();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(1)

@@ -633,6 +633,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) wr[o][j] = w[o * Cin + sub * 8 + j];
   const long ppb = 256 / lp;            // pixels per block-iteration
+  // (one pixel per thread and iteration: with several unrolled copies a pixel's sums depended, in the last bit, on
+  // which copy it met -- i.e. on the batch size; patches must not see each other)
   for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
     const long p = p0 + threadIdx.x / lp;
     float acc[NC];
@@ -668,7 +670,101 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
         for (int o = 0; o < NC; ++o) z[o] /= den;
       }
       long b, hw;
-    pix_split(p, HW, b, hw);
+      pix_split(p, HW, b, hw);
+#pragma unroll
+      for (int o = 0; o < NC; ++o) logits[(b * NC + o) * HW + hw] = z[o];
+    }
+  }
+}
+
+// Cin == 64 (the configured net): a group of 8 lanes takes 8 consecutive pixels.  Lane s loads channel chunk s of each
+// of them (every load instruction of the wave covers whole 128-byte pixel rows) and forms the partial dot products;
+// a TRANSPOSING butterfly (xor 4, 2, 1: each step hands half of the pixels to the partner lane) leaves lane s with
+// the complete sums of pixel s -- the same pairing, hence bit for bit the same sums, as the all-reduce butterfly of
+// the generic kernel above, with 21 shuffles per 8 pixels instead of 72, the softmax evaluated once per pixel instead
+// of in 8 lanes of which 7 are discarded, and the 64 pixels of a wave stored as 256 contiguous bytes per class plane.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void head_fwd64_kernel(const T* __restrict__ x, long x_ld, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ logits,
+                                                         long npix, long HW, int softmax,
+                                                         const float* __restrict__ bn_scale,
+                                                         const float* __restrict__ bn_shift) {
+  const int sub = threadIdx.x & 7;
+  float bsc[8], bsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bsc[j] = bn_scale ? bn_scale[sub * 8 + j] : 1.f;
+    bsh[j] = bn_scale ? bn_shift[sub * 8 + j] : 0.f;
+  }
+  float wr[NC][8];
+#pragma unroll
+  for (int o = 0; o < NC; ++o)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[o][j] = w[o * 64 + sub * 8 + j];
+  float bz[NC];
+#pragma unroll
+  for (int o = 0; o < NC; ++o) bz[o] = bias[o];
+  const bool b4 = (sub & 4) != 0, b2 = (sub & 2) != 0, b1 = (sub & 1) != 0;
+  const long step = (long)gridDim.x * 256;
+  for (long g0 = (long)blockIdx.x * 256 + (threadIdx.x & ~7); g0 < npix; g0 += step) {
+    float a[8][NC];
+    float v[8][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (g0 + u < npix) load8(x + (g0 + u) * x_ld + sub * 8, v[u]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (bn_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = (float)(T)fmaxf(v[u][j] * bsc[j] + bsh[j], 0.f);
+      }
+#pragma unroll
+      for (int o = 0; o < NC; ++o) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_ += v[u][j] * wr[o][j];
+        a[u][o] = s_;
+      }
+    }
+    float r4[4][NC], r2[2][NC], z[NC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int o = 0; o < NC; ++o) {
+        const float mine = b4 ? a[u + 4][o] : a[u][o], theirs = b4 ? a[u][o] : a[u + 4][o];
+        r4[u][o] = mine + __shfl_xor(theirs, 4, 64);
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int o = 0; o < NC; ++o) {
+        const float mine = b2 ? r4[u + 2][o] : r4[u][o], theirs = b2 ? r4[u][o] : r4[u + 2][o];
+        r2[u][o] = mine + __shfl_xor(theirs, 2, 64);
+      }
+#pragma unroll
+    for (int o = 0; o < NC; ++o) {
+      const float mine = b1 ? r2[1][o] : r2[0][o], theirs = b1 ? r2[0][o] : r2[1][o];
+      z[o] = mine + __shfl_xor(theirs, 1, 64) + bz[o];
+    }
+    const long p = g0 + sub;
+    if (p < npix) {
+      if (softmax) {
+        float mx = z[0];
+#pragma unroll
+        for (int o = 1; o < NC; ++o) mx = fmaxf(mx, z[o]);
+        float den = 0.f;
+#pragma unroll
+        for (int o = 0; o < NC; ++o) { z[o] = expf(z[o] - mx); den += z[o]; }
+#pragma unroll
+        for (int o = 0; o < NC; ++o) z[o] /= den;
+      }
+      long b, hw;
+      pix_split(p, HW, b, hw);
 #pragma unroll
       for (int o = 0; o < NC; ++o) logits[(b * NC + o) * HW + hw] = z[o];
     }
@@ -1149,6 +1245,16 @@ static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, co
                            float* logits, long npix, long HW, int ncls, int softmax, const float* bn_scale,
                            const float* bn_shift, hipStream_t st) {
   const int lp = Cin / 8;
+  if (Cin == 64) {
+    const int grid64 = grid_for(npix, 256 * 4);
+#define HF64(NC)                                                                                              \
+  hipLaunchKernelGGL((head_fwd64_kernel<T, NC>), dim3(grid64), dim3(256), 0, st, (const T*)x, x_ld, w, b, logits, \
+                     npix, HW, softmax, bn_scale, bn_shift)
+    if (ncls == 2) HF64(2); else if (ncls == 3) HF64(3); else HF64(4);
+#undef HF64
+    CRIMAC_LAUNCH_CHECK();
+    return CRIMAC_OK;
+  }
   const int grid = grid_for(npix, (256 / lp) * 8);
 #define HF(NC)                                                                                      \
   hipLaunchKernelGGL((head_fwd_kernel<T, NC>), dim3(grid), dim3(256), 0, st, (const T*)x, x_ld, Cin, \

@@ -47,6 +47,14 @@ def main():
     t = timeit(head_bwd, a.iters)
     print(f"head_bwd (+BN-bwd sums) 64ch@256   {t:8.1f} us   {3 * M * C * 2 / t / 1e6:6.2f} TB/s")
 
+    logits = torch.empty(B, NC, H, H, device="cuda")
+    bias3 = torch.randn(NC, device="cuda")
+
+    def head_fwd():
+        call("crimac_head_fwd", P, ptr(x), C, C, ptr(w), ptr(bias3), ptr(logits), B, H, H, NC, 1, ptr(vec[2]), ptr(vec[3]))
+    t = timeit(head_fwd, a.iters)
+    print(f"head_fwd (BN+ReLU+1x1+softmax) 64ch@256 {t:8.1f} us   {(M * C * 2 + M * NC * 4) / t / 1e6:6.2f} TB/s")
+
     # first layer: Cin 4 (padded to 16) -> 64
     Ci = 16
     x0 = torch.randn(M, Ci, device="cuda").bfloat16()
