@@ -487,6 +487,10 @@ void wgrad_kernel(WgradParams p) {
           have = has_next;
           ++ntaken;
         }
+#ifndef CRIMAC_DIAG_PHASES
+        CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
+        if (team == 0) { CRIMAC_DIAG_STORE(crimac_diag_clock_wgrad, dg_t0, dg_r0, dg_t1, dg_r1) }
+#endif
       } else {
         if (t_begin < t_end) issue_tile(t_begin, 0);
         CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
@@ -506,6 +510,10 @@ void wgrad_kernel(WgradParams p) {
           CRIMAC_WPH(2)
           ++ntaken;
         }
+#ifndef CRIMAC_DIAG_PHASES
+        CRIMAC_DIAG_STAMP(dg_t1, dg_r1)
+        CRIMAC_DIAG_STORE(crimac_diag_clock_wgrad, dg_t0, dg_r0, dg_t1, dg_r1)
+#endif
       }
       CRIMAC_WRT(2)
 #ifdef CRIMAC_DIAG_PHASES
