@@ -911,14 +911,35 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         const u32x4 val = *reinterpret_cast<const u32x4*>(sp);
         __builtin_amdgcn_raw_buffer_store_b128(val, ro, (int)(ok ? o_rel + (unsigned)(i * out_row + 8 * k * e.out_ld * 2) : OOB), 0, 0);
         if constexpr (mode == 2) {
-          float g[8], yv[8];
-          load8(sp, g);
-          load8(reinterpret_cast<const T16*>(&yreg[i & 1][k]), yv);
+          // This epilogue sits at the 256-register limit and hipcc's allocation around it is erratic (spill counts
+          // between 3 and 220 for equivalent formulations).  Two forms, each kept for the storage type where it
+          // compiles without heavy spilling AND passes test_conv3x3_dgrad_with_fused_bn_backward_sums: unpacking two
+          // channels at a time from the packed registers (fp16: 60 -> 18 spilled registers, 393 -> 251 us; the same
+          // source gave WRONG sums for channels 2 mod 8 in the bf16 build), and unpacking both vectors first (bf16).
+          if constexpr (sizeof(T16) == 2 && __is_same(T16, half_t)) {
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const float dz = (ok && (yv[kk] * sc[kk] + sh[kk]) > 0.f) ? g[kk] : 0.f;
-            d1[kk] += dz;
-            d2[kk] += dz * (yv[kk] - mu[kk]);
+            for (int h = 0; h < 4; ++h) {
+              const unsigned gw = val[h], yw = yreg[i & 1][k][h];
+#pragma unroll
+              for (int q2 = 0; q2 < 2; ++q2) {
+                const int kk = 2 * h + q2;
+                const float gk = E16<T16>::val((unsigned short)(q2 ? gw >> 16 : gw & 0xffffu));
+                const float yk = E16<T16>::val((unsigned short)(q2 ? yw >> 16 : yw & 0xffffu));
+                const float dz = (ok && (yk * sc[kk] + sh[kk]) > 0.f) ? gk : 0.f;
+                d1[kk] += dz;
+                d2[kk] += dz * (yk - mu[kk]);
+              }
+            }
+          } else {
+            float g[8], yv[8];
+            load8(sp, g);
+            load8(reinterpret_cast<const T16*>(&yreg[i & 1][k]), yv);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              const float dz = (ok && (yv[kk] * sc[kk] + sh[kk]) > 0.f) ? g[kk] : 0.f;
+              d1[kk] += dz;
+              d2[kk] += dz * (yv[kk] - mu[kk]);
+            }
           }
         }
       }

@@ -8,14 +8,16 @@ from crimac_classifiers_unet_amd import hip
 from crimac_classifiers_unet_amd.hip import call, ptr
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-P = hip.PREC_NAMES["bf16"]
+PN = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+P = hip.PREC_NAMES[PN]
+DT = torch.bfloat16 if PN == "bf16" else torch.float16
 H = 256; C = 64; M = B * H * H
-x = torch.randn(M, C, device="cuda").bfloat16()
-y = torch.randn(M, C, device="cuda").bfloat16()
+x = torch.randn(M, C, device="cuda").to(DT)
+y = torch.randn(M, C, device="cuda").to(DT)
 w = torch.randint(-3000, 3000, (9 * C * C,), dtype=torch.int16, device="cuda")
 bias = torch.randn(C, device="cuda")
-out = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
-pool = torch.empty(M // 4, C, device="cuda", dtype=torch.bfloat16)
+out = torch.empty(M, C, device="cuda", dtype=DT)
+pool = torch.empty(M // 4, C, device="cuda", dtype=DT)
 st = torch.zeros(2, 64, C, dtype=torch.float64, device="cuda")
 vec = torch.rand(4, C, device="cuda") + 0.5
 forms = {
@@ -40,4 +42,4 @@ for name, fn in forms.items():
         fn()
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 20 * 1e3
-    print(f"B={B} {name:6s} {us:7.1f} us  {flops / us / 1e6:7.1f} TFLOP/s  {(2 + (name == 'bnb')) * M * C * 2 / us / 1e6:5.2f} TB/s", flush=True)
+    print(f"B={B} {PN} {name:6s} {us:7.1f} us  {flops / us / 1e6:7.1f} TFLOP/s  {(2 + (name == 'bnb')) * M * C * 2 / us / 1e6:5.2f} TB/s", flush=True)
