@@ -700,14 +700,11 @@ int launch_c16(ConvParams p, hipStream_t st) {
 //   * output through wave-private slabs inside the (then dead) halo buffer, one 16-pixel image row (2 KB
 //     contiguous) at a time; BatchNorm statistics (mode 1) and BatchNorm-backward sums (mode 2) stay in
 //     registers across tiles and are flushed once per workgroup.
-// Three workgroup barriers per tile (halo written | halo consumed | slabs consumed) instead of 9+.
-// Measured (64->64 @256x256, B = 32, no statistics): 195 us vs 252-263 us (W4); MFMAs + loads alone 83 us, loads +
-// output alone 110 us -- the two still add up, because all 8 waves are in the same phase.  Tried: the two teams in
-// OPPOSITE roles (one runs its MFMAs while the other writes out and refills its halo; 8-pixel slabs outside the
-// halo buffers, one LDS-only barrier per role switch): 188 us.  The MFMA role alone (one wave per SIMD, no
-// output) still takes only 82 us in that form and the output role alone 115 us, yet together 188 us: it is not
-// a scheduling artefact (nor the vmcnt(0) drain of __syncthreads -- the barriers here wait for LDS only) but
-// the MFMA stream slowing down while the HBM stream runs, as everywhere else in this file.
+// Three barriers per tile (halo written | halo consumed | slabs consumed) instead of 9+.
+// Round 1 (workgroup barriers, loads / stores under branches): 195 us vs 252-263 us (W4) at 64->64 @256x256, B = 32;
+// MFMAs + loads alone 83 us, loads + output alone 110 us -- the two added up, which round 1 blamed on the power
+// budget.  The phase stamps of round 2 (tools/diag_p64_phases.py) showed a compiler-inserted vmcnt(0) in front of
+// the halo's register -> LDS move and the two teams in lock step; see below and DESIGN.md section 4.
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for every
 // outstanding global STORE and prefetch load of the wave -- in a persistent kernel that drains the memory
 // pipeline at every barrier and serialises the output stream with the MFMA phase.
