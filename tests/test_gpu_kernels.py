@@ -534,7 +534,7 @@ def test_conv3x3_halo_strided_io_and_dgrad(prec):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 24, 40, 128, 64), (2, 32, 32, 128, 256),
-                                   (3, 256, 256, 64, 64), (7, 120, 100, 64, 64)])     # (persistent 64->64 kernel)
+                                   (3, 256, 256, 64, 64), (5, 256, 256, 64, 64), (7, 120, 100, 64, 64)])     # (persistent 64->64 kernel: 768 / 1280 tiles)
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(prec, shape):
     """stat_mode 2: the dgrad convolution also produces sum dz / sum dz*xhat of the BatchNorm block its
     output feeds (== crimac_bn_bwd_reduce on (da, y))."""
@@ -787,7 +787,8 @@ def test_conv3x3_forward_f32h3_fp16_planes(shape):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "f32x3"])
-@pytest.mark.parametrize("shape", [(2, 32, 32, 128, 128), (3, 256, 256, 64, 64), (1, 24, 40, 64, 64), (2, 16, 48, 256, 128)])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 128, 128), (3, 256, 256, 64, 64), (9, 256, 256, 64, 64), (1, 24, 40, 64, 64),
+                                   (2, 16, 48, 256, 128)])
 def test_conv3x3_with_fused_maxpool_equals_conv_then_pool(prec, shape):
     """crimac_conv3x3_pool (eval encoder tail): the output equals crimac_conv3x3 bit for bit and pool_out equals
     crimac_bn_act_pool (identity + 2x2 max-pool) of it -- channel-split kernel, persistent 64-channel kernel
@@ -819,3 +820,29 @@ def test_conv3x3_with_fused_maxpool_equals_conv_then_pool(prec, shape):
     with pytest.raises(hip.HipLibraryError):           # odd size: refused, not silently wrong
         call("crimac_conv3x3_pool", P, ptr(xin), Ci, B, H - 1, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(out), ld_o, 1,
              ptr(pool), ld_p)
+
+
+@pytest.mark.parametrize("prec", LOWP)
+@pytest.mark.parametrize("target", [2, 8, 24])
+def test_wgrad_two_teams_long_tile_queue(prec, target):
+    """The 8-wave weight-gradient kernel (16-bit conv3x3): few workgroups with LONG tile queues (target_blocks 2 ->
+    one workgroup per channel pair with 256 tiles, 8 -> 64 tiles, 24 -> a ragged last split), so both teams take many
+    tiles from the queue in LDS, finish at different times and meet in the accumulator exchange; against torch."""
+    B, H, W, Ci, Co = 2, 128, 128, 128, 64
+    g = torch.Generator().manual_seed(91)
+    x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+    ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), dy, padding=1)
+    P = hip.PREC_NAMES[prec]
+    dyn, xn = to_nhwc(dy, prec), to_nhwc(x, prec)
+    outs = []
+    for rep in range(2):
+        dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+        call("crimac_wgrad", P, 0, ptr(dyn), Co, Co, ptr(xn), Ci, Ci, B, H, W, ptr(dwp), target)
+        grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+        call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+        torch.cuda.synchronize()
+        outs.append(grad.cpu())
+        assert relerr(outs[-1], ref) < 1e-4
+    # (the queue makes the tile -> team assignment timing dependent: equal up to the order of fp32 additions)
+    assert relerr(outs[0], outs[1]) < 1e-5
