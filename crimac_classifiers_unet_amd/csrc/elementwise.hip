@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int o = 0; o < NC; ++o)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[o] += v[j] * wr[o][j];
+        for (int j = 0; j < 8; ++j) acc[o] = __builtin_fmaf(v[j], wr[o][j], acc[o]);
     }
     for (int off = lp >> 1; off > 0; off >>= 1)
 #pragma unroll
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void head_fwd64_kernel(const T* __restrict__ x
       for (int o = 0; o < NC; ++o) {
         float s_ = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s_ += v[u][j] * wr[o][j];
+        for (int j = 0; j < 8; ++j) s_ = __builtin_fmaf(v[u][j], wr[o][j], s_);     // (explicit fma: left to contraction, the third class came out 1 ulp different between unrolled copies)
         a[u][o] = s_;
       }
     }
