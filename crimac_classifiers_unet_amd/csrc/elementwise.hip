@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
     float v[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (m + u * stride < M) load8(y + (m + u * stride) * y_ld + c0, v[u]);
+      if (m + u * stride < M) load8s(y + (m + u * stride) * y_ld + c0, v[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (m + u * stride >= M) continue;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
     for (int d = 0; d < 4; ++d) {
       const long pix = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
       float v[8];
-      load8(y + pix * y_ld + c0, v);
+      load8s(y + pix * y_ld + c0, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         v[j] = v[j] * sc[j] + sh[j];
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
       const int yp = (int)(t % Hp);
       const long b = t / Hp;
       float g[8], av[4][8], yv[4][8];
-      load8(dp + r * dp_ld + c0, g);
+      load8s(dp + r * dp_ld + c0, g);
       long pix[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -451,11 +451,11 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
           // the block's conv output y is read for the fused sums anyway: the pooled activation is rebuilt from it,
           // a = round(relu(y * scale + shift)) exactly as bn_act_pool stored it (same fma, same rounding, so the same
           // ties and the same first maximum) -- `a` is not read at all (one tensor less: 0.5 GB per step)
-          load8(reinterpret_cast<const T*>(bnb.y) + pix[d] * bnb.y_ld + c0, yv[d]);
+          load8s(reinterpret_cast<const T*>(bnb.y) + pix[d] * bnb.y_ld + c0, yv[d]);
 #pragma unroll
           for (int j = 0; j < 8; ++j) av[d][j] = (float)(T)fmaxf(yv[d][j] * k.sc[j] + k.sh[j], 0.f);
         } else {
-          load8(a + pix[d] * a_ld + c0, av[d]);
+          load8s(a + pix[d] * a_ld + c0, av[d]);
         }
       }
       int arg[8];
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         float o[8];
-        if (ds) load8(ds + pix[d] * ds_ld + c0, o);
+        if (ds) load8s(ds + pix[d] * ds_ld + c0, o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           o[j] = (ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f);
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (m + u * stride < M) {
-        load8(da + (m + u * stride) * da_ld + c0, g[u]);
-        load8(y + (m + u * stride) * y_ld + c0, yv[u]);
+        load8s(da + (m + u * stride) * da_ld + c0, g[u]);
+        load8s(y + (m + u * stride) * y_ld + c0, yv[u]);
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void head_fwd64_kernel(const T* __restrict__ x
     float v[8][8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (g0 + u < npix) load8(x + (g0 + u) * x_ld + sub * 8, v[u]);
+      if (g0 + u < npix) load8s(x + (g0 + u) * x_ld + sub * 8, v[u]);
       else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[u][j] = 0.f;
@@ -820,8 +820,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       if (ok[u]) {
 #pragma unroll
         for (int o = 0; o < NC; ++o) g[u][o] = dl[(pb[u] * NC + o) * HW + phw[u]];
-        if (x) load8(x + pu * x_ld + sub * 8, v[u]);
-        if constexpr (BNB) load8(reinterpret_cast<const T*>(bnb.y) + pu * bnb.y_ld + sub * 8, yv[u]);
+        if (x) load8s(x + pu * x_ld + sub * 8, v[u]);
+        if constexpr (BNB) load8s(reinterpret_cast<const T*>(bnb.y) + pu * bnb.y_ld + sub * 8, yv[u]);
       }
       pb[u] += step_b;
       phw[u] += step_hw;
@@ -973,15 +973,24 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
        i += (long)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+#if CRIMAC_STREAM_NT      // (gradient and velocity are touched once per step: streamed past the caches)
+    f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
+#else
     f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       vv[j] = mom * vv[j] + gv[j] * gscale;
       pv[j] -= lr * vv[j];
     }
     reinterpret_cast<f32x4*>(p)[i] = pv;
+#if CRIMAC_STREAM_NT
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
+#else
     reinterpret_cast<f32x4*>(v)[i] = vv;
+#endif
     if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // tail (n not a multiple of 4)
