@@ -99,7 +99,12 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
   // (row by row: a flat index would cost an integer division by the run length per element)
   for (int ol = threadIdx.x >> 6; ol < TILE; ol += 4) {
     const float* src = d.w + ((long)(o0 + ol) * g.inner + i0) * T;
+    // (weights and packed gradients are touched once per step: streamed past the caches, common.h load8s)
+#if CRIMAC_STREAM_NT
+    for (int r = threadIdx.x & 63; r < run; r += 64) tile[ol][r] = r < valid ? __builtin_nontemporal_load(src + r) : 0.f;
+#else
     for (int r = threadIdx.x & 63; r < run; r += 64) tile[ol][r] = r < valid ? src[r] : 0.f;
+#endif
   }
   __syncthreads();
   const long n = (long)T * g.outer * g.inner_pad;
@@ -190,9 +195,15 @@ __global__ __launch_bounds__(256) void unpack_layers_kernel(Table tb) {
     const int il = idx % TILE, ol = (idx / TILE) % TILE, t = idx / (TILE * TILE);
     if (il < nin) {
       const float* src = d.dw + ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il;
+#if CRIMAC_STREAM_NT
+      float v = __builtin_nontemporal_load(src);
+      const int nsl = d.dw_splits < kFold ? d.dw_splits : kFold;                       // (folded by fold_slabs_kernel)
+      for (int sp = 1; sp < nsl; ++sp) v += __builtin_nontemporal_load(src + (long)sp * d.dw_stride);   // fixed order: reproducible
+#else
       float v = src[0];
       const int nsl = d.dw_splits < kFold ? d.dw_splits : kFold;                       // (folded by fold_slabs_kernel)
       for (int sp = 1; sp < nsl; ++sp) v += src[(long)sp * d.dw_stride];              // fixed order: reproducible
+#endif
       tile[ol][il * T + t] = v;
     }
   }
