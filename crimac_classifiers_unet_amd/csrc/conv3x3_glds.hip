@@ -24,6 +24,12 @@
 #include "conv_epilogue.h"
 
 CRIMAC_DIAG_DECLARE(crimac_diag_clock_conv)
+#ifndef CRIMAC_P64_HALO_AUX
+#define CRIMAC_P64_HALO_AUX 0      // cache policy of the halo loads (2: non-temporal)
+#endif
+#ifndef CRIMAC_WCH_HALO_AUX
+#define CRIMAC_WCH_HALO_AUX 0
+#endif
 
 namespace {
 
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (wave + NW * i < HALO_INSTR)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rsrc, (__attribute__((address_space(3))) void*)(sA + (wave + NW * i) * 1024), 16, (int)h_off[i],
-            kc * BK * 2, 0, 0);
+            kc * BK * 2, 0, CRIMAC_WCH_HALO_AUX);
   };
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -842,7 +848,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
     for (int i = 0; i < NHU; ++i)
       if (i >= i0 && i < i1)
         hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(
-            rs, (int)((h_rel[i] & border) ? OOB : ((h_rel[i] & ~15u) | kill)), 0, 0);
+            rs, (int)((h_rel[i] & border) ? OOB : ((h_rel[i] & ~15u) | kill)), 0, CRIMAC_P64_HALO_AUX);
   };
 
   // this lane's output units: rows wave * 4 + i, pixels (lane >> 3) + 8 k, channel chunk c8
