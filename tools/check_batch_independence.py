@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Eval-mode patch independence at full size: logits of patches 9..10 inside a batch of 32 == the same two patches
+alone, bit for bit (usage: check_batch_independence.py [precision] [start_filts]).  A context-dependent fp contraction
+in the 1x1 head once broke this in the last bit."""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch
