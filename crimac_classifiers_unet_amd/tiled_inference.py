@@ -157,6 +157,9 @@ class ChunkPredictor:
         return self.out
 
 
+_STAGING = {}          # (device, sizes) -> pinned / device staging buffers of predict_survey
+
+
 def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, preload_n_pings,
                    start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, **kwargs):
     """Generator over chunks: yields ``(start_ping, end_ping, out[2, n_range, end-start] numpy)``.
@@ -181,16 +184,34 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
     halo = patch_size[1]
     n_data = n_freq * (widest + 2 * halo) * n_range
     NS = 3                               # host staging slots: two chunks are being read while one is uploaded
-    stage_data = [torch.empty(n_data, dtype=torch.float32).pin_memory() for _ in range(NS)]
-    stage_lab = [torch.empty((widest, n_range), dtype=torch.int16).pin_memory() for _ in range(NS)]
     max_patches = 4 * (widest // (patch_size[0] - 2 * patch_overlap) + 2) * (n_range // (patch_size[1] - 2 * patch_overlap) + 2)
     n_misc = (widest + 2 * halo) + 4 * max_patches            # int32: seabed | global centres | slice-relative centres
-    stage_misc = [torch.empty(n_misc, dtype=torch.int32).pin_memory() for _ in range(NS)]
-    dev_misc = [torch.empty(n_misc, dtype=torch.int32, device=dev) for _ in range(2)]
+    # staging (pinned host + device) is kept between surveys of the same geometry: page-locking 3 x 75 MB + the result
+    # buffers costs 10-20 ms per call, a tenth of a 65536-ping survey
+    key = (str(dev), n_data, widest, n_range, n_misc, f16)
+    bufs = _STAGING.get(key)
+    if bufs is None or bufs["busy"]:     # (busy: another generator over the same geometry is still running)
+        fresh = {
+            "stage_data": [torch.empty(n_data, dtype=torch.float32).pin_memory() for _ in range(NS)],
+            "stage_lab": [torch.empty((widest, n_range), dtype=torch.int16).pin_memory() for _ in range(NS)],
+            "stage_misc": [torch.empty(n_misc, dtype=torch.int32).pin_memory() for _ in range(NS)],
+            "dev_misc": [torch.empty(n_misc, dtype=torch.int32, device=dev) for _ in range(2)],
+            "dev_data": [torch.empty(n_data, dtype=torch.float32, device=dev) for _ in range(2)],
+            "dev_lab": [torch.empty((widest, n_range), dtype=torch.int16, device=dev) for _ in range(2)],
+            "pinned": [torch.empty(2 * n_range * widest, dtype=torch.float16 if f16 else torch.float32).pin_memory()
+                       for _ in range(2)],
+            "busy": False,
+        }
+        if bufs is None:
+            _STAGING.clear()             # (one geometry at a time: the buffers are large)
+            _STAGING[key] = fresh
+        bufs = fresh
+    bufs["busy"] = True
+    stage_data, stage_lab, stage_misc = bufs["stage_data"], bufs["stage_lab"], bufs["stage_misc"]
+    dev_misc = bufs["dev_misc"]
     uploaded = [torch.cuda.Event() for _ in range(NS)]        # host slot k may be overwritten once this has passed
     # device side: two resident chunk buffers; chunk i is uploaded on the copy stream while chunk i-1 computes
-    dev_data = [torch.empty(n_data, dtype=torch.float32, device=dev) for _ in range(2)]
-    dev_lab = [torch.empty((widest, n_range), dtype=torch.int16, device=dev) for _ in range(2)]
+    dev_data, dev_lab = bufs["dev_data"], bufs["dev_lab"]
     computed = [torch.cuda.Event() for _ in range(2)]         # device slot may be overwritten once this has passed
     copy_stream = torch.cuda.Stream(device=dev)
 
@@ -232,64 +253,71 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
         note("fetch_s", t0)
         return grid, lo, hi, d_t, l_t, stage_misc[k][:hi - lo + 4 * P]
 
-    pinned = [torch.empty(2 * n_range * widest, dtype=torch.float16 if f16 else torch.float32).pin_memory()
-              for _ in range(2)]                 # flat: every chunk's [2, range, e - s] view of it is contiguous
+    pinned = bufs["pinned"]                      # flat: every chunk's [2, range, e - s] view of it is contiguous
     events = [torch.cuda.Event() for _ in range(2)]
     pending = None                      # (s, e, slot) of the chunk whose D2H copy is in flight
     main = torch.cuda.current_stream()
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        futs = {j: pool.submit(fetch, j, *chunks[j]) for j in range(min(2, len(chunks)))}
-        for i, (s, e) in enumerate(chunks):
-            t0 = tick()
-            grid, lo, hi, d_t, l_t, sb = futs.pop(i).result()
-            note("wait_fetch_s", t0)
-            t0 = tick()
-            if i + 2 < len(chunks):
-                futs[i + 2] = pool.submit(fetch, i + 2, *chunks[i + 2])
-            slot = i & 1
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(computed[slot])                   # chunk i-2 is done with this device slot
-                d_d = dev_data[slot][:d_t.numel()].view(d_t.shape)
-                d_d.copy_(d_t, non_blocking=True)
-                l_d = None
-                if l_t is not None:
-                    l_d = dev_lab[slot][:e - s]
-                    l_d.copy_(l_t, non_blocking=True)
-                m_d = dev_misc[slot][:sb.numel()]
-                m_d.copy_(sb, non_blocking=True)                        # (sb: seabed | centres, pinned)
-                uploaded[i % NS].record()
-            note("enq_upload_s", t0)
-            t1 = tick()
-            main.wait_stream(copy_stream)
-            P = len(grid)
-            if stats is not None:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            cp.load_chunk(d_d, lo, l_d, None, s, e, seabed=m_d[:hi - lo], seabed_ping0=lo)
-            note("enq_load_s", t1)
-            t1 = tick()
-            out = cp.predict(grid, centres_dev=m_d[hi - lo:].view(2, P, 2))
-            note("enq_predict_s", t1)
-            if stats is not None:
-                ev1.record()
-                stats.setdefault("gpu_events", []).append((ev0, ev1))
-            computed[slot].record()
-            pinned[slot][:out.numel()].view(out.shape).copy_(out, non_blocking=True)
-            events[slot].record()
-            note("enqueue_s", t0)
-            if pending is not None:
-                ps, pe, pslot = pending
+    def _loop():
+        nonlocal pending
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            futs = {j: pool.submit(fetch, j, *chunks[j]) for j in range(min(2, len(chunks)))}
+            for i, (s, e) in enumerate(chunks):
                 t0 = tick()
-                events[pslot].synchronize()
-                note("wait_gpu_s", t0)
+                grid, lo, hi, d_t, l_t, sb = futs.pop(i).result()
+                note("wait_fetch_s", t0)
                 t0 = tick()
-                res = pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
-                note("copy_out_s", t0)
-                yield ps, pe, res
-            pending = (s, e, slot)
-        ps, pe, pslot = pending
-        events[pslot].synchronize()
-        yield ps, pe, pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
+                if i + 2 < len(chunks):
+                    futs[i + 2] = pool.submit(fetch, i + 2, *chunks[i + 2])
+                slot = i & 1
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(computed[slot])                   # chunk i-2 is done with this device slot
+                    d_d = dev_data[slot][:d_t.numel()].view(d_t.shape)
+                    d_d.copy_(d_t, non_blocking=True)
+                    l_d = None
+                    if l_t is not None:
+                        l_d = dev_lab[slot][:e - s]
+                        l_d.copy_(l_t, non_blocking=True)
+                    m_d = dev_misc[slot][:sb.numel()]
+                    m_d.copy_(sb, non_blocking=True)                        # (sb: seabed | centres, pinned)
+                    uploaded[i % NS].record()
+                note("enq_upload_s", t0)
+                t1 = tick()
+                main.wait_stream(copy_stream)
+                P = len(grid)
+                if stats is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                cp.load_chunk(d_d, lo, l_d, None, s, e, seabed=m_d[:hi - lo], seabed_ping0=lo)
+                note("enq_load_s", t1)
+                t1 = tick()
+                out = cp.predict(grid, centres_dev=m_d[hi - lo:].view(2, P, 2))
+                note("enq_predict_s", t1)
+                if stats is not None:
+                    ev1.record()
+                    stats.setdefault("gpu_events", []).append((ev0, ev1))
+                computed[slot].record()
+                pinned[slot][:out.numel()].view(out.shape).copy_(out, non_blocking=True)
+                events[slot].record()
+                note("enqueue_s", t0)
+                if pending is not None:
+                    ps, pe, pslot = pending
+                    t0 = tick()
+                    events[pslot].synchronize()
+                    note("wait_gpu_s", t0)
+                    t0 = tick()
+                    res = pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
+                    note("copy_out_s", t0)
+                    yield ps, pe, res
+                pending = (s, e, slot)
+            ps, pe, pslot = pending
+            events[pslot].synchronize()
+            yield ps, pe, pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
+
+    try:
+        yield from _loop()
+    finally:
+        torch.cuda.current_stream().synchronize()     # (nothing of this survey still reads or writes the staging)
+        bufs["busy"] = False
 
 
 def predict_echogram_memm(echogram, segpipe, patch_size, patch_overlap, batch_size, predict_fn=None, **kwargs):
