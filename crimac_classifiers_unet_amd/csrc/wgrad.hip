@@ -360,6 +360,14 @@ void wgrad_kernel(WgradParams p) {
       const bool ok = k < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
       s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * 2) : OOB;
     }
+    // an operand tile that only ONE channel tile of the other operand multiplies is read exactly once from memory:
+    // non-temporal (it would only displace what other kernels keep in the caches); otherwise the default policy --
+    // the workgroups of the other channel tiles find it in L2
+#ifdef CRIMAC_EXP_WGRAD_NT
+    const bool stream_f = cs_tiles == 1, stream_s = (p.CF + 63) / 64 == 1;
+#else
+    const bool stream_f = false, stream_s = false;
+#endif
     auto issue_tile = [&](long tile, int buf) {
       long b; int y0, x0;
       tile_origin(tile, b, y0, x0);
@@ -371,8 +379,12 @@ void wgrad_kernel(WgradParams p) {
         int ry, rx;
         f_geo(i, ry, rx);
         const bool ok = (y0 + ry) < p.Hf && (x0 + rx) < p.Wf;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
-                                                 16, (int)(ok ? f_rel[i] : OOB), 0, 0, 0);
+        if (stream_f)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
+                                                   16, (int)(ok ? f_rel[i] : OOB), 0, 0, 2);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
+                                                   16, (int)(ok ? f_rel[i] : OOB), 0, 0, 0);
       }
       unsigned char* sbase = base + F_BYTES;
       const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0, sx0 = MODE == 0 ? x0 - 1 : 2 * x0;
@@ -386,8 +398,12 @@ void wgrad_kernel(WgradParams p) {
         s_geo(i, ry, rx);
         const unsigned y = (unsigned)(sy0 + ry), x = (unsigned)(sx0 + rx);
         const bool ok = y < (unsigned)Hs && x < (unsigned)Ws;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sbase + k * 1024), 16,
-                                                 (int)(ok ? s_rel[i] : OOB), 0, 0, 0);
+        if (stream_s)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sbase + k * 1024), 16,
+                                                   (int)(ok ? s_rel[i] : OOB), 0, 0, 2);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sbase + k * 1024), 16,
+                                                   (int)(ok ? s_rel[i] : OOB), 0, 0, 0);
       }
     };
     // wave -> (S half ws, tap group tg); the tile loop and the epilogue are instantiated per tap group
