@@ -117,13 +117,13 @@ def cpu_baseline():
     t_train2 = statistics.median(train_times(x2, l2, 2, 5))
     t_inf2 = statistics.median(infer_times(x2, 2, 5))
     x32, l32 = data(32)
-    t_inf32 = statistics.median(infer_times(x32, 1, 3))
-    t_train32 = train_times(x32, l32, 0, 1)[0]
+    t_inf32 = statistics.median(infer_times(x32, 1, 2))
+    t_train32 = train_times(x32, l32, 1, 1)[0]
     return {"value": 2 / t_train2, "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": "oracle (torch CPU fp32) train step, batch 2 x 4x256x256, median of 5 after 2 warm-ups",
             "infer_value": 2 / t_inf2,
-            "batch32": {"train_value": 32 / t_train32, "train_sample": "1 iteration, no warm-up",
-                        "infer_value": 32 / t_inf32, "infer_sample": "median of 3 after 1 warm-up"}}
+            "batch32": {"train_value": 32 / t_train32, "train_sample": "1 iteration after 1 warm-up",
+                        "infer_value": 32 / t_inf32, "infer_sample": "median of 2 after 1 warm-up"}}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -181,6 +181,10 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
     prof_timed, hip.PROFILE = hip.PROFILE, None
     final_loss = float(loss)
     assert final_loss == final_loss, "training diverged (NaN loss)"
+    skipped = eng.skipped_steps()
+    assert eng.loss_scale == 1.0 or skipped < steps + warmup, (
+        f"every loss-scaled step was skipped (scale {eng.loss_scale}): the number would be the throughput of steps "
+        "whose update never ran")
     log(f"{precision}: timed region done: {1e3 * elapsed / steps:.2f} ms/step")
 
     # Per-kernel durations: in the timed region the weight gradients run on a side stream CONCURRENTLY with the
@@ -223,7 +227,7 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
     res = {"precision": precision, "dtype": DTYPE_LABEL[precision],
            "train_patches_per_s": world * B * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
            "train_tflops": world * B * steps / elapsed * TRAIN_GFLOP_PER_PATCH * scale_f / 1e3,
-           "final_loss": final_loss,
+           "final_loss": final_loss, "loss_scale": eng.loss_scale, "skipped_steps": skipped,
            "roofline": roofline("crimac_conv3x3", CONV_KERNELS if precision in ("bf16", "fp16") else
                                 "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)"),
            "roofline_wgrad": roofline("crimac_wgrad", "wgrad_kernel (weight gradient, all shapes)")}
@@ -241,6 +245,50 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
         res["infer_patches_per_s"] = world * B * steps / ti
         res["infer_tflops"] = res["infer_patches_per_s"] * FWD_GFLOP_PER_PATCH * scale_f / 1e3
     return res, model
+
+
+def golden_parity(precision, dev, log):
+    """Parity of the binaries this run times, measured here and now: the 2 x 4 x 256 x 256 golden crop of the imported
+    reference (tests/golden/full64_256.npz, tools/make_golden.py: reference UNet_Baseline on the CPU, same synthetic
+    weights and crops) through the engine in ``precision`` -- eval logits (BatchNorm running statistics), train-mode
+    logits (batch statistics) and the weighted cross entropy.  rel = max |delta| / max |reference| (the north-star
+    bar is 1e-3 with identical argmax masks)."""
+    import numpy as np
+    import torch
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    path = os.path.join(ROOT, "tests", "golden", "full64_256.npz")
+    if not os.path.exists(path):
+        return {"error": "tests/golden/full64_256.npz not found"}
+    fix = np.load(path)
+    model = pkg.UNet_Baseline(3, 4, precision=precision)
+    model.load_state_dict(synth.synth_state_dict(seed=0))
+    model.to(dev)
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 256, 256, seed=1)).to(dev)
+    lab = torch.from_numpy(synth.synth_labels(2, 256, 256, seed=2)).to(dev)
+
+    def cmp(out, ref):
+        out, ref = out.detach().float().cpu(), torch.from_numpy(ref)
+        return (float((out - ref).abs().max() / ref.abs().max()), int((out.argmax(1) != ref.argmax(1)).sum()))
+
+    model.eval()
+    with torch.no_grad():
+        r_e, f_e = cmp(model(x), fix["logits_eval"])
+    model.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).to(dev)
+    logits = model(x)
+    loss = float(crit(logits, lab.long()))
+    r_t, f_t = cmp(logits, fix["logits_train"])
+    ref_loss = float(fix["losses"][0])
+    res = {"crop": "tests/golden/full64_256.npz (reference UNet_Baseline on CPU, 2 x 4 x 256 x 256)",
+           "pixels": int(fix["logits_eval"][:, 0].size),
+           "eval_logits_rel": r_e, "eval_argmax_flips": f_e, "train_logits_rel": r_t, "train_argmax_flips": f_t,
+           "loss_rel": abs(loss - ref_loss) / abs(ref_loss),
+           "meets_north_star": bool(r_e <= 1e-3 and f_e == 0)}
+    log(f"{precision}: golden crop: eval rel {r_e:.2e} flips {f_e}, train rel {r_t:.2e} flips {f_t}, "
+        f"loss rel {res['loss_rel']:.2e}")
+    del model
+    return res
 
 
 def measure_tiled(model, args, log):
@@ -265,7 +313,10 @@ def measure_tiled(model, args, log):
         written += int((out[0, :, ::64] != 0).sum())
     dt = time.perf_counter() - t0
     return {"workload": f"BASELINE configs[3]: synthetic survey sv [4, {n_pings}, {n_range}] fp32, flat seabed 900, "
-                        f"preload_n_pings {preload}, patch 256, overlap 20, batch {args.batch}, 1 GPU streamed",
+                        f"preload_n_pings {preload}, patch 256, overlap 20, 1 GPU streamed; the {len(ti.plan_grid(n_range, 900, 0, preload))} "
+                        f"patches of a chunk run as forward calls of up to {max(args.batch, ti.INTERNAL_BATCH)} patches "
+                        f"(eval mode: results do not depend on the batch; the caller's batch_size {args.batch} is a lower bound)",
+            "patches_per_forward_call": max(args.batch, ti.INTERNAL_BATCH),
             "patches_per_s": n_patches / dt, "pings_per_s": n_pings / dt, "n_patches": n_patches, "seconds": dt,
             "precision": model.precision,
             "timed": "host reader + H2D + crop/dB gather + U-Net + softmax + scatter + D2H of [2, range, pings] float16",
@@ -274,7 +325,9 @@ def measure_tiled(model, args, log):
 
 def load_profile_json(name):
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        d["_file"] = "profiles/" + name
+        return d
     except Exception:
         return None
 
@@ -312,6 +365,17 @@ def run_rank(args):
     local = local % max(torch.cuda.device_count(), 1)     # (rehearsals with several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    census = None
+    if world > 1:
+        # which ranks really take part, on which devices: an all-reduce of ones and an all-gather of the device indices
+        # over the SAME backend the gradients use
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([local], dtype=torch.int64, device=dev))
+        census = {"ranks_counted": int(ones.item()), "backend": dist.get_backend(),
+                  "device_of_rank": [int(d.item()) for d in devs],
+                  "distinct_devices": len({int(d.item()) for d in devs})}
     grad_sync = parallel.GradSync()
     main, model = measure_mode(args, args.precision, args.steps, args.warmup, world, rank, dev, grad_sync,
                                infer=not args.no_infer, log=log)
@@ -326,8 +390,8 @@ def run_rank(args):
         parity, pm = measure_mode(args, args.parity_precision, max(3, args.steps // 2), 2, world, rank, dev,
                                   grad_sync, infer=not args.no_infer, log=log)
         del pm
-        parity["meets"] = ("north-star parity bar: logits <= 1e-3 rel (measured 1e-6 class), identical argmax masks vs the "
-                           "reference golden and vs the oracle at B = 32 (tests/test_gpu_unet.py)")
+        parity["golden_parity"] = golden_parity(args.parity_precision, dev, log)
+    main["golden_parity"] = golden_parity(args.precision, dev, log) if (args.start_filts == 64 and rank == 0) else None
 
     if rank == 0:
         sf = args.start_filts
@@ -337,12 +401,15 @@ def run_rank(args):
             sel = [v for k, v in pmc["kernels"].items() if k.startswith("conv3x3")]
             nl = sum(v["launches"] for v in sel)
             rl["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
-            rl["traffic_note"] = "HBM (L2-miss) bytes per launch, rocprofv3 PMC passes (profiles/*_pmc_traffic.json)"
+            rl["traffic_source"] = ("REPLAYED from the committed profile " + pmc.get("_file", "profiles/*_pmc_traffic.json") +
+                                    " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; "
+                                    "not observed in this run): HBM (L2-miss) bytes per launch")
         util = load_profile_json("r02_mfma_util.json")
         if util and args.precision == "bf16" and sf == 64:
             rl["mfma_busy_frac"] = util.get("conv3x3", {}).get("mfma_busy_frac")
             rl["clock_ghz"] = util.get("conv3x3", {}).get("clock_ghz")
-            rl["util_note"] = util.get("note")
+            rl["util_source"] = ("REPLAYED from the committed profile " + util.get("_file", "profiles/*_mfma_util.json") +
+                                 " (not observed in this run): " + str(util.get("note")))
             main["roofline_wgrad"]["mfma_busy_frac"] = util.get("wgrad", {}).get("mfma_busy_frac")
             main["roofline_wgrad"]["clock_ghz"] = util.get("wgrad", {}).get("clock_ghz")
         workload = ("BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, batch 32 x 4x256x256 per GPU"
@@ -350,7 +417,9 @@ def run_rank(args):
                     f"BASELINE configs[4]: wide U-Net (depth 5, {sf} filters) train step, batch {args.batch} x 4x256x256 "
                     "per GPU" + (", on-GPU add_noise/flip augment" if args.gpu_augment else ""))
         if world > 1:
-            workload += f", data-parallel over {world} GPUs (RCCL gradient exchange overlapped with backward)"
+            be = dist.get_backend()
+            workload += (f", data-parallel over {world} ranks ({'RCCL over xGMI' if be == 'nccl' else be + ' (rehearsal backend)'} "
+                         "gradient exchange overlapped with backward)")
         out = {
             "metric": "echogram patches/sec (4ch 256x256), training step (fwd+weighted CE+bwd+SGD)",
             "value": main["train_patches_per_s"], "unit": "patches/s", "n_gpus": world, "steps": args.steps,
@@ -358,14 +427,15 @@ def run_rank(args):
             "vs_baseline": None, "dtype": main["dtype"], "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * args.batch, "patch": [4, 256, 256],
                        "precision": args.precision, "start_filts": sf, "parallelism": f"dp{world}",
-                       "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+                       "ranks": world, "backend": (dist.get_backend() if world > 1 else None), "rank_census": census,
                        "launcher": "self-spawned" if os.environ.get("CRIMAC_SELF_LAUNCHED") == "1" else
                                    ("torchrun" if world > 1 else "single process")},
             "per_gpu_patches_per_s": main["train_patches_per_s"] / world,
             "train_tflops": main["train_tflops"],
             "infer_patches_per_s": main.get("infer_patches_per_s"),
             "infer_tflops": main.get("infer_tflops"),
-            "final_loss": main["final_loss"],
+            "final_loss": main["final_loss"], "loss_scale": main["loss_scale"], "skipped_steps": main["skipped_steps"],
+            "golden_parity": main["golden_parity"],
             "roofline": rl, "roofline_wgrad": main["roofline_wgrad"],
         }
         if parity is not None:

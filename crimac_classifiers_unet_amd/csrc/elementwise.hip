@@ -17,7 +17,8 @@ void crimac_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* crimac_last_error(void) { return g_err; }
-extern "C" int crimac_version(void) { return 1; }
+extern "C" int crimac_version(void) { return CRIMAC_ABI_VERSION; }
+extern "C" int crimac_layer_desc_size(void) { return (int)sizeof(crimac_layer_desc); }
 
 namespace {
 

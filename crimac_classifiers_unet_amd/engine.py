@@ -1122,10 +1122,19 @@ class UNetEngine:
             call("crimac_grad_overflow_flag", ptr(self.flat_g), self.n_flat, ptr(st))
             call("crimac_sgd_momentum_guarded", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
                  float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0, ptr(st))
+            # dynamic scale: the pipeline's loss flush re-evaluates it where it synchronises anyway; callers of the bare
+            # step (bench.py, engine.train_step, the autograd path + SGDMomentum.step) get the same policy every
+            # `loss_scale_check_every` guarded steps -- without it a scale that overflows would skip every step for
+            # ever, silently (one host read of two ints per interval)
+            self._guarded_steps = getattr(self, "_guarded_steps", 0) + 1
+            if self.loss_scale_check_every and self._guarded_steps % self.loss_scale_check_every == 0:
+                self.update_loss_scale()
         else:
             call("crimac_sgd_momentum", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_v), self.n_flat,
                  float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0)
         self.mark_dirty()
+
+    loss_scale_check_every = 25      # guarded steps between two host reads of the skip counter inside train_step (0: never)
 
     def skipped_steps(self):
         """Steps whose update was skipped because a scaled gradient overflowed (host sync)."""

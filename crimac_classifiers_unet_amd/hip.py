@@ -30,6 +30,8 @@ PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: PLANES
 PREC_BACKWARD = {PREC_F32H3: PREC_F32X3}
 PREC_16BIT = (PREC_BF16, PREC_FP16)
 
+ABI_VERSION = 3          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
+
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # name -> argtypes, exactly the prototypes of include/crimac_unet_hip.h
@@ -122,6 +124,17 @@ def load_library():
     lib.crimac_version.argtypes = []
     lib.crimac_last_error.restype = C.c_char_p
     lib.crimac_last_error.argtypes = []
+    ver = lib.crimac_version()
+    if ver != ABI_VERSION:
+        raise HipLibraryError(f"{path} has ABI version {ver}, this binding needs {ABI_VERSION}: rebuild it "
+                              "(`python -m crimac_classifiers_unet_amd.build --force`)")
+    if not hasattr(lib, "crimac_layer_desc_size"):
+        raise HipLibraryError(f"{path} does not export crimac_layer_desc_size: stale build")
+    lib.crimac_layer_desc_size.restype = C.c_int
+    lib.crimac_layer_desc_size.argtypes = []
+    if lib.crimac_layer_desc_size() != C.sizeof(LayerDesc):
+        raise HipLibraryError(f"{path}: crimac_layer_desc is {lib.crimac_layer_desc_size()} bytes in the library, "
+                              f"{C.sizeof(LayerDesc)} in this binding")
     lib.crimac_wgrad_splits.restype = C.c_int          # (returns a count, not a status; no stream argument)
     lib.crimac_wgrad_splits.argtypes = [_i, _i, _i, _i, _i, _i, _i, _i]
     for name, argtypes in SIGNATURES.items():

@@ -49,6 +49,8 @@ def spawn_ranks(argv, n_ranks, extra_env=None, timeout=None):
     t0 = time.time()
     rc = 0
     out0 = ""
+    kill_at = None               # after a SIGTERM the survivors get GRACE_S seconds, then SIGKILL (a rank stuck in the
+    GRACE_S = 10.0               # driver or in a collective may ignore SIGTERM: the parent must not wait for it for ever)
     try:
         # rank 0's stdout is small (one JSON line): read it to the end, then reap everyone
         alive = list(range(n_ranks))
@@ -67,12 +69,25 @@ def spawn_ranks(argv, n_ranks, extra_env=None, timeout=None):
                     print(f"[launch] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
                     for q in alive:
                         procs[q].send_signal(signal.SIGTERM)
+                    kill_at = kill_at or time.time() + GRACE_S
             if timeout is not None and time.time() - t0 > timeout:
                 rc = rc or 124
                 print(f"[launch] timeout after {timeout} s; stopping all ranks", file=sys.stderr)
                 for q in alive:
                     procs[q].send_signal(signal.SIGTERM)
                 timeout = None
+                kill_at = kill_at or time.time() + GRACE_S
+            if kill_at is not None and alive and time.time() > kill_at:
+                print(f"[launch] ranks {alive} ignored SIGTERM for {GRACE_S:.0f} s: killing them", file=sys.stderr)
+                for q in alive:
+                    procs[q].kill()                    # (by PID: children of this process only)
+                for q in alive:
+                    try:
+                        procs[q].wait(timeout=5)
+                    except subprocess.TimeoutExpired:
+                        pass
+                rc = rc or 137
+                break
             time.sleep(0.05)
         reader.join(timeout=5)
         out0 = buf[0] if buf else ""

@@ -138,6 +138,7 @@ class SegPipe:
         criterion = self.get_criterion()
         engine = self.model.engine
         engine.sync_bn = self.sync_bn
+        engine.loss_scale_check_every = 0       # (the dynamic loss scale is re-evaluated in flush() below)
         grad_sync = parallel.GradSync()
         is_rank0 = parallel.env_world()[1] == 0
         pending = []

@@ -175,6 +175,7 @@ class SyntheticSurveyReader:
         self.sv = np.ascontiguousarray(np.tile(blk, (1, reps, 1))[:, :n_pings])
         self.labels = np.zeros((n_pings, n_range), dtype=np.int16)
         self.seabed = np.full(n_pings, seabed_index, dtype=np.int64)
+        self._mask = None
         self.shape = (n_pings, n_range)
         self.time_vector = np.arange(n_pings)
         self.range_vector = np.arange(n_range) * 0.19
@@ -195,8 +196,10 @@ class SyntheticSurveyReader:
     def get_seabed_mask(self, idx_ping, n_pings, idx_range=None, n_range=None, return_numpy=False, seabed_pad=0):
         idx_range = 0 if idx_range is None else idx_range
         hi = self.shape[1] if n_range is None else idx_range + n_range
-        r = np.arange(idx_range, min(hi, self.shape[1]))
-        m = (r[None, :] >= self.seabed[idx_ping:idx_ping + n_pings, None]).astype(np.float64)
+        if self._mask is None:
+            # stored like the reader's `bottom_range` array (1 below the seabed), not rebuilt per request
+            self._mask = (np.arange(self.shape[1])[None, :] >= self.seabed[:, None]).astype(np.uint8)
+        m = self._mask[idx_ping:idx_ping + n_pings, idx_range:min(hi, self.shape[1])]
         if seabed_pad != 0:
             out = np.zeros_like(m)
             out[:, seabed_pad:] = m[:, :-seabed_pad]

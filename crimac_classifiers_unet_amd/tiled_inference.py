@@ -157,6 +157,35 @@ class ChunkPredictor:
         return self.out
 
 
+def seabed_vector_or_mask(reader, s, e, n_range, sb, sb_ping0):
+    """The scatter kernel rebuilds the reader's 2-D seabed mask (``get_seabed_mask``: 1 below the seabed, what
+    ``mask_label_seabed`` uses, mask_label_seabed.py:47-49) from the seabed VECTOR as ``range >= seabed[ping]``.  The zarr
+    reader derives that vector as ``argmax(range)`` of the stored mask (data_reader.py:864-865), so the two agree only
+    where the mask of a ping is exactly "zeros, then ones to the end": a ping with NO detected bottom has an all-zero
+    mask (``fillna(0)``) and argmax 0 -- the vector rule would mask its whole water column, the reference masks
+    nothing -- and a mask with holes is not a threshold at all.  Checked here per chunk on the reader's own mask for
+    the pings [s, e) the chunk writes: no-bottom pings get seabed = n_range (nothing below it), and a mask the vector
+    cannot express is returned as uint8 [e - s, n_range] to be uploaded instead (``ChunkPredictor.load_chunk``).
+
+    Returns (seabed vector to upload, mask or None).  ``sb`` covers pings [sb_ping0, sb_ping0 + len(sb))."""
+    if not hasattr(reader, "get_seabed_mask"):
+        return sb, None
+    m = reader.get_seabed_mask(int(s), int(e - s), 0, int(n_range), return_numpy=True)
+    m = np.asarray(getattr(m, "values", m))
+    if m.shape != (e - s, n_range):
+        raise ValueError(f"get_seabed_mask returned {m.shape}, expected {(e - s, n_range)}")
+    below = m != 0
+    cnt = np.count_nonzero(below, axis=1)
+    vec = sb[s - sb_ping0:e - sb_ping0]
+    none = cnt == 0
+    if np.array_equal(np.where(none, 0, n_range - vec), cnt):      # every column: zeros, then ones from seabed[ping] on
+        if none.any():
+            sb = sb.copy()
+            sb[s - sb_ping0:e - sb_ping0][none] = n_range
+        return sb, None
+    return sb, np.ascontiguousarray(below.astype(np.uint8))
+
+
 _STAGING = {}          # (device, sizes) -> pinned / device staging buffers of predict_survey
 
 
@@ -167,12 +196,13 @@ def release_staging():
 
 
 def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, preload_n_pings,
-                   start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, **kwargs):
+                   start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, predict_fn=None, **kwargs):
     """Generator over chunks: yields ``(start_ping, end_ping, out[2, n_range, end-start] numpy)``.
 
     ``reader``: the reference's zarr reader API (shape, get_data_slice, get_label_slice, get_seabed);
     ``segpipe``: a ``SegPipeUNet`` with loaded parameters.  ``out_dtype=np.float16`` returns what the reference
     stores (save_predict.py:212) and halves the bytes that come back; float32 (default) keeps full probabilities.
+    ``predict_fn(x_nhwc, P, H, W) -> probs [P,3,H,W]`` replaces the network (tests of the plumbing).
 
     Three stages overlap: a host thread reads chunk i+1 from ``reader`` straight into pinned staging buffers
     (numpy / zarr I/O, no GPU calls) while the GPU uploads (copy stream), gathers, predicts and scatters chunk i, and
@@ -247,6 +277,7 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
             np.copyto(l_t.numpy(), lab, casting="unsafe")
         # the seabed of every ping a patch of the chunk can touch (the scatter kernel evaluates the mask from it)
         sb = np.asarray(reader.get_seabed(lo, hi - lo, return_numpy=True)).astype(np.int32)
+        sb, mask = seabed_vector_or_mask(reader, s, e, n_range, sb, lo)
         P = len(grid)
         assert (hi - lo) + 4 * P <= n_misc, "misc staging too small"
         m = stage_misc[k].numpy()
@@ -257,7 +288,7 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
         loc[:, 1] -= lo
         m[hi - lo + 2 * P:hi - lo + 4 * P] = loc.reshape(-1)
         note("fetch_s", t0)
-        return grid, lo, hi, d_t, l_t, stage_misc[k][:hi - lo + 4 * P]
+        return grid, lo, hi, d_t, l_t, stage_misc[k][:hi - lo + 4 * P], mask
 
     pinned = bufs["pinned"]                      # flat: every chunk's [2, range, e - s] view of it is contiguous
     events = [torch.cuda.Event() for _ in range(2)]
@@ -269,7 +300,7 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
             futs = {j: pool.submit(fetch, j, *chunks[j]) for j in range(min(2, len(chunks)))}
             for i, (s, e) in enumerate(chunks):
                 t0 = tick()
-                grid, lo, hi, d_t, l_t, sb = futs.pop(i).result()
+                grid, lo, hi, d_t, l_t, sb, mask = futs.pop(i).result()
                 note("wait_fetch_s", t0)
                 t0 = tick()
                 if i + 2 < len(chunks):
@@ -293,10 +324,13 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                 if stats is not None:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
-                cp.load_chunk(d_d, lo, l_d, None, s, e, seabed=m_d[:hi - lo], seabed_ping0=lo)
+                if mask is None:
+                    cp.load_chunk(d_d, lo, l_d, None, s, e, seabed=m_d[:hi - lo], seabed_ping0=lo)
+                else:                                 # (a mask the vector rule cannot express: uploaded as it is)
+                    cp.load_chunk(d_d, lo, l_d, mask, s, e)
                 note("enq_load_s", t1)
                 t1 = tick()
-                out = cp.predict(grid, centres_dev=m_d[hi - lo:].view(2, P, 2))
+                out = cp.predict(grid, predict_fn=predict_fn, centres_dev=m_d[hi - lo:].view(2, P, 2))
                 note("enq_predict_s", t1)
                 if stats is not None:
                     ev1.record()

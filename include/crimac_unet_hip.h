@@ -71,8 +71,14 @@ extern "C" {
 /* F32H3: two fp16 forward planes of w * 2^CRIMAC_F32H3_WSHIFT (bits 8-15 carry the shift), two bf16 dgrad planes */
 #define CRIMAC_PLANES_F32H3 (2 | CRIMAC_PLANES_FWD_FP16 | (CRIMAC_F32H3_WSHIFT << 8))
 
-/* Library identity / error text. */
+/* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
+ * struct passed by pointer (crimac_layer_desc), the meaning of an argument or the set of precisions changes, and a
+ * binding must refuse a library whose version differs from the header it was written against (an older build that
+ * happens to export every symbol would walk a descriptor array with the wrong stride).  crimac_layer_desc_size() is
+ * sizeof(crimac_layer_desc) as the library was compiled. */
+#define CRIMAC_ABI_VERSION 3
 int crimac_version(void);
+int crimac_layer_desc_size(void);
 const char* crimac_last_error(void);
 
 /* ---- dense contractions (MFMA) ------------------------------------------------------------- */

@@ -85,11 +85,15 @@ def data_transform(data):
     return db, nonfinite0
 
 
-def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfinite0, seabed_rule="zarr"):
+def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfinite0, seabed_rule="zarr",
+                 seabed_mask=None):
     """Labels of one patch after the test-time transforms, as far as they decide validity.
 
     raw_labels: [n_range, chunk_pings] crop source (chunk-local ping axis, already offset);
     seabed: per-ping seabed index vector indexable by the GLOBAL ping of each patch column.
+    ``seabed_mask`` [n_pings_total, n_range] (zarr rule only): the reader's own 2-D mask (``get_seabed_mask``, 1 below the
+    seabed) -- what mask_label_seabed.py:47-49 really reads; ``seabed`` is then only its argmax (data_reader.py:864-865)
+    and the two differ for pings without a detected bottom (all-zero column) and for masks with holes.
     Returns the label patch with values in {-100, -70, -50, -10, 0, 1, 2} (refine_label_boundary's
     -30 never changes validity and is not modelled).
     """
@@ -114,7 +118,10 @@ def patch_labels(raw_labels, centre, size, seabed, n_range, patch_overlap, nonfi
             continue
         ok_rows = (y_data >= 0) & (y_data < n_range)
         r = y_data - y_top
-        if seabed_rule == "zarr":      # zarr reader: the 10-pixel pad shifts the mask down INSIDE the requested slice
+        if seabed_rule == "zarr" and seabed_mask is not None:
+            src = np.clip(y_data - SEABED_PAD, 0, n_range - 1)
+            below[:, j] = ok_rows & (r >= SEABED_PAD) & (np.asarray(seabed_mask)[x, src] != 0)
+        elif seabed_rule == "zarr":    # zarr reader: the 10-pixel pad shifts the mask down INSIDE the requested slice
             below[:, j] = ok_rows & (r >= SEABED_PAD) & ((y_data - SEABED_PAD) >= seabed[x])
         else:                          # Echogram.get_seabed_mask (data_reader.py:407-431): absolute rows >= seabed + pad
             below[:, j] = ok_rows & ((y_data - SEABED_PAD) >= seabed[x])
@@ -145,7 +152,7 @@ def fill_out_array(out_array, preds, labels, centre, ping_start):
 
 
 def predict_chunk(sv, raw_labels, seabed, start_ping, end_ping, predict_fn, patch_size=(256, 256),
-                  patch_overlap=20):
+                  patch_overlap=20, seabed_mask=None):
     """One chunk of ``save_survey_predictions_zarr`` (save_predict.py:171-209) on in-memory arrays.
 
     sv [C, n_pings_total, n_range] linear (zarr orientation), raw_labels [n_pings_total, n_range],
@@ -164,7 +171,7 @@ def predict_chunk(sv, raw_labels, seabed, start_ping, end_ping, predict_fn, patc
         d = crop(data, (c[0], c[1] - lo), patch_size, 0)
         d, nonfinite0 = data_transform(d)          # stays in the reader's dtype (float32 on the preload path)
         lab = patch_labels(labels, {"local": (c[0], c[1] - start_ping), "global": (c[0], c[1])},
-                           patch_size, seabed, n_range, patch_overlap, nonfinite0)
+                           patch_size, seabed, n_range, patch_overlap, nonfinite0, seabed_mask=seabed_mask)
         preds = predict_fn(d.astype(np.float32))
         fill_out_array(out, preds, lab, c, start_ping)
     return out, grid

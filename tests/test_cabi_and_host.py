@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
     # and the binding table covers the header exactly (plus version / last_error)
-    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error", "crimac_wgrad_splits"} == set(syms)
+    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error", "crimac_wgrad_splits",
+                                  "crimac_layer_desc_size"} == set(syms)
     # the split planner is a host-only query (no GPU): the level-0 shape fills one resident round
     lib2 = hip.load_library()
     assert lib2.crimac_wgrad_splits(0, 0, 64, 64, 32, 256, 256, 0) == 256        # bf16: one 8-wave workgroup per CU
@@ -37,7 +38,18 @@ def test_library_exports_every_declared_symbol():
     assert lib2.crimac_wgrad_splits(0, 0, 1024, 1024, 32, 16, 16, 0) >= 1
     assert lib2.crimac_wgrad_splits(0, 2, 64, 64, 32, 256, 256, 0) < 0          # bad mode
     assert lib2.crimac_wgrad_splits(9, 0, 64, 64, 32, 256, 256, 0) < 0          # bad precision
-    assert hip.load_library().crimac_version() >= 1
+    # ABI identity: the binding refuses a library of another version or with another descriptor layout
+    header = open(os.path.join(ROOT, "include", "crimac_unet_hip.h")).read()
+    assert int(re.search(r"#define CRIMAC_ABI_VERSION (\d+)", header).group(1)) == hip.ABI_VERSION
+    assert lib2.crimac_version() == hip.ABI_VERSION
+    assert lib2.crimac_layer_desc_size() == ctypes.sizeof(hip.LayerDesc)
+
+
+def test_binding_refuses_a_library_with_another_abi_version(monkeypatch):
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "ABI_VERSION", hip.ABI_VERSION + 1)
+    with pytest.raises(hip.HipLibraryError, match="ABI version"):
+        hip.load_library()
 
 
 def test_argument_validation_runs_without_gpu():

@@ -18,10 +18,15 @@ class _Val:
 class FakeZarrReader:
     data_format = "zarr"
 
-    def __init__(self, sv, labels, seabed, name="fake_survey"):
+    def __init__(self, sv, labels, seabed, name="fake_survey", mask=None):
         self.sv = sv                    # [C, pings, range] linear sv, float32
         self.labels = labels            # [pings, range] raw species labels
         self.seabed = seabed            # [pings] seabed range index
+        # mask [pings, range]: the stored `bottom_range` array (1 below the seabed) is then the authority and the
+        # seabed vector is its argmax, as in the real reader (data_reader.py:837, :864-865)
+        self.mask = None if mask is None else np.asarray(mask)
+        if self.mask is not None:
+            self.seabed = self.mask.argmax(axis=1).astype(np.int64)
         self.shape = (sv.shape[1], sv.shape[2])
         self.time_vector = np.arange(sv.shape[1])
         self.range_vector = np.arange(sv.shape[2]) * 0.19
@@ -45,12 +50,25 @@ class FakeZarrReader:
         idx_range = 0 if idx_range is None else idx_range
         hi = self.shape[1] if n_range is None else idx_range + n_range
         r = np.arange(idx_range, min(hi, self.shape[1]))
-        m = (r[None, :] >= self.seabed[idx_ping:idx_ping + n_pings, None]).astype(np.float64)
+        if self.mask is not None:
+            m = self.mask[idx_ping:idx_ping + n_pings, r[0]:r[-1] + 1].astype(np.float64)
+        else:
+            m = (r[None, :] >= self.seabed[idx_ping:idx_ping + n_pings, None]).astype(np.float64)
         if seabed_pad != 0:
             out = np.zeros_like(m)
             out[:, seabed_pad:] = m[:, :-seabed_pad]
             return out
         return m
+
+
+def holey_seabed_mask(seabed, n_range):
+    """A stored seabed mask the seabed VECTOR cannot express: pings 100-130 have no detected bottom (all-zero column,
+    ``fillna(0)`` in the real reader) and pings 300-340 have a hole of zeros below the first seabed rows."""
+    m = (np.arange(n_range)[None, :] >= np.asarray(seabed)[:, None]).astype(np.uint8)
+    m[100:131] = 0
+    for x in range(300, 341):
+        m[x, seabed[x] + 15:seabed[x] + 40] = 0
+    return m
 
 
 def synth_survey(n_pings=1200, n_range=600, channels=4, seed=7):
