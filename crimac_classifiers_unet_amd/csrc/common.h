@@ -126,33 +126,76 @@ template <> struct PlaneOf<float> { using type = bf16_t; };
 
 // Number of operand planes of a precision mode.
 __host__ __device__ constexpr int planes_of(int prec) {
-  return (prec == 0 || prec == 3) ? 1 : ((prec == 1 || prec == 4) ? 2 : 3);
+  return (prec == 0 || prec == 3) ? 1 : ((prec == 1 || prec == 4 || prec == 5) ? 2 : 3);
+}
+
+// ---- fp16 plane pairs ("hp" storage, CRIMAC_PREC_H3P) -----------------------------------------------------------
+// A tensor of this storage type has the ADDRESSING of an fp32 tensor -- 4 bytes per element, pixel stride `ld`
+// elements, channel slices at 4 * c bytes -- but every aligned group of 8 channels holds
+//     [8 x fp16 hi][8 x fp16 lo]      value = hi + lo   (hi = rn16(x), lo = rn16(x - hi): 22 significant bits)
+// i.e. the operand planes of the 3-MFMA product (hi*hi + hi*lo + lo*hi) are split ONCE, by the kernel that produces
+// the tensor, and every consumer takes them as they are: an MFMA kernel sees a 16-bit tensor with twice the channels
+// (K' = 2K; a 32-channel chunk = 64 halves = 128 bytes per pixel, moved global -> LDS by LDS-DMA like a bf16 chunk)
+// and an elementwise kernel sees 32-byte groups it loads / stores with load8 / store8 below.  Because the addressing
+// is that of fp32, fp32 and plane-pair tensors may share one buffer (the two halves of a concat buffer).
+struct hp_t { unsigned int raw; };          // never used as a value: only through load8 / store8 / storage_round
+static_assert(sizeof(hp_t) == 4, "hp_t must address like float");
+
+// value -> what a tensor of storage type T holds for it
+template <typename T> __device__ __forceinline__ float storage_round(float x) { return (float)(T)x; }
+template <> __device__ __forceinline__ float storage_round<float>(float x) { return x; }
+template <> __device__ __forceinline__ float storage_round<hp_t>(float x) {
+  const half_t h = (half_t)x;
+  const half_t l = (half_t)(x - (float)h);
+  return (float)h + (float)l;               // exact: hi + lo spans at most 23 bits
 }
 // `planes` argument of the packing entry points (crimac_unet_hip.h, CRIMAC_PLANES_*)
 struct PlaneFmt {
   int npl, fwd_fp16, dg_fp16;
-  float fwd_scale;
+  float fwd_scale, dg_scale;
+  int interleaved;            // CRIMAC_PLANES_INTERLEAVED: plane k of channel c of a row of K channels at il_pos(c, K) + k * CB
 };
 __host__ __device__ inline PlaneFmt plane_fmt(int planes_arg) {
   PlaneFmt f;
   f.npl = planes_arg & 15;
   f.fwd_fp16 = (planes_arg >> 4) & 1;
   f.dg_fp16 = (planes_arg >> 5) & 1;
+  f.interleaved = (planes_arg >> 6) & 1;
   f.fwd_scale = (float)(1 << ((planes_arg >> 8) & 255));
+  f.dg_scale = ((planes_arg >> 7) & 1) ? f.fwd_scale : 1.f;
   return f;
 }
 __host__ inline bool planes_arg_ok(int planes_arg) {
   const int npl = planes_arg & 15, sh = (planes_arg >> 8) & 255;
-  return npl >= 1 && npl <= 3 && (planes_arg >> 16) == 0 && (planes_arg & 0xC0) == 0 && sh <= 16;
+  if ((planes_arg & 0x40) && npl != 2) return false;           // interleaved rows are plane PAIRS
+  return npl >= 1 && npl <= 3 && (planes_arg >> 16) == 0 && sh <= 16;
+}
+// Interleaved plane-pair rows (CRIMAC_PLANES_INTERLEAVED): a row of K channels is 2K halves, block size CB = min(K, 32);
+// channel c of plane k sits at (c / CB) * 2CB + k * CB + c % CB.
+__host__ __device__ constexpr int il_cb(int K) { return K < 32 ? K : 32; }
+__host__ __device__ inline long il_pos(int c, int K) {
+  const int cb = il_cb(K);
+  return (long)(c / cb) * 2 * cb + c % cb;
 }
 
 // Storage-type dispatch of an entry point: `T` is bf16_t (CRIMAC_PREC_BF16), half_t (CRIMAC_PREC_FP16) or float
-// (the fp32-storage modes) inside the statement.
+// (the fp32-storage modes) inside the statement.  CRIMAC_PREC_H3P: `T` is the type of the tensors that stay fp32 in
+// that mode (convolution outputs, activation gradients) -- float; entry points with plane-pair operands dispatch on
+// the precision themselves.
 #define CRIMAC_FOR_STORAGE(prec, T, ...)                                  \
   do {                                                                    \
     if ((prec) == CRIMAC_PREC_BF16) { using T = bf16_t; __VA_ARGS__; }    \
     else if ((prec) == CRIMAC_PREC_FP16) { using T = half_t; __VA_ARGS__; } \
     else { using T = float; __VA_ARGS__; }                                \
+  } while (0)
+// Two storage types: TF for the tensors that are fp32 in H3P (conv outputs y, activation gradients da), TP for the
+// MFMA operands of that mode (activations a, output gradients dy): hp_t.  All other modes: both the mode's type.
+#define CRIMAC_FOR_STORAGE2(prec, TF, TP, ...)                                            \
+  do {                                                                                    \
+    if ((prec) == CRIMAC_PREC_BF16) { using TF = bf16_t; using TP = bf16_t; __VA_ARGS__; } \
+    else if ((prec) == CRIMAC_PREC_FP16) { using TF = half_t; using TP = half_t; __VA_ARGS__; } \
+    else if ((prec) == CRIMAC_PREC_H3P) { using TF = float; using TP = hp_t; __VA_ARGS__; } \
+    else { using TF = float; using TP = float; __VA_ARGS__; }                             \
   } while (0)
 
 // Activation element traits: T = bf16_t (16-bit storage) or float (fp32 storage).
@@ -166,6 +209,10 @@ template <> struct ActT<half_t> {
   static constexpr int kVec = 8;
 };
 template <> struct ActT<float> {
+  static constexpr int kBytes = 4;
+  static constexpr int kVec = 4;
+};
+template <> struct ActT<hp_t> {
   static constexpr int kBytes = 4;
   static constexpr int kVec = 4;
 };
@@ -187,6 +234,29 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
 }
+// plane pairs: 8 channels = [8 hi][8 lo] (32 bytes, 16-byte aligned like the two halves of an fp32 group)
+__device__ __forceinline__ void hp_join(const u32x4& h, const u32x4& l, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[2 * j] = E16<half_t>::val((unsigned short)(h[j] & 0xffffu)) + E16<half_t>::val((unsigned short)(l[j] & 0xffffu));
+    v[2 * j + 1] = E16<half_t>::val((unsigned short)(h[j] >> 16)) + E16<half_t>::val((unsigned short)(l[j] >> 16));
+  }
+}
+__device__ __forceinline__ void hp_split(const float (&v)[8], u32x4& h, u32x4& l) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned short h0 = E16<half_t>::bits(v[2 * j]), h1 = E16<half_t>::bits(v[2 * j + 1]);
+    const unsigned short l0 = E16<half_t>::bits(v[2 * j] - E16<half_t>::val(h0));
+    const unsigned short l1 = E16<half_t>::bits(v[2 * j + 1] - E16<half_t>::val(h1));
+    h[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+    l[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+}
+__device__ __forceinline__ void load8(const hp_t* p, float (&v)[8]) {
+  const u32x4 h = *reinterpret_cast<const u32x4*>(p);
+  const u32x4 l = *(reinterpret_cast<const u32x4*>(p) + 1);
+  hp_join(h, l, v);
+}
 // The same load for data a streaming kernel reads exactly once (non-temporal: it does not displace what the MFMA
 // kernels running beside it keep in L2 / the Infinity Cache).  bn_bwd_apply with it: 161 -> 144 us at level 0, and
 // -0.8 % on the whole step in the same call (-DCRIMAC_STREAM_NT=0 builds the plain form for A/B runs).
@@ -196,7 +266,11 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
 template <typename T>
 __device__ __forceinline__ void load8s(const T* p, float (&v)[8]) {
 #if CRIMAC_STREAM_NT
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (__is_same(T, hp_t)) {
+    const u32x4 h = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    const u32x4 l = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + 1);
+    hp_join(h, l, v);
+  } else if constexpr (sizeof(T) == 2) {
     const u16x8 r = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p));
     load8(reinterpret_cast<const T*>(&r), v);
   } else {
@@ -227,6 +301,13 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
   *reinterpret_cast<f32x4*>(p) = a;
   *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+__device__ __forceinline__ void store8(hp_t* p, const float (&v)[8]) {
+  u32x4 h, l;
+  hp_split(v, h, l);
+  *reinterpret_cast<u32x4*>(p) = h;
+  *(reinterpret_cast<u32x4*>(p) + 1) = l;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -38,6 +38,7 @@ struct ConvParams {
   int Cin, N;
   const unsigned short* w_hi;
   const unsigned short* w_lo;
+  int w_il;                    // weight planes interleaved in w_hi (CRIMAC_PLANES_INTERLEAVED); else w_hi | w_lo planes
   EpiParams epi;
   int tiles_y, tiles_x;
 };
@@ -64,13 +65,17 @@ template <int BK> struct Sw {
 
 // TR = tile rows: 8 (128-pixel tile, wave 64 x BN/2, 2 workgroups per CU) or 16 (256-pixel tile,
 // wave 128 x BN/2: 25 % fewer LDS fragment bytes per MFMA, 1 workgroup per CU).
-template <typename TA, int NPL, int BN, int BK, int TR, typename P16 = typename PlaneOf<TA>::type>
+// TA = hp_t: the input is already split (fp16 plane pairs, common.h): the staging copies the two 16-byte halves of
+// an 8-channel group into the two plane images instead of splitting fp32 values.  TO: storage type of the output.
+template <typename TA, int NPL, int BN, int BK, int TR, typename P16 = typename PlaneOf<TA>::type, typename TO = TA>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   constexpr int HALO_ROWS = (TR + 2) * HP;
   constexpr int BM = TR * TC;
   constexpr int MT = BM / 64;                            // 32-row MFMA tiles per wave
   constexpr bool X3 = sizeof(TA) == 4;                  // fp32 activations, split into NPL bf16 planes
+  constexpr bool PRE = __is_same(TA, hp_t);             // ... or plane pairs split by the producer
   static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
+  static_assert(!PRE || NPL == 2, "plane pairs are two planes");
   constexpr int UPR = BK / 8;
   constexpr int NU_H = (HALO_ROWS * UPR + 255) / 256;   // halo units per thread
   constexpr int NU_B = (BN * UPR + 255) / 256;
@@ -79,7 +84,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   constexpr int KS = BK / 16;
   constexpr int A_BYTES = HALO_ROWS * BK * 2;           // one plane, one buffer
   constexpr int B_BYTES = BN * BK * 2;
-  constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;  // epilogue staging row pitch (bytes)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [buffer][plane] images
@@ -142,7 +146,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NU_H; ++i) {
       if (h_lds[i] < 0) continue;
-      if constexpr (X3) {
+      if constexpr (PRE) {
+        *reinterpret_cast<u32x4*>(sA(buf, 0) + h_lds[i]) = rh[i][0];
+        *reinterpret_cast<u32x4*>(sA(buf, 1) + h_lds[i]) = rh[i][1];
+      } else if constexpr (X3) {
         u32x4 pl[NPL];
         split8<NPL, P16>(rh[i][0], rh[i][1], pl);
 #pragma unroll
@@ -158,6 +165,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
       const int q = tid + 256 * i;
       if (B_GUARD && q >= BN * UPR) continue;
       const int row = q / UPR, u = q % UPR;
+      if (NPL == 2 && p.w_il) {                  // interleaved plane pairs: [CB hi | CB lo] per block of CB channels
+        const long off = ((long)t * p.N + n0 + row) * 2 * p.Cin + il_pos(kc * BK + u * 8, p.Cin);
+        rb[set][i][0] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
+        rb[set][i][NPL - 1] = *reinterpret_cast<const u32x4*>(p.w_hi + off + il_cb(p.Cin));
+        continue;
+      }
       const long off = ((long)t * p.N + n0 + row) * p.Cin + kc * BK + u * 8;
       rb[set][i][0] = *reinterpret_cast<const u32x4*>(p.w_hi + off);
 #pragma unroll
@@ -269,10 +282,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   if (s < nsteps) step(I0{}, s);
 
   // ---- epilogue (conv_epilogue.h): bias/ReLU, fused reductions, LDS-staged coalesced stores -------
-  conv_epilogue<TA, BN, BM, 256, MT, NT, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
+  conv_epilogue<TO, BN, BM, 256, MT, NT, f32x16>(acc, p.epi, smem, b, y0, x0, n0, TR, wr, wc);
 }
 
-template <typename TA, int NPL, int BN, int BK, int TR, typename P16 = typename PlaneOf<TA>::type>
+template <typename TA, int NPL, int BN, int BK, int TR, typename P16 = typename PlaneOf<TA>::type, typename TO = TA>
 int launch(ConvParams p, hipStream_t st) {
   constexpr int HALO_ROWS = (TR + 2) * HP;
   constexpr int BM = TR * TC;
@@ -284,10 +297,10 @@ int launch(ConvParams p, hipStream_t st) {
   if (stage > lds) lds = stage;      // the epilogue staging tile reuses the operand buffers
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, NPL, BN, BK, TR, P16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<TA, NPL, BN, BK, TR, P16, TO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((conv3x3_kernel<TA, NPL, BN, BK, TR, P16>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv3x3_kernel<TA, NPL, BN, BK, TR, P16, TO>), dim3((unsigned)ntiles), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -299,6 +312,9 @@ int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int 
                            const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16);
 int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
                           const EpiParams& epi, hipStream_t st, int fp16);
+// conv3x3_glds.hip: plane-pair input (CRIMAC_PREC_H3P), Cin % 32 == 0; out_planes: plane-pair output, else fp32
+int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w,
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes);
 
 // register-staged kernel for one 16-bit storage type (odd channel counts, A/B runs)
 template <typename T16>
@@ -331,7 +347,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && in && w_hi && out, "conv3x3: bad arguments");
   const bool is16 = prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16;
   const int fp16 = prec == CRIMAC_PREC_FP16;
-  CRIMAC_REQUIRE(is16 || w_lo, "conv3x3: split precisions need the low weight plane(s)");
+  CRIMAC_REQUIRE(is16 || w_lo || prec == CRIMAC_PREC_H3P, "conv3x3: split precisions need the low weight plane(s)");
   CRIMAC_REQUIRE(stat_mode >= 0 && stat_mode <= 2, "conv3x3: stat_mode=%d", stat_mode);
   CRIMAC_REQUIRE(stat_mode == 0 || (stat_sum && stat_sumsq && stat_replicas >= 1),
                  "conv3x3: stat_mode %d needs both accumulators and replicas >= 1", stat_mode);
@@ -341,11 +357,16 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
   p.w_hi = (const unsigned short*)w_hi; p.w_lo = (const unsigned short*)w_lo;
   EpiParams& e = p.epi;
+  const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
+  relu &= CRIMAC_EPI_RELU;
+  CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode == 0),
+                 "conv3x3: plane-pair output is an H3P option without a fused reduction");
+  p.w_il = prec == CRIMAC_PREC_H3P;
   e.bias = bias; e.out = out; e.out_ld = out_ld; e.relu = relu; e.H = H; e.W = W; e.N = N;
   e.stat_mode = stat_mode; e.stat_sum = stat_mode ? stat_sum : nullptr; e.stat_sumsq = stat_sumsq;
   e.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
   e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
-  e.acc_scale = prec == CRIMAC_PREC_F32H3 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
+  e.acc_scale = (prec == CRIMAC_PREC_F32H3 || prec == CRIMAC_PREC_H3P) ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
   e.pool_out = pool_out; e.pool_ld = pool_ld;
   hipStream_t st = (hipStream_t)stream;
   const bool n128 = N % 128 == 0;
@@ -360,9 +381,24 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   // the N = 64 layers (4-wave kernel, two workgroups per CU).
   static const int use_glds = getenv("CRIMAC_CONV_GLDS") ? atoi(getenv("CRIMAC_CONV_GLDS")) : 1;
   const bool ranged = n_first != 0 || n_count != N;
-  CRIMAC_REQUIRE(!ranged || (n_first >= 0 && n_count > 0 && n_first + n_count <= N && is16 &&
-                             Cin % 64 == 0 && use_glds),
-                 "conv3x3_cols: a channel range needs the 16-bit LDS-DMA kernels (Cin %% 64 == 0)");
+  CRIMAC_REQUIRE(!ranged || (n_first >= 0 && n_count > 0 && n_first + n_count <= N && use_glds &&
+                             ((is16 && Cin % 64 == 0) || (prec == CRIMAC_PREC_H3P && Cin % 32 == 0))),
+                 "conv3x3_cols: a channel range needs the LDS-DMA kernels (16-bit storage: Cin %% 64 == 0, plane pairs: "
+                 "Cin %% 32 == 0)");
+  if (prec == CRIMAC_PREC_H3P) {
+    // plane-pair input: the 16-bit LDS-DMA kernels on a tensor of 2 Cin halves per pixel (3 MFMAs per product);
+    // the first layer (4 input channels padded to 16) runs on the register-staged kernel, whose staging copies the
+    // pre-split halves
+    if (Cin % 32 == 0 && use_glds)
+      return crimac_conv3x3_glds_hp(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, out_planes);
+    CRIMAC_REQUIRE(!pool_out, "conv3x3_pool (plane pairs): Cin %% 32 == 0 only");
+    if (Cin % 32 == 0) {
+      if (out_planes) return n128 ? launch<hp_t, 2, 128, 32, 8, half_t, hp_t>(p, st) : launch<hp_t, 2, 64, 32, 8, half_t, hp_t>(p, st);
+      return n128 ? launch<hp_t, 2, 128, 32, 8, half_t, float>(p, st) : launch<hp_t, 2, 64, 32, 8, half_t, float>(p, st);
+    }
+    if (out_planes) return n128 ? launch<hp_t, 2, 128, 16, 8, half_t, hp_t>(p, st) : launch<hp_t, 2, 64, 16, 8, half_t, hp_t>(p, st);
+    return n128 ? launch<hp_t, 2, 128, 16, 8, half_t, float>(p, st) : launch<hp_t, 2, 64, 16, 8, half_t, float>(p, st);
+  }
   if (is16 && Cin % 64 == 0 && use_glds)
     return crimac_conv3x3_glds_16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, fp16);
   // first layer (4 input channels padded to 16): persistent one-barrier kernel

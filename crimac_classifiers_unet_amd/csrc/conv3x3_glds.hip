@@ -44,6 +44,13 @@ struct ConvParams {
   int n_first, n_count;      // output-channel range of this launch (crimac_conv3x3_cols); default the whole N
 };
 
+// Epilogue staging of an output storage type: 16-bit types stage the whole 256-row tile; fp32 and plane pairs (staged
+// as fp32) go through the staging area in two slices of 128 rows (conv_epilogue.h) so that two workgroups still fit a CU.
+template <typename TO> struct EpiPasses {
+  static constexpr int kStageBytes = sizeof(TO) == 2 ? 2 : 4;
+  static constexpr int value = sizeof(TO) == 2 ? 1 : 2;
+};
+
 constexpr int TR = 16, TC = 16, HP = TC + 2;
 constexpr int BM = TR * TC;                       // 256 pixels
 constexpr int HALO_ROWS = (TR + 2) * HP;          // 324
@@ -66,6 +73,12 @@ __device__ __forceinline__ int halo_swz(int hx) {
   return (int)((0xd92dad912240ull >> (3 * hx)) & 7);
 #endif
 }
+
+// Plane-pair input (hp_t, common.h): a 32-channel chunk of a pixel is 128 bytes = 4 groups of [8 hi | 8 lo] halves.
+// The LDS image keeps the 16-bit kernels' shape -- logical 16-byte units 0-3 = the first k-step of 32 (here: the hi
+// plane of the 32 channels), units 4-7 = the second (the lo plane) -- so logical unit u comes from source unit
+// 2 * (u & 3) + (u >> 2); the permutation rides on the per-lane DMA source address like the bank swizzle does.
+template <bool PP> __device__ __forceinline__ int src_unit(int u) { return PP ? (((u & 3) << 1) | (u >> 2)) : u; }
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
 #ifdef CRIMAC_EXP_NOGLDS
@@ -103,7 +116,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // drains the DMA queue: 470-610 us).
 // (BN = 128 instantiates too -- 64 x 128 per wave, 2-slot ring, 74 KB -- and was the default for N >= 128 until
 // the channel-split kernel below beat it by 12 %; CRIMAC_CONV_W4=1 selects it for A/B runs.)
-template <int BN, typename T16, int MODE>     // MODE: the epilogue's fused reduction (0 none, 1 statistics, 2 BatchNorm-backward sums)
+// PP: plane-pair input (p.Cin / p.in_ld count HALVES: twice the channels), 3 MFMAs per fragment pair; TO: output storage
+template <int BN, typename T16, int MODE, typename TO = T16, bool PP = false>     // MODE: the epilogue's fused reduction (0 none, 1 statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void conv3x3_glds_w4_kernel(ConvParams p) {
   constexpr int NW = 4, NT = BN / 16;
@@ -129,7 +143,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
   const int tyi = tile_m % p.tiles_y;
   const int b = tile_m / p.tiles_y;
   const int y0 = tyi * TR, x0 = txi * TC;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = p.n_first + blockIdx.y * BN;
   const T16* inp = reinterpret_cast<const T16*>(p.in);
 
   long h_src[NH];
@@ -141,7 +155,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
     if (k < HALO_INSTR && row < HALO_ROWS) {
       const int hy = row / HP, hx = row % HP;
       const int y = y0 + hy - 1, x = x0 + hx - 1;
-      const int u = c8 ^ halo_swz(hx);
+      const int u = src_unit<PP>(c8 ^ halo_swz(hx));
       if (y >= 0 && y < p.H && x >= 0 && x < p.W)
         h_src[i] = (((long)b * p.H + y) * p.W + x) * p.in_ld + u * 8;
       else
@@ -179,6 +193,38 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
     const int kx = t % 3;
     const unsigned char* a0 = sA + ((wave * 4 + t / 3) * HP + fr + kx) * RB;
     const int aswz = halo_swz(fr + kx);
+    if constexpr (PP) {
+      // k-step 0 = hi planes, k-step 1 = lo planes of the same 32 channels: lo*hi + hi*lo + hi*hi (smallest first)
+      bf16x8 af[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          af[ks][i] = *reinterpret_cast<const bf16x8*>(a0 + i * (HP * RB) + (((4 * ks + fq) ^ aswz) << 4));
+#pragma unroll
+      for (int jh = 0; jh < NT; jh += 4) {
+        bf16x8 bfr[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = (jh + j) * 16 + fr;
+            bfr[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + row * RB + (((4 * ks + fq) ^ ((row >> 1) & 7)) << 4));
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][jh + j] = E16<T16>::mfma16(af[1][i], bfr[0][j], acc[i][jh + j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][jh + j] = E16<T16>::mfma16(af[0][i], bfr[1][j], acc[i][jh + j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][jh + j] = E16<T16>::mfma16(af[0][i], bfr[0][j], acc[i][jh + j]);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       const int unit = 4 * ks + fq;
@@ -196,6 +242,7 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = E16<T16>::mfma16(af[i], bfr[j], acc[i][j]);
+    }
     }
   };
 
@@ -240,31 +287,38 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
       for (int r = 0; r < 4; ++r) sum += acc[i][j][r];
   if (sum == 12345.678f) reinterpret_cast<float*>(p.epi.out)[tid] = sum;
 #else
-  conv_epilogue<T16, BN, BM, 256, 4, NT, f32x4, MODE>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
+  conv_epilogue<TO, BN, BM, 256, 4, NT, f32x4, MODE, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TR, wave, 0);
 #endif
 }
 
-template <int BN, typename T16>
+template <int BN, typename T16, typename TO = T16, bool PP = false>
 int launch_w4(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   const size_t lds = (size_t)A_BYTES + (BN == 64 ? 3 : 2) * BN * RB;
-  static_assert(BM * (BN * 2 + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB, "epilogue staging must fit");
+  static_assert(BM / EpiPasses<TO>::value * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB,
+                "epilogue staging must fit");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 0>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (!__is_same(TO, hp_t)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 1, TO, PP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 2, TO, PP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
   }
-  const dim3 grid((unsigned)ntiles, p.N / BN);
+  const dim3 grid((unsigned)ntiles, p.n_count / BN);
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
-  if (mode == 0) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0>), grid, dim3(256), lds, st, p);
-  else if (mode == 1) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 2>), grid, dim3(256), lds, st, p);
+  if constexpr (__is_same(TO, hp_t)) {          // (plane-pair outputs carry no fused reduction: checked by the caller)
+    hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 2, TO, PP>), grid, dim3(256), lds, st, p);
+  }
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -334,7 +388,10 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
       : "v"(s0), "v"(s1)
       : "memory");
 }
-template <typename T16, int H, typename ACC>
+// PP (plane pairs): k-step 0 of a chunk is the hi plane of 32 channels, k-step 1 their lo plane, in both operands: the
+// hi fragments of A meet both weight planes (hi*lo, then hi*hi), the lo fragments the hi weights only -- 3 MFMAs per
+// fragment pair, 16 + 8 per pair of groups, on the same reads and weight loads as the 16-bit kernel's 8 + 8.
+template <typename T16, bool PP, int H, typename ACC>
 __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsigned short* wtap, long w_tap, long w_nb,
                                            const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
   constexpr int t = H / 8, ks2 = (H / 4) % 2, q = H % 4, NH = 72;
@@ -359,16 +416,23 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
   } else {
     wch_release<true>(f, H & 1);
   }
+  if constexpr (PP && ks2 == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][2 + nb], acc[4 * q + j][nb]);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
-      acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][ks2 * 2 + nb],
+      acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][(PP ? 0 : ks2 * 2) + nb],
                                                                     acc[4 * q + j][nb]);
-  if constexpr (H + 1 < NH) wch_step<T16, H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
+  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
-template <typename T16, int MODE>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+template <typename T16, int MODE, typename TO = T16, bool PP = false>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel(ConvParams p) {
   constexpr int BN = 128, NW = 4;
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
@@ -408,7 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int hy = row / HP, hx = row - hy * HP;
     const unsigned y = (unsigned)(y0 + hy - 1), x = (unsigned)(x0 + hx - 1);
     const bool ok = k < HALO_INSTR && row < HALO_ROWS && y < (unsigned)p.H && x < (unsigned)p.W;
-    h_off[i] = ok ? (unsigned)(((((long)b * p.H + y) * p.W + x) * p.in_ld + (c8 ^ halo_swz(hx)) * 8) * 2)
+    h_off[i] = ok ? (unsigned)(((((long)b * p.H + y) * p.W + x) * p.in_ld + src_unit<PP>(c8 ^ halo_swz(hx)) * 8) * 2)
                   : 0x80000000u;
   }
   auto issue_halo = [&](int kc) {
@@ -462,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned short* wtap = wrow + kc * BK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
     wch_issue<0>(av, f);
-    wch_step<T16, 0>(av, wtap, w_tap, w_nb, wnext, f, acc);
+    wch_step<T16, PP, 0>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(2)
@@ -471,7 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifndef CRIMAC_DIAG_PHASES
   CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
 #endif
-  conv_epilogue<T16, BN, BM, 256, 16, 2, f32x4, MODE>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
+  conv_epilogue<TO, BN, BM, 256, 16, 2, f32x4, MODE, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
 #ifdef CRIMAC_DIAG_PHASES
   // cycles of wave 0: prologue | waiting for the halo chunks | MFMA steps | epilogue (stores issued)
   CRIMAC_CPH(3)
@@ -481,28 +545,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
-template <typename T16>
+template <typename T16, typename TO = T16, bool PP = false>
 int launch_wch(ConvParams p, hipStream_t st) {
   constexpr int BN = 128;
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;
+  constexpr size_t stage = (size_t)(BM / EpiPasses<TO>::value) * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4;
   const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
+  static_assert(stage <= 72 * 1024, "two workgroups per CU");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (!__is_same(TO, hp_t)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2, TO, PP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
   }
   const dim3 grid((unsigned)ntiles, p.n_count / BN);
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
-  if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0>), grid, dim3(256), lds, st, p);
-  else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2>), grid, dim3(256), lds, st, p);
+  if constexpr (__is_same(TO, hp_t)) {
+    hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2, TO, PP>), grid, dim3(256), lds, st, p);
+  }
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -1212,6 +1283,27 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
   return (w4 == 1 || !small) ? launch_w4<128, T16>(p, st) : launch_wch<T16>(p, st);
 }
 }  // namespace
+
+// Plane-pair input (CRIMAC_PREC_H3P), Cin % 32 == 0, N % 64 == 0: the 16-bit kernels on a tensor of 2 Cin halves per
+// pixel (3 MFMAs per product); output fp32 (out_planes == 0) or plane pairs.  The persistent 64 -> 64 kernel has no
+// plane-pair form (144 KB of weights do not fit beside the halos): those layers take the pixel-split kernel.
+int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w,
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes) {
+  ConvParams p;
+  p.in = in; p.in_ld = 2 * in_ld; p.B = B; p.H = H; p.W = W; p.Cin = 2 * Cin; p.N = N;
+  p.w_hi = (const unsigned short*)w;
+  p.epi = epi;
+  p.n_first = n_first; p.n_count = n_count;
+  const bool small = (((long)B * H * W - 1) * p.in_ld + p.Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
+  static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
+  if (n_count % 128 == 0 && n_first % 128 == 0 && small && w4 != 1)
+    return out_planes ? launch_wch<half_t, hp_t, true>(p, st) : launch_wch<half_t, float, true>(p, st);
+  CRIMAC_REQUIRE(n_first % 64 == 0 && n_count % 64 == 0, "conv3x3 (plane pairs): channel range [%d, +%d) must be "
+                 "multiples of 64", n_first, n_count);
+  if (n_count % 128 == 0 && n_first % 128 == 0)
+    return out_planes ? launch_w4<128, half_t, hp_t, true>(p, st) : launch_w4<128, half_t, float, true>(p, st);
+  return out_planes ? launch_w4<64, half_t, hp_t, true>(p, st) : launch_w4<64, half_t, float, true>(p, st);
+}
 
 // 16-bit storage, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
 int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,

@@ -9,6 +9,8 @@
 //                  xhat = (y-mean)*invstd:  stat_sum += sum dz, stat_sumsq += sum dz*xhat
 //                  -- the bn_bwd_reduce pass over (da, y) is fused away.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 struct EpiParams {
@@ -52,36 +54,52 @@ template <> struct AccLayout<f32x4> {
 // cycles per workgroup of the channel-split kernel (two 64-channel chunks of MFMAs take 18 k), phase stamps of
 // tools/diag_wch_phases.py.  Stores (and the mode-2 loads) are buffer operations on a resource rebased at the tile's
 // first pixel: 32-bit offsets, `row * pitch` instead of 64-bit pixel arithmetic per row, out of range = dropped.
-template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, bool FULL, typename ACC>
+// TA: storage type of the OUTPUT (bf16_t / half_t / float, or hp_t: fp16 plane pairs, staged as fp32 and split when
+// the tile is stored).  PASSES > 1: the tile goes through the staging area in PASSES slices of BM / PASSES rows (fp32
+// staging of a 256 x 128 tile would need 135 KB of LDS: one workgroup per CU instead of two).
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, bool FULL, typename ACC, int PASSES = 1>
 __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], const EpiParams& e,
                                                    unsigned char* smem, int b, int y0, int x0, int n0,
                                                    int wr, int wc) {
   using L = AccLayout<ACC>;
-  constexpr int STAGE_PITCH = BN * (int)sizeof(TA) + 16;
-  constexpr bool F32 = sizeof(TA) == 4;
+  constexpr bool HPO = __is_same(TA, hp_t);
+  using TS = typename std::conditional<HPO, float, TA>::type;           // element type of the staging tile
+  static_assert(!HPO || MODE == 0, "plane-pair outputs carry no fused reduction (inference / up-conv outputs)");
+  constexpr int STAGE_PITCH = BN * (int)sizeof(TS) + 16;
+  constexpr bool F32 = sizeof(TS) == 4;
   constexpr unsigned OOB = 0x80000000u;
+  constexpr int RPASS = BM / PASSES;                                     // rows per pass
+  static_assert(BM % PASSES == 0 && RPASS % 32 == 0, "a pass covers whole pairs of image rows");
   const int tid = threadIdx.x, lane = tid & 63;
-  unsigned char* stage = smem;                                           // [BM][STAGE_PITCH]
-  float* sstat = reinterpret_cast<float*>(smem + BM * STAGE_PITCH);     // [2][BN]
+  unsigned char* stage = smem;                                           // [RPASS][STAGE_PITCH]
+  float* sstat = reinterpret_cast<float*>(smem + RPASS * STAGE_PITCH);  // [2][BN]
   constexpr int mode = MODE;
   if (mode)
     for (int i = tid; i < 2 * BN; i += NTHREADS) sstat[i] = 0.f;
   float cs1[NT], cs2[NT];
 #pragma unroll
+  for (int j = 0; j < NT; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; }
+  float d1[8], d2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { d1[k] = 0.f; d2[k] = 0.f; }
+#pragma unroll
+ for (int ps = 0; ps < PASSES; ++ps) {
+  if (ps > 0) __syncthreads();                                           // the previous slice has been stored
+#pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = wc * (NT * L::TS) + j * L::TS + L::col(lane);
     const float bv = e.bias ? e.bias[n0 + col] : 0.f;
-    cs1[j] = 0.f;
-    cs2[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+      const int row0 = wr * (MT * L::TS) + i * L::TS;                    // (wave-uniform: an M tile lies in one pass)
+      if (PASSES > 1 && row0 / RPASS != ps) continue;
 #pragma unroll
       for (int r = 0; r < L::NR; ++r) {
-        const int row = wr * (MT * L::TS) + i * L::TS + L::row(r, lane);
+        const int row = row0 + L::row(r, lane);
         float v = acc[i][j][r] * e.acc_scale + bv;
         if (e.relu) v = fmaxf(v, 0.f);
-        const TA q = (TA)v;
-        *reinterpret_cast<TA*>(stage + row * STAGE_PITCH + col * (int)sizeof(TA)) = q;
+        const TS q = (TS)v;
+        *reinterpret_cast<TS*>(stage + (row - ps * RPASS) * STAGE_PITCH + col * (int)sizeof(TS)) = q;
         if (mode == 1) {
           const float vs = (float)q;       // statistics of the value as STORED
           const bool ok = FULL || ((y0 + (row >> 4) < e.H) && (x0 + (row & 15) < e.W));
@@ -89,9 +107,10 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
           cs2[j] += ok ? vs * vs : 0.f;
         }
       }
+    }
   }
   __syncthreads();
-  if (mode == 1) {
+  if (mode == 1 && ps == PASSES - 1) {
     // rows live in registers and in the lane groups above the column lanes: fold with shuffles,
     // then one LDS add per column
 #pragma unroll
@@ -111,8 +130,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
   }
   {
     constexpr int CPR = BN / 8;                 // 8-channel chunks per row
-    constexpr int RPP = NTHREADS / CPR;         // rows per pass
-    static_assert(RPP % 16 == 0 || 16 % RPP == 0, "a pass covers whole image rows or a fraction of one");
+    constexpr int RPP = NTHREADS / CPR;         // rows per store round
+    static_assert(RPP % 16 == 0 || 16 % RPP == 0, "a round covers whole image rows or a fraction of one");
     const int c8 = tid % CPR, r0 = tid / CPR;
     TA* outp = reinterpret_cast<TA*>(e.out);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -122,14 +141,14 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       ry = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<TA*>(reinterpret_cast<const TA*>(e.bnb_y) + (((long)b * e.H + y0) * e.W + x0) * e.bnb_y_ld + n0), 0,
           0x7FFFFFFF, 0x00020000);
-    // this thread's rows: r0 + rr * RPP -> (image row, column) of the tile; byte offsets from the tile's first pixel
-    const int ty0 = r0 >> 4, tx = r0 & 15;
+    // this thread's rows: ps * RPASS + r0 + rr * RPP -> (image row, column) of the tile; byte offsets from the tile's first pixel
+    const int ty0 = (ps * RPASS + r0) >> 4, tx = r0 & 15;
     const unsigned o0 = (unsigned)((((long)ty0 * e.W + tx) * e.out_ld + c8 * 8) * (int)sizeof(TA));
     const unsigned o_step = (unsigned)(((long)(RPP >> 4) * e.W * e.out_ld + (RPP & 15) * e.out_ld) * (int)sizeof(TA));
     const unsigned q0 = mode == 2 ? (unsigned)((((long)ty0 * e.W + tx) * e.bnb_y_ld + c8 * 8) * (int)sizeof(TA)) : 0u;
     const unsigned q_step = mode == 2 ? (unsigned)(((long)(RPP >> 4) * e.W * e.bnb_y_ld + (RPP & 15) * e.bnb_y_ld) * (int)sizeof(TA)) : 0u;
     static_assert(RPP >= 16, "rows of one thread differ by whole image rows");
-    float sc[8], sh[8], mu[8], is[8], d1[8], d2[8];
+    float sc[8], sh[8], mu[8], is[8];
     if (mode == 2) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -138,17 +157,25 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
         is[k] = e.bnb_vec[e.bnb_stride + c];
         sc[k] = e.bnb_vec[2 * e.bnb_stride + c];
         sh[k] = e.bnb_vec[3 * e.bnb_stride + c];
-        d1[k] = 0.f;
-        d2[k] = 0.f;
       }
     }
-#pragma unroll
-    for (int rr = 0; rr < BM / RPP; ++rr) {
-      const int row = r0 + rr * RPP;
+    // (fp32 tiles with the fused BatchNorm-backward sums: 16 registers of y and g per row next to the accumulators of
+    // the slices still to come -- fully unrolled, hipcc hoists every load and spills ~100 registers)
+    constexpr int UNR = (MODE == 2 && F32 && PASSES > 1) ? 2 : RPASS / RPP;
+#pragma unroll(UNR)
+    for (int rr = 0; rr < RPASS / RPP; ++rr) {
+      const int lrow = r0 + rr * RPP, row = ps * RPASS + lrow;
       const bool ok = FULL || ((y0 + (row >> 4) < e.H) && (x0 + tx < e.W));
-      const TA* sp = reinterpret_cast<const TA*>(stage + row * STAGE_PITCH) + c8 * 8;
+      const TS* sp = reinterpret_cast<const TS*>(stage + lrow * STAGE_PITCH) + c8 * 8;
       const int off = (int)(ok ? o0 + rr * o_step : OOB);
-      if constexpr (F32) {
+      if constexpr (HPO) {
+        float v[8];
+        load8(sp, v);
+        u32x4 hi, lo;
+        hp_split(v, hi, lo);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, ro, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, ro, off, 16, 0);
+      } else if constexpr (F32) {
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp), ro, off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp + 4), ro, off, 16, 0);
       } else {
@@ -162,10 +189,10 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
           u32x4 t[2];
           t[0] = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 0, 0);
           t[1] = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 16, 0);
-          load8(reinterpret_cast<const TA*>(t), yv);
+          load8(reinterpret_cast<const TS*>(t), yv);
         } else {
           const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 0, 0);
-          load8(reinterpret_cast<const TA*>(&t), yv);
+          load8(reinterpret_cast<const TS*>(&t), yv);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -175,7 +202,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
         }
       }
     }
-    if (mode == 2) {
+    if (mode == 2 && ps == PASSES - 1) {
       // threads of one chunk sit CPR lanes apart: fold inside the wave, then one LDS add per wave
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -195,28 +222,30 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
     }
   }
   if (e.pool_out) {
-    // the staged tile still holds the values as stored: 2x2 windows never straddle tiles (y0, x0 are even)
+    // the staged slice still holds the values as stored (plane pairs: the fp32 values, rounding is monotone so the
+    // maximum of the stored values is the stored maximum): 2x2 windows never straddle tiles or slices (y0, x0 even)
     constexpr int CPR = BN / 8;
-    constexpr int PROWS = BM / 32;                      // pooled rows of the tile (tile rows / 2), 8 pooled columns
+    constexpr int PROWS = RPASS / 32;                   // pooled rows of the slice (rows / 2), 8 pooled columns
     TA* pool = reinterpret_cast<TA*>(e.pool_out);
     const int Hp = e.H >> 1, Wp = e.W >> 1;
     for (int i = tid; i < PROWS * 8 * CPR; i += NTHREADS) {
       const int c8 = i % CPR, pp = i / CPR;
       const int pyl = pp >> 3, pxl = pp & 7;
-      const int yp = (y0 >> 1) + pyl, xp = (x0 >> 1) + pxl;
+      const int yp = (y0 >> 1) + ps * PROWS + pyl, xp = (x0 >> 1) + pxl;
       if (yp >= Hp || xp >= Wp) continue;
       const int r00 = (2 * pyl) * 16 + 2 * pxl;
       float m[8], v[8];
-      load8(reinterpret_cast<const TA*>(stage + r00 * STAGE_PITCH) + c8 * 8, m);
+      load8(reinterpret_cast<const TS*>(stage + r00 * STAGE_PITCH) + c8 * 8, m);
 #pragma unroll
       for (int d = 1; d < 4; ++d) {
-        load8(reinterpret_cast<const TA*>(stage + (r00 + (d >> 1) * 16 + (d & 1)) * STAGE_PITCH) + c8 * 8, v);
+        load8(reinterpret_cast<const TS*>(stage + (r00 + (d >> 1) * 16 + (d & 1)) * STAGE_PITCH) + c8 * 8, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
       }
       store8(pool + (((long)b * Hp + yp) * Wp + xp) * e.pool_ld + n0 + c8 * 8, m);
     }
   }
+ }   // passes
   if (mode) {
     __syncthreads();
     // thousands of workgroups add to the same N channels: spread them over replicas (the atomic
@@ -230,7 +259,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
 }
 
 // Dispatch on the (workgroup-uniform) tile position and, when MODE < 0, on the runtime statistics mode.
-template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC, int MODE = -1>
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC, int MODE = -1, int PASSES = 1>
 __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
                                               unsigned char* smem, int b, int y0, int x0, int n0,
                                               int tile_rows, int wr, int wc) {
@@ -238,8 +267,8 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
   const int mode = MODE >= 0 ? MODE : (e.stat_sum ? e.stat_mode : 0);
 #define CRIMAC_EPI(M)                                                                                      \
   do {                                                                                                     \
-    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC>(acc, e, smem, b, y0, x0, n0, wr, wc);   \
-    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC>(acc, e, smem, b, y0, x0, n0, wr, wc);       \
+    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC, PASSES>(acc, e, smem, b, y0, x0, n0, wr, wc);   \
+    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC, PASSES>(acc, e, smem, b, y0, x0, n0, wr, wc);       \
   } while (0)
   if constexpr (MODE >= 0) {
     CRIMAC_EPI(MODE);

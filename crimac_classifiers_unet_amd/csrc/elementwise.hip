@@ -76,6 +76,14 @@ __device__ __forceinline__ void put_planes(float v, int npl, int fp16, unsigned 
   }
 }
 
+// the same for interleaved plane pairs: element `col` of row `row` (rows of `rowlen` channels)
+__device__ __forceinline__ void put_planes_il(float v, int fp16, unsigned short* buf, long row, int col, int rowlen) {
+  unsigned short* dst = buf + row * 2L * rowlen + il_pos(col, rowlen);
+  const unsigned short b = f2bits16(v, fp16);
+  dst[0] = b;
+  dst[il_cb(rowlen)] = f2bits16(v - bits162f(b, fp16), fp16);
+}
+
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int Ci_pad,
                                     const float* __restrict__ scale, int npl, unsigned short* fwd_hi,
                                     unsigned short* fwd_lo, unsigned short* dg_hi,
@@ -92,7 +100,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       v = w[((long)co * Ci + ci) * 9 + t];
       if (scale) v *= scale[co];
     }
-    put_planes(v * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n_fwd);
+    if (pf.interleaved) put_planes_il(v * pf.fwd_scale, pf.fwd_fp16, fwd_hi, r, ci, Ci_pad);
+    else put_planes(v * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n_fwd);
   }
   if (dg_hi) {
     const long n_dg = 9L * Ci * Co;
@@ -101,7 +110,9 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       const int co = (int)(i % Co);
       const long r = i / Co;
       const int ci = (int)(r % Ci), t = (int)(r / Ci);
-      put_planes(w[((long)co * Ci + ci) * 9 + (8 - t)], pf.npl, pf.dg_fp16, dg_hi, dg_lo, i, n_dg);
+      const float v = w[((long)co * Ci + ci) * 9 + (8 - t)] * pf.dg_scale;
+      if (pf.interleaved) put_planes_il(v, pf.dg_fp16, dg_hi, r, co, Co);
+      else put_planes(v, pf.npl, pf.dg_fp16, dg_hi, dg_lo, i, n_dg);
     }
   }
 }
@@ -118,13 +129,17 @@ __global__ void pack_upconv_kernel(const float* __restrict__ w, int Ci, int Co, 
       const int ci = (int)(i % Ci);
       const long r = i / Ci;
       const int co = (int)(r % Co), ab = (int)(r / Co);
-      put_planes(w[((long)ci * Co + co) * 4 + ab] * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n);
+      const float v = w[((long)ci * Co + co) * 4 + ab] * pf.fwd_scale;
+      if (pf.interleaved) put_planes_il(v, pf.fwd_fp16, fwd_hi, r, ci, Ci);
+      else put_planes(v, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n);
     }
     if (dg_hi) {
       const int co = (int)(i % Co);
       const long r = i / Co;
       const int ci = (int)(r % Ci), ab = (int)(r / Ci);
-      put_planes(w[((long)ci * Co + co) * 4 + ab], pf.npl, pf.dg_fp16, dg_hi, dg_lo, i, n);
+      const float v = w[((long)ci * Co + co) * 4 + ab] * pf.dg_scale;
+      if (pf.interleaved) put_planes_il(v, pf.dg_fp16, dg_hi, r, co, Co);
+      else put_planes(v, pf.npl, pf.dg_fp16, dg_hi, dg_lo, i, n);
     }
   }
 }
@@ -1031,7 +1046,8 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
                                    int planes, void* fwd_hi, void* fwd_lo, void* dg_hi, void* dg_lo,
                                    void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0 && Ci_pad >= Ci, "pack_conv3x3: bad arguments");
-  CRIMAC_REQUIRE(planes_arg_ok(planes) && ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
+  CRIMAC_REQUIRE(planes_arg_ok(planes) && ((planes & 15) == 1 || (planes & CRIMAC_PLANES_INTERLEAVED) || fwd_lo) &&
+                     ((planes & 15) == 1 || (planes & CRIMAC_PLANES_INTERLEAVED) || !dg_hi || dg_lo),
                  "pack_conv3x3: planes=%d needs the lo plane buffers", planes);
   CRIMAC_REQUIRE(!dg_hi || Ci_pad == Ci, "pack_conv3x3: dgrad planes need Ci_pad == Ci");
   const int grid = grid_for(9L * Co * Ci_pad, 256);
@@ -1045,7 +1061,8 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
 extern "C" int crimac_pack_upconv2x2(const float* w, int Ci, int Co, int planes, void* fwd_hi,
                                      void* fwd_lo, void* dg_hi, void* dg_lo, void* stream) {
   CRIMAC_REQUIRE(w && fwd_hi && Co > 0 && Ci > 0, "pack_upconv2x2: bad arguments");
-  CRIMAC_REQUIRE(planes_arg_ok(planes) && ((planes & 15) == 1 || fwd_lo) && ((planes & 15) == 1 || !dg_hi || dg_lo),
+  CRIMAC_REQUIRE(planes_arg_ok(planes) && ((planes & 15) == 1 || (planes & CRIMAC_PLANES_INTERLEAVED) || fwd_lo) &&
+                     ((planes & 15) == 1 || (planes & CRIMAC_PLANES_INTERLEAVED) || !dg_hi || dg_lo),
                  "pack_upconv2x2: planes=%d needs the lo plane buffers", planes);
   const int grid = grid_for(4L * Co * Ci, 256);
   hipLaunchKernelGGL(pack_upconv_kernel, dim3(grid), dim3(256), 0, ST, w, Ci, Co, planes,

@@ -84,6 +84,12 @@ __device__ __forceinline__ void put_planes8(float (&v)[8], int npl, unsigned sho
   }
 }
 
+// interleaved plane pairs (CRIMAC_PLANES_INTERLEAVED): 8 adjacent channels col .. col+7 of a row of `rowlen` channels
+__device__ __forceinline__ void put_planes8_il(float (&v)[8], unsigned short* buf, long row, int col, int rowlen, int fp16) {
+  unsigned short* dst = buf + row * 2L * rowlen + il_pos(col, rowlen);
+  put_planes8(v, 2, dst, dst + il_cb(rowlen), 0, 0, fp16);
+}
+
 __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_arg) {
   __shared__ float tile[TILE][TILE * 9 + 1];
   const PlaneFmt pf = plane_fmt(planes_arg);
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
   unsigned short* a_hi = d.kind == 0 ? d.fwd_hi : d.dg_hi;
   unsigned short* a_lo = d.kind == 0 ? d.fwd_lo : d.dg_lo;
   const int a_fp16 = d.kind == 0 ? pf.fwd_fp16 : pf.dg_fp16, b_fp16 = d.kind == 0 ? pf.dg_fp16 : pf.fwd_fp16;
-  const float a_sc = d.kind == 0 ? pf.fwd_scale : 1.f, b_sc = d.kind == 0 ? 1.f : pf.fwd_scale;
+  const float a_sc = d.kind == 0 ? pf.fwd_scale : pf.dg_scale, b_sc = d.kind == 0 ? pf.dg_scale : pf.fwd_scale;
   if (a_hi && g.inner_pad % 8 == 0) {
     for (int idx = threadIdx.x; idx < T * TILE * (TILE / 8); idx += 256) {
       const int il = (idx % (TILE / 8)) * 8, ol = (idx / (TILE / 8)) % TILE, t = idx / (TILE * TILE / 8);
@@ -120,7 +126,8 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol][(il + q) * T + t] * a_sc;
-      put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, a_fp16);
+      if (pf.interleaved) put_planes8_il(v, a_hi, (long)t * g.outer + o0 + ol, i0 + il, g.inner_pad, a_fp16);
+      else put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, a_fp16);
     }
   } else if (a_hi) {
     for (int idx = threadIdx.x; idx < T * TILE * (TILE / 2); idx += 256) {
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol + q][il * T + t] * b_sc;
-      put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, b_fp16);
+      if (pf.interleaved) put_planes8_il(v, b_hi, (long)tt * g.inner + i0 + il, o0 + ol, g.outer, b_fp16);
+      else put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, b_fp16);
     }
   }
 }
@@ -239,8 +247,10 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream
                      "layer %d: Co (and the transposed convolution's Ci) must be multiples of %d", base + i, TILE);
       CRIMAC_REQUIRE(h.kind == 1 || (h.Ci_pad >= h.Ci && h.Ci_pad % 2 == 0), "layer %d: bad Ci_pad", base + i);
       if (mode == 0) {
-        CRIMAC_REQUIRE(h.w && h.fwd_hi && (planes == 1 || h.fwd_lo) && (planes == 1 || !h.dg_hi || h.dg_lo),
+        const bool il = (planes_arg & CRIMAC_PLANES_INTERLEAVED) != 0;       // (one buffer holds both planes)
+        CRIMAC_REQUIRE(h.w && h.fwd_hi && (planes == 1 || il || h.fwd_lo) && (planes == 1 || il || !h.dg_hi || h.dg_lo),
                        "layer %d: missing weight / plane pointers", base + i);
+        CRIMAC_REQUIRE(!il || h.kind == 1 || h.Ci_pad % 8 == 0, "layer %d: interleaved planes need Ci_pad %% 8 == 0", base + i);
         CRIMAC_REQUIRE(h.kind == 1 || !h.dg_hi || h.Ci_pad == h.Ci, "layer %d: dgrad planes need Ci_pad == Ci",
                        base + i);
       } else {

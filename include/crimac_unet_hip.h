@@ -59,7 +59,19 @@ extern "C" {
                              * weights pre-scaled by 2^CRIMAC_F32H3_WSHIFT when packed, undone in the conv epilogue);
                              * gradients span too many decades, so the backward kernels of this mode are called with
                              * CRIMAC_PREC_F32X3 (entry points that only exist for the backward pass reject F32H3). */
-#define CRIMAC_PREC_MAX 4
+#define CRIMAC_PREC_H3P 5   /* PRE-SPLIT fp16 plane pairs: the arithmetic of F32H3 (hi*hi + hi*lo + lo*hi on fp16 planes, 3 MFMAs per
+                             * product, fp32 accumulate, ~2^-21 per product) with the split done ONCE by the kernel that PRODUCES
+                             * a tensor instead of by every consumer while it stages its tiles.  MFMA operand tensors
+                             * (activations, the gradients dy that feed input- and weight-gradient contractions) are stored as
+                             * "plane pairs": addressed like fp32 (4 bytes per element, `ld` in elements) but every aligned
+                             * group of 8 channels holds [8 x fp16 hi][8 x fp16 lo], value = hi + lo.  The 16-bit LDS-DMA
+                             * kernels then take them as 16-bit tensors of twice the channels.  Tensors only elementwise
+                             * kernels read (convolution outputs in training, activation gradients da) stay fp32.  Forward AND
+                             * backward run on fp16 planes: gradients travel scaled by the caller's loss scale exactly as in
+                             * CRIMAC_PREC_FP16 (crimac_wce_bwd `upstream`, crimac_sgd_momentum `grad_scale`, overflow guard).
+                             * Weight planes: crimac_pack_* with CRIMAC_PLANES_H3P (interleaved [32 hi | 32 lo] per 32-channel
+                             * block, both directions fp16 and pre-scaled by 2^CRIMAC_F32H3_WSHIFT; `w_lo` is unused). */
+#define CRIMAC_PREC_MAX 5
 #define CRIMAC_F32H3_WSHIFT 8
 /* `planes` argument of the weight-packing entry points: 1..3 bf16 planes (BF16 / F32X3 / F32X6), or
  * CRIMAC_PLANES_FP16 = one IEEE-half plane each way (FP16), or CRIMAC_PLANES_F32H3.  Layout of the argument: bits
@@ -70,6 +82,17 @@ extern "C" {
 #define CRIMAC_PLANES_FP16 (1 | CRIMAC_PLANES_FWD_FP16 | CRIMAC_PLANES_DG_FP16)                /* FP16 storage mode */
 /* F32H3: two fp16 forward planes of w * 2^CRIMAC_F32H3_WSHIFT (bits 8-15 carry the shift), two bf16 dgrad planes */
 #define CRIMAC_PLANES_F32H3 (2 | CRIMAC_PLANES_FWD_FP16 | (CRIMAC_F32H3_WSHIFT << 8))
+#define CRIMAC_PLANES_INTERLEAVED 64 /* both planes in ONE buffer (`*_hi`; `*_lo` unused), per row of K input channels:
+                                      * [CB hi | CB lo] per block of CB = 32 channels (CB = K when K < 32) */
+#define CRIMAC_PLANES_DG_SCALED 128  /* the scale of bits 8-15 is applied to the input-gradient planes as well */
+/* H3P: interleaved fp16 plane pairs, forward and input-gradient planes, both pre-scaled by 2^CRIMAC_F32H3_WSHIFT */
+#define CRIMAC_PLANES_H3P (2 | CRIMAC_PLANES_FWD_FP16 | CRIMAC_PLANES_DG_FP16 | CRIMAC_PLANES_INTERLEAVED | \
+                           CRIMAC_PLANES_DG_SCALED | (CRIMAC_F32H3_WSHIFT << 8))
+
+/* `relu` argument of the convolution entry points: bit 0 = ReLU on the output; bit 1 (CRIMAC_PREC_H3P only, no fused
+ * reduction) = store the output as fp16 plane pairs (it feeds another contraction) instead of fp32. */
+#define CRIMAC_EPI_RELU 1
+#define CRIMAC_EPI_OUT_PLANES 2
 
 /* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
  * struct passed by pointer (crimac_layer_desc), the meaning of an argument or the set of precisions changes, and a
