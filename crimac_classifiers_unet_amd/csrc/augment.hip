@@ -106,7 +106,7 @@ extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* l
   if (blocks > 4096) blocks = 4096;
   const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
   hipStream_t st = (hipStream_t)stream;
-  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(augment_db_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, data,
+  CRIMAC_FOR_STORAGE2(prec, TF_, T, hipLaunchKernelGGL(augment_db_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, data,
                                                  labels_in, label_bytes, (T*)out, labels_out, aux_mask, thr_channel,
                                                  thr_lo, thr_hi, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
                                                  0.05f));

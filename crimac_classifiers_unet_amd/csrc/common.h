@@ -123,6 +123,8 @@ __device__ __forceinline__ void mfma_planes(const bf16x8 (&a)[NPL], const bf16x8
 // is split into bf16 planes.
 template <typename TA> struct PlaneOf { using type = TA; };
 template <> struct PlaneOf<float> { using type = bf16_t; };
+struct hp_t;
+template <> struct PlaneOf<hp_t> { using type = half_t; };      // plane pairs (below): fp16 hi / lo
 
 // Number of operand planes of a precision mode.
 __host__ __device__ constexpr int planes_of(int prec) {

@@ -359,8 +359,8 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   EpiParams& e = p.epi;
   const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
   relu &= CRIMAC_EPI_RELU;
-  CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode == 0),
-                 "conv3x3: plane-pair output is an H3P option without a fused reduction");
+  CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode != 2),
+                 "conv3x3: plane-pair output is an H3P option (never with the fused BatchNorm-backward sums)");
   p.w_il = prec == CRIMAC_PREC_H3P;
   e.bias = bias; e.out = out; e.out_ld = out_ld; e.relu = relu; e.H = H; e.W = W; e.N = N;
   e.stat_mode = stat_mode; e.stat_sum = stat_mode ? stat_sum : nullptr; e.stat_sumsq = stat_sumsq;

@@ -303,17 +303,18 @@ int launch_w4(ConvParams p, hipStream_t st) {
   if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if constexpr (!__is_same(TO, hp_t)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 1, TO, PP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 1, TO, PP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (!__is_same(TO, hp_t))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_glds_w4_kernel<BN, T16, 2, TO, PP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
   }
   const dim3 grid((unsigned)ntiles, p.n_count / BN);
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
-  if constexpr (__is_same(TO, hp_t)) {          // (plane-pair outputs carry no fused reduction: checked by the caller)
-    hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+  if constexpr (__is_same(TO, hp_t)) {          // (a plane-pair output is never the `da` of a BatchNorm block: no mode 2)
+    CRIMAC_REQUIRE(mode != 2, "conv3x3: plane-pair output with fused BatchNorm-backward sums");
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
   } else {
     if (mode == 0) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
     else if (mode == 1) hipLaunchKernelGGL((conv3x3_glds_w4_kernel<BN, T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
@@ -558,17 +559,18 @@ int launch_wch(ConvParams p, hipStream_t st) {
   if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if constexpr (!__is_same(TO, hp_t)) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (!__is_same(TO, hp_t))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2, TO, PP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
   }
   const dim3 grid((unsigned)ntiles, p.n_count / BN);
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
   if constexpr (__is_same(TO, hp_t)) {
-    hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+    CRIMAC_REQUIRE(mode != 2, "conv3x3: plane-pair output with fused BatchNorm-backward sums");
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
   } else {
     if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
     else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP>), grid, dim3(256), lds, st, p);

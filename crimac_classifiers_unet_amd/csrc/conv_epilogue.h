@@ -64,7 +64,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
   using L = AccLayout<ACC>;
   constexpr bool HPO = __is_same(TA, hp_t);
   using TS = typename std::conditional<HPO, float, TA>::type;           // element type of the staging tile
-  static_assert(!HPO || MODE == 0, "plane-pair outputs carry no fused reduction (inference / up-conv outputs)");
+  static_assert(!HPO || MODE != 2, "a plane-pair output is an MFMA operand, never the `da` of a BatchNorm block");
   constexpr int STAGE_PITCH = BN * (int)sizeof(TS) + 16;
   constexpr bool F32 = sizeof(TS) == 4;
   constexpr unsigned OOB = 0x80000000u;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
         const TS q = (TS)v;
         *reinterpret_cast<TS*>(stage + (row - ps * RPASS) * STAGE_PITCH + col * (int)sizeof(TS)) = q;
         if (mode == 1) {
-          const float vs = (float)q;       // statistics of the value as STORED
+          const float vs = HPO ? storage_round<hp_t>(v) : (float)q;       // statistics of the value as STORED
           const bool ok = FULL || ((y0 + (row >> 4) < e.H) && (x0 + (row & 15) < e.W));
           cs1[j] += ok ? vs : 0.f;
           cs2[j] += ok ? vs * vs : 0.f;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
   } else {
     if (mode == 0) CRIMAC_EPI(0);
     else if (mode == 1) CRIMAC_EPI(1);
-    else CRIMAC_EPI(2);
+    else if constexpr (!__is_same(TA, hp_t)) CRIMAC_EPI(2);      // (plane-pair outputs: rejected by the entry point)
   }
 #undef CRIMAC_EPI
 }

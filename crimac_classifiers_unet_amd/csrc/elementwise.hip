@@ -286,11 +286,12 @@ __global__ __launch_bounds__(256) void sum_replicas_kernel(const double* __restr
 }
 
 // ---- BN apply (+ReLU) (+2x2 max-pool) -------------------------------------------------------------
-template <typename T>
+// T: storage type of the convolution output y; TO: of the activation (H3P: fp32 in, fp16 plane pairs out)
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, long y_ld,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
-                                                     T* __restrict__ out, long out_ld, long M, int C) {
+                                                     TO* __restrict__ out, long out_ld, long M, int C) {
   // thread -> fixed 8-channel chunk (its scale/shift live in registers), rows strided over the grid
   const int cpr = C / 8;
   const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
@@ -323,12 +324,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
   }
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ y, long y_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu,
-                                                          T* __restrict__ out, long out_ld,
-                                                          T* __restrict__ pool, long pool_ld, int B,
+                                                          TO* __restrict__ out, long out_ld,
+                                                          TO* __restrict__ pool, long pool_ld, int B,
                                                           int H, int W, int C) {
   const int cpr = C / 8;
   const int Hp = H / 2, Wp = W / 2;
@@ -428,9 +429,10 @@ __device__ __forceinline__ void bnb_flush(const BnbArgs& a, float* lds, int C, i
 // ---- backward of max-pool + skip add ---------------------------------------------------------------
 // thread -> fixed 8-channel chunk, pooled pixels strided over the grid (channels contiguous across the lanes of
 // a pixel); BNB: da feeds a BatchNorm+ReLU block whose backward sums are accumulated on the fly
-template <typename T, bool BNB>
+// T: storage type of the gradients (and of y); TA: of the forward activation `a` (H3P: fp16 plane pairs)
+template <typename T, bool BNB, typename TA = T>
 __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ dp, long dp_ld,
-                                                         const T* __restrict__ a, long a_ld,
+                                                         const TA* __restrict__ a, long a_ld,
                                                          const T* __restrict__ ds, long ds_ld,
                                                          T* __restrict__ da, long da_ld, int B, int H,
                                                          int W, int C, BnbArgs bnb) {
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
           // ties and the same first maximum) -- `a` is not read at all (one tensor less: 0.5 GB per step)
           load8s(reinterpret_cast<const T*>(bnb.y) + pix[d] * bnb.y_ld + c0, yv[d]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) av[d][j] = (float)(T)fmaxf(yv[d][j] * k.sc[j] + k.sh[j], 0.f);
+          for (int j = 0; j < 8; ++j) av[d][j] = storage_round<TA>(fmaxf(yv[d][j] * k.sc[j] + k.sh[j], 0.f));
         } else {
           load8s(a + pix[d] * a_ld + c0, av[d]);
         }
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           o[j] = (ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f);
-          if constexpr (BNB) o[j] = (float)(T)o[j];          // the sums see da as it is stored
+          if constexpr (BNB) o[j] = storage_round<T>(o[j]);          // the sums see da as it is stored
         }
         store8(da + pix[d] * da_ld + c0, o);
         if constexpr (BNB) bnb_accum_v(k, yv[d], o, d1, d2);
@@ -532,12 +534,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                           sum_dz, sum_dzx);
 }
 
-template <typename T>
+// T: storage type of da and y; TD: of the output gradient dy (H3P: fp16 plane pairs -- it feeds two contractions)
+template <typename T, typename TD = T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const double* __restrict__ sum_dz,
-    const double* __restrict__ sum_dzx, long M, long count, int C, T* __restrict__ dy, long dy_ld, float* dgamma,
+    const double* __restrict__ sum_dzx, long M, long count, int C, TD* __restrict__ dy, long dy_ld, float* dgamma,
     float* dbeta, float* dbias) {
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -574,12 +577,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 // The same without the (never used) pre-BatchNorm bias gradient: a pure streaming kernel like bn_act_kernel --
 // thread-fixed channel chunk, constants in registers, U rows in flight, no LDS, no reduction tail.
-template <typename T>
+template <typename T, typename TD = T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, long M, long count, int C,
-    T* __restrict__ dy, long dy_ld, float* dgamma, float* dbeta) {
+    TD* __restrict__ dy, long dy_ld, float* dgamma, float* dbeta) {
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
       dgamma[c] = (float)sum_dzx[c];
@@ -626,7 +629,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
 }
 
 // ---- 1x1 head --------------------------------------------------------------------------------------------
-template <typename T, int NC>
+// T: storage type of x; TR: the type the activation formed on the fly (bn_scale given) is rounded to -- what bn_act
+// would have stored (H3P: x = fp32 conv output, activation = fp16 plane pairs)
+template <typename T, int NC, typename TR = T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, long x_ld, int Cin,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
       load8(x + p * x_ld + sub * 8, v);
       if (bn_scale) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)(T)fmaxf(v[j] * bsc[j] + bsh[j], 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = storage_round<TR>(fmaxf(v[j] * bsc[j] + bsh[j], 0.f));
       }
 #pragma unroll
       for (int o = 0; o < NC; ++o)
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 // the complete sums of pixel s -- the same pairing, hence bit for bit the same sums, as the all-reduce butterfly of
 // the generic kernel above, with 21 shuffles per 8 pixels instead of 72, the softmax evaluated once per pixel instead
 // of in 8 lanes of which 7 are discarded, and the 64 pixels of a wave stored as 256 contiguous bytes per class plane.
-template <typename T, int NC>
+template <typename T, int NC, typename TR = T>
 __global__ __launch_bounds__(256) void head_fwd64_kernel(const T* __restrict__ x, long x_ld, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ logits,
                                                          long npix, long HW, int softmax,
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(256) void head_fwd64_kernel(const T* __restrict__ x
     for (int u = 0; u < 8; ++u) {
       if (bn_scale) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[u][j] = (float)(T)fmaxf(v[u][j] * bsc[j] + bsh[j], 0.f);
+        for (int j = 0; j < 8; ++j) v[u][j] = storage_round<TR>(fmaxf(v[u][j] * bsc[j] + bsh[j], 0.f));
       }
 #pragma unroll
       for (int o = 0; o < NC; ++o) {
@@ -787,9 +792,11 @@ __global__ __launch_bounds__(256) void head_fwd64_kernel(const T* __restrict__ x
   }
 }
 
-template <typename T, int NC, bool BNB>
+// T: storage type of dx and of the y read for the fused sums; TX: of the head input x / of the activation rebuilt
+// from y (H3P: fp16 plane pairs)
+template <typename T, int NC, bool BNB, typename TX = T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl,
-                                                       const T* __restrict__ x, long x_ld, int Cin,
+                                                       const TX* __restrict__ x, long x_ld, int Cin,
                                                        const float* __restrict__ w, T* __restrict__ dx,
                                                        long dx_ld, float* dw, float* db, long npix,
                                                        long HW, BnbArgs bnb) {
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       if constexpr (BNB) {
         if (!x) {        // the head input is the activation of the block whose y is at hand: rebuild it
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[u][j] = (float)(T)fmaxf(yv[u][j] * k.sc[j] + k.sh[j], 0.f);
+          for (int j = 0; j < 8; ++j) v[u][j] = storage_round<TX>(fmaxf(yv[u][j] * k.sc[j] + k.sh[j], 0.f));
         }
       }
 #pragma unroll
@@ -865,7 +872,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int o = 0; o < NC; ++o) gb[o] += g[u][o];
       if constexpr (BNB) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o8[j] = (float)(T)o8[j];      // the sums see dx as it is stored
+        for (int j = 0; j < 8; ++j) o8[j] = storage_round<T>(o8[j]);      // the sums see dx as it is stored
       }
       store8(dx + pu * dx_ld + sub * 8, o8);
       if constexpr (BNB) bnb_accum_v(k, yv[u], o8, d1, d2);
@@ -1036,8 +1043,8 @@ extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, 
                  "nchw_to_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
   const long npix = (long)B * H * W;
   const int grid = grid_for(npix, 256);
-  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid), dim3(256), 0, ST, in, (T*)out, C,
-                                                 (long)H * W, npix, ld));
+  CRIMAC_FOR_STORAGE2(prec, TF, T, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid), dim3(256), 0, ST, in, (T*)out, C,
+                                                      (long)H * W, npix, ld));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -1154,19 +1161,19 @@ extern "C" int crimac_bn_finalize(const double* sum, const double* sumsq, int re
 
 static int colreduce_grid(long M, int C);
 
-template <typename T>
+template <typename T, typename TO = T>
 static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, const float* shift,
                               int relu, void* out, long out_ld, void* pool_out, long pool_ld, int B,
                               int H, int W, int C, hipStream_t st) {
   if (pool_out) {
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(bn_act_pool_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, st,
-                       (const T*)y, y_ld, scale, shift, relu, (T*)out, out_ld, (T*)pool_out, pool_ld, B,
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO>), dim3(grid_for(total, 256)), dim3(256), 0, st,
+                       (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, (TO*)pool_out, pool_ld, B,
                        H, W, C);
   } else {
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL(bn_act_kernel<T>, dim3(colreduce_grid(M, C)), dim3(256), 0, st,
-                       (const T*)y, y_ld, scale, shift, relu, (T*)out, out_ld, M, C);
+    hipLaunchKernelGGL((bn_act_kernel<T, TO>), dim3(colreduce_grid(M, C)), dim3(256), 0, st,
+                       (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, M, C);
   }
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1184,6 +1191,12 @@ extern "C" int crimac_bn_act_pool(int prec, const void* y, long y_ld, const floa
                      (!pool_out || (pool_ld >= C && pool_ld % 8 == 0)),
                  "bn_act_pool: bad pixel strides");
   CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0), "bn_act_pool: pooling needs even H, W");
+  if (prec == CRIMAC_PREC_H3P) {
+    // training: y = fp32 conv output (scale / shift given), activation and pooled tensor = plane pairs; inference
+    // max-pool (no scale): plane pairs in and out
+    if (scale) return bn_act_pool_launch<float, hp_t>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld, B, H, W, C, ST);
+    return bn_act_pool_launch<hp_t, hp_t>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld, B, H, W, C, ST);
+  }
   CRIMAC_FOR_STORAGE(prec, T, return bn_act_pool_launch<T>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld,
                                                            B, H, W, C, ST));
 }
@@ -1210,12 +1223,12 @@ extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const voi
   const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
   const int grid = grid_for(total, 256);
   BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
-#define UA(T, BNB, LDS)                                                                                   \
-  hipLaunchKernelGGL((unpool_add_kernel<T, BNB>), dim3(grid), dim3(256), LDS, ST, (const T*)dp, dp_ld,     \
-                     (const T*)a, a_ld, (const T*)ds, ds_ld, (T*)da, da_ld, B, H, W, C, bnb)
+#define UA(T, TA, BNB, LDS)                                                                               \
+  hipLaunchKernelGGL((unpool_add_kernel<T, BNB, TA>), dim3(grid), dim3(256), LDS, ST, (const T*)dp, dp_ld, \
+                     (const TA*)a, a_ld, (const T*)ds, ds_ld, (T*)da, da_ld, B, H, W, C, bnb)
   const size_t lds = 2 * (size_t)C * sizeof(float);
-  if (stat_sum) CRIMAC_FOR_STORAGE(prec, T, UA(T, true, lds));
-  else CRIMAC_FOR_STORAGE(prec, T, UA(T, false, 0));
+  if (stat_sum) CRIMAC_FOR_STORAGE2(prec, T, TA, UA(T, TA, true, lds));
+  else CRIMAC_FOR_STORAGE2(prec, T, TA, UA(T, TA, false, 0));
 #undef UA
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1256,18 +1269,18 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
   const size_t lds = 2 * C * sizeof(float);
   static const int stream_form = getenv("CRIMAC_BNB_STREAM") ? atoi(getenv("CRIMAC_BNB_STREAM")) : 1;
   if (!dbias && stream_form && C <= 2048)
-    CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_apply_stream_kernel<T>, dim3(grid), dim3(256), 0, ST,
+    CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD>), dim3(grid), dim3(256), 0, ST,
                                                    (const T*)da, da_ld, (const T*)y, y_ld, scale, shift, mean, invstd,
-                                                   sum_dz, sum_dz_xhat, M, count, C, (T*)dy, dy_ld, dgamma, dbeta));
+                                                   sum_dz, sum_dz_xhat, M, count, C, (TD*)dy, dy_ld, dgamma, dbeta));
   else
-    CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), lds, ST, (const T*)da,
+    CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3(grid), dim3(256), lds, ST, (const T*)da,
                                                    da_ld, (const T*)y, y_ld, scale, shift, mean, invstd, sum_dz,
-                                                   sum_dz_xhat, M, count, C, (T*)dy, dy_ld, dgamma, dbeta, dbias));
+                                                   sum_dz_xhat, M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, dbias));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
 
-template <typename T>
+template <typename T, typename TR = T>
 static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, const float* b,
                            float* logits, long npix, long HW, int ncls, int softmax, const float* bn_scale,
                            const float* bn_shift, hipStream_t st) {
@@ -1275,7 +1288,7 @@ static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, co
   if (Cin == 64) {
     const int grid64 = grid_for(npix, 256 * 4);
 #define HF64(NC)                                                                                              \
-  hipLaunchKernelGGL((head_fwd64_kernel<T, NC>), dim3(grid64), dim3(256), 0, st, (const T*)x, x_ld, w, b, logits, \
+  hipLaunchKernelGGL((head_fwd64_kernel<T, NC, TR>), dim3(grid64), dim3(256), 0, st, (const T*)x, x_ld, w, b, logits, \
                      npix, HW, softmax, bn_scale, bn_shift)
     if (ncls == 2) HF64(2); else if (ncls == 3) HF64(3); else HF64(4);
 #undef HF64
@@ -1284,7 +1297,7 @@ static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, co
   }
   const int grid = grid_for(npix, (256 / lp) * 8);
 #define HF(NC)                                                                                      \
-  hipLaunchKernelGGL((head_fwd_kernel<T, NC>), dim3(grid), dim3(256), 0, st, (const T*)x, x_ld, Cin, \
+  hipLaunchKernelGGL((head_fwd_kernel<T, NC, TR>), dim3(grid), dim3(256), 0, st, (const T*)x, x_ld, Cin, \
                      w, b, logits, npix, HW, softmax, bn_scale, bn_shift)
   if (ncls == 2) HF(2); else if (ncls == 3) HF(3); else HF(4);
 #undef HF
@@ -1307,11 +1320,17 @@ extern "C" int crimac_head_fwd(int prec, const void* x, long x_ld, int Cin, cons
                  "head_fwd: Cin=%d must be 8*2^k <= 512", Cin);
   CRIMAC_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "head_fwd: bn_scale and bn_shift go together");
   const long HW = (long)H * W;
+  if (prec == CRIMAC_PREC_H3P) {
+    // x = the fp32 conv output of the last block (its activation is formed on the fly, rounded to plane pairs), or --
+    // inference -- the plane-pair activation itself
+    if (bn_scale) return head_fwd_launch<float, hp_t>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale, bn_shift, ST);
+    return head_fwd_launch<hp_t, hp_t>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale, bn_shift, ST);
+  }
   CRIMAC_FOR_STORAGE(prec, T, return head_fwd_launch<T>(x, x_ld, Cin, w, b, logits, B * HW, HW, ncls, softmax, bn_scale,
                                                         bn_shift, ST));
 }
 
-template <typename T>
+template <typename T, typename TX = T>
 static int head_bwd_launch(const float* dl, const void* x, long x_ld, int Cin, const float* w, void* dx,
                            long dx_ld, float* dw, float* db, long npix, long HW, int ncls, const BnbArgs& bnb,
                            hipStream_t st) {
@@ -1320,7 +1339,7 @@ static int head_bwd_launch(const float* dl, const void* x, long x_ld, int Cin, c
   if (grid > 1024) grid = 1024;
   const size_t lds = (size_t)(ncls * Cin + ncls + (bnb.sum_dz ? 2 * Cin : 0)) * sizeof(float);
 #define HB(NC, BNB)                                                                                          \
-  hipLaunchKernelGGL((head_bwd_kernel<T, NC, BNB>), dim3(grid), dim3(256), lds, st, dl, (const T*)x, x_ld,   \
+  hipLaunchKernelGGL((head_bwd_kernel<T, NC, BNB, TX>), dim3(grid), dim3(256), lds, st, dl, (const TX*)x, x_ld,   \
                      Cin, w, (T*)dx, dx_ld, dw, db, npix, HW, bnb)
   if (bnb.sum_dz) {
     if (ncls == 2) HB(2, true); else if (ncls == 3) HB(3, true); else HB(4, true);
@@ -1347,8 +1366,8 @@ extern "C" int crimac_head_bwd(int prec, const float* dlogits, const void* x, lo
                  "head_bwd: bad arguments of the fused BatchNorm-backward sums");
   const long HW = (long)H * W;
   const BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
-  CRIMAC_FOR_STORAGE(prec, T, return head_bwd_launch<T>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls,
-                                                        bnb, ST));
+  CRIMAC_FOR_STORAGE2(prec, T, TX, return (head_bwd_launch<T, TX>(dlogits, x, x_ld, Cin, w, dx, dx_ld, dw, db, B * HW, HW, ncls,
+                                                                    bnb, ST)));
 }
 
 extern "C" int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes,

@@ -301,6 +301,9 @@ int dispatch(const IgemmParams& p, hipStream_t st) {
 bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, long out_ld);
 int crimac_upconv_wch_16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
                          const float* bias, int cout_up, void* out, long out_ld, hipStream_t st, int fp16);
+bool crimac_upconv_wch_hp_ok(int ntaps, long in_bytes, int K, int N, int cout_up, long out_ld);
+int crimac_upconv_wch_hp(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
+                         const float* bias, int cout_up, void* out, long out_ld, hipStream_t st, int out_planes);
 
 extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, int Hi, int Wi, int Ho,
                                  int Wo, int Cin, int N, int ntaps, int tw, int pad, int stride,
@@ -315,7 +318,10 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   CRIMAC_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "igemm: bad grid");
   CRIMAC_REQUIRE(in && w_hi && out, "igemm: null pointer");
   const bool is16 = prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16;
-  CRIMAC_REQUIRE(is16 || w_lo, "igemm: split precisions need the low weight plane(s)");
+  const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
+  relu &= CRIMAC_EPI_RELU;
+  CRIMAC_REQUIRE(!out_planes || prec == CRIMAC_PREC_H3P, "igemm: plane-pair output is an H3P option");
+  CRIMAC_REQUIRE(is16 || w_lo || prec == CRIMAC_PREC_H3P, "igemm: split precisions need the low weight plane(s)");
   CRIMAC_REQUIRE(out_mode == 0 || (out_mode == 1 && cout_up > 0 && N == 4 * cout_up),
                  "igemm: bad output mode / cout_up");
   CRIMAC_REQUIRE(out_mode == 1 ? out_ld >= cout_up : out_ld >= N, "igemm: out_ld too small");
@@ -330,6 +336,19 @@ extern "C" int crimac_igemm_conv(int prec, const void* in, long in_ld, int B, in
   p.M = (long)B * Ho * Wo;
   p.acc_scale = prec == CRIMAC_PREC_F32H3 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
   hipStream_t st = (hipStream_t)stream;
+  if (prec == CRIMAC_PREC_H3P) {
+    // plane-pair tensors: only the two transposed-convolution contractions exist in this mode (upconv.hip); forward:
+    // plane-pair output (it feeds the decoder's first convolution), input gradient: fp32
+    const long in_bytes = (((long)B * Hi * Wi - 1) * in_ld + Cin) * 4;
+    const bool fwd = out_mode == 1 && ntaps == 1 && stride == 1 && pad == 0 && Hi == Ho && Wi == Wo &&
+                     (!bias || bias_mod == cout_up) && out_planes;
+    const bool dgr = out_mode == 0 && ntaps == 4 && tw == 2 && stride == 2 && pad == 0 && Hi == 2 * Ho &&
+                     Wi == 2 * Wo && !bias && !out_planes;
+    CRIMAC_REQUIRE(!relu && (fwd || dgr) && crimac_upconv_wch_hp_ok(ntaps, in_bytes, Cin, N, cout_up, out_ld),
+                   "igemm (plane pairs): only ConvTranspose2d k2 s2 forward (plane-pair output) and its input gradient "
+                   "(fp32 output), Cin %% 32 == 0, N %% 128 == 0, tensors below 2 GiB");
+    return crimac_upconv_wch_hp(ntaps, in, in_ld, B, Ho, Wo, Cin, N, w_hi, bias, cout_up, out, out_ld, st, out_planes);
+  }
   if (is16 && !relu) {
     // ConvTranspose2d(k2, s2): forward (1 tap, scatter) and input gradient (4 taps, stride 2) go to upconv.hip
     static const int use_wch = getenv("CRIMAC_UPCONV_WCH") ? atoi(getenv("CRIMAC_UPCONV_WCH")) : 1;

@@ -198,7 +198,7 @@ static int gather_run(int prec, const float* data, int C, int Wd, int H, const i
   dim3 grid((pw + TS - 1) / TS, (ph + TS - 1) / TS, P);
   const size_t lds = (size_t)C * TS * (TS + 1) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  CRIMAC_FOR_STORAGE(prec, T, hipLaunchKernelGGL(gather_patches_kernel<T>, grid, dim3(256), lds, st, data, C, Wd, H,
+  CRIMAC_FOR_STORAGE2(prec, TF_, T, hipLaunchKernelGGL(gather_patches_kernel<T>, grid, dim3(256), lds, st, data, C, Wd, H,
                                                  centres, ph, pw, (T*)out, (int)ld, border_labels));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;

@@ -12,6 +12,8 @@
 // chunk (64 MFMAs of 16x16x32 per wave), fragment reads one group ahead of the MFMAs (inline asm, counted lgkmcnt).
 // Two workgroups per CU (70.6 KB LDS: the epilogue staging tile).  Replaces the register-staged igemm kernel
 // for these two ops (0.43 -> see DESIGN.md PFLOP/s); igemm remains for the fp32 parity modes and odd shapes.
+#include <type_traits>
+
 #include "common.h"
 #include "conv_epilogue.h"
 
@@ -69,7 +71,9 @@ __device__ __forceinline__ void release_half(Frags& f, int set) {
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.a[set][0]), "+v"(f.a[set][1]), "+v"(f.a[set][2]), "+v"(f.a[set][3])
                  :: "memory");
 }
-template <typename T16, int H, typename ACC>
+// PP (plane pairs, common.h hp_t): k-step 0 of a chunk = hi plane of 32 channels, k-step 1 = their lo plane, in both
+// operands -> hi*lo + hi*hi on the first k-step's fragments, lo*hi on the second's (3 MFMAs per fragment pair)
+template <typename T16, bool PP, int H, typename ACC>
 __device__ __forceinline__ void half(const unsigned (&av)[2], Frags& f, ACC& acc) {
   constexpr int ks = H / 4, q = H % 4;
   if constexpr (H + 1 < 8) {
@@ -78,12 +82,19 @@ __device__ __forceinline__ void half(const unsigned (&av)[2], Frags& f, ACC& acc
   } else {
     release_half<true>(f, H & 1);
   }
+  if constexpr (PP && ks == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        acc[q * 4 + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[0][2 + nb], acc[q * 4 + j][nb]);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
-      acc[q * 4 + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[0][ks * 2 + nb], acc[q * 4 + j][nb]);
-  if constexpr (H + 1 < 8) half<T16, H + 1>(av, f, acc);
+      acc[q * 4 + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[0][(PP ? 0 : ks * 2) + nb], acc[q * 4 + j][nb]);
+  if constexpr (H + 1 < 8) half<T16, PP, H + 1>(av, f, acc);
 }
 // s0: row of the wave's first 16 columns, s1: of the second 16; fragments [ks * 2 + nb]
 __device__ __forceinline__ void load_b(const unsigned short* s0, const unsigned short* s1, bf16x8 (&bf)[4]) {
@@ -97,8 +108,16 @@ __device__ __forceinline__ void load_b(const unsigned short* s0, const unsigned 
       : "memory");
 }
 
-// SCATTER: forward (output on the fine grid, column group (a,b) -> pixel (2y+a, 2x+b)); else dense dgrad tile
-template <bool SCATTER, typename T16>
+// Epilogue staging of an output storage type (as in conv3x3_glds.hip): fp32 / plane pairs in two 128-row slices
+template <typename TO> struct EpiPasses {
+  static constexpr int kStageBytes = sizeof(TO) == 2 ? 2 : 4;
+  static constexpr int value = sizeof(TO) == 2 ? 1 : 2;
+};
+template <bool PP> __device__ __forceinline__ int src_unit(int u) { return PP ? (((u & 3) << 1) | (u >> 2)) : u; }
+
+// SCATTER: forward (output on the fine grid, column group (a,b) -> pixel (2y+a, 2x+b)); else dense dgrad tile.
+// PP: plane-pair input (p.K / p.in_ld count halves); TO: output storage type (T16, float, or hp_t plane pairs)
+template <bool SCATTER, typename T16, typename TO = T16, bool PP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void upconv_wch_kernel(UpParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -127,7 +146,7 @@ void upconv_wch_kernel(UpParams p) {
   for (int i = 0; i < NA; ++i) {
     const int row = 8 * (wave + NW * i) + (lane >> 3);
     const int y = y0 + (row >> 4), x = x0 + (row & 15);
-    const int us = (lane & 7) ^ ((row >> 1) & 7);
+    const int us = src_unit<PP>((lane & 7) ^ ((row >> 1) & 7));
     const long pix = SCATTER ? ((long)b * Hi + y) * Wi + x : ((long)b * Hi + 2 * y) * Wi + 2 * x;
     voff[i] = (y < p.H && x < p.W) ? (unsigned)((pix * p.in_ld + us * 8) * 2) : 0x80000000u;
   }
@@ -192,61 +211,78 @@ void upconv_wch_kernel(UpParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) av[ks] = av0[ks] + buf * A_BYTES;
     issue_half<0>(av, f);
-    half<T16, 0>(av, f, acc);
+    half<T16, PP, 0>(av, f, acc);
     // chunk c+1's A tile and weight fragments were requested 64 MFMAs ago
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[1][2]), "+v"(f.b[1][3]) :: "memory");
   }
   __syncthreads();                       // staging below reuses the A buffers
 
   if constexpr (!SCATTER) {
-    conv_epilogue<T16, BN, BM, 256, 16, 2, f32x4>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
+    conv_epilogue<TO, BN, BM, 256, 16, 2, f32x4, -1, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
   } else {
-    // bias, then the tile through LDS: [256 rows][128 cols + pad] bf16, then 16-byte stores scattered to the
-    // fine grid: column n = (a*2 + bb) * cout + co -> pixel (2y + a, 2x + bb), channel co
-    constexpr int PITCH = BN * 2 + 16;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int col = wave * 32 + nb * 16 + (lane & 15);
-      const float bv = p.bias ? p.bias[(n0 + col) % p.cout] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i * 16 + (lane >> 4) * 4 + r;
-          *reinterpret_cast<T16*>(smem + row * PITCH + col * 2) = (T16)(acc[i][nb][r] + bv);
-        }
-    }
-    __syncthreads();
-    T16* outp = reinterpret_cast<T16*>(p.out);
-    const int c8 = tid & 15, r0 = tid >> 4;          // 16 chunks of 8 columns per row, 16 rows per pass
+    // bias, then the tile through LDS: [256 rows][128 cols + pad] (16-bit types: all rows at once; fp32 / plane pairs:
+    // two slices of 128 rows, staged as fp32), then 16-byte stores scattered to the fine grid: column
+    // n = (a*2 + bb) * cout + co -> pixel (2y + a, 2x + bb), channel co
+    constexpr bool HPO = __is_same(TO, hp_t);
+    using TS = typename std::conditional<HPO, float, TO>::type;
+    constexpr int PASSES = EpiPasses<TO>::value, RPASS = BM / PASSES;
+    constexpr int PITCH = BN * (int)sizeof(TS) + 16;
+    TO* outp = reinterpret_cast<TO*>(p.out);
+    const int c8 = tid & 15, r0 = tid >> 4;          // 16 chunks of 8 columns per row, 16 rows per round
     const int n = n0 + c8 * 8;
     const int ab = n / p.cout, co = n - ab * p.cout;
 #pragma unroll
-    for (int rr = 0; rr < BM / 16; ++rr) {
-      const int row = r0 + rr * 16;
-      const int y = y0 + (row >> 4), x = x0 + (row & 15);
-      if (y < p.H && x < p.W) {
-        const long pix = ((long)b * 2 * p.H + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
-        *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) =
-            *reinterpret_cast<const u32x4*>(smem + row * PITCH + c8 * 16);
+    for (int ps = 0; ps < PASSES; ++ps) {
+      if (ps > 0) __syncthreads();
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int col = wave * 32 + nb * 16 + (lane & 15);
+        const float bv = p.bias ? p.bias[(n0 + col) % p.cout] : 0.f;
+#pragma unroll
+        for (int i = ps * (16 / PASSES); i < (ps + 1) * (16 / PASSES); ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i * 16 + (lane >> 4) * 4 + r - ps * RPASS;
+            *reinterpret_cast<TS*>(smem + row * PITCH + col * (int)sizeof(TS)) = (TS)(acc[i][nb][r] * p.epi.acc_scale + bv);
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < RPASS / 16; ++rr) {
+        const int lrow = r0 + rr * 16, row = ps * RPASS + lrow;
+        const int y = y0 + (row >> 4), x = x0 + (row & 15);
+        if (y < p.H && x < p.W) {
+          const long pix = ((long)b * 2 * p.H + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
+          const TS* sp = reinterpret_cast<const TS*>(smem + lrow * PITCH) + c8 * 8;
+          if constexpr (HPO) {
+            float v[8];
+            load8(sp, v);
+            store8(outp + pix * p.out_ld + co, v);
+          } else if constexpr (sizeof(TS) == 4) {
+            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) = *reinterpret_cast<const u32x4*>(sp);
+            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co + 4) = *reinterpret_cast<const u32x4*>(sp + 4);
+          } else {
+            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) = *reinterpret_cast<const u32x4*>(sp);
+          }
+        }
       }
     }
   }
 }
 
-template <bool SCATTER, typename T16>
+template <bool SCATTER, typename T16, typename TO = T16, bool PP = false>
 int launch(UpParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TP);
   p.tiles_x = cdiv(p.W, TP);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t stage = (size_t)BM * (BN * 2 + 16) + 2 * BN * 4;
+  constexpr size_t stage = (size_t)(BM / EpiPasses<TO>::value) * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4;
   const size_t lds = stage > 2 * (size_t)A_BYTES ? stage : 2 * (size_t)A_BYTES;
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER, T16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER, T16, TO, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER, T16>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER, T16, TO, PP>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -262,14 +298,18 @@ bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, l
   return ntaps == 4;
 }
 
+// fmt: 0 bf16, 1 fp16, 2 plane pairs in / plane pairs out, 3 plane pairs in / fp32 out (CRIMAC_PREC_H3P; K, in_ld in
+// ELEMENTS of the plane-pair tensor: the kernel sees twice as many halves)
 static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
                       const float* bias, int cout_up, void* out, long out_ld, const EpiParams* bnb, hipStream_t st,
-                      int fp16) {
+                      int fmt) {
+  const int fp16 = fmt == 1;
+  if (fmt >= 2) { K *= 2; in_ld *= 2; }
   UpParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.ntaps = ntaps;
   p.w = (const unsigned short*)w; p.bias = bias; p.cout = cout_up; p.out = out; p.out_ld = out_ld;
   p.epi = EpiParams{};
-  p.epi.acc_scale = 1.f;
+  p.epi.acc_scale = fmt >= 2 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
   p.epi.bias = nullptr; p.epi.out = out; p.epi.out_ld = out_ld; p.epi.relu = 0; p.epi.H = H; p.epi.W = W; p.epi.N = N;
   p.epi.stat_sum = nullptr; p.epi.stat_sumsq = nullptr; p.epi.stat_replicas = 1; p.epi.stat_mode = 0;
   if (bnb) {
@@ -277,8 +317,24 @@ static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W
     p.epi.stat_replicas = bnb->stat_replicas; p.epi.bnb_y = bnb->bnb_y; p.epi.bnb_y_ld = bnb->bnb_y_ld;
     p.epi.bnb_vec = bnb->bnb_vec; p.epi.bnb_stride = bnb->bnb_stride;
   }
+  if (fmt == 2) {            // (plane-pair OUTPUT: the forward pass only; an input gradient is read by elementwise kernels)
+    CRIMAC_REQUIRE(ntaps == 1, "upconv (plane pairs): the input gradient is stored as fp32");
+    return launch<true, half_t, hp_t, true>(p, st);
+  }
+  if (fmt == 3) return ntaps == 1 ? launch<true, half_t, float, true>(p, st) : launch<false, half_t, float, true>(p, st);
   if (fp16) return ntaps == 1 ? launch<true, half_t>(p, st) : launch<false, half_t>(p, st);
   return ntaps == 1 ? launch<true, bf16_t>(p, st) : launch<false, bf16_t>(p, st);
+}
+
+// plane-pair input (CRIMAC_PREC_H3P): K % 32 == 0, N % 128 == 0, tensor below 2 GiB
+bool crimac_upconv_wch_hp_ok(int ntaps, long in_bytes, int K, int N, int cout_up, long out_ld) {
+  if (in_bytes >= (1L << 31) || K % 32 != 0 || N % BN != 0 || out_ld % 8 != 0) return false;
+  if (ntaps == 1) return cout_up % 32 == 0;
+  return ntaps == 4;
+}
+int crimac_upconv_wch_hp(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
+                         const float* bias, int cout_up, void* out, long out_ld, hipStream_t st, int out_planes) {
+  return upconv_run(ntaps, in, in_ld, B, H, W, K, N, w, bias, cout_up, out, out_ld, nullptr, st, out_planes ? 2 : 3);
 }
 
 int crimac_upconv_wch_16(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
@@ -293,12 +349,15 @@ extern "C" int crimac_upconv2x2_dgrad_bnb_prec(int prec, const void* dy, long dy
                                           const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y,
                                           long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
                                           double* stat_sumsq, int stat_replicas, void* stream) {
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16, "upconv2x2_dgrad_bnb: 16-bit storage modes only (prec=%d)", prec);
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16 || prec == CRIMAC_PREC_H3P,
+                 "upconv2x2_dgrad_bnb: 16-bit storage modes and plane pairs only (prec=%d)", prec);
+  const bool hp = prec == CRIMAC_PREC_H3P;
   CRIMAC_REQUIRE(dy && w_dg_hi && dx && B > 0 && H > 0 && W > 0, "upconv2x2_dgrad_bnb: bad arguments");
   CRIMAC_REQUIRE(dy_ld >= Cout && dy_ld % 8 == 0 && dx_ld >= Cin && dx_ld % 8 == 0,
                  "upconv2x2_dgrad_bnb: bad pixel strides (dy_ld=%ld dx_ld=%ld)", dy_ld, dx_ld);
-  const long in_bytes = (((long)B * 2 * H * 2 * W - 1) * dy_ld + Cout) * 2;
-  CRIMAC_REQUIRE(Cout > 0 && Cin > 0 && crimac_upconv_wch_ok(4, in_bytes, Cout, Cin, 0, dx_ld),
+  const long in_bytes = (((long)B * 2 * H * 2 * W - 1) * dy_ld + Cout) * (hp ? 4 : 2);
+  CRIMAC_REQUIRE(Cout > 0 && Cin > 0 && (hp ? crimac_upconv_wch_hp_ok(4, in_bytes, Cout, Cin, 0, dx_ld)
+                                            : crimac_upconv_wch_ok(4, in_bytes, Cout, Cin, 0, dx_ld)),
                  "upconv2x2_dgrad_bnb: needs Cout %% 64 == 0, Cin %% 128 == 0 and a gradient tensor below 2 GiB "
                  "(got Cout=%d Cin=%d); use crimac_igemm_conv + crimac_bn_bwd_reduce", Cout, Cin);
   CRIMAC_REQUIRE(bnb_y && bnb_vec && stat_sum && stat_sumsq && stat_replicas >= 1 && bnb_y_ld >= Cin &&
@@ -308,7 +367,7 @@ extern "C" int crimac_upconv2x2_dgrad_bnb_prec(int prec, const void* dy, long dy
   e.stat_sum = stat_sum; e.stat_sumsq = stat_sumsq; e.stat_replicas = stat_replicas;
   e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
   return upconv_run(4, dy, dy_ld, B, H, W, Cout, Cin, w_dg_hi, nullptr, 0, dx, dx_ld, &e, (hipStream_t)stream,
-                    prec == CRIMAC_PREC_FP16);
+                    hp ? 3 : (prec == CRIMAC_PREC_FP16 ? 1 : 0));
 }
 
 // bf16 form (kept for existing callers)

@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256 * TEAMS) __attribute__((amdgpu_waves_per_eu(2, 
 void wgrad_kernel(WgradParams p) {
   static_assert(TEAMS == 1 || (sizeof(TA) == 2 && MODE == 0), "two teams: 16-bit conv3x3 only (LDS: 4 tile buffers)");
   constexpr bool X3 = sizeof(TA) == 4;     // fp32 activations, split into NPL bf16 planes
+  constexpr bool PRE = __is_same(TA, hp_t);   // ... or fp16 plane pairs split by their producer (common.h)
   static_assert(X3 ? (NPL == 2 || NPL == 3) : NPL == 1, "bf16 -> 1 plane, fp32 -> 2 or 3 planes");
+  static_assert(!PRE || NPL == 2, "plane pairs are two planes");
   constexpr int TR = MODE == 0 ? 8 : 4;
   constexpr int NTAPS = MODE == 0 ? 9 : 4;
   constexpr int F_ROWS = TR * 16;
@@ -617,10 +619,15 @@ void wgrad_kernel(WgradParams p) {
         v0 = *reinterpret_cast<const u32x4*>(src);
         v1 = *reinterpret_cast<const u32x4*>(src + 4);
       }
-      u32x4 pl[NPL];
-      split8<NPL>(v0, v1, pl);
+      if constexpr (PRE) {                      // [8 hi | 8 lo] as stored: the two planes of this 8-channel group
+        *reinterpret_cast<u32x4*>(img + o) = v0;
+        *reinterpret_cast<u32x4*>(img + plane_bytes + o) = v1;
+      } else {
+        u32x4 pl[NPL];
+        split8<NPL>(v0, v1, pl);
 #pragma unroll
-      for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(img + k * plane_bytes + o) = pl[k];
+        for (int k = 0; k < NPL; ++k) *reinterpret_cast<u32x4*>(img + k * plane_bytes + o) = pl[k];
+      }
     };
     for (long tile = t_begin; tile < t_end; ++tile) {
       long b; int y0, x0;
@@ -730,7 +737,7 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
               int Wf, float* dw, long partial_stride, int target_blocks, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "wgrad: bad precision %d", prec);
   CRIMAC_REQUIRE(prec != CRIMAC_PREC_F32H3, "wgrad: F32H3 is a forward-operand mode (fp16 planes have no range for "
-                 "gradients); call the backward kernels with CRIMAC_PREC_F32X3");
+                 "unscaled gradients); call the backward kernels with CRIMAC_PREC_F32X3, or use CRIMAC_PREC_H3P");
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "wgrad: bad mode %d", mode);
   CRIMAC_REQUIRE(CF > 0 && CF % 8 == 0 && CS > 0 && CS % 8 == 0, "wgrad: channels must be multiples of 8");
   CRIMAC_REQUIRE(f_ld >= CF && s_ld >= CS && f_ld % 8 == 0 && s_ld % 8 == 0, "wgrad: bad pixel strides");
@@ -757,6 +764,8 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
   }
   if (prec == CRIMAC_PREC_F32X3)
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
+  if (prec == CRIMAC_PREC_H3P)      // both operands are fp16 plane pairs (activation x loss-scaled output gradient)
+    return mode == 0 ? launch<hp_t, 2, 0>(p, target_blocks, st) : launch<hp_t, 2, 1>(p, target_blocks, st);
   return mode == 0 ? launch<float, 3, 0>(p, target_blocks, st) : launch<float, 3, 1>(p, target_blocks, st);
 }
 

@@ -80,12 +80,17 @@ class UNetEngine:
         self.planes = hip.PREC_PLANES[self.prec]
         self.planes_arg = hip.PREC_PLANES_ARG[self.prec]     # what the packing entry points take
         self.is16 = self.prec in hip.PREC_16BIT
+        # h3p: MFMA operand tensors (activations, output gradients) are fp16 plane pairs split by their producer; the
+        # buffers have fp32 addressing (4 bytes per element), so fp32 and plane-pair tensors share concat buffers
+        self.is_hp = self.prec == hip.PREC_H3P
+        self.lds_dma = self.is16 or self.is_hp           # the LDS-DMA kernel family (and its fused epilogues) applies
         self.prec_bwd = hip.PREC_BACKWARD.get(self.prec, self.prec)      # (f32h3: backward on the bf16 2-plane split)
         # fp16 storage: the loss gradient is scaled by `loss_scale` (crimac_wce_bwd upstream) so that activation
         # gradients (1e-5 .. 1e-8 unscaled) sit in fp16's normal range; SGD divides it out again and skips the
         # step when a gradient overflowed (crimac_grad_overflow_flag / crimac_sgd_momentum_guarded)
-        self.loss_scale = 2.0 ** 16 if precision == "fp16" else 1.0
-        self.dynamic_loss_scale = precision == "fp16"
+        # (h3p: the output gradients dy are fp16 PLANE PAIRS -- same range, 11 more bits -- and travel scaled likewise)
+        self.loss_scale = 2.0 ** 16 if precision in ("fp16", "h3p") else 1.0
+        self.dynamic_loss_scale = precision in ("fp16", "h3p")
         self._scale_state = None            # int32[2] on the GPU: [overflow this step, steps skipped]
         self._skipped_seen = 0
         self._good_checks = 0
@@ -187,28 +192,31 @@ class UNetEngine:
         self.dw_plan = None       # (B, H, W) the partial-sum workspace of the weight gradients is laid out for
         self.dw_off = {}          # layer key -> (first float, slabs, floats per slab) in self.dw_packed
         self.dw_packed = None
+        # interleaved plane pairs (h3p): the `hi` buffer holds both planes, `lo` is a placeholder
+        il = self.is_hp
+        m_hi = 2 if il else 1
         for b in self.blocks:
             n_f = 9 * b.cout * b.cin_pad
             n_lo = max(self.planes - 1, 1)        # the lo buffer holds planes 1..planes-1
             has_dg = b.cin_pad == b.cin
             self.pk[b.conv_key] = {
-                "fwd_hi": torch.empty(n_f, dtype=i16, device=dev),
-                "fwd_lo": torch.empty(n_lo * n_f, dtype=i16, device=dev),
-                "dg_hi": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
-                "dg_lo": torch.empty(n_lo * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
+                "fwd_hi": torch.empty(m_hi * n_f, dtype=i16, device=dev),
+                "fwd_lo": torch.empty(8 if il else n_lo * n_f, dtype=i16, device=dev),
+                "dg_hi": torch.empty(m_hi * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
+                "dg_lo": torch.empty(8 if il else n_lo * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
             }
             self.pk_eval[b.conv_key] = {
-                "fwd_hi": torch.empty(n_f, dtype=i16, device=dev),
-                "fwd_lo": torch.empty(n_lo * n_f, dtype=i16, device=dev),
+                "fwd_hi": torch.empty(m_hi * n_f, dtype=i16, device=dev),
+                "fwd_lo": torch.empty(8 if il else n_lo * n_f, dtype=i16, device=dev),
                 "bias": torch.empty(b.cout, dtype=torch.float32, device=dev),
             }
         for u in self.ups:
             n = 4 * u.cin * u.cout
             n_lo = max(self.planes - 1, 1)
-            self.pk[u.key] = {"fwd_hi": torch.empty(n, dtype=i16, device=dev),
-                              "fwd_lo": torch.empty(n_lo * n, dtype=i16, device=dev),
-                              "dg_hi": torch.empty(n, dtype=i16, device=dev),
-                              "dg_lo": torch.empty(n_lo * n, dtype=i16, device=dev)}
+            self.pk[u.key] = {"fwd_hi": torch.empty(m_hi * n, dtype=i16, device=dev),
+                              "fwd_lo": torch.empty(8 if il else n_lo * n, dtype=i16, device=dev),
+                              "dg_hi": torch.empty(m_hi * n, dtype=i16, device=dev),
+                              "dg_lo": torch.empty(8 if il else n_lo * n, dtype=i16, device=dev)}
         cmax = self.sf * 2 ** (self.depth - 1)
         nb = len(self.blocks)
         # fp64 scratch: [0:2] loss sums, then per BN layer (2*R + 2) x cmax:
@@ -499,12 +507,14 @@ class UNetEngine:
     fuse_head_bn = fuse_bn_bwd and os.environ.get("CRIMAC_FUSE_HEADBN", "1") != "0"
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
-                 stats=None, bnb=None, cols=None):
+                 stats=None, bnb=None, cols=None, out_planes=False):
         """3x3 conv (forward planes, or dgrad planes).  ``stats=(sum, sumsq)``: fused statistics of
         the stored output (stat_mode 1).  ``bnb=(block, y)``: the output is the ``da`` of that
         BatchNorm block -> its backward sums are fused in (stat_mode 2, into the block's replica
-        accumulators).  Returns True if the requested fusion ran inside the conv kernel."""
+        accumulators).  ``out_planes`` (h3p): the output feeds another contraction -> stored as fp16 plane pairs
+        instead of fp32.  Returns True if the requested fusion ran inside the conv kernel."""
         flops = 2.0 * 9 * (cin_real or cin) * cout * B * H * W
+        relu = (hip.EPI_RELU if relu else 0) | (hip.EPI_OUT_PLANES if (out_planes and self.is_hp) else 0)
         w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
         prec = self.prec_bwd if dgrad else self.prec
         if self.conv_impl == "halo":
@@ -517,15 +527,17 @@ class UNetEngine:
                 by, by_ld, bvec = y.p, y.ld, ptr(self._bnf(blk, 0))
             if cols is not None:                      # a range of the output channels (crimac_conv3x3_cols)
                 call("crimac_conv3x3_cols", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
-                     out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
+                     out.p, out.ld, relu, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
                      cols[0], cols[1], flops=flops * cols[1] / cout)
                 return mode != 0
             call("crimac_conv3x3", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
-                 out.p, out.ld, 1 if relu else 0, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
+                 out.p, out.ld, relu, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
                  flops=flops)
             return mode != 0
+        if self.is_hp:
+            raise NotImplementedError("precision 'h3p' runs on the halo convolution kernels only (CRIMAC_CONV_IMPL=halo)")
         call("crimac_igemm_conv", prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1, w_hi, w_lo,
-             ptr(bias), cout, out.p, out.ld, 1 if relu else 0, 0, 0, flops=flops)
+             ptr(bias), cout, out.p, out.ld, relu, 0, 0, flops=flops)
         if stats:
             call("crimac_colstats", self.prec, out.p, out.ld, B * H * W, cout, ptr(stats[0]), ptr(stats[1]))
             return True
@@ -543,7 +555,7 @@ class UNetEngine:
         pk = self.pk[u.key]
         call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, u.cin, 4 * u.cout, 1, 1, 0, 1,
              ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(self.P[u.key + ".bias"]), u.cout, out.p, out.ld,
-             0, 1, u.cout, flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+             hip.EPI_OUT_PLANES if self.is_hp else 0, 1, u.cout, flops=2.0 * 4 * u.cin * u.cout * B * H * W)
 
     def _upconv_dgrad(self, dy: Act, u, out: Act, B, H, W, next_bn=None):
         """dy on the fine grid [B,2H,2W,cout] -> dx on the coarse grid [B,H,W,cin].
@@ -551,8 +563,9 @@ class UNetEngine:
         next_bn=(block, y): dx is the ``da`` of that BatchNorm block -> take its backward sums in the epilogue
         (bf16 kernel shapes only).  Returns whether they were taken."""
         pk = self.pk[u.key]
-        if (next_bn is not None and self.fuse_bn_bwd and self.fuse_up_bnb and self.is16
-                and u.cout % 64 == 0 and u.cin % 128 == 0 and 8 * B * H * W * dy.ld < (1 << 31)):
+        if (next_bn is not None and self.fuse_bn_bwd and self.fuse_up_bnb and self.lds_dma
+                and u.cout % (32 if self.is_hp else 64) == 0 and u.cin % 128 == 0
+                and (16 if self.is_hp else 8) * B * H * W * dy.ld < (1 << 31)):
             blk, y = next_bn
             call("crimac_upconv2x2_dgrad_bnb_prec", self.prec, dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]),
                  out.p, out.ld,
@@ -777,14 +790,16 @@ class UNetEngine:
                 saved[f"e{i}"] = (cur, y1, a1, y2, a2)
             else:
                 pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
-                self._conv3x3(cur, pe1, pe1["bias"], a1, B, h, w, b1.cin_pad, c, relu=True, cin_real=b1.cin)
+                self._conv3x3(cur, pe1, pe1["bias"], a1, B, h, w, b1.cin_pad, c, relu=True, cin_real=b1.cin,
+                              out_planes=True)
                 if pool is not None and self.fuse_eval_pool and self.conv_impl == "halo":
                     # the max-pool comes out of the conv epilogue (the tile is still in LDS)
                     call("crimac_conv3x3_pool", self.prec, a1.p, a1.ld, B, h, w, c, c, ptr(pe2["fwd_hi"]),
-                         ptr(pe2["fwd_lo"]), ptr(pe2["bias"]), a2.p, a2.ld, 1, pool.p, pool.ld,
+                         ptr(pe2["fwd_lo"]), ptr(pe2["bias"]), a2.p, a2.ld,
+                         hip.EPI_RELU | (hip.EPI_OUT_PLANES if self.is_hp else 0), pool.p, pool.ld,
                          flops=2.0 * 9 * c * c * B * h * w)
                 else:
-                    self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
+                    self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True, out_planes=True)
                     if pool is not None:
                         self._act(b2, a2, None, pool, B, h, w, train=False)
             cur = pool if pool is not None else a2
@@ -821,8 +836,8 @@ class UNetEngine:
                 saved[f"d{j}"] = (cur, catA, y1, a1, y2, a2)
             else:
                 pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
-                self._conv3x3(catA, pe1, pe1["bias"], a1, B, h, w, 2 * c, c, relu=True)
-                self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True)
+                self._conv3x3(catA, pe1, pe1["bias"], a1, B, h, w, 2 * c, c, relu=True, out_planes=True)
+                self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True, out_planes=True)
             cur = a2
         logits = out if out is not None else torch.empty((B, self.n_classes, H, W), dtype=torch.float32,
                                                          device=self.device)
@@ -897,7 +912,30 @@ class UNetEngine:
                 stats = (scr[:per // 2], scr[per // 2:])
             C_up = bias_from_stats[1] if bias_from_stats is not None else 0
             side = self._side[0] if (self._side is not None and len(self._side) == 1) else None
-            if (stats is not None and side is not None and self.split_skip_dgrad and not self._gloo_ranks()
+            side_ok = side is not None and self.split_skip_dgrad and not self._gloo_ranks()
+            if self.is_hp and bias_from_stats is not None:
+                # plane pairs: the up half of d(concat) feeds two contractions (transposed-conv input and weight
+                # gradients) -> plane pairs; the skip half is read by unpool_add -> fp32: always two launches
+                if stats is None or b.cin != 2 * C_up or C_up % 64 != 0:
+                    raise NotImplementedError("h3p: decoder convolution shape outside the plane-pair kernels")
+                self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                              dgrad=True, stats=stats, cols=(0, C_up), out_planes=True)
+                if side_ok:
+                    ev = self._side_events[self._side_i % len(self._side_events)]
+                    self._side_i += 1
+                    ev.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                                      dgrad=True, cols=(C_up, C_up))
+                        done = torch.cuda.Event()
+                        done.record()
+                    self._skip_done[bias_from_stats[2]] = done
+                else:
+                    self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                                  dgrad=True, cols=(C_up, C_up))
+                fused = True
+            elif (stats is not None and side_ok
                     and b.cin == 2 * C_up and b.cout % 64 == 0 and self.is16
                     and (C_up % 128 == 0 or (C_up == 64 and b.cout == 64 and B * ((h + 15) // 16) * ((w + 15) // 16) >= 512))):
                 # decoder conv1: dx_out = d(concat [up | skip]).  The up half (and its column sums = the transposed

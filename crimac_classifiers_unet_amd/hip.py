@@ -18,13 +18,19 @@ PREC_F32X3 = 1
 PREC_F32X6 = 2
 PREC_FP16 = 3
 PREC_F32H3 = 4
-PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16, "f32h3": PREC_F32H3}
-PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1, PREC_F32H3: 2}   # 16-bit planes per operand
+PREC_H3P = 5             # pre-split fp16 plane pairs (CRIMAC_PREC_H3P): F32H3's arithmetic on the LDS-DMA kernels
+PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16, "f32h3": PREC_F32H3,
+              "h3p": PREC_H3P}
+PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1, PREC_F32H3: 2, PREC_H3P: 2}   # 16-bit planes per operand
 # `planes` argument of the packing entry points (CRIMAC_PLANES_* of the header): bits 0-3 planes, bit 4 / 5 forward /
 # input-gradient planes in IEEE half, bits 8-15 log2 of the scale on the forward planes
 PLANES_FP16 = 1 | 16 | 32
 PLANES_F32H3 = 2 | 16 | (8 << 8)
-PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: PLANES_FP16, PREC_F32H3: PLANES_F32H3}
+PLANES_INTERLEAVED = 64      # both planes in the `hi` buffer, [32 hi | 32 lo] per 32-channel block of a row
+PLANES_H3P = 2 | 16 | 32 | PLANES_INTERLEAVED | 128 | (8 << 8)        # CRIMAC_PLANES_H3P
+PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: PLANES_FP16, PREC_F32H3: PLANES_F32H3,
+                   PREC_H3P: PLANES_H3P}
+EPI_RELU, EPI_OUT_PLANES = 1, 2      # `relu` argument of the convolution entry points (CRIMAC_EPI_*)
 # precision the BACKWARD kernels (input gradients, weight gradients) are called with: F32H3 is a forward-operand
 # mode (fp16 planes have no range for gradients), its backward pass runs on the 2-plane bf16 split
 PREC_BACKWARD = {PREC_F32H3: PREC_F32X3}
