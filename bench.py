@@ -38,9 +38,12 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_PATCH = 96.43      # SURVEY.md §8(a) a10, hook-counted on the reference module (start_filts 64)
 TRAIN_GFLOP_PER_PATCH = 288.98
 # dense 16-bit MFMA peak / MFMAs per product of the mode
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32x3": 2500.0 / 3.0, "f32h3": 2500.0 / 3.0, "f32x6": 2500.0 / 6.0}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32x3": 2500.0 / 3.0, "f32h3": 2500.0 / 3.0, "h3p": 2500.0 / 3.0,
+                    "f32x6": 2500.0 / 6.0}
 DTYPE_LABEL = {"bf16": "bf16", "fp16": "fp16", "f32x3": "fp32 storage, 3x bf16 MFMA per product",
                "f32h3": "fp32 storage, 3x MFMA per product (fp16 planes forward ~2^-21, bf16 planes backward)",
+               "h3p": "fp16 plane pairs (hi + lo, 22 significant bits) split once by the producer, 3x fp16 MFMA per product "
+                      "(~2^-21), fp32 accumulate; conv outputs / activation gradients fp32; loss-scaled backward",
                "f32x6": "fp32 storage, 6x bf16 MFMA per product (fp32-equivalent)"}
 CONV_KERNELS = ("crimac_conv3x3: conv3x3_wch_kernel + conv3x3_p64_kernel + conv3x3_glds_w4_kernel + "
                 "conv3x3_c16_kernel (halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)")

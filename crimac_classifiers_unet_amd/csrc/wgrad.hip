@@ -105,8 +105,8 @@ __device__ __forceinline__ void wg_rd_a(unsigned fv0, WgFrags& f) {
 // S fragments of step S (row pair S / N, local tap S % N).  swz16(c + 4 + R) = swz16(c + R) ^ 32: the bases of
 // the classes c & 7 >= 4 are those of c & 3 with the two 16-channel slots exchanged -> 4 registers, not 8.
 // NARROW: only the first 16-channel S fragment of the wave is real (first layer: 4 input channels padded to 16)
-template <int MODE, int TG, int S, bool NARROW>
-__device__ __forceinline__ void wg_rd_b(const unsigned (&sv)[4], WgFrags& f) {
+template <int MODE, int TG, int S, bool NARROW, typename FR>
+__device__ __forceinline__ void wg_rd_b(const unsigned (&sv)[4], FR& f) {
   using G = WgTaps<MODE, TG>;
   constexpr int c = G::srow(2 * (S / G::N), G::T0 + S % G::N);
   constexpr int x = (c >> 2) & 1;
@@ -160,6 +160,220 @@ __device__ __forceinline__ void wg_step(unsigned fv0, const unsigned (&sv)[4], W
   if constexpr (S + 1 < NSTEP) wg_rd_b<MODE, TG, S + 1, NARROW>(sv, f);
   wg_fh<T16, MODE, TG, S, 0, NARROW>(fv0, f, acc);
   if constexpr (S + 1 < NSTEP) wg_step<T16, MODE, TG, S + 1, NARROW>(fv0, sv, f, acc);
+}
+
+// ---- plane pairs (CRIMAC_PREC_H3P), conv3x3: 64 x 64 REAL channels per workgroup of 8 waves ------------------------
+// Both operands are fp16 plane pairs (common.h hp_t): dW = Fh^T Sh + Fh^T Sl + Fl^T Sh, 3 MFMAs per fragment pair.
+// A tile of 64 real channels is 256 bytes per pixel; it is staged as TWO images per operand (real channels 0-31 and
+// 32-63), each with exactly the 16-bit kernel's shape -- 128-byte rows of four 32-byte slots -- so the transposing reads,
+// their swizzle and the hand-placed read / MFMA cadence above carry over.  The slots of an image row are
+// [ch 0-15 hi | ch 0-15 lo | ch 16-31 hi | ch 16-31 lo]: the permutation from the [8 hi | 8 lo] groups in memory rides on
+// the per-lane DMA source offset (as the swizzle does).
+// Why 64 x 64 and not the 16-bit tile shape reinterpreted (32 x 32 real channels): per loaded byte that form does 3/4 of
+// the 16-bit kernel's MFMAs -- and the 16-bit kernel is already limited by its LDS-DMA issue -- this one 3/2.
+// Wave roles (8 waves, one workgroup per CU, double-buffered tiles, one barrier per tile): S image sa x 16-channel S
+// slot pair ws x tap group tg; every wave covers all 64 F channels = 8 plane fragments (image, 16 channels, plane).
+// Per tap step: 4 S reads (hi, lo fragments), 12 MFMAs (hi*lo, hi*hi on the hi F fragments, lo*hi on the lo ones).
+constexpr int PP_F_IMG = 128 * 128;                 // one F image: 8 x 16 pixel rows of 128 bytes
+constexpr int PP_S_IMG = 184 * 128;                 // one S image: (8 + 2) x 18 = 180 halo rows, padded to 184
+constexpr int PP_BUF = 2 * PP_F_IMG + 2 * PP_S_IMG;   // 79,872 bytes per tile buffer
+
+struct PpFrags {
+  bf16x4 a[8][2];         // [F plane fragment: image * 4 + slot][read]
+  bf16x4 b[2][2][2];      // [step parity][S fragment: hi, lo][read]
+};
+template <int RP, int FH>
+__device__ __forceinline__ void pp_rd_a(unsigned fv0, PpFrags& f) {
+  f.a[FH][0] = lds_tr16_asm<(RP * 32) * 128 + (FH >> 2) * PP_F_IMG>(fv0 ^ ((FH & 3) << 5));
+  f.a[FH][1] = lds_tr16_asm<(RP * 32 + 8) * 128 + (FH >> 2) * PP_F_IMG>(fv0 ^ ((FH & 3) << 5));
+}
+// F plane fragment FH of step S (the 16-bit kernel's wg_fh with 8 fragments; even FH = hi plane: two MFMAs, with the lo
+// and the hi S fragment; odd FH = lo plane: one, with the hi S fragment)
+template <int TG, int S, int FH, typename ACC>
+__device__ __forceinline__ void pp_fh(unsigned fv0, PpFrags& f, ACC& acc) {
+  using G = WgTaps<0, TG>;
+  constexpr int NSTEP = G::NRP * G::N, rp = S / G::N, L = S % G::N;
+  constexpr int nb = S + 1 < NSTEP ? 4 : 0;          // S reads of the next step, issued at the top of this one
+  if constexpr (L == 0) {
+    // (lgkmcnt is a 4-bit counter: where more than 15 reads would be allowed to stay in flight, waiting for 15 is the
+    // conservative form -- it only asks for a few reads more than needed to have landed)
+    constexpr int allow = nb + (rp > 0 ? 2 * (7 - FH) : 0);
+    if constexpr (rp > 0 || FH == 0) wait_lgkm<(allow < 15 ? allow : 15)>();
+    if constexpr (FH == 0) {
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
+    }
+    if constexpr (rp > 0) { tie(f.a[FH][0]); tie(f.a[FH][1]); }
+    else if constexpr (FH == 0) {
+#pragma unroll
+      for (int fh = 0; fh < 8; ++fh) { tie(f.a[fh][0]); tie(f.a[fh][1]); }
+    }
+  } else if constexpr (FH == 0) {
+    wait_lgkm<nb>();
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) { tie(f.b[S & 1][sh][0]); tie(f.b[S & 1][sh][1]); }
+  }
+  const bf16x8 af = __builtin_shufflevector(f.a[FH][0], f.a[FH][1], 0, 1, 2, 3, 4, 5, 6, 7);
+  const bf16x8 b_hi = __builtin_shufflevector(f.b[S & 1][0][0], f.b[S & 1][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+  if constexpr ((FH & 1) == 0) {
+    const bf16x8 b_lo = __builtin_shufflevector(f.b[S & 1][1][0], f.b[S & 1][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[L][FH >> 1] = E16<half_t>::mfma16(af, b_lo, acc[L][FH >> 1]);
+  }
+  acc[L][FH >> 1] = E16<half_t>::mfma16(af, b_hi, acc[L][FH >> 1]);
+  if constexpr (L == G::N - 1 && rp + 1 < G::NRP) pp_rd_a<rp + 1, FH>(fv0, f);
+  if constexpr (FH + 1 < 8) pp_fh<TG, S, FH + 1>(fv0, f, acc);
+}
+template <int TG, int S, typename ACC>
+__device__ __forceinline__ void pp_step(unsigned fv0, const unsigned (&sv)[4], PpFrags& f, ACC& acc) {
+  using G = WgTaps<0, TG>;
+  constexpr int NSTEP = G::NRP * G::N;
+  if constexpr (S + 1 < NSTEP) wg_rd_b<0, TG, S + 1, false>(sv, f);
+  pp_fh<TG, S, 0>(fv0, f, acc);
+  if constexpr (S + 1 < NSTEP) pp_step<TG, S + 1>(fv0, sv, f, acc);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wgrad_pp_kernel(WgradParams p) {
+  constexpr int TR = 8;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NI = (2 * 16 + 2 * 23 + 7) / 8;        // DMA wave-instructions per wave and tile: 78 / 8 -> 10
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ws = wave & 1, sa = (wave >> 1) & 1, tg = wave >> 2;
+  // workgroup -> (64 x 64 channel tile, pixel split): as the 16-bit kernel (XCD-aware: equal id % 8 share an L2)
+  const int cs_tiles = p.CS / 64;
+  const int ch_tiles = (p.CF / 64) * cs_tiles;
+  int qt, split;
+  if (p.nsplits % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    qt = j % ch_tiles;
+    split = xcd + 8 * (j / ch_tiles);
+  } else if (ch_tiles % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, R = ch_tiles >> 3;
+    qt = xcd * R + j % R;
+    split = j / R;
+  } else {
+    qt = blockIdx.x % ch_tiles;
+    split = blockIdx.x / ch_tiles;
+  }
+  const int cf0 = (qt / cs_tiles) * 64, cs0 = (qt % cs_tiles) * 64;
+  const hp_t* fp = reinterpret_cast<const hp_t*>(p.f);
+  const hp_t* sp = reinterpret_cast<const hp_t*>(p.s);
+
+  // ---- DMA plan: wave-instruction k = wave + 8 i moves 8 pixel rows (1 KiB) of one image ------------------------
+  // k in [0,16): F image 0 | [16,32): F image 1 | [32,55): S image 0 | [55,78): S image 1
+  const int sub = lane >> 3, c = lane & 7;
+  unsigned rel[NI];          // byte offset from the tile origin pixel (S: the halo's first pixel); OOB = no lane data
+  int lds_at[NI];            // byte offset of the instruction's 1 KiB inside a tile buffer; -1: no such instruction
+  auto geo = [&](int k, bool& is_s, int& img, int& row) {
+    is_s = k >= 32;
+    const int kk = is_s ? k - 32 : k;
+    img = is_s ? (kk >= 23 ? 1 : 0) : (kk >> 4);
+    row = 8 * (is_s ? kk - 23 * img : (kk & 15)) + sub;
+  };
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = wave + 8 * i;
+    bool is_s; int img, row;
+    geo(k, is_s, img, row);
+    const int u = c ^ (swz16(row) >> 4);                       // logical 16-byte unit this lane's LDS position holds
+    const int su = (((u >> 2) * 2 + (u & 1)) << 1) | ((u >> 1) & 1);   // its source unit: group (2 fh + half), plane
+    lds_at[i] = k < 78 ? (is_s ? 2 * PP_F_IMG + img * PP_S_IMG + (row - sub) * 128 : img * PP_F_IMG + (row - sub) * 128) : -1;
+    if (!is_s) {
+      const int ry = row >> 4, rx = row & 15;
+      rel[i] = (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + 32 * img) * 4 + su * 16);
+    } else {
+      const int ry = (row * 3641) >> 16, rx = row - ry * 18;
+      rel[i] = row < 180 ? (unsigned)(((ry * (long)p.Wf + rx) * p.s_ld + cs0 + 32 * img) * 4 + su * 16) : OOB;
+    }
+  }
+  auto tile_origin = [&](long tile, long& b, int& y0, int& x0) {
+    const int txi = (int)(tile % p.tiles_x);
+    const long tt = tile / p.tiles_x;
+    const int tyi = (int)(tt % p.tiles_y);
+    b = tt / p.tiles_y;
+    y0 = tyi * TR;
+    x0 = txi * 16;
+  };
+  auto issue_tile = [&](long tile, int buf) {
+    long b; int y0, x0;
+    tile_origin(tile, b, y0, x0);
+    unsigned char* base = smem + buf * PP_BUF;
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<hp_t*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<hp_t*>(sp + ((b * p.Hf + y0 - 1) * (long)p.Wf + x0 - 1) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = wave + 8 * i;
+      if (k >= 78) continue;                         // wave-uniform
+      bool is_s; int img, row;
+      geo(k, is_s, img, row);
+      if (!is_s) {
+        const bool ok = (y0 + (row >> 4)) < p.Hf && (x0 + (row & 15)) < p.Wf;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + lds_at[i]), 16,
+                                                 (int)(ok ? rel[i] : OOB), 0, 0, 0);
+      } else {
+        const int ry = (row * 3641) >> 16, rx = row - ry * 18;
+        const unsigned y = (unsigned)(y0 - 1 + ry), x = (unsigned)(x0 - 1 + rx);
+        const bool ok = y < (unsigned)p.Hf && x < (unsigned)p.Wf;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(base + lds_at[i]), 16,
+                                                 (int)(ok ? rel[i] : OOB), 0, 0, 0);
+      }
+    }
+  };
+
+  const long t_begin = (long)split * p.tiles_per_block;
+  const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
+  // lane roles of the transposing reads (as in the 16-bit kernel)
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  auto run = [&](auto tgc) {
+    constexpr int TG = decltype(tgc)::value;
+    using G = WgTaps<0, TG>;
+    f32x4 acc[G::N][4];
+#pragma unroll
+    for (int t = 0; t < G::N; ++t)
+#pragma unroll
+      for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][fr][r] = 0.f;
+    const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
+    const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
+    const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
+    if (t_begin < t_end) issue_tile(t_begin, 0);
+    for (long tile = t_begin; tile < t_end; ++tile) {
+      const int cur = (int)((tile - t_begin) & 1);
+      __syncthreads();           // vmcnt(0) + barrier: the tile has landed for everyone, the other buffer is free
+      if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+      const unsigned aF = lds0 + cur * PP_BUF, aS = aF + 2 * PP_F_IMG + sa * PP_S_IMG;
+      const unsigned fv0 = aF + RF * 128 + 8 * pp + swz16(RF);
+      unsigned sv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv[k] = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(k + RSl));
+      PpFrags f;
+      pp_rd_a<0, 0>(fv0, f); pp_rd_a<0, 1>(fv0, f); pp_rd_a<0, 2>(fv0, f); pp_rd_a<0, 3>(fv0, f);
+      pp_rd_a<0, 4>(fv0, f); pp_rd_a<0, 5>(fv0, f); pp_rd_a<0, 6>(fv0, f); pp_rd_a<0, 7>(fv0, f);
+      wg_rd_b<0, TG, 0, false>(sv, f);
+      pp_step<TG, 0>(fv0, sv, f, acc);
+    }
+    // dw[t][cf][cs] += acc: F rows cf0 + 16 fr .. +15, S columns cs0 + 32 sa + 16 ws .. +15, this wave's taps
+    float* dwp = p.dw + (p.partial_stride > 0 ? (long)split * p.partial_stride : 0);
+    const int col = cs0 + sa * 32 + ws * 16 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < G::N; ++t)
+#pragma unroll
+      for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = cf0 + fr * 16 + (lane >> 4) * 4 + r;
+          float* dst = dwp + ((long)(G::T0 + t) * p.CF + row) * p.CS + col;
+          if (p.partial_stride > 0) *dst = acc[t][fr][r];
+          else atomicAdd(dst, acc[t][fr][r]);
+        }
+  };
+  if (tg == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
 }
 
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
@@ -726,7 +940,27 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
   return CRIMAC_OK;
 }
 
+int launch_pp(WgradParams p, int target_blocks, hipStream_t st) {
+  plan_splits(p, 0, target_blocks, 2);           // (one 8-wave workgroup per CU, like the two-team kernel)
+  const int ch_tiles = (p.CF / 64) * (p.CS / 64);
+  const size_t lds = 2 * (size_t)PP_BUF;
+  static unsigned long long attr_devs = 0;
+  if (crimac_first_use_on_device(&attr_devs)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  }
+  hipLaunchKernelGGL(wgrad_pp_kernel, dim3(ch_tiles * p.nsplits), dim3(512), lds, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
 // 16-bit storage, conv3x3: the two-team kernel (CRIMAC_WGRAD_TEAMS=1 selects the 4-wave kernel for A/B runs)
+// plane pairs, conv3x3, whole 64-channel tiles both ways, 32-bit DMA offsets inside a tile: the 8-wave kernel above
+bool pp_ok(int prec, int mode, int CF, int CS, long f_ld, long s_ld, int Wf) {
+  static const int off = getenv("CRIMAC_WGRAD_PP") ? atoi(getenv("CRIMAC_WGRAD_PP")) == 0 : 0;
+  return !off && prec == CRIMAC_PREC_H3P && mode == 0 && CF % 64 == 0 && CS % 64 == 0 &&
+         (10L * Wf + 18) * (f_ld > s_ld ? f_ld : s_ld) * 4 < (1L << 31);
+}
 int teams_of(int prec, int mode) {
   static const int forced = getenv("CRIMAC_WGRAD_TEAMS") ? atoi(getenv("CRIMAC_WGRAD_TEAMS")) : 0;
   if (forced == 1) return 1;
@@ -764,8 +998,10 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
   }
   if (prec == CRIMAC_PREC_F32X3)
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
-  if (prec == CRIMAC_PREC_H3P)      // both operands are fp16 plane pairs (activation x loss-scaled output gradient)
+  if (prec == CRIMAC_PREC_H3P) {    // both operands are fp16 plane pairs (activation x loss-scaled output gradient)
+    if (pp_ok(prec, mode, CF, CS, f_ld, s_ld, Wf)) return launch_pp(p, target_blocks, st);
     return mode == 0 ? launch<hp_t, 2, 0>(p, target_blocks, st) : launch<hp_t, 2, 1>(p, target_blocks, st);
+  }
   return mode == 0 ? launch<float, 3, 0>(p, target_blocks, st) : launch<float, 3, 1>(p, target_blocks, st);
 }
 
@@ -783,7 +1019,7 @@ extern "C" int crimac_wgrad_splits(int prec, int mode, int CF, int CS, int B, in
     return CRIMAC_ERR_INVALID;
   WgradParams p;
   p.CF = CF; p.CS = CS; p.B = B; p.Hf = Hf; p.Wf = Wf;
-  plan_splits(p, mode, target_blocks, teams_of(prec, mode));
+  plan_splits(p, mode, target_blocks, pp_ok(prec, mode, CF, CS, CF, CS, Wf) ? 2 : teams_of(prec, mode));
   return p.nsplits;
 }
 

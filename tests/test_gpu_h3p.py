@@ -1,0 +1,455 @@
+"""GPU parity tests of precision 'h3p' (CRIMAC_PREC_H3P: fp16 plane pairs split once by the producer, 3 MFMAs per
+product), one kernel at a time through the C ABI, against the torch CPU fp32 op the reference dispatches for the same
+step -- then the whole network against the reference golden.
+
+A plane-pair tensor has fp32 addressing; every aligned group of 8 channels holds [8 x fp16 hi][8 x fp16 lo],
+value = hi + lo (22 significant bits).  Inputs are pre-rounded to that format on the host, so what a kernel adds is
+the dropped lo*lo products (~2^-22) and fp32 accumulation order: tolerance 5e-6 of max|ref| for one contraction.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import crimac_classifiers_unet_amd as pkg
+from crimac_classifiers_unet_amd import hip, synth
+from crimac_classifiers_unet_amd.hip import call, ptr
+
+pytestmark = pytest.mark.gpu
+
+P = hip.PREC_H3P
+TOL = 5e-6
+WS = 2.0 ** 8                       # weight planes are pre-scaled by 2^CRIMAC_F32H3_WSHIFT, undone in the epilogues
+
+
+def hp_round(x):
+    """fp32 -> the value a plane pair holds for it (hi + lo, both fp16)."""
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return hi.float() + lo.float()
+
+
+def hp_pack(m):
+    """[M, C] fp32 (cpu) -> [M, C] 'float32' tensor whose bytes are the plane pairs of m."""
+    M, C = m.shape
+    assert C % 8 == 0
+    hi = m.half()
+    lo = (m - hi.float()).half()
+    both = torch.stack([hi.view(M, C // 8, 8), lo.view(M, C // 8, 8)], dim=2)      # [M, C/8, 2, 8] halves
+    return both.contiguous().view(torch.float32).view(M, C).clone()
+
+
+def hp_unpack(t):
+    """inverse of hp_pack: [M, C] plane-pair bytes (any device) -> fp32 values (cpu)."""
+    M, C = t.shape
+    h = t.contiguous().cpu().view(torch.float16).view(M, C // 8, 2, 8).float()
+    return (h[:, :, 0] + h[:, :, 1]).reshape(M, C)
+
+
+def to_nhwc_hp(x, ld=None, off=0):
+    """[B,C,H,W] fp32 (cpu) -> device [B*H*W, ld] buffer with the plane pairs of x in channels [off, off + C)."""
+    B, C, H, W = x.shape
+    ld = ld or C
+    full = torch.zeros(B * H * W, ld, dtype=torch.float32)
+    full[:, off:off + C] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    return hp_pack(full).cuda()                   # (zeros pack to zeros: the padding channels stay 0)
+
+
+def from_nhwc(t, B, H, W):
+    return t.float().cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def from_nhwc_hp(t, B, H, W):
+    return hp_unpack(t).reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def w_round(w):
+    """What the packed fp16 weight planes represent: hp_round(w * 2^8) / 2^8."""
+    return hp_round(w * WS) / WS
+
+
+def pack_conv(w, cin_pad=None, scale=None, dgrad=True):
+    Co, Ci = w.shape[:2]
+    cin_pad = cin_pad or Ci
+    wd = w.float().cuda().contiguous()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl = torch.empty(2 * 9 * Co * cin_pad, **i16), torch.empty(8, **i16)
+    dh = torch.empty(2 * 9 * Ci * Co, **i16) if dgrad and cin_pad == Ci else None
+    dl = torch.empty(8, **i16) if dh is not None else None
+    sc = scale.float().cuda() if scale is not None else None
+    call("crimac_pack_conv3x3", ptr(wd), Co, Ci, cin_pad, ptr(sc), hip.PLANES_H3P, ptr(fh), ptr(fl), ptr(dh), ptr(dl))
+    torch.cuda.synchronize()
+    return fh, fl, dh, dl
+
+
+def conv(x_hp, ld, B, H, W, Cin, Cout, w, wl, bias, relu=0, out_planes=False, stats=None, bnb=None, cols=None, out=None,
+         out_ld=None, out_off=0, pool=None):
+    out_ld = out_ld or Cout
+    if out is None:
+        out = torch.full((B * H * W, out_ld), 7.0, dtype=torch.float32, device="cuda")
+    flags = (hip.EPI_RELU if relu else 0) | (hip.EPI_OUT_PLANES if out_planes else 0)
+    mode, s0, s1, by, by_ld, bvec, bstride = 0, None, None, None, 0, None, 0
+    if stats is not None:
+        mode, s0, s1 = 1, ptr(stats[0]), ptr(stats[1])
+    if bnb is not None:
+        mode = 2
+        y, vec, s0t, s1t = bnb
+        s0, s1, by, by_ld, bvec, bstride = ptr(s0t), ptr(s1t), ptr(y), y.shape[1], ptr(vec), vec.shape[1]
+    if pool is not None:
+        call("crimac_conv3x3_pool", P, ptr(x_hp), ld, B, H, W, Cin, Cout, ptr(w), ptr(wl), ptr(bias), ptr(out, out_off), out_ld,
+             flags, ptr(pool), pool.shape[1])
+    elif cols is not None:
+        call("crimac_conv3x3_cols", P, ptr(x_hp), ld, B, H, W, Cin, Cout, ptr(w), ptr(wl), ptr(bias), ptr(out, out_off), out_ld,
+             flags, mode, s0, s1, 4, by, by_ld, bvec, bstride, cols[0], cols[1])
+    else:
+        call("crimac_conv3x3", P, ptr(x_hp), ld, B, H, W, Cin, Cout, ptr(w), ptr(wl), ptr(bias), ptr(out, out_off), out_ld,
+             flags, mode, s0, s1, 4, by, by_ld, bvec, bstride)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_layout_conversion_writes_plane_pairs():
+    B, C, H, W = 2, 4, 8, 16
+    x = torch.randn(B, C, H, W) * 30
+    out = torch.empty(B * H * W, 16, dtype=torch.float32, device="cuda")
+    xd = x.cuda()
+    call("crimac_nchw_to_nhwc", P, ptr(xd), ptr(out), B, C, H, W, 16)
+    torch.cuda.synchronize()
+    ref = torch.zeros(B * H * W, 16)
+    ref[:, :C] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    assert torch.equal(out.cpu().view(torch.int32), hp_pack(ref).view(torch.int32))          # bit for bit
+    assert relerr(hp_unpack(out), ref) < 2.0 ** -21
+
+
+# (B, H, W, Cin, Cout): channel-split kernel (Cout % 128 == 0), pixel-split kernel (Cout = 64), first layer (Cin = 4 -> 16),
+# partial tiles, many workgroups
+CONV_SHAPES = [(2, 16, 16, 64, 128), (1, 16, 32, 128, 128), (3, 8, 8, 256, 64), (2, 16, 16, 4, 64), (1, 24, 40, 64, 192),
+               (2, 21, 37, 32, 64), (1, 19, 23, 96, 256), (4, 64, 64, 128, 256), (8, 64, 64, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_forward_fp32_and_plane_pair_outputs(shape):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(1)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g) * 3)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    cin_pad = 16 if Ci < 16 else Ci
+    fh, fl, _, _ = pack_conv(w, cin_pad, dgrad=False)
+    ref = F.conv2d(x.double(), w_round(w).double(), b.double(), padding=1).float()
+    xin = to_nhwc_hp(x, ld=cin_pad)
+    bd = b.cuda()
+    out = conv(xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, bd)
+    assert relerr(from_nhwc(out, B, H, W), ref) < TOL
+    # ReLU + plane-pair output (what the next convolution of an inference pass reads)
+    out = conv(xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, bd, relu=1, out_planes=True)
+    got = from_nhwc_hp(out, B, H, W)
+    assert relerr(got, torch.relu(ref)) < TOL
+    # fused BatchNorm statistics of the fp32 output
+    st = [torch.zeros(4 * Co, dtype=torch.float64, device="cuda") for _ in range(2)]
+    out = conv(xin, cin_pad, B, H, W, cin_pad, Co, fh, fl, bd, stats=st)
+    y = from_nhwc(out, B, H, W).double()
+    s1, s2 = st[0].view(4, Co).sum(0).cpu(), st[1].view(4, Co).sum(0).cpu()
+    assert relerr(s1, y.sum((0, 2, 3))) < 1e-5 and relerr(s2, (y * y).sum((0, 2, 3))) < 1e-5
+
+
+def test_conv3x3_strided_io_and_channel_ranges():
+    """Input and output in channel slices of wider buffers (the concat buffers), and crimac_conv3x3_cols: the two halves
+    of a decoder input gradient, the first as plane pairs with column sums, the second as fp32 -- in ONE buffer."""
+    B, H, W, Ci, Co = 2, 32, 32, 64, 256
+    g = torch.Generator().manual_seed(2)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 24
+    fh, fl, _, _ = pack_conv(w, dgrad=False)
+    ref = F.conv2d(x.double(), w_round(w).double(), None, padding=1).float()
+    big_in = to_nhwc_hp(x, ld=2 * Ci, off=Ci)
+    out = torch.full((B * H * W, Co + 64), 7.0, dtype=torch.float32, device="cuda")
+    st = [torch.zeros(4 * Co, dtype=torch.float64, device="cuda") for _ in range(2)]
+    xs = big_in[:, Ci:]
+    call("crimac_conv3x3_cols", P, ptr(big_in, Ci), 2 * Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), None, ptr(out, 32), Co + 64,
+         hip.EPI_OUT_PLANES, 1, ptr(st[0]), ptr(st[1]), 4, None, 0, None, 0, 0, 128)
+    call("crimac_conv3x3_cols", P, ptr(big_in, Ci), 2 * Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), None, ptr(out, 32), Co + 64,
+         0, 0, None, None, 4, None, 0, None, 0, 128, 128)
+    torch.cuda.synchronize()
+    del xs
+    first = from_nhwc_hp(out[:, 32:32 + 128].contiguous(), B, H, W)
+    second = from_nhwc(out[:, 32 + 128:32 + 256].contiguous(), B, H, W)
+    assert relerr(first, ref[:, :128]) < TOL and relerr(second, ref[:, 128:]) < TOL
+    assert float((out[:, :32] - 7).abs().max()) == 0 and float((out[:, 32 + 256:] - 7).abs().max()) == 0
+    s1 = st[0].view(4, Co).sum(0).cpu()
+    assert relerr(s1[:128], first.double().sum((0, 2, 3))) < 1e-5 and float(s1[128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 32, 32, 128, 64), (2, 32, 32, 64, 64)])
+def test_conv3x3_dgrad_with_fused_bn_backward_sums(shape):
+    """Input gradient (dgrad planes, fp32 output `da`) with the BatchNorm-backward sums of the block it feeds."""
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    dy = hp_round(torch.randn(B, Co, H, W, generator=g) * 50)
+    _, _, dh, dl = pack_conv(w)
+    ref = torch.nn.grad.conv2d_input((B, Ci, H, W), w_round(w).double(), dy.double(), padding=1).float()
+    dyn = to_nhwc_hp(dy)
+    y = torch.randn(B * H * W, Ci, generator=g)
+    vec = torch.stack([torch.randn(Ci, generator=g) * 0.1, torch.rand(Ci, generator=g) + 0.5,
+                       torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3])      # mean, invstd, scale, shift
+    yd, vd = y.cuda(), vec.cuda().contiguous()
+    st = [torch.zeros(4 * Ci, dtype=torch.float64, device="cuda") for _ in range(2)]
+    out = conv(dyn, Co, B, H, W, Co, Ci, dh, dl, None, bnb=(yd, vd, st[0], st[1]))
+    da = from_nhwc(out, B, H, W)
+    assert relerr(da, ref) < TOL
+    dam = out.cpu().double()
+    mask = (y.double() * vec[2].double() + vec[3].double()) > 0
+    dz = torch.where(mask, dam, torch.zeros_like(dam))
+    xh = (y.double() - vec[0].double()) * vec[1].double()
+    assert relerr(st[0].view(4, Ci).sum(0).cpu(), dz.sum(0)) < 1e-5
+    assert relerr(st[1].view(4, Ci).sum(0).cpu(), (dz * xh).sum(0)) < 1e-5
+
+
+def test_conv3x3_with_fused_maxpool_plane_pairs():
+    B, H, W, C = 2, 32, 32, 128
+    g = torch.Generator().manual_seed(4)
+    x = hp_round(torch.randn(B, C, H, W, generator=g))
+    w = torch.randn(C, C, 3, 3, generator=g) / 34
+    b = torch.randn(C, generator=g) * 0.1
+    fh, fl, _, _ = pack_conv(w, dgrad=False)
+    ref = torch.relu(F.conv2d(x.double(), w_round(w).double(), b.double(), padding=1)).float()
+    xin, bd = to_nhwc_hp(x), b.cuda()
+    pool = torch.empty(B * H * W // 4, C, dtype=torch.float32, device="cuda")
+    out = conv(xin, C, B, H, W, C, C, fh, fl, bd, relu=1, out_planes=True, pool=pool)
+    a = from_nhwc_hp(out, B, H, W)
+    assert relerr(a, ref) < TOL
+    assert torch.equal(from_nhwc_hp(pool, B, H // 2, W // 2), F.max_pool2d(a, 2))     # pool of the values as stored, exactly
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 4, 8, 256, 128), (2, 24, 40, 128, 64), (2, 64, 64, 256, 128)])
+def test_upconv2x2_forward_dgrad_wgrad(shape):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(5)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g))
+    w = torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5
+    b = torch.randn(Co, generator=g)
+    i16 = dict(dtype=torch.int16, device="cuda")
+    n = 4 * Ci * Co
+    fh, dh = torch.empty(2 * n, **i16), torch.empty(2 * n, **i16)
+    fl, dl = torch.empty(8, **i16), torch.empty(8, **i16)
+    wd, bd, xn = w.cuda(), b.cuda(), to_nhwc_hp(x)
+    call("crimac_pack_upconv2x2", ptr(wd), Ci, Co, hip.PLANES_H3P, ptr(fh), ptr(fl), ptr(dh), ptr(dl))
+    wr = w_round(w)
+    ref = F.conv_transpose2d(x.double(), wr.double(), b.double(), stride=2).float()
+    cat = torch.zeros(B * 4 * H * W, 2 * Co, dtype=torch.float32, device="cuda")
+    call("crimac_igemm_conv", P, ptr(xn), Ci, B, H, W, H, W, Ci, 4 * Co, 1, 1, 0, 1, ptr(fh), ptr(fl), ptr(bd), Co,
+         ptr(cat), 2 * Co, hip.EPI_OUT_PLANES, 1, Co)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc_hp(cat[:, :Co].contiguous(), B, 2 * H, 2 * W), ref) < TOL
+    assert float(cat[:, Co:].abs().max()) == 0
+    # input gradient (fp32) with the fused BatchNorm-backward sums, and the plain form
+    dy = hp_round(torch.randn(B, Co, 2 * H, 2 * W, generator=g) * 20)
+    xg = x.double().clone().requires_grad_(True)
+    wg = wr.double().clone().requires_grad_(True)
+    F.conv_transpose2d(xg, wg, None, stride=2).backward(dy.double())
+    dyn = to_nhwc_hp(dy)
+    dx = torch.empty(B * H * W, Ci, dtype=torch.float32, device="cuda")
+    call("crimac_igemm_conv", P, ptr(dyn), Co, B, 2 * H, 2 * W, H, W, Co, Ci, 4, 2, 0, 2, ptr(dh), ptr(dl), None, 0,
+         ptr(dx), Ci, 0, 0, 0)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(dx, B, H, W), xg.grad.float()) < TOL
+    y = torch.randn(B * H * W, Ci, generator=g)
+    vec = torch.stack([torch.randn(Ci, generator=g) * 0.1, torch.rand(Ci, generator=g) + 0.5,
+                       torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3])
+    yd, vd = y.cuda(), vec.cuda().contiguous()
+    st = [torch.zeros(4 * Ci, dtype=torch.float64, device="cuda") for _ in range(2)]
+    dx2 = torch.empty_like(dx)
+    call("crimac_upconv2x2_dgrad_bnb_prec", P, ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dx2), Ci, ptr(yd), Ci, ptr(vd), Ci,
+         ptr(st[0]), ptr(st[1]), 4)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    dam = dx.cpu().double()
+    dz = torch.where((y.double() * vec[2].double() + vec[3].double()) > 0, dam, torch.zeros_like(dam))
+    assert relerr(st[0].view(4, Ci).sum(0).cpu(), dz.sum(0)) < 1e-5
+    # weight gradient: F = x (plane pairs), S = dY (plane pairs)
+    dwp = torch.zeros(n, dtype=torch.float32, device="cuda")
+    call("crimac_wgrad", P, 1, ptr(xn), Ci, Ci, ptr(dyn), Co, Co, B, H, W, ptr(dwp), 2)
+    grad = torch.empty(Ci, Co, 2, 2, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_upconv2x2", ptr(dwp), Ci, Co, ptr(grad))
+    torch.cuda.synchronize()
+    assert relerr(grad.cpu(), wg.grad.float()) < 2 * TOL
+
+
+# (B, H, W, Ci, Co): the 8-wave plane-pair kernel (Ci, Co multiples of 64), several channel tiles, partial tiles at the image
+# border, many tiles per workgroup; and the shapes it does not take (first layer: Ci = 16; Co = 32)
+@pytest.mark.parametrize("target", [0, 2, 24])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 32, 32, 128, 64), (2, 21, 37, 64, 128), (2, 64, 64, 128, 128),
+                                   (4, 128, 128, 64, 64), (2, 16, 16, 16, 64), (2, 16, 16, 64, 32)])
+def test_wgrad_conv3x3(shape, target):
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(6)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g))
+    dy = hp_round(torch.randn(B, Co, H, W, generator=g) * 40)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), dy.double(), padding=1).float()
+    dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+    dyn, xn = to_nhwc_hp(dy), to_nhwc_hp(x)
+    call("crimac_wgrad", P, 0, ptr(dyn), Co, Co, ptr(xn), Ci, Ci, B, H, W, ptr(dwp), target)
+    grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+    torch.cuda.synchronize()
+    assert relerr(grad.cpu(), ref) < 2 * TOL
+
+
+def test_wgrad_operands_in_channel_slices():
+    """F and S living in slices of wider buffers (the decoder's first convolution reads the concat buffer)."""
+    B, H, W, Ci, Co = 2, 32, 32, 128, 64
+    g = torch.Generator().manual_seed(7)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g))
+    dy = hp_round(torch.randn(B, Co, H, W, generator=g))
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), dy.double(), padding=1).float()
+    xn, dyn = to_nhwc_hp(x, ld=Ci + 64, off=64), to_nhwc_hp(dy, ld=2 * Co, off=Co)
+    dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+    call("crimac_wgrad", P, 0, ptr(dyn, Co), 2 * Co, Co, ptr(xn, 64), Ci + 64, Ci, B, H, W, ptr(dwp), 0)
+    grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+    torch.cuda.synchronize()
+    assert relerr(grad.cpu(), ref) < 2 * TOL
+
+
+@pytest.mark.parametrize("C", [64, 256])
+def test_elementwise_kernels_read_fp32_and_write_plane_pairs(C):
+    B, H, W = 2, 8, 8
+    M = B * H * W
+    g = torch.Generator().manual_seed(8)
+    y = torch.randn(M, C, generator=g) * 2 + 0.5
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    yd, scd, shd = y.cuda(), sc.cuda(), sh.cuda()
+    a = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    pool = torch.empty(M // 4, C, dtype=torch.float32, device="cuda")
+    call("crimac_bn_act_pool", P, ptr(yd), C, ptr(scd), ptr(shd), 1, ptr(a), C, ptr(pool), C, B, H, W, C)
+    torch.cuda.synchronize()
+    ref = hp_round(torch.relu(torch.addcmul(sh, y, sc)))
+    got = hp_unpack(a)
+    assert relerr(got, ref) < 2e-7
+    ref_pool = F.max_pool2d(got.view(B, H, W, C).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, C)
+    assert torch.equal(hp_unpack(pool), ref_pool)
+    # inference max-pool alone: plane pairs in and out
+    pool2 = torch.empty_like(pool)
+    call("crimac_bn_act_pool", P, ptr(a), C, None, None, 0, None, 0, ptr(pool2), C, B, H, W, C)
+    torch.cuda.synchronize()
+    assert torch.equal(hp_unpack(pool2), ref_pool)
+    # BatchNorm backward: fp32 da, y -> plane-pair dy
+    da = torch.randn(M, C, generator=g) * 1e-2
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    act = y * sc + sh
+    dz = torch.where(act > 0, da, torch.zeros_like(da)).double()
+    xh = ((y - mean) * invstd).double()
+    s_dz, s_dzx = dz.sum(0), (dz * xh).sum(0)
+    dyr = (sc.double() * (dz - s_dz / M - xh * s_dzx / M)).float()
+    dad, md, isd = da.cuda(), mean.cuda(), invstd.cuda()
+    sdz, sdzx = s_dz.cuda(), s_dzx.cuda()
+    dy = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    call("crimac_bn_bwd_apply", P, ptr(dad), C, ptr(yd), C, ptr(scd), ptr(shd), ptr(md), ptr(isd), ptr(sdz), ptr(sdzx), M, M, C,
+         ptr(dy), C, ptr(dg), ptr(db), None)
+    torch.cuda.synchronize()
+    assert relerr(hp_unpack(dy), dyr) < 2e-6
+
+
+# ---- whole network -----------------------------------------------------------------------------------------------------
+def _model(seed=0):
+    m = pkg.UNet_Baseline(3, 4, precision="h3p")
+    m.load_state_dict(synth.synth_state_dict(seed=seed))
+    return m.cuda()
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def _l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def test_network_eval_and_train_step_match_reference_golden(golden_dir):
+    """The north-star bar in the fast parity precision: eval logits <= 1e-3 (here 1e-5) with IDENTICAL argmax masks vs the
+    imported reference; one training step: logits, loss, BatchNorm buffers, every gradient within a few multiples of the
+    reference's own fp32-vs-fp64 noise (the backward pass runs on loss-scaled fp16 plane pairs)."""
+    import re
+    pre_bn_bias = re.compile(r"(down_convs\.\d+\.main\.[03]|up_convs\.\d+\.conv[12])\.bias")
+    fix = np.load(os.path.join(golden_dir, "full64_256.npz"))
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 256, 256, seed=1)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(2, 256, 256, seed=2)).cuda()
+    m = _model().eval()
+    with torch.no_grad():
+        out = m(x)
+    ref = torch.from_numpy(fix["logits_eval"])
+    flips = int((out.argmax(1).cpu() != ref.argmax(1)).sum())
+    print(f"eval h3p: rel={_rel(out, ref):.3e} argmax flips={flips}/{ref[:, 0].numel()}")
+    assert _rel(out, ref) < 1e-5 and flips == 0
+    m.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    logits = m(x)
+    loss = crit(logits, lab.long())
+    loss.backward()
+    ref_t = torch.from_numpy(fix["logits_train"])
+    assert _rel(logits.detach(), ref_t) < 2e-5 and int((logits.argmax(1).cpu() != ref_t.argmax(1)).sum()) == 0
+    assert abs(float(loss) - float(fix["losses"][0])) < 1e-5 * abs(float(fix["losses"][0]))
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert _rel(v.float(), fix["stat1/" + k]) < 1e-4, k
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if pre_bn_bias.fullmatch(k):
+            continue
+        gn, noise = float(fix["gnorm/" + k]), float(fix["gnoise/" + k])
+        tol = max(6 * noise, 3e-3)
+        g_ = p.grad.detach().cpu()
+        assert abs(float(g_.double().norm()) - gn) <= tol * gn, (k, float(g_.double().norm()), gn)
+        if "grad/" + k in fix.files:
+            r = _l2(g_, fix["grad/" + k])
+            worst = max(worst, r / tol)
+            assert r < tol, (k, r, tol)
+    print("h3p worst gradient L2-rel / tolerance:", worst)
+    assert m.engine.skipped_steps() == 0
+
+
+def test_network_batch32_full_size_matches_oracle():
+    """BASELINE configs[1] size (32 x 4 x 256 x 256) in the fast parity precision against the CPU oracle: every kernel at
+    the dispatch the benchmark uses.  Identical argmax masks except where the oracle's own two top logits tie to fp32
+    round-off; the number of such pixels is printed (the bench line records the golden-crop count)."""
+    from oracle import unet_oracle as orc
+    sd = synth.synth_state_dict(seed=0)
+    x = torch.from_numpy(synth.synth_echogram_batch(32, 4, 256, 256, seed=100))
+    ref = orc.predict(sd, x)
+    m = _model().eval()
+    with torch.no_grad():
+        out = m(x.cuda()).cpu()
+    r = _rel(out, ref)
+    diff = out.argmax(1) != ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[diff]
+    print(f"B=32 eval h3p: rel={r:.3e} argmax flips={int(diff.sum())}/{ref[:, 0].numel()} margins={margin.tolist()}")
+    assert r < 1e-5
+    assert int(diff.sum()) <= 2 and bool((margin < 2e-6).all())
+
+
+def test_training_trajectory_and_loss_scale_bookkeeping():
+    """Three fused training steps (forward, weighted CE, loss-scaled backward on fp16 plane pairs, guarded SGD) track
+    the reference golden trajectory; no step is skipped at the default scale."""
+    fixp = os.path.join(os.path.dirname(__file__), "golden", "full64_256.npz")
+    fix = np.load(fixp)
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 256, 256, seed=1)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(2, 256, 256, seed=2)).cuda()
+    m = _model().train()
+    eng = m.engine
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    losses = [float(eng.train_step(x, lab, cw, lr=0.005, momentum=0.95)) for _ in range(3)]
+    print("h3p losses", losses, "golden", fix["losses"].tolist())
+    assert eng.skipped_steps() == 0
+    for a, b in zip(losses, fix["losses"]):
+        assert abs(a - float(b)) < 2e-3 * abs(float(b))
