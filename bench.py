@@ -13,8 +13,9 @@ per GPU (BASELINE.json configs[1]); for N > 1 the mini-batches shard over ranks 
 over RCCL every step (configs[2], weak scaling).  The JSON line also carries
   * ``infer_patches_per_s``   eval forward + softmax (pipeline.py:205-219) on the same batch;
   * ``parity_mode``           the same two measurements in a precision that meets the north-star parity bar
-                              (f32h3: fp32 storage, forward products on two fp16 planes, ~2^-21: <= 1e-3 rel on logits
-                              and identical argmax masks; --parity-precision f32x6 for the 6-MFMA mode), with its roofline;
+                              (h3p: fp16 plane pairs, 3 MFMAs per product, ~2^-21: <= 1e-3 rel on logits and identical
+                              argmax masks -- measured in this run on the reference's golden crop, ``golden_parity``;
+                              --parity-precision f32x6 for the 6-MFMA mode), with its roofline;
   * ``tiled``                 BASELINE configs[3]: tiled whole-survey inference (save_predict.py path), synthetic
                               survey 4 x 65536 pings x 1024 range, preload_n_pings 4096, host reader + H2D + crop/dB +
                               U-Net + softmax + scatter + D2H all inside the timed region;
@@ -59,9 +60,10 @@ def parse_args(argv=None):
     ap.add_argument("--start-filts", type=int, default=64, help="128 = BASELINE configs[4] (2x channels)")
     ap.add_argument("--gpu-augment", action="store_true",
                     help="train on raw linear sv with add_noise / flip / dB on the GPU (configs[4])")
-    ap.add_argument("--parity-precision", default="f32h3", choices=["f32x3", "f32h3", "f32x6"],
-                    help="f32h3: fp16-plane forward (fp32-class logits, identical argmax masks) at 3 MFMAs per product; "
-                         "f32x6: 6 MFMAs, fp32-equivalent gradients too")
+    ap.add_argument("--parity-precision", default="h3p", choices=["f32x3", "f32h3", "h3p", "f32x6"],
+                    help="h3p: fp16 plane pairs split by the producer (fp32-class logits, identical argmax masks) at 3 MFMAs "
+                         "per product on the LDS-DMA kernels; f32h3: the same arithmetic forward with fp32 storage (split "
+                         "while staging) and a bf16-plane backward; f32x6: 6 MFMAs, fp32-equivalent gradients too")
     ap.add_argument("--tiled-pings", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -232,8 +234,11 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
            "train_tflops": world * B * steps / elapsed * TRAIN_GFLOP_PER_PATCH * scale_f / 1e3,
            "final_loss": final_loss, "loss_scale": eng.loss_scale, "skipped_steps": skipped,
            "roofline": roofline("crimac_conv3x3", CONV_KERNELS if precision in ("bf16", "fp16") else
-                                "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)"),
-           "roofline_wgrad": roofline("crimac_wgrad", "wgrad_kernel (weight gradient, all shapes)")}
+                                ("crimac_conv3x3: conv3x3_wch_kernel + conv3x3_glds_w4_kernel (plane-pair forms: 3 MFMAs per "
+                                 "fragment pair) + conv3x3_kernel (first layer)" if precision == "h3p" else
+                                 "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)")),
+           "roofline_wgrad": roofline("crimac_wgrad", "wgrad_pp_kernel + wgrad_kernel (weight gradient, all shapes)"
+                                      if precision == "h3p" else "wgrad_kernel (weight gradient, all shapes)")}
     if infer:
         model.eval()
         with torch.no_grad():

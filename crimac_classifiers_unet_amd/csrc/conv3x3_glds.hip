@@ -370,9 +370,11 @@ struct WchFrags {
   bf16x8 a[2][4];
   bf16x8 b[2][4];        // [tap parity][ks2 * 2 + nb]
 };
-template <int H>
+// NQ: groups of 4 image rows per wave (4: the wave covers all 16 rows of the tile; 2: the 2 x 2 form for 64-channel
+// tiles, waves = 2 pixel halves x 2 channel halves, the half's row offset rides in the address registers)
+template <int H, int NQ = 4>
 __device__ __forceinline__ void wch_issue(const unsigned (&av)[3][2], WchFrags& f) {
-  constexpr int t = H / 8, ks2 = (H / 4) % 2, q = H % 4;
+  constexpr int t = H / (2 * NQ), ks2 = (H / NQ) % 2, q = H % NQ;
   constexpr int base = (t / 3 + 4 * q) * (HP * RB);
   f.a[H & 1][0] = lds_read128_asm<base + 0 * (HP * RB)>(av[t % 3][ks2]);
   f.a[H & 1][1] = lds_read128_asm<base + 1 * (HP * RB)>(av[t % 3][ks2]);
@@ -392,11 +394,11 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
 // PP (plane pairs): k-step 0 of a chunk is the hi plane of 32 channels, k-step 1 their lo plane, in both operands: the
 // hi fragments of A meet both weight planes (hi*lo, then hi*hi), the lo fragments the hi weights only -- 3 MFMAs per
 // fragment pair, 16 + 8 per pair of groups, on the same reads and weight loads as the 16-bit kernel's 8 + 8.
-template <typename T16, bool PP, int H, typename ACC>
+template <typename T16, bool PP, int H, int NQ = 4, typename ACC>
 __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsigned short* wtap, long w_tap, long w_nb,
                                            const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
-  constexpr int t = H / 8, ks2 = (H / 4) % 2, q = H % 4, NH = 72;
-  if constexpr (H % 8 == 0) {
+  constexpr int t = H / (2 * NQ), ks2 = (H / NQ) % 2, q = H % NQ, NH = 18 * NQ;
+  if constexpr (H % (2 * NQ) == 0) {
     if constexpr (t == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) f.b[0][k] = f.b[1][k];
@@ -412,7 +414,7 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
     }
   }
   if constexpr (H + 1 < NH) {
-    wch_issue<H + 1>(av, f);
+    wch_issue<H + 1, NQ>(av, f);
     wch_release<false>(f, H & 1);
   } else {
     wch_release<true>(f, H & 1);
@@ -430,12 +432,15 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
     for (int nb = 0; nb < 2; ++nb)
       acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][(PP ? 0 : ks2 * 2) + nb],
                                                                     acc[4 * q + j][nb]);
-  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
+  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1, NQ>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
-template <typename T16, int MODE, typename TO = T16, bool PP = false>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wch_kernel(ConvParams p) {
-  constexpr int BN = 128, NW = 4;
+// S22: the 2 x 2 form for 64-channel tiles: waves = 2 pixel halves (8 image rows each) x 2 channel halves (32 channels
+// each); the wave's weight fragments still come straight from global memory (each half is fetched by two waves).
+template <typename T16, int MODE, typename TO = T16, bool PP = false, bool S22 = false>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2, S22 ? 3 : 2))) void conv3x3_wch_kernel(ConvParams p) {
+  constexpr int BN = S22 ? 64 : 128, NW = 4;
+  constexpr int NQ = S22 ? 2 : 4, WR = 4 * NQ;       // image rows (16-pixel M tiles) per wave
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef CRIMAC_DIAG_PHASES
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int wc = wave;
+  const int wc = S22 ? (wave & 1) : wave, wp = S22 ? (wave >> 1) : 0;
   // weight fragments of this lane: rows n0 + 32*wc + nb*16 + fr of tap t, k = kc*64 + ks2*32 + fq*8 .. +8
   const unsigned short* wrow = p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
   const long w_tap = (long)p.N * p.Cin, w_nb = 16L * p.Cin;
@@ -498,12 +503,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2)
-        av[kx][ks2] = a_lds + (fr + kx) * RB + (((4 * ks2 + fq) ^ halo_swz(fr + kx)) << 4);
+        av[kx][ks2] = a_lds + (wp * WR * HP + fr + kx) * RB + (((4 * ks2 + fq) ^ halo_swz(fr + kx)) << 4);
   }
 
-  f32x4 acc[16][2];
+  f32x4 acc[WR][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < WR; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -526,8 +531,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     CRIMAC_CPH(1)
     const unsigned short* wtap = wrow + kc * BK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
-    wch_issue<0>(av, f);
-    wch_step<T16, PP, 0>(av, wtap, w_tap, w_nb, wnext, f, acc);
+    wch_issue<0, NQ>(av, f);
+    wch_step<T16, PP, 0, NQ>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(2)
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifndef CRIMAC_DIAG_PHASES
   CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
 #endif
-  conv_epilogue<TO, BN, BM, 256, 16, 2, f32x4, MODE, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TR, 0, wc);
+  conv_epilogue<TO, BN, BM, 256, WR, 2, f32x4, MODE, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TR, wp, wc);
 #ifdef CRIMAC_DIAG_PHASES
   // cycles of wave 0: prologue | waiting for the halo chunks | MFMA steps | epilogue (stores issued)
   CRIMAC_CPH(3)
@@ -546,9 +551,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
-template <typename T16, typename TO = T16, bool PP = false>
+template <typename T16, typename TO = T16, bool PP = false, bool S22 = false>
 int launch_wch(ConvParams p, hipStream_t st) {
-  constexpr int BN = 128;
+  constexpr int BN = S22 ? 64 : 128;
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
@@ -557,24 +562,24 @@ int launch_wch(ConvParams p, hipStream_t st) {
   static_assert(stage <= 72 * 1024, "two workgroups per CU");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP, S22>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP, S22>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (!__is_same(TO, hp_t))
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2, TO, PP>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2, TO, PP, S22>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const dim3 grid((unsigned)ntiles, p.n_count / BN);
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
   if constexpr (__is_same(TO, hp_t)) {
     CRIMAC_REQUIRE(mode != 2, "conv3x3: plane-pair output with fused BatchNorm-backward sums");
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP, S22>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP, S22>), grid, dim3(256), lds, st, p);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP>), grid, dim3(256), lds, st, p);
-    else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2, TO, PP>), grid, dim3(256), lds, st, p);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP, S22>), grid, dim3(256), lds, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP, S22>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2, TO, PP, S22>), grid, dim3(256), lds, st, p);
   }
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1304,6 +1309,9 @@ int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int 
                  "multiples of 64", n_first, n_count);
   if (n_count % 128 == 0 && n_first % 128 == 0)
     return out_planes ? launch_w4<128, half_t, hp_t, true>(p, st) : launch_w4<128, half_t, float, true>(p, st);
+  static const int s22 = getenv("CRIMAC_CONV_S22") ? atoi(getenv("CRIMAC_CONV_S22")) : 1;
+  if (s22 && small)
+    return out_planes ? launch_wch<half_t, hp_t, true, true>(p, st) : launch_wch<half_t, float, true, true>(p, st);
   return out_planes ? launch_w4<64, half_t, hp_t, true>(p, st) : launch_w4<64, half_t, float, true>(p, st);
 }
 

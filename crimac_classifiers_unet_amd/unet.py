@@ -116,6 +116,9 @@ class UNet_Baseline(nn.Module):
                             the parity mode, <=1e-3 on logits with bit-exact argmax masks)
                  'f32h3' -- fp32 activations; forward products on a 2-plane fp16 split (~2^-21 per product, 3 MFMAs:
                             fp32-class logits at half the MFMAs of 'f32x6'), backward on the 2-plane bf16 split
+                 'h3p'   -- the fast parity mode: f32h3's forward arithmetic with the operands stored as fp16 PLANE PAIRS
+                            (hi + lo) split once by the kernel that produces them, so every contraction runs on the LDS-DMA
+                            kernels; the backward pass runs on loss-scaled fp16 plane pairs as well (overflow skip as 'fp16')
                  'fp16'  -- fp16 activations / MFMA, fp32 accumulate, loss-scaled gradients with overflow skip
                             (BASELINE configs[4]); same kernels and rate as 'bf16'
     """
