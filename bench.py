@@ -299,10 +299,13 @@ def golden_parity(precision, dev, log):
     return res
 
 
-def measure_tiled(model, args, log):
-    """BASELINE configs[3]: whole-survey tiled inference, end to end (host reader included)."""
+def measure_tiled(model, args, log, world=1):
+    """BASELINE configs[3]: whole-survey tiled inference, end to end (host reader included).  world > 1: the chunks of
+    the survey are sharded over the ranks (rank r owns chunks r, r + N, ...; no collective in the data path); the
+    figure is all patches of the survey / the slowest rank's time."""
     import types
     import torch
+    import torch.distributed as dist
     from crimac_classifiers_unet_amd import synth, tiled_inference as ti
     n_pings, n_range, preload = args.tiled_pings, 1024, 4096
     t0 = time.perf_counter()
@@ -314,14 +317,28 @@ def measure_tiled(model, args, log):
     for _ in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, **f16):
         pass                                             # warm-up: one untimed pass over the survey
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    n_patches, written = 0, 0
+    n_patches, written, n_mine = 0, 0, 0
     for s, e, out in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, **f16):
         n_patches += len(ti.plan_grid(n_range, 900, s, e))
         written += int((out[0, :, ::64] != 0).sum())
+        n_mine += e - s
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if world > 1:
+        dev = next(model.parameters()).device
+        agg = torch.tensor([n_patches, written, n_mine], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        n_patches, written, n_mine, dt = int(agg[0]), int(agg[1]), int(agg[2]), float(tmax)
+        assert n_mine == n_pings, (n_mine, n_pings)          # the ranks covered the survey exactly once
     return {"workload": f"BASELINE configs[3]: synthetic survey sv [4, {n_pings}, {n_range}] fp32, flat seabed 900, "
-                        f"preload_n_pings {preload}, patch 256, overlap 20, 1 GPU streamed; the {len(ti.plan_grid(n_range, 900, 0, preload))} "
+                        f"preload_n_pings {preload}, patch 256, overlap 20, "
+                        + ("1 GPU streamed" if world == 1 else f"chunks sharded over {world} ranks, no data-path collective")
+                        + f"; the {len(ti.plan_grid(n_range, 900, 0, preload))} "
                         f"patches of a chunk run as forward calls of up to {max(args.batch, ti.INTERNAL_BATCH)} patches "
                         f"(eval mode: results do not depend on the batch; the caller's batch_size {args.batch} is a lower bound)",
             "patches_per_forward_call": max(args.batch, ti.INTERNAL_BATCH),
@@ -388,8 +405,8 @@ def run_rank(args):
     main, model = measure_mode(args, args.precision, args.steps, args.warmup, world, rank, dev, grad_sync,
                                infer=not args.no_infer, log=log)
     tiled = None
-    if world == 1 and not args.no_tiled and args.start_filts == 64:
-        tiled = measure_tiled(model, args, log)
+    if not args.no_tiled and args.start_filts == 64:
+        tiled = measure_tiled(model, args, log, world)
         log(f"tiled: {tiled['patches_per_s']:.0f} patches/s end to end")
     del model
     parity = None
@@ -397,6 +414,9 @@ def run_rank(args):
         torch.cuda.empty_cache()
         parity, pm = measure_mode(args, args.parity_precision, max(3, args.steps // 2), 2, world, rank, dev,
                                   grad_sync, infer=not args.no_infer, log=log)
+        if not args.no_tiled:
+            parity["tiled"] = measure_tiled(pm, args, log)       # configs[3] in the parity precision as well
+            log(f"tiled ({args.parity_precision}): {parity['tiled']['patches_per_s']:.0f} patches/s end to end")
         del pm
         parity["golden_parity"] = golden_parity(args.parity_precision, dev, log)
     main["golden_parity"] = golden_parity(args.precision, dev, log) if (args.start_filts == 64 and rank == 0) else None

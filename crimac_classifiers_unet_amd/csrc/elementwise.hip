@@ -970,6 +970,25 @@ __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// softmax over the class axis of NCHW logits (F.softmax(dim=1), pipeline.py:218, :269): one pixel per thread
+template <int NC>
+__global__ __launch_bounds__(256) void softmax_nchw_kernel(const float* __restrict__ logits, float* __restrict__ out,
+                                                           long npix, long HW) {
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    long b, hw;
+    pix_split(p, HW, b, hw);
+    float z[NC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int o = 0; o < NC; ++o) { z[o] = logits[(b * NC + o) * HW + hw]; mx = fmaxf(mx, z[o]); }
+    float den = 0.f;
+#pragma unroll
+    for (int o = 0; o < NC; ++o) { z[o] = expf(z[o] - mx); den += z[o]; }      // (same arithmetic as the head's fused softmax)
+#pragma unroll
+    for (int o = 0; o < NC; ++o) out[(b * NC + o) * HW + hw] = z[o] / den;
+  }
+}
+
 // ---- SGD with momentum over a flat parameter buffer -------------------------------------------------------------
 // Loss-scaled training (fp16 storage): state[0] = 1 if any gradient is not finite (this step), state[1] counts
 // the steps skipped because of it.  The check is a pass of its own over the flat gradient (31 M floats, ~25 us).
@@ -1401,6 +1420,18 @@ extern "C" int crimac_wce_bwd(const float* logits, const void* labels, int label
                      class_w, ignore_index, npix, HW, sums, upstream, dlogits)
   if (ncls == 2) WB(2); else if (ncls == 3) WB(3); else WB(4);
 #undef WB
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_softmax_nchw(const float* logits, float* out, int B, int ncls, int H, int W, void* stream) {
+  CRIMAC_REQUIRE(logits && out && B > 0 && H > 0 && W > 0, "softmax_nchw: bad arguments");
+  CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "softmax_nchw: ncls=%d unsupported (2..4)", ncls);
+  const long HW = (long)H * W, npix = B * HW;
+  const int grid = grid_for(npix, 256 * 4);
+#define SM(NC) hipLaunchKernelGGL(softmax_nchw_kernel<NC>, dim3(grid), dim3(256), 0, ST, logits, out, npix, HW)
+  if (ncls == 2) SM(2); else if (ncls == 3) SM(3); else SM(4);
+#undef SM
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

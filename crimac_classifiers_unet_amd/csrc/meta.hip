@@ -226,6 +226,53 @@ __global__ __launch_bounds__(256) void meta_bwd_kernel(const float* __restrict__
   }
 }
 
+
+// ---- metadata planes of a crop (batch/dataset.py:288-351, get_crop_memmap) -----------------------------------------------
+// Seven planes at most, every one a function of the crop centre and of three per-ping vectors of the echogram:
+//   portion_year      : the echogram's scalar
+//   portion_day (x2)  : sin / cos of 2 pi * portion_of_day_vector[centre ping]           (index clamped: < 0 -> 0, >= n -> last)
+//   time_diff         : time_vector_diff[ping of the column]                             (same clamping, per column)
+//   depth_rel         : row / seabed[ping]         depth_abs_surface : row / H         depth_abs_seabed : (seabed[ping] - row) / H
+// with row = cy - H/2 + y, ping = cx - W/2 + x -- the reference's arange(c - w // 2, c + w // 2), one pixel up / left of the
+// DATA crop's grid (getGrid: c - (w + 1) // 2 + 1 ...): reproduced, not "fixed".  The reference computes in float64 and the
+// batch is cast to float32 by SegPipe.predict_batch (.float()): the same here (double arithmetic, one rounding).
+struct MetaPlaneArgs {
+  const int* centres;            // [P][2] (range idx, ping idx)
+  int P, H, W, flags;            // flags: bit 0 portion_year, 1 portion_day, 2 time_diff, 3 depth_rel, 4 depth_abs_surface, 5 depth_abs_seabed
+  double portion_year;
+  const double* portion_day; int n_day;
+  const double* time_diff; int n_td;
+  const long long* seabed; int n_sb;
+  float* out;                    // [P][Cm][H][W]
+  int Cm;
+};
+__device__ __forceinline__ int clamp_last(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+__global__ __launch_bounds__(256) void meta_planes_kernel(MetaPlaneArgs a) {
+  const long HW = (long)a.H * a.W, total = (long)a.P * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i / HW);
+    const int rem = (int)(i - p * HW);
+    const int y = rem / a.W, x = rem - y * a.W;
+    const int cy = a.centres[2 * p], cx = a.centres[2 * p + 1];
+    const int row = cy - a.H / 2 + y, ping = cx - a.W / 2 + x;
+    float* o = a.out + ((long)p * a.Cm) * HW + rem;
+    int c = 0;
+    if (a.flags & 1) { o[c * HW] = (float)a.portion_year; ++c; }
+    if (a.flags & 2) {
+      const double t = a.portion_day[clamp_last(cx, a.n_day)];
+      o[c * HW] = (float)sin(2.0 * 3.141592653589793 * t); ++c;
+      o[c * HW] = (float)cos(2.0 * 3.141592653589793 * t); ++c;
+    }
+    if (a.flags & 4) { o[c * HW] = (float)a.time_diff[clamp_last(ping, a.n_td)]; ++c; }
+    if (a.flags & 56) {
+      const double sb = (double)a.seabed[clamp_last(ping, a.n_sb)];
+      if (a.flags & 8) { o[c * HW] = (float)((double)row / sb); ++c; }
+      if (a.flags & 16) { o[c * HW] = (float)((double)row / (double)a.H); ++c; }
+      if (a.flags & 32) { o[c * HW] = (float)((sb - (double)row) / (double)a.H); ++c; }
+    }
+  }
+}
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -281,6 +328,28 @@ extern "C" int crimac_meta_bwd(const float* dlogits, const float* meta, int Cm, 
 #define MB(NC) hipLaunchKernelGGL(meta_bwd_kernel<NC>, dim3((unsigned)blocks), dim3(256), lds, ST, dlogits, meta, Cm, npix, HW, wm, w, dwm, gw1, gb1, gw2, gb2, gw3, gb3)
   if (ncls == 2) MB(2); else if (ncls == 3) MB(3); else MB(4);
 #undef MB
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+
+// Metadata planes of P crops (reference batch/dataset.py:288-351, the `meta` half of get_crop_memmap's result): what the
+// reference's Dataset builds per patch in numpy DataLoader workers, built on the GPU from the echogram's three per-ping
+// vectors.  flags: bit 0 portion_year, 1 portion_day (two planes: sin, cos), 2 time_diff, 3 depth_rel,
+// 4 depth_abs_surface, 5 depth_abs_seabed; the planes come out in that order, out [P][Cm][H][W] fp32.
+extern "C" int crimac_meta_planes(const int* centres, int P, int H, int W, int flags, double portion_year,
+                                  const double* portion_day, int n_day, const double* time_diff, int n_td,
+                                  const long long* seabed, int n_sb, float* out, void* stream) {
+  CRIMAC_REQUIRE(centres && out && P > 0 && H > 0 && W > 0 && flags > 0 && flags < 64, "meta_planes: bad arguments");
+  CRIMAC_REQUIRE(!(flags & 2) || (portion_day && n_day > 0), "meta_planes: portion_day needs its vector");
+  CRIMAC_REQUIRE(!(flags & 4) || (time_diff && n_td > 0), "meta_planes: time_diff needs its vector");
+  CRIMAC_REQUIRE(!(flags & 56) || (seabed && n_sb > 0), "meta_planes: the depth planes need the seabed vector");
+  MetaPlaneArgs a{centres, P, H, W, flags, portion_year, portion_day, n_day, time_diff, n_td, seabed, n_sb, out, 0};
+  a.Cm = (flags & 1) + 2 * ((flags >> 1) & 1) + ((flags >> 2) & 1) + ((flags >> 3) & 1) + ((flags >> 4) & 1) + ((flags >> 5) & 1);
+  const long total = (long)P * H * W;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(meta_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

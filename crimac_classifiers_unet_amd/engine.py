@@ -1236,6 +1236,21 @@ class UNetEngine:
             return (sums[0] / sums[1]).float()
         if grad_sync is not None and hasattr(grad_sync, "launch"):
             self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
+            if not single and self.early_sgd and hasattr(grad_sync, "finish_range"):
+                # N > 1: the gradient ranges were handed to the exchange in the order the backward pass completed them
+                # (decoder first, shallow encoder blocks last).  Each range is applied, and its weight planes re-packed
+                # for the next step, as soon as ITS collectives are done -- the update of the decoder (40 % of the
+                # parameters) runs while the later ranges are still on the links, instead of the whole optimiser step
+                # and the whole re-pack queuing behind the last collective.
+                self.mark_dirty()
+                for g, (lo, hi) in enumerate(self.grad_ranges()):
+                    scale = grad_sync.finish_range(lo, hi)
+                    self._sgd_range(lo, hi, lr, momentum, scale)
+                    if self.early_pack:
+                        self._pack_group(g)
+                        self._packed_groups.add(g)
+                grad_sync.finish()
+                return (sums[0] / sums[1]).float()
             scale = grad_sync.finish()
         else:
             self.backward(dl)
@@ -1261,9 +1276,9 @@ class UNetEngine:
                 self._packed_groups.add(g)
         self._sgd_left = left
 
-    def _sgd_range(self, lo, hi, lr, momentum):
+    def _sgd_range(self, lo, hi, lr, momentum, grad_scale=1.0):
         call("crimac_sgd_momentum", ptr(self.flat_p, lo), ptr(self.flat_g, lo), ptr(self.flat_v, lo), hi - lo,
-             float(lr), float(momentum), 1.0, 0)
+             float(lr), float(momentum), float(grad_scale), 0)
 
     # ------------------------------------------------------------------------------------------
     # on-GPU augmentation (BASELINE configs[4]; reference: batch/data_augmentation/*)

@@ -74,11 +74,13 @@ SIGNATURES = {
     "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp,
                         _i, _vp],
+    "crimac_softmax_nchw": [_vp, _vp, _i, _i, _i, _i, _vp],
     "crimac_wce_fwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "crimac_wce_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp],
     "crimac_sgd_momentum": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp],
     "crimac_grad_overflow_flag": [_vp, _l, _vp, _vp],
     "crimac_sgd_momentum_guarded": [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _vp],
+    "crimac_meta_planes": [_vp, _i, _i, _i, _i, C.c_double, _vp, _i, _vp, _i, _vp, _i, _vp, _vp],
     "crimac_meta_mlp_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "crimac_meta_inject_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "crimac_meta_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -69,15 +69,22 @@ class GradSync:
         self.algo = algo or os.environ.get("CRIMAC_GRAD_EXCHANGE", "all_reduce")
         if self.algo not in ("all_reduce", "rs_ag"):
             raise ValueError(f"GradSync: unknown algo {self.algo!r}")
-        self._works = []
+        self._works = []         # (range, work) in flight
         self._done = []          # [(lo, hi)] ranges already in flight this step
         self._shards = {}        # bucket -> reduce-scatter output buffer
-        self._gathers = []       # (reduce-scatter work, bucket, shard) whose all-gather is still to be issued
+        self._gathers = []       # (range, reduce-scatter work, bucket, shard) whose all-gather is still to be issued
 
     def world(self):
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         return dist.get_world_size(self.group)
+
+    def _stream_ordered(self):
+        """RCCL ("nccl"): the collectives of one process group run on its own stream IN ISSUE ORDER, and ``wait()`` makes
+        the current stream wait (no host block) -- an all-gather can be queued right behind its reduce-scatter.  gloo
+        runs asynchronous collectives on worker threads without mutual order: the all-gather has to be issued after the
+        reduce-scatter has completed (host wait)."""
+        return dist.get_backend(self.group) == "nccl"
 
     def launch(self, flat_grad, lo, hi):
         if self.world() == 1 or hi <= lo:
@@ -87,6 +94,7 @@ class GradSync:
                 raise RuntimeError(f"GradSync: range [{lo},{hi}) overlaps [{a},{b}) already in flight")
         self._done.append((lo, hi))
         world = self.world()
+        rng = (lo, hi)
         for s, e in bucket_bounds(hi - lo, self.bucket_elems):
             buf = flat_grad[lo + s:lo + e]
             n = e - s
@@ -95,13 +103,16 @@ class GradSync:
                 shard = self._shards.get(key)
                 if shard is None or shard.device != buf.device:
                     shard = self._shards[key] = torch.empty(n // world, dtype=buf.dtype, device=buf.device)
-                # the reduce-scatter starts now (overlapped with the rest of the backward pass); its all-gather is
-                # issued from finish() once the reduce-scatter has completed -- a backend whose asynchronous
-                # collectives are not ordered among themselves (gloo) would otherwise gather a stale shard
+                # the reduce-scatter starts now (overlapped with the rest of the backward pass)
                 w = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._gathers.append((w, buf, shard))
+                if self._stream_ordered():
+                    # ... and its all-gather is chained behind it on the process group's stream: no host wait anywhere
+                    self._works.append((rng, w))
+                    self._works.append((rng, dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)))
+                else:
+                    self._gathers.append((rng, w, buf, shard))         # issued by finish_range() / finish()
             else:
-                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._works.append((rng, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def pending_ranges(self, n):
         """Complement of the launched ranges in [0, n)."""
@@ -114,12 +125,34 @@ class GradSync:
             out.append((pos, n))
         return out
 
+    def finish_range(self, lo, hi):
+        """Wait (RCCL: the current STREAM waits, the host does not) for the collectives of the launched range
+        [lo, hi) only, so that the optimiser step of that range can run while later ranges are still being exchanged.
+        Returns the 1/world averaging scale."""
+        rng = (lo, hi)
+        if rng not in self._done and self.world() > 1:
+            raise RuntimeError(f"GradSync.finish_range: [{lo},{hi}) was not launched")
+        keep = []
+        for g in self._gathers:
+            if g[0] != rng:
+                keep.append(g)
+                continue
+            _, w, buf, shard = g
+            w.wait()
+            self._works.append((rng, dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)))
+        self._gathers = keep
+        rest = []
+        for r, w in self._works:
+            if r == rng:
+                w.wait()
+            else:
+                rest.append((r, w))
+        self._works = rest
+        return 1.0 / self.world()
+
     def finish(self):
-        for w, buf, shard in self._gathers:
-            w.wait()
-            self._works.append(dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True))
-        for w in self._works:
-            w.wait()
+        for rng in list(self._done):
+            self.finish_range(*rng)
         self._works, self._done, self._gathers = [], [], []
         return 1.0 / self.world()
 

@@ -224,6 +224,16 @@ class SegPipe:
         labels[labels == LABEL_SEABED_MASK_VAL] = 0
         return labels
 
+    def _softmax(self, logits):
+        """F.softmax(logits, dim=1) (pipeline.py:269) as a HIP kernel; the product path has no torch arithmetic."""
+        from .hip import call, ptr
+        logits = logits.contiguous().float()
+        B, C, H, W = logits.shape
+        out = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            call("crimac_softmax_nchw", ptr(logits), ptr(out), B, C, H, W)
+        return out
+
     def get_predictions_dataloader(self, dataloader, criterion=None, disable_tqdm=False):
         """Sandeel-probability vector + labels over a dataloader (reference pipeline.py:242-282)."""
         preds, labels = [], []
@@ -238,7 +248,7 @@ class SegPipe:
                     labels_input = self.set_label_ignore_val(labels_input)
                     loss_test = criterion(outputs_test, labels_input)
                     sum_loss = loss_test if sum_loss is None else sum_loss + loss_test
-                preds_softmax = torch.softmax(outputs_test, dim=1)      # 3-class epilogue: plumbing
+                preds_softmax = self._softmax(outputs_test)             # (the logits above feed the loss)
                 preds += [preds_softmax[:, SANDEEL].to(torch.float16)]
                 labels += [batch_test["labels"].numpy().ravel()]
         preds = torch.cat([p.reshape(-1) for p in preds]).cpu().numpy().astype(np.float16)

@@ -57,6 +57,47 @@ def plan_grid(n_range, max_seabed, start_ping, end_ping, patch_size=(256, 256), 
     return np.array(np.meshgrid(ys, xs)).T.reshape(-1, 2)
 
 
+META_FLAGS = {"portion_year": 1, "portion_day": 2, "time_diff": 4, "depth_rel": 8, "depth_abs_surface": 16,
+              "depth_abs_seabed": 32}          # planes come out in this order (batch/dataset.py:288-351)
+
+
+class MetaSource:
+    """The per-ping vectors the metadata planes of an echogram are built from (data_reader.py:98-100), resident on the
+    GPU: ``crimac_meta_planes`` turns them into the ``[P, Cm, H, W]`` planes of a batch of crops -- what the reference's
+    ``get_crop_memmap`` builds per patch in numpy DataLoader workers (batch/dataset.py:288-351)."""
+
+    def __init__(self, meta_channels, portion_year, portion_day_vector, time_vector_diff, seabed, device):
+        if set(meta_channels) != set(META_FLAGS) or not all(isinstance(v, bool) for v in meta_channels.values()):
+            raise ValueError(f"meta_channels must be a dict of booleans with the keys {sorted(META_FLAGS)}")    # dataset.py:60-66
+        self.flags = sum(f for k, f in META_FLAGS.items() if meta_channels[k])
+        if self.flags == 0:
+            raise ValueError("no metadata channel is switched on")
+        self.n_planes = sum((2 if k == "portion_day" else 1) for k in META_FLAGS if meta_channels[k])
+        self.portion_year = float(portion_year)
+
+        def dev(a, dt):
+            return torch.as_tensor(np.ascontiguousarray(np.asarray(a)).astype(dt)).to(device)
+        self.portion_day = dev(portion_day_vector, np.float64)
+        self.time_diff = dev(time_vector_diff, np.float64)
+        self.seabed = dev(seabed, np.int64)
+
+    @classmethod
+    def from_echogram(cls, echogram, meta_channels, device):
+        return cls(meta_channels, echogram.portion_of_year_scalar, echogram.portion_of_day_vector,
+                   echogram.time_vector_diff, echogram._seabed, device)
+
+    def planes(self, centres_dev, patch_size):
+        """centres_dev int32 [P, 2] (range idx, ping idx) on the GPU -> float32 [P, Cm, H, W]."""
+        P = centres_dev.shape[0]
+        H, W = int(patch_size[1]), int(patch_size[0])
+        out = torch.empty((P, self.n_planes, H, W), dtype=torch.float32, device=centres_dev.device)
+        with torch.cuda.device(centres_dev.device):
+            call("crimac_meta_planes", ptr(centres_dev), P, H, W, self.flags, self.portion_year, ptr(self.portion_day),
+                 self.portion_day.numel(), ptr(self.time_diff), self.time_diff.numel(), ptr(self.seabed),
+                 self.seabed.numel(), ptr(out))
+        return out
+
+
 class ChunkPredictor:
     """GPU state of one preloaded chunk: data, labels, seabed; gathers, predicts, scatters."""
 
@@ -70,6 +111,7 @@ class ChunkPredictor:
         self.out_f16 = bool(out_f16)
         self.flavour = "zarr"
         self.seabed = self.mask = None
+        self.meta_source = None          # MetaSource: needed by a UNet_LateMetInject model (metadata planes per crop)
 
     def _device(self):
         return self.engine.device or next(self.model.parameters()).device
@@ -107,8 +149,12 @@ class ChunkPredictor:
         self.out = torch.zeros((2, self.n_range, self.end_ping - self.start_ping),
                                dtype=torch.float16 if self.out_f16 else torch.float32, device=dev)
 
-    def predict(self, grid, predict_fn=None, centres_dev=None):
+    def predict(self, grid, predict_fn=None, centres_dev=None, share_patches=True):
         """Run all patches of ``grid`` ([P,2] global centres) and scatter them into ``self.out``.
+
+        ``share_patches`` (with torch.distributed initialised): the patches of THIS chunk are dealt round-robin to the
+        ranks and the per-rank outputs are summed (one collective per chunk); False: this rank computes the whole chunk
+        on its own (``predict_survey`` with chunk sharding: the ranks own different chunks, no collective at all).
 
         ``predict_fn(x_nhwc, P, H, W) -> probs [P,3,H,W]`` overrides the network (tests).
         ``centres_dev``: int32 [2, P, 2] on the GPU = (global centres, centres relative to the data slice), uploaded
@@ -119,7 +165,7 @@ class ChunkPredictor:
         ph, pw = self.patch_size[1], self.patch_size[0]
         C = self.data.shape[0]
         world, rank = 1, 0
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        if share_patches and torch.distributed.is_available() and torch.distributed.is_initialized():
             world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
         mine = parallel.shard_indices(len(grid), rank, world)
         memm = self.flavour == "memm"
@@ -142,10 +188,16 @@ class ChunkPredictor:
             else:
                 call("crimac_gather_patches", eng.prec, ptr(self.data), C, self.data.shape[1], self.n_range,
                      ptr(loc_d), P, ph, pw, ptr(x), 16)
-            if predict_fn is None:
-                probs = eng.forward_nhwc_eval_split(x, P, ph, pw, softmax=True)
-            else:
+            if predict_fn is not None:
                 probs = predict_fn(x, P, ph, pw)
+            elif eng.lmi:
+                if self.meta_source is None:
+                    raise ValueError("a UNet_LateMetInject model needs the metadata planes: set ChunkPredictor.meta_source "
+                                     "(MetaSource.from_echogram(...))")
+                meta = self.meta_source.planes(cen_d.contiguous(), self.patch_size)
+                probs = eng.forward_nhwc(x, P, ph, pw, False, softmax=True, meta=meta)
+            else:
+                probs = eng.forward_nhwc_eval_split(x, P, ph, pw, softmax=True)
             call("crimac_scatter_patches_ex", ptr(probs), probs.shape[1], ptr(cen_d), P, ph, pw,
                  self.patch_overlap, self.start_ping, self.end_ping - self.start_ping, self.n_range,
                  ptr(self.labels), ptr(self.mask), self.start_ping, self.end_ping - self.start_ping,
@@ -196,8 +248,16 @@ def release_staging():
 
 
 def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, preload_n_pings,
-                   start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, predict_fn=None, **kwargs):
+                   start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, predict_fn=None,
+                   shard="chunk", **kwargs):
     """Generator over chunks: yields ``(start_ping, end_ping, out[2, n_range, end-start] numpy)``.
+
+    Multi-GPU (torch.distributed initialised, one process per GPU):
+      ``shard="chunk"`` (default) -- rank r owns chunks r, r + N, r + 2N, ...: every rank reads, uploads, predicts and
+          returns only ITS ping ranges (disjoint regions of the output array / zarr store) -- no collective anywhere,
+          the reader I/O and the PCIe traffic scale with the ranks too; each rank's generator yields its own chunks;
+      ``shard="patch"`` -- every rank walks every chunk, takes patches p = rank (mod N) of it and the per-rank float16
+          outputs are summed (one all-reduce of the chunk per chunk): every rank yields every chunk.
 
     ``reader``: the reference's zarr reader API (shape, get_data_slice, get_label_slice, get_seabed);
     ``segpipe``: a ``SegPipeUNet`` with loaded parameters.  ``out_dtype=np.float16`` returns what the reference
@@ -215,6 +275,13 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
     f16 = np.dtype(out_dtype) == np.float16
     cp = ChunkPredictor(model, n_range, patch_size, patch_overlap, batch_size, out_f16=f16)
     chunks = plan_chunks(start_ping, n_pings, preload_n_pings)
+    if shard not in ("chunk", "patch"):
+        raise ValueError(f"predict_survey: shard must be 'chunk' or 'patch', got {shard!r}")
+    share_patches = shard == "patch"
+    if not share_patches and torch.distributed.is_available() and torch.distributed.is_initialized():
+        chunks = chunks[torch.distributed.get_rank()::torch.distributed.get_world_size()]
+        if not chunks:
+            return
     n_freq = len(segpipe.frequencies)
     widest = max(e - s for s, e in chunks)
     halo = patch_size[1]
@@ -330,7 +397,8 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                     cp.load_chunk(d_d, lo, l_d, mask, s, e)
                 note("enq_load_s", t1)
                 t1 = tick()
-                out = cp.predict(grid, predict_fn=predict_fn, centres_dev=m_d[hi - lo:].view(2, P, 2))
+                out = cp.predict(grid, predict_fn=predict_fn, centres_dev=m_d[hi - lo:].view(2, P, 2),
+                                 share_patches=share_patches)
                 note("enq_predict_s", t1)
                 if stats is not None:
                     ev1.record()
@@ -360,7 +428,8 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
         bufs["busy"] = False
 
 
-def predict_echogram_memm(echogram, segpipe, patch_size, patch_overlap, batch_size, predict_fn=None, **kwargs):
+def predict_echogram_memm(echogram, segpipe, patch_size, patch_overlap, batch_size, predict_fn=None, meta_channels=None,
+                          **kwargs):
     """``save_reader_predictions_memm`` (save_predict.py:222-265) for one memmap echogram: returns the
     ``[2, n_range, n_pings]`` float64 array the reference ``np.save``s (probabilities rounded to float16 first, :252).
 
@@ -381,6 +450,8 @@ def predict_echogram_memm(echogram, segpipe, patch_size, patch_overlap, batch_si
     data = data.permute(0, 2, 1).contiguous()                                     # [C, pings, range]
     labels = torch.as_tensor(np.ascontiguousarray(echogram.label_memmap()).astype(np.int16)).to(dev).t().contiguous()
     cp = ChunkPredictor(model, n_range, patch_size, patch_overlap, batch_size, out_f16=True)
+    if meta_channels:                    # late metadata injection: the planes are built on the GPU, per batch of crops
+        cp.meta_source = MetaSource.from_echogram(echogram, meta_channels, dev)
     cp.load_chunk(data, 0, labels, None, 0, n_pings, seabed=seabed, flavour="memm")
     out = cp.predict(grid, predict_fn=predict_fn)
     return out.cpu().numpy().astype(np.float64)

@@ -305,6 +305,11 @@ int crimac_head_bwd(int prec, const float* dlogits, const void* x, long x_ld, in
                     void* dx, long dx_ld, float* dw, float* db, int B, int H, int W, int ncls,
                     const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
                     double* stat_sumsq, int stat_replicas, void* stream);
+/* F.softmax(outputs, dim=1) on NCHW logits (SegPipe.predict_batch(return_softmax=True), pipeline.py:218; the validation
+ * loop, pipeline.py:269, where the logits themselves are still needed for the loss): out[b][c][h][w] fp32.  (When only the
+ * probabilities are wanted crimac_head_fwd(softmax = 1) produces them directly.) */
+int crimac_softmax_nchw(const float* logits, float* out, int B, int ncls, int H, int W, void* stream);
+
 /* nn.CrossEntropyLoss(weight) (pipeline.py:132-141): sums[0] += sum w[y]*nll, sums[1] += sum w[y]
  * over pixels with y != ignore_index.  labels: int16/int32/int64 selected by label_bytes. */
 int crimac_wce_fwd(const float* logits, const void* labels, int label_bytes, const float* class_w,
@@ -383,6 +388,18 @@ int crimac_scatter_patches_ex(const float* probs, int ncls, const int* centres, 
 #define CRIMAC_PR_NAN_BIN (CRIMAC_PR_BINS - 1)
 int crimac_pr_histogram(const float* logits, int ncls, const void* labels, int label_bytes, int B, int H,
                         int W, unsigned int* hist_pos, unsigned int* hist_neg, void* stream);
+
+/* Metadata planes of P crops (reference batch/dataset.py:288-351: the `meta` half of get_crop_memmap's result, which the
+ * Dataset appends to the data channels, :109 / :241): built from the echogram's scalar `portion_of_year_scalar` and its
+ * per-ping vectors `portion_of_day_vector`, `time_vector_diff`, `_seabed` (data_reader.py:98-100) instead of per patch
+ * in numpy DataLoader workers.  centres [P][2] = (range idx, ping idx); flags: bit 0 portion_year, bit 1 portion_day (two
+ * planes: sin, cos of 2 pi t at the centre ping), bit 2 time_diff (per column), bit 3 depth_rel = row / seabed[ping],
+ * bit 4 depth_abs_surface = row / H, bit 5 depth_abs_seabed = (seabed[ping] - row) / H, with row = cy - H/2 + y and
+ * ping = cx - W/2 + x, vector indices clamped as the reference does (< 0 -> 0, >= n -> last).  float64 arithmetic, one
+ * rounding to out [P][Cm][H][W] fp32 (planes in flag order), as the reference's float64 planes after `.float()`. */
+int crimac_meta_planes(const int* centres, int P, int H, int W, int flags, double portion_year,
+                       const double* portion_day, int n_day, const double* time_diff, int n_td,
+                       const long long* seabed, int n_sb, float* out, void* stream);
 
 /* ---- late metadata injection (UNet_LateMetInject, unet.py:346-391; MetaPostProcessing, unet.py:140-166) ---- */
 

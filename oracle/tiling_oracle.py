@@ -207,3 +207,44 @@ def predict_echogram_memm(sv_hw, raw_labels_hw, seabed, predict_fn, patch_size=(
         preds = predict_fn(db.astype(np.float32)).astype(np.float16)
         fill_out_array(out, preds, lab, c, 0)
     return out
+
+
+META_KEYS = ("portion_year", "portion_day", "time_diff", "depth_rel", "depth_abs_surface", "depth_abs_seabed")
+
+
+def meta_planes(centre, window_size, meta_channels, portion_year, portion_day_vector, time_vector_diff, seabed):
+    """The metadata planes of one crop: the ``meta`` half of ``get_crop_memmap`` (batch/dataset.py:288-351), float64
+    [Cm, H, W].  ``centre`` = (range idx, ping idx) AFTER the water-column adjustment of dataset.py:256-258;
+    ``meta_channels``: dict of the six booleans.  Note the index ranges: arange(c - w // 2, c + w // 2) -- one pixel up
+    and left of the data crop's grid (patch_offsets above) -- and the clamping of the vector indices (< 0 -> 0,
+    >= size -> last element)."""
+    H, W = window_size
+    meta = []
+    if meta_channels["portion_year"]:
+        meta.append(np.full((H, W), float(portion_year)))
+    if meta_channels["portion_day"]:
+        i = int(centre[1])
+        i = 0 if i < 0 else (-1 if i >= portion_day_vector.size else i)
+        t = portion_day_vector[i]
+        meta.append(np.full((H, W), np.sin(2 * np.pi * t)))
+        meta.append(np.full((H, W), np.cos(2 * np.pi * t)))
+    cols = np.arange(centre[1] - W // 2, centre[1] + W // 2)
+    rows = np.arange(centre[0] - H // 2, centre[0] + H // 2)
+    if meta_channels["time_diff"]:
+        idx = cols.copy()
+        idx[idx < 0] = 0
+        idx[idx >= time_vector_diff.size] = -1
+        meta.append(time_vector_diff[idx].reshape(1, -1) * np.ones((H, 1)))
+    if any(meta_channels[k] for k in ("depth_rel", "depth_abs_surface", "depth_abs_seabed")):
+        idx = cols.copy()
+        idx[idx < 0] = 0
+        idx[idx >= seabed.size] = -1
+        sb = seabed[idx].reshape(1, -1)
+        if meta_channels["depth_rel"]:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                meta.append(rows.reshape(-1, 1) / sb)
+        if meta_channels["depth_abs_surface"]:
+            meta.append(rows.reshape(-1, 1) * np.ones((1, W)) / H)
+        if meta_channels["depth_abs_seabed"]:
+            meta.append((sb - rows.reshape(-1, 1)) / H)
+    return np.stack(meta, 0)

@@ -161,9 +161,18 @@ def test_pr_report_csv_has_the_reference_dataframe_layout(tmp_path):
 
 
 def test_evaluate_flow_needs_the_reference_data_stack_or_injected_factories():
+    import inspect
     from crimac_classifiers_unet_amd import evaluate
     with pytest.raises(ImportError, match="dataset_cls"):
         evaluate.validate_model_survey_memm([], None, [], [256, 256], 20, "all", 4, 0, "/tmp", "/tmp")
+    with pytest.raises(ImportError, match="label_transform_factory"):
+        evaluate.validate_model_survey_zarr([1], None, [], [256, 256], 20, "all", 4, 0, "/tmp", "/tmp",
+                                            dataset_cls=object, data_transform_factory=lambda m: None)
+    # the product module never imports the reference package by itself: only from a path the caller names
+    src = inspect.getsource(evaluate)
+    assert "from batch" not in src and "import batch" not in src
+    with pytest.raises(ImportError, match="host data stack"):
+        evaluate.data_stack_factories("/nonexistent/path", memm=True)
 
 
 def test_spawned_ranks_time_out_and_are_reaped():

@@ -958,6 +958,59 @@ def test_evaluate_flow_writes_the_pr_report(tmp_path):
     assert abs(m2["F1"].max() - m["F1"].max()) < 1e-9
 
 
+def test_evaluate_main_mirrors_the_reference_cli_with_an_injected_data_stack(tmp_path):
+    """``python -m crimac_classifiers_unet_amd.evaluate`` (reference evaluate.py:120-167): yaml + command line ->
+    SegPipeUNet.load_model_params -> every evaluation survey of the partition -> <survey>_test.csv under
+    <save_path>/<experiment>/<checkpoint run>/; partition and Dataset factories injected."""
+    import csv
+    import yaml
+    from crimac_classifiers_unet_amd import evaluate
+
+    class GridDs(torch.utils.data.Dataset):
+        def __init__(self, reader, patch_size, frequencies, meta_channels=(), **kw):
+            self.items = _val_batches(2, seed0=reader)
+
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            b = self.items[i // 2]
+            return {k: v[i % 2].numpy() for k, v in b.items()}
+
+    class Partition:
+        def __init__(self, **cfg):
+            assert cfg["data_mode"] == "memm" and "checkpoint_path" in cfg
+            self.cfg = cfg
+
+        def get_evaluation_surveys(self):
+            return [2017, 2019]
+
+        def get_survey_readers(self, survey):
+            return [survey - 1300, survey - 1100]
+
+    cfg = _pipe_cfg(precision="h3p", data_mode="memm", num_workers=0, batch_size=2)
+    ypath = tmp_path / "exp7.yaml"
+    yaml.safe_dump(cfg, open(ypath, "w"))
+    run_dir = tmp_path / "runA"
+    run_dir.mkdir()
+    m = pkg.UNet_Baseline(3, 4)
+    m.load_state_dict(synth.synth_state_dict(seed=0))
+    torch.save(m.state_dict(), run_dir / "best.pt")
+    outm, outp = tmp_path / "metrics", tmp_path / "plots"
+    outm.mkdir(); outp.mkdir()
+    res = evaluate.main(["--yaml_path", str(ypath), "--checkpoint_path", str(run_dir / "best.pt"), "--save_path_metrics",
+                         str(outm), "--save_path_plot", str(outp)],
+                        data_partition_factory=Partition,
+                        factories=(GridDs, lambda use_meta: "DT", lambda **kw: "LT"))
+    assert sorted(res) == [2017, 2019]
+    for survey in (2017, 2019):
+        rows = list(csv.reader(open(outm / "exp7" / "runA" / f"{survey}_test.csv")))
+        assert rows[0] == ["", "precision", "recall", "thresholds", "F1"] and len(rows) == len(res[survey]["F1"]) + 1
+    with pytest.raises(SystemExit):          # no data stack named, nothing injected: refuses instead of importing on its own
+        evaluate.main(["--yaml_path", str(ypath), "--checkpoint_path", str(run_dir / "best.pt"), "--save_path_metrics",
+                       str(outm), "--save_path_plot", str(outp)])
+
+
 def test_f32h3_eval_is_fp32_class_and_train_step_matches_golden(full_case):
     """'f32h3': forward on two fp16 planes (3 MFMAs per product, ~2^-21), backward on the bf16 2-plane split.
     Forward parity like the 6-MFMA mode (<= 1e-3 bar, identical argmax masks); gradients like f32x3."""

@@ -50,6 +50,23 @@ def _worker(rank, world, port, results):
     except RuntimeError as e:            # a backend without reduce_scatter_tensor must say so, not corrupt data
         ok_grad = ok_grad and ("reduce_scatter" in str(e).lower() or "not supported" in str(e).lower()
                                or "unsupported" in str(e).lower())
+    # per-range completion (the optimiser step of a range runs while later ranges are still being exchanged)
+    for algo in ("all_reduce", "rs_ag"):
+        gs = parallel.GradSync(bucket_mb=0.001, algo=algo)
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        gs.launch(flat, 600, 1000)
+        gs.launch(flat, 0, 600)
+        sc = gs.finish_range(600, 1000)
+        ok_grad = ok_grad and bool(torch.equal(flat[600:], expect[600:])) and abs(sc - 1.0 / world) < 1e-12
+        gs.finish_range(0, 600)
+        ok_grad = ok_grad and bool(torch.equal(flat, expect))
+        try:
+            gs.finish_range(1, 2)
+            ok_grad = False
+        except RuntimeError:
+            pass
+        gs.finish()
+        ok_grad = ok_grad and gs.pending_ranges(1000) == [(0, 1000)]
     # SGD with grad_scale=1/world on the summed gradient == SGD on the mean gradient
     # inference: 7 "patches", each rank computes its shard, all-gather restores patch order
     n = 7

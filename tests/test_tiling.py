@@ -386,17 +386,21 @@ def _tiled_rank_worker(rank, world, port, out):
     model = pkg.UNet_Baseline(3, 4, precision="f32x6")
     model.load_state_dict(synth.synth_state_dict(seed=0))
     pipe = types.SimpleNamespace(model=model, device=torch.device("cuda"), frequencies=[18, 38, 120, 200])
-    chunks = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16))
+    chunks = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16, shard="patch"))
     if rank == 0:
         out["chunks"] = [(s, e, o.copy()) for s, e, o in chunks]
+    # chunk sharding: rank r owns chunks r, r + N, ...; no collective; together the ranks cover the survey once
+    mine = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16))
+    out[f"own{rank}"] = [(s, e, o.copy()) for s, e, o in mine]
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
 def test_two_ranks_share_the_patches_of_a_chunk_and_merge_exactly():
-    """SURVEY.md §8e inference partition: patch p of a chunk -> rank p % 2; the per-rank float16 outputs are summed
-    (disjoint interiors): bit-identical to the single-process result."""
+    """SURVEY.md §8e inference partition, both forms: patch p of a chunk -> rank p % 2, the per-rank float16 outputs
+    summed (disjoint interiors); and chunk c -> rank c % 2 with no collective at all.  Both bit-identical to the
+    single-process result."""
     import socket
     import types
     import torch.multiprocessing as mp
@@ -421,5 +425,103 @@ def test_two_ranks_share_the_patches_of_a_chunk_and_merge_exactly():
             p.join(300)
             assert p.exitcode == 0
         multi = out["chunks"]
+        own = [out["own0"], out["own1"]]
     for (s0, e0, o0), (s1, e1, o1) in zip(single, multi):
         assert (s0, e0) == (s1, e1) and np.array_equal(o0, o1) and (o0 != 0).any()
+    # chunk sharding: rank 0 produced chunk 0, rank 1 chunk 1, each bit-identical to the single-process result
+    assert [c[:2] for c in own[0]] == [single[0][:2]] and [c[:2] for c in own[1]] == [single[1][:2]]
+    assert np.array_equal(own[0][0][2], single[0][2]) and np.array_equal(own[1][0][2], single[1][2])
+
+
+# ---- metadata planes (late metadata injection) --------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fix_meta():
+    return np.load(os.path.join(ROOT, "tests", "golden", "meta_planes.npz"))
+
+
+def _meta_channels(name):
+    mc = {k: True for k in orc.META_KEYS}
+    if name == "subset":
+        mc.update(portion_day=False, depth_rel=False)
+    return mc
+
+
+@pytest.mark.parametrize("name", ["all", "subset"])
+def test_metadata_planes_oracle_matches_reference_golden(fix_meta, name):
+    """oracle/tiling_oracle.meta_planes == the reference's get_crop_memmap (tools/make_golden_meta.py: equal bit for bit
+    in float64 there; the fixture stores the float32 the batch is cast to)."""
+    for i, c in enumerate(fix_meta["centres"]):
+        got = orc.meta_planes(c, (256, 256), _meta_channels(name), float(fix_meta["portion_year"]), fix_meta["portion_day"],
+                              fix_meta["time_diff"], fix_meta["seabed"])
+        assert np.array_equal(got.astype(np.float32), fix_meta["planes_" + name][i], equal_nan=True)
+    got = orc.meta_planes(fix_meta["shallow_centre"], (256, 256), _meta_channels("all"), float(fix_meta["portion_year"]),
+                          fix_meta["portion_day"], fix_meta["time_diff"], fix_meta["shallow_seabed"])
+    assert np.array_equal(got.astype(np.float32), fix_meta["shallow_planes"], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["all", "subset"])
+def test_metadata_planes_kernel_matches_reference_golden(fix_meta, name):
+    """crimac_meta_planes (float64 arithmetic on the GPU, one rounding) == the reference's planes cast to float32: exact for
+    every plane but sin / cos of the time of day, where the device libm may differ from numpy's in the last bit."""
+    src = ti.MetaSource(_meta_channels(name), float(fix_meta["portion_year"]), fix_meta["portion_day"], fix_meta["time_diff"],
+                        fix_meta["seabed"], "cuda")
+    cen = torch.as_tensor(fix_meta["centres"].astype(np.int32)).cuda()
+    got = src.planes(cen, (256, 256)).cpu().numpy()
+    ref = fix_meta["planes_" + name]
+    assert got.shape == ref.shape
+    trig = [1, 2] if name == "all" else []
+    for c in range(ref.shape[1]):
+        if c in trig:
+            assert np.abs(got[:, c] - ref[:, c]).max() <= 1.2e-7
+        else:
+            assert np.array_equal(got[:, c], ref[:, c], equal_nan=True), c
+    with pytest.raises(ValueError):
+        ti.MetaSource({"portion_year": True}, 0.5, fix_meta["portion_day"], fix_meta["time_diff"], fix_meta["seabed"], "cuda")
+
+
+@pytest.mark.gpu
+def test_late_metadata_injection_through_tiled_inference_builds_the_planes_on_the_gpu():
+    """predict_echogram_memm with a UNet_LateMetInject model: the metadata planes of every crop come from
+    crimac_meta_planes.  Equal to feeding the SAME network the oracle's planes (reference semantics, golden above) crop by
+    crop and scattering with the oracle's fill_out_array."""
+    import types
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    sv, labels, seabed = synth_survey(n_pings=520, n_range=300, seed=21)
+    sv_hw, labels_hw = np.ascontiguousarray(sv.swapaxes(1, 2)), np.ascontiguousarray(labels.T)
+    seabed = np.clip(seabed, 40, 280)
+    eg = FakeEchogram(sv_hw, labels_hw, seabed)
+    rng = np.random.Generator(np.random.PCG64(9))
+    tv = 737000.5 + np.cumsum(rng.uniform(5e-6, 9e-6, size=520))
+    eg.portion_of_day_vector = tv % 1
+    eg.portion_of_year_scalar = 0.61
+    eg.time_vector_diff = np.concatenate((np.diff(tv), [tv[-1] - tv[-2]])) / 6e-6 - 1
+    mc = {k: True for k in orc.META_KEYS}
+    model = pkg.UNet_LateMetInject(3, 4, 7, precision="f32x6")
+    model.load_state_dict(synth.synth_state_dict(seed=3, meta_in_channels=7))
+    model.cuda().eval()
+    pipe = types.SimpleNamespace(model=model, device=torch.device("cuda"), frequencies=[18, 38, 120, 200])
+    out = ti.predict_echogram_memm(eg, pipe, (256, 256), 20, 4, meta_channels=mc)
+
+    def net(db, centre):
+        meta = orc.meta_planes(centre, (256, 256), mc, eg.portion_of_year_scalar, eg.portion_of_day_vector,
+                               eg.time_vector_diff, eg._seabed).astype(np.float32)
+        with torch.no_grad():
+            z = model(torch.from_numpy(db[None]).cuda(), torch.from_numpy(meta[None]).cuda())
+            return torch.softmax(z, 1)[0].cpu().numpy()
+
+    n_range, n_pings = eg.shape
+    grid = orc.get_data_grid(n_range, int(seabed.max()), 0, n_pings, (256, 256), 20)
+    ref = np.zeros([2, n_range, n_pings])
+    for c in grid:
+        c = np.array(c)
+        d = orc.crop(sv_hw, c, (256, 256), 0)
+        d = np.where(np.isfinite(d), d, d.dtype.type(0))
+        lab = orc.patch_labels(labels_hw, {"local": tuple(c), "global": tuple(c)}, (256, 256), seabed, n_range, 20, None,
+                               seabed_rule="memm")
+        db, _ = orc.data_transform(d)
+        db[:, lab == orc.LABEL_BOUNDARY_VAL] = 0.0
+        orc.fill_out_array(ref, net(db.astype(np.float32), c).astype(np.float16), lab, c, 0)
+    assert np.array_equal(out != 0, ref != 0) and (out != 0).any()
+    assert np.abs(out - ref).max() <= 2e-3                      # float16-rounded probabilities
