@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-tiled", action="store_true")
+    ap.add_argument("--no-wide", action="store_true", help="skip the configs[4] (wide net, fp16, GPU augmentation) leg")
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="only start the ranks, all-reduce their ids and print the census (tests/test_bench_spawn.py)")
     return ap.parse_args(argv)
@@ -77,9 +78,11 @@ def parse_args(argv=None):
 # ----------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle, "port")
 # ----------------------------------------------------------------------------------------------------------
-def cpu_baseline():
-    """Oracle train step and eval forward on the host cores, bounded to ~25 s (same synthetic
-    crops, B = 2 and B = 32, median after warm-ups; the B = 32 train step is a single iteration)."""
+def cpu_baseline(parity_check=None):
+    """Oracle train step and eval forward on the host cores, bounded to ~30 s (same synthetic
+    crops, B = 2 and B = 32, median after warm-ups; the B = 32 train step is a single iteration).
+    ``parity_check(x32, probs32) -> dict``: the oracle's B = 32 softmax output is handed to the caller, who compares the
+    GPU path in the parity precision with it on the same 32 crops (the oracle as the checker: no extra CPU time)."""
     import torch
     from crimac_classifiers_unet_amd import synth
     from oracle import unet_oracle as orc
@@ -109,11 +112,14 @@ def cpu_baseline():
                 ts.append(time.perf_counter() - t0)
         return ts
 
+    last = {}
+
     def infer_times(x, warm, iters):
         ts = []
         for i in range(warm + iters):
             t0 = time.perf_counter()
-            orc.predict(sd, x, return_softmax=True)
+            last["logits"] = orc.predict(sd, x, return_softmax=False)
+            torch.softmax(last["logits"], dim=1)
             if i >= warm:
                 ts.append(time.perf_counter() - t0)
         return ts
@@ -124,7 +130,8 @@ def cpu_baseline():
     x32, l32 = data(32)
     t_inf32 = statistics.median(infer_times(x32, 1, 2))
     t_train32 = train_times(x32, l32, 1, 1)[0]
-    return {"value": 2 / t_train2, "unit": "patches/s", "cores": cores, "kind": "port",
+    parity32 = parity_check(x32, last["logits"]) if parity_check is not None else None
+    return {"parity_batch32": parity32, "value": 2 / t_train2, "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": "oracle (torch CPU fp32) train step, batch 2 x 4x256x256, median of 5 after 2 warm-ups",
             "infer_value": 2 / t_inf2,
             "batch32": {"train_value": 32 / t_train32, "train_sample": "1 iteration after 1 warm-up",
@@ -421,6 +428,23 @@ def run_rank(args):
         parity["golden_parity"] = golden_parity(args.parity_precision, dev, log)
     main["golden_parity"] = golden_parity(args.precision, dev, log) if (args.start_filts == 64 and rank == 0) else None
 
+    wide = None
+    if world == 1 and not args.no_wide and args.start_filts == 64 and not args.gpu_augment:
+        # BASELINE configs[4] on one GPU, driver-timed: 2x channels, fp16 + MFMA with loss scaling, on-GPU add_noise / flip
+        torch.cuda.empty_cache()
+        wargs = argparse.Namespace(**vars(args))
+        wargs.start_filts, wargs.gpu_augment = 128, True
+        wres, wm = measure_mode(wargs, "fp16", 3, 2, world, rank, dev, grad_sync, infer=not args.no_infer, log=log)
+        del wm
+        torch.cuda.empty_cache()
+        wide = {"workload": "BASELINE configs[4] on ONE GPU: wide U-Net (depth 5, 128 filters), batch "
+                            f"{args.batch} x 4x256x256, fp16 + MFMA, dynamic loss scaling, on-GPU add_noise / flip / dB",
+                "train_patches_per_s": wres["train_patches_per_s"], "ms_per_step": wres["ms_per_step"],
+                "infer_patches_per_s": wres.get("infer_patches_per_s"), "train_tflops": wres["train_tflops"],
+                "skipped_steps": wres["skipped_steps"], "loss_scale": wres["loss_scale"],
+                "conv_frac_of_peak": wres["roofline"]["frac"], "wgrad_frac_of_peak": wres["roofline_wgrad"]["frac"],
+                "steps": 3, "warmup": 2}
+        log(f"wide fp16 (configs[4], 1 GPU): {wide['train_patches_per_s']:.0f} patches/s")
     if rank == 0:
         sf = args.start_filts
         rl = main["roofline"]
@@ -470,8 +494,31 @@ def run_rank(args):
             out["parity_mode"] = parity
         if tiled is not None:
             out["tiled"] = tiled
+        if wide is not None:
+            out["wide_fp16"] = wide
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            def parity32(x32, ref_logits):
+                """The parity precision on the 32 crops the oracle has just been timed on: logits rel, argmax flips and the
+                oracle's own top-2 margin at every flipped pixel (a flip below ~2e-6 is the oracle's fp32 round-off)."""
+                import torch
+                import crimac_classifiers_unet_amd as pkg
+                from crimac_classifiers_unet_amd import synth
+                m = pkg.UNet_Baseline(3, 4, precision=args.parity_precision)
+                m.load_state_dict(synth.synth_state_dict(seed=0))
+                m.to(dev).eval()
+                with torch.no_grad():
+                    got = m(x32.to(dev)).float().cpu()
+                diff = got.argmax(1) != ref_logits.argmax(1)
+                top2 = ref_logits.topk(2, dim=1).values
+                margins = (top2[:, 0] - top2[:, 1])[diff]
+                return {"precision": args.parity_precision, "crops": "32 x 4 x 256 x 256 (synthetic, seed 1) vs the CPU oracle",
+                        "pixels": int(diff.numel()), "logits_rel": float((got - ref_logits).abs().max() / ref_logits.abs().max()),
+                        "argmax_flips": int(diff.sum()), "oracle_top2_margin_at_flips": [float(v) for v in margins[:8]]}
+            cb = cpu_baseline(parity32 if (parity is not None and args.start_filts == 64) else None)
+            p32 = cb.pop("parity_batch32")
+            if p32 is not None:
+                out["parity_mode"]["batch32_vs_oracle"] = p32
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
