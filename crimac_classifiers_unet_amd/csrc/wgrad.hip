@@ -182,14 +182,17 @@ struct PpFrags {
   bf16x4 a[8][2];         // [F plane fragment: image * 4 + slot][read]
   bf16x4 b[2][2][2];      // [step parity][S fragment: hi, lo][read]
 };
-template <int RP, int FH>
+// NFW: F plane fragments per wave -- 8: all 64 F channels (fragment FH = image FH / 4, slot FH % 4); 2: the hi / lo
+// planes of ONE 16-channel fragment whose image and slot pair are folded into fv0 (the first-layer form below)
+template <int RP, int FH, int NFW = 8>
 __device__ __forceinline__ void pp_rd_a(unsigned fv0, PpFrags& f) {
-  f.a[FH][0] = lds_tr16_asm<(RP * 32) * 128 + (FH >> 2) * PP_F_IMG>(fv0 ^ ((FH & 3) << 5));
-  f.a[FH][1] = lds_tr16_asm<(RP * 32 + 8) * 128 + (FH >> 2) * PP_F_IMG>(fv0 ^ ((FH & 3) << 5));
+  constexpr int img_off = NFW == 8 ? (FH >> 2) * PP_F_IMG : 0;
+  f.a[FH][0] = lds_tr16_asm<(RP * 32) * 128 + img_off>(fv0 ^ ((FH & 3) << 5));
+  f.a[FH][1] = lds_tr16_asm<(RP * 32 + 8) * 128 + img_off>(fv0 ^ ((FH & 3) << 5));
 }
 // F plane fragment FH of step S (the 16-bit kernel's wg_fh with 8 fragments; even FH = hi plane: two MFMAs, with the lo
 // and the hi S fragment; odd FH = lo plane: one, with the hi S fragment)
-template <int TG, int S, int FH, typename ACC>
+template <int TG, int S, int FH, int NFW = 8, typename ACC>
 __device__ __forceinline__ void pp_fh(unsigned fv0, PpFrags& f, ACC& acc) {
   using G = WgTaps<0, TG>;
   constexpr int NSTEP = G::NRP * G::N, rp = S / G::N, L = S % G::N;
@@ -197,7 +200,7 @@ __device__ __forceinline__ void pp_fh(unsigned fv0, PpFrags& f, ACC& acc) {
   if constexpr (L == 0) {
     // (lgkmcnt is a 4-bit counter: where more than 15 reads would be allowed to stay in flight, waiting for 15 is the
     // conservative form -- it only asks for a few reads more than needed to have landed)
-    constexpr int allow = nb + (rp > 0 ? 2 * (7 - FH) : 0);
+    constexpr int allow = nb + (rp > 0 ? 2 * (NFW - 1 - FH) : 0);
     if constexpr (rp > 0 || FH == 0) wait_lgkm<(allow < 15 ? allow : 15)>();
     if constexpr (FH == 0) {
 #pragma unroll
@@ -206,7 +209,7 @@ __device__ __forceinline__ void pp_fh(unsigned fv0, PpFrags& f, ACC& acc) {
     if constexpr (rp > 0) { tie(f.a[FH][0]); tie(f.a[FH][1]); }
     else if constexpr (FH == 0) {
 #pragma unroll
-      for (int fh = 0; fh < 8; ++fh) { tie(f.a[fh][0]); tie(f.a[fh][1]); }
+      for (int fh = 0; fh < NFW; ++fh) { tie(f.a[fh][0]); tie(f.a[fh][1]); }
     }
   } else if constexpr (FH == 0) {
     wait_lgkm<nb>();
@@ -220,29 +223,38 @@ __device__ __forceinline__ void pp_fh(unsigned fv0, PpFrags& f, ACC& acc) {
     acc[L][FH >> 1] = E16<half_t>::mfma16(af, b_lo, acc[L][FH >> 1]);
   }
   acc[L][FH >> 1] = E16<half_t>::mfma16(af, b_hi, acc[L][FH >> 1]);
-  if constexpr (L == G::N - 1 && rp + 1 < G::NRP) pp_rd_a<rp + 1, FH>(fv0, f);
-  if constexpr (FH + 1 < 8) pp_fh<TG, S, FH + 1>(fv0, f, acc);
+  if constexpr (L == G::N - 1 && rp + 1 < G::NRP) pp_rd_a<rp + 1, FH, NFW>(fv0, f);
+  if constexpr (FH + 1 < NFW) pp_fh<TG, S, FH + 1, NFW>(fv0, f, acc);
 }
-template <int TG, int S, typename ACC>
+template <int TG, int S, int NFW = 8, typename ACC>
 __device__ __forceinline__ void pp_step(unsigned fv0, const unsigned (&sv)[4], PpFrags& f, ACC& acc) {
   using G = WgTaps<0, TG>;
   constexpr int NSTEP = G::NRP * G::N;
   if constexpr (S + 1 < NSTEP) wg_rd_b<0, TG, S + 1, false>(sv, f);
-  pp_fh<TG, S, 0>(fv0, f, acc);
-  if constexpr (S + 1 < NSTEP) pp_step<TG, S + 1>(fv0, sv, f, acc);
+  pp_fh<TG, S, 0, NFW>(fv0, f, acc);
+  if constexpr (S + 1 < NSTEP) pp_step<TG, S + 1, NFW>(fv0, sv, f, acc);
 }
 
+// NARROW: the first layer (S = the network input, 4 channels padded to 16: ONE 16-channel S fragment).  All 64 F channels
+// x 16 S channels x 9 taps per workgroup; the 8 waves split tap group x F image x F 16-channel fragment (2 plane fragments
+// and 3 MFMAs per tap step each): the launch is its F stream (dY: 256 bytes per pixel).
+template <bool NARROW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void wgrad_pp_kernel(WgradParams p) {
   constexpr int TR = 8;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NI = (2 * 16 + 2 * 23 + 7) / 8;        // DMA wave-instructions per wave and tile: 78 / 8 -> 10
+  constexpr int NSI = NARROW ? 1 : 2;                  // S images staged
+  constexpr int NDMA = 2 * 16 + NSI * 23;              // DMA wave-instructions per tile
+  constexpr int NI = (NDMA + 7) / 8;                   // ... per wave: 10 (7)
+  constexpr int NFW = NARROW ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ws = wave & 1, sa = (wave >> 1) & 1, tg = wave >> 2;
+  // roles: S image sa, S slot pair ws (NARROW: the one real S fragment for everybody, F image fi / fragment ff instead)
+  const int ws = NARROW ? 0 : (wave & 1), sa = NARROW ? 0 : ((wave >> 1) & 1), tg = wave >> 2;
+  const int ff = wave & 1, fi = (wave >> 1) & 1;
   // workgroup -> (64 x 64 channel tile, pixel split): as the 16-bit kernel (XCD-aware: equal id % 8 share an L2)
-  const int cs_tiles = p.CS / 64;
+  const int cs_tiles = NARROW ? 1 : p.CS / 64;
   const int ch_tiles = (p.CF / 64) * cs_tiles;
   int qt, split;
   if (p.nsplits % 8 == 0) {
@@ -279,13 +291,15 @@ void wgrad_pp_kernel(WgradParams p) {
     geo(k, is_s, img, row);
     const int u = c ^ (swz16(row) >> 4);                       // logical 16-byte unit this lane's LDS position holds
     const int su = (((u >> 2) * 2 + (u & 1)) << 1) | ((u >> 1) & 1);   // its source unit: group (2 fh + half), plane
-    lds_at[i] = k < 78 ? (is_s ? 2 * PP_F_IMG + img * PP_S_IMG + (row - sub) * 128 : img * PP_F_IMG + (row - sub) * 128) : -1;
+    lds_at[i] = k < NDMA ? (is_s ? 2 * PP_F_IMG + img * PP_S_IMG + (row - sub) * 128 : img * PP_F_IMG + (row - sub) * 128) : -1;
     if (!is_s) {
       const int ry = row >> 4, rx = row & 15;
       rel[i] = (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + 32 * img) * 4 + su * 16);
     } else {
       const int ry = (row * 3641) >> 16, rx = row - ry * 18;
-      rel[i] = row < 180 ? (unsigned)(((ry * (long)p.Wf + rx) * p.s_ld + cs0 + 32 * img) * 4 + su * 16) : OOB;
+      // NARROW: the pixel holds 16 channels = source units 0 .. 3 (slots 0, 1); the rest of the row is zero-filled
+      const bool real = row < 180 && (!NARROW || (u >> 2) == 0);
+      rel[i] = real ? (unsigned)(((ry * (long)p.Wf + rx) * p.s_ld + cs0 + 32 * img) * 4 + su * 16) : OOB;
     }
   }
   auto tile_origin = [&](long tile, long& b, int& y0, int& x0) {
@@ -307,7 +321,7 @@ void wgrad_pp_kernel(WgradParams p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = wave + 8 * i;
-      if (k >= 78) continue;                         // wave-uniform
+      if (k >= NDMA) continue;                       // wave-uniform
       bool is_s; int img, row;
       geo(k, is_s, img, row);
       if (!is_s) {
@@ -331,11 +345,12 @@ void wgrad_pp_kernel(WgradParams p) {
   auto run = [&](auto tgc) {
     constexpr int TG = decltype(tgc)::value;
     using G = WgTaps<0, TG>;
-    f32x4 acc[G::N][4];
+    constexpr int NFR = NFW / 2;                       // 16-channel F fragments of this wave: 4 (1)
+    f32x4 acc[G::N][NFR];
 #pragma unroll
     for (int t = 0; t < G::N; ++t)
 #pragma unroll
-      for (int fr = 0; fr < 4; ++fr)
+      for (int fr = 0; fr < NFR; ++fr)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][fr][r] = 0.f;
     const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
@@ -347,26 +362,31 @@ void wgrad_pp_kernel(WgradParams p) {
       __syncthreads();           // vmcnt(0) + barrier: the tile has landed for everyone, the other buffer is free
       if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
       const unsigned aF = lds0 + cur * PP_BUF, aS = aF + 2 * PP_F_IMG + sa * PP_S_IMG;
-      const unsigned fv0 = aF + RF * 128 + 8 * pp + swz16(RF);
+      // (NARROW: this wave's F image and 16-channel fragment -- slots 2 ff, 2 ff + 1 -- ride in the address)
+      const unsigned fv0 = aF + (NARROW ? fi * PP_F_IMG : 0) + ((RF * 128 + 8 * pp + swz16(RF)) ^ (NARROW ? ff << 6 : 0));
       unsigned sv[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) sv[k] = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(k + RSl));
       PpFrags f;
-      pp_rd_a<0, 0>(fv0, f); pp_rd_a<0, 1>(fv0, f); pp_rd_a<0, 2>(fv0, f); pp_rd_a<0, 3>(fv0, f);
-      pp_rd_a<0, 4>(fv0, f); pp_rd_a<0, 5>(fv0, f); pp_rd_a<0, 6>(fv0, f); pp_rd_a<0, 7>(fv0, f);
+      pp_rd_a<0, 0, NFW>(fv0, f); pp_rd_a<0, 1, NFW>(fv0, f);
+      if constexpr (!NARROW) {
+        pp_rd_a<0, 2>(fv0, f); pp_rd_a<0, 3>(fv0, f);
+        pp_rd_a<0, 4>(fv0, f); pp_rd_a<0, 5>(fv0, f); pp_rd_a<0, 6>(fv0, f); pp_rd_a<0, 7>(fv0, f);
+      }
       wg_rd_b<0, TG, 0, false>(sv, f);
-      pp_step<TG, 0>(fv0, sv, f, acc);
+      pp_step<TG, 0, NFW>(fv0, sv, f, acc);
     }
     // dw[t][cf][cs] += acc: F rows cf0 + 16 fr .. +15, S columns cs0 + 32 sa + 16 ws .. +15, this wave's taps
     float* dwp = p.dw + (p.partial_stride > 0 ? (long)split * p.partial_stride : 0);
     const int col = cs0 + sa * 32 + ws * 16 + (lane & 15);
+    const int fr0 = NARROW ? 2 * fi + ff : 0;          // (NARROW: this wave's one F fragment)
 #pragma unroll
     for (int t = 0; t < G::N; ++t)
 #pragma unroll
-      for (int fr = 0; fr < 4; ++fr)
+      for (int fr = 0; fr < NFR; ++fr)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = cf0 + fr * 16 + (lane >> 4) * 4 + r;
+          const int row = cf0 + (fr0 + fr) * 16 + (lane >> 4) * 4 + r;
           float* dst = dwp + ((long)(G::T0 + t) * p.CF + row) * p.CS + col;
           if (p.partial_stride > 0) *dst = acc[t][fr][r];
           else atomicAdd(dst, acc[t][fr][r]);
@@ -942,14 +962,18 @@ int launch(WgradParams p, int target_blocks, hipStream_t st) {
 
 int launch_pp(WgradParams p, int target_blocks, hipStream_t st) {
   plan_splits(p, 0, target_blocks, 2);           // (one 8-wave workgroup per CU, like the two-team kernel)
-  const int ch_tiles = (p.CF / 64) * (p.CS / 64);
+  const bool narrow = p.CS == 16;
+  const int ch_tiles = (p.CF / 64) * (narrow ? 1 : p.CS / 64);
   const size_t lds = 2 * (size_t)PP_BUF;
   static unsigned long long attr_devs = 0;
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   }
-  hipLaunchKernelGGL(wgrad_pp_kernel, dim3(ch_tiles * p.nsplits), dim3(512), lds, st, p);
+  if (narrow) hipLaunchKernelGGL(wgrad_pp_kernel<true>, dim3(ch_tiles * p.nsplits), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL(wgrad_pp_kernel<false>, dim3(ch_tiles * p.nsplits), dim3(512), lds, st, p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -958,7 +982,7 @@ int launch_pp(WgradParams p, int target_blocks, hipStream_t st) {
 // plane pairs, conv3x3, whole 64-channel tiles both ways, 32-bit DMA offsets inside a tile: the 8-wave kernel above
 bool pp_ok(int prec, int mode, int CF, int CS, long f_ld, long s_ld, int Wf) {
   static const int off = getenv("CRIMAC_WGRAD_PP") ? atoi(getenv("CRIMAC_WGRAD_PP")) == 0 : 0;
-  return !off && prec == CRIMAC_PREC_H3P && mode == 0 && CF % 64 == 0 && CS % 64 == 0 &&
+  return !off && prec == CRIMAC_PREC_H3P && mode == 0 && CF % 64 == 0 && (CS % 64 == 0 || CS == 16) &&
          (10L * Wf + 18) * (f_ld > s_ld ? f_ld : s_ld) * 4 < (1L << 31);
 }
 int teams_of(int prec, int mode) {

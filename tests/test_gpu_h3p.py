@@ -453,3 +453,60 @@ def test_training_trajectory_and_loss_scale_bookkeeping():
     assert eng.skipped_steps() == 0
     for a, b in zip(losses, fix["losses"]):
         assert abs(a - float(b)) < 2e-3 * abs(float(b))
+
+
+@pytest.mark.parametrize("cfg", [dict(in_channels=11), dict(depth=3), dict(depth=4, in_channels=6, start_filts=128),
+                                 dict(batch=1, hw=(16, 48)), dict(batch=5, hw=(80, 32))])
+def test_other_architectures_and_ragged_shapes_match_oracle(cfg):
+    """Away from the benchmark shape (metadata planes as input channels, shallower / wider nets, odd batches, the smallest
+    legal crop, non-square crops): eval logits and one training step against the oracle."""
+    from oracle import unet_oracle as orc
+    depth, cin, sf = cfg.get("depth", 5), cfg.get("in_channels", 4), cfg.get("start_filts", 64)
+    B = cfg.get("batch", 2)
+    H, W = cfg.get("hw", (32, 48))
+    sd = synth.synth_state_dict(in_channels=cin, depth=depth, start_filts=sf, seed=9)
+    x = torch.from_numpy(synth.synth_echogram_batch(B, cin, H, W, seed=91))
+    lab = torch.from_numpy(synth.synth_labels(B, H, W, seed=92))
+    m = pkg.UNet_Baseline(3, cin, depth=depth, start_filts=sf, precision="h3p")
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    assert _rel(out, orc.predict(sd, x)) < 1e-5
+    ref_loss, ref_logits, ref_grads, ref_stats = orc.loss_and_grads(sd, x, lab)
+    m.train()
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    logits = m(x.cuda())
+    loss = crit(logits, lab.long().cuda())
+    loss.backward()
+    assert _rel(logits.detach(), ref_logits) < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    g = {k: p.grad for k, p in m.named_parameters()}
+    deep = f"down_convs.{depth - 1}.main.3.weight"
+    for k in ("conv_final.weight", "down_convs.0.main.0.weight", deep, "up_convs.0.upconv.weight"):
+        assert _l2(g[k], ref_grads[k]) < (5e-2 if min(H, W) >> (depth - 1) <= 2 else 2e-2), k
+    assert m.engine.skipped_steps() == 0
+
+
+def test_tiled_inference_and_pipeline_surface_in_h3p():
+    """predict_survey (gather -> plane pairs, U-Net, softmax, scatter) in the parity precision against the oracle, and the
+    SegPipe surface: predict_batch + the yaml's `precision: 'h3p'`."""
+    import types
+    from crimac_classifiers_unet_amd import tiled_inference as ti
+    from oracle import tiling_oracle as torc, unet_oracle as orc
+    from tools.fake_reader import FakeZarrReader, synth_survey
+    sv, labels, seabed = synth_survey()
+    sv, labels, seabed = sv[:, :440, :300], labels[:440, :300], np.clip(seabed[:440], 0, 230)
+    reader = FakeZarrReader(sv, labels, seabed)
+    model = _model(seed=0)
+    sd = synth.synth_state_dict(seed=0)
+    pipe = types.SimpleNamespace(model=model, device=torch.device("cuda"), frequencies=[18, 38, 120, 200])
+    chunks = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 440))
+    assert len(chunks) == 1
+
+    def net(d):
+        return orc.predict(sd, torch.from_numpy(d[None]), return_softmax=True)[0].numpy()
+
+    ref, _ = torc.predict_chunk(sv, labels, seabed, 0, 440, net)
+    out = chunks[0][2]
+    assert np.array_equal(out != 0, ref != 0) and np.abs(out - ref).max() < 1e-5

@@ -80,7 +80,7 @@ def test_host_planners_match_oracle_and_reference(fix, survey):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["f32x6", "bf16"])
+@pytest.mark.parametrize("prec", ["f32x6", "bf16", "h3p"])
 def test_gather_patches_matches_oracle_crop_and_transform(survey, prec):
     from crimac_classifiers_unet_amd import hip
     from crimac_classifiers_unet_amd.hip import call, ptr
@@ -96,10 +96,14 @@ def test_gather_patches_matches_oracle_crop_and_transform(survey, prec):
     call("crimac_gather_patches", hip.PREC_NAMES[prec], ptr(data), 4, hi - lo, sv.shape[2], ptr(loc_d),
          len(centres), 256, 256, ptr(out), 16)
     torch.cuda.synchronize()
-    got = out.float().cpu().numpy().reshape(len(centres), 256, 256, 16)
+    if prec == "h3p":          # fp16 plane pairs: every 8-channel group holds [8 hi][8 lo], value = hi + lo
+        h = out.cpu().view(torch.float16).view(-1, 2, 2, 8).float()
+        got = (h[:, :, 0] + h[:, :, 1]).reshape(len(centres), 256, 256, 16).numpy()
+    else:
+        got = out.float().cpu().numpy().reshape(len(centres), 256, 256, 16)
     for i, c in enumerate(local):
         ref, _ = orc.data_transform(orc.crop(sv[:, lo:hi].swapaxes(1, 2), c, (256, 256), 0))
-        tol = 0.3 if prec == "bf16" else 2e-5          # bf16: 8 mantissa bits on values up to 75
+        tol = 0.3 if prec == "bf16" else (4e-5 if prec == "h3p" else 2e-5)    # bf16: 8 mantissa bits on values up to 75; plane pairs: 22
         assert np.abs(got[i, :, :, :4].transpose(2, 0, 1) - ref).max() < tol
         assert np.abs(got[i, :, :, 4:]).max() == 0
 
