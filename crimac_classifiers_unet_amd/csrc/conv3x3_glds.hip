@@ -27,6 +27,9 @@ CRIMAC_DIAG_DECLARE(crimac_diag_clock_conv)
 #ifndef CRIMAC_P64_HALO_AUX
 #define CRIMAC_P64_HALO_AUX 0      // cache policy of the halo loads (2: non-temporal)
 #endif
+#ifndef CRIMAC_W4_NSLOT64
+#define CRIMAC_W4_NSLOT64 3        // weight-ring slots of the 64-channel pixel-split kernel (the ring runs NSLOT - 1 taps ahead)
+#endif
 #ifndef CRIMAC_WCH_HALO_AUX
 #define CRIMAC_WCH_HALO_AUX 0
 #endif
@@ -121,7 +124,7 @@ template <int BN, typename T16, int MODE, typename TO = T16, bool PP = false>   
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 registers: 2 workgroups/CU
 void conv3x3_glds_w4_kernel(ConvParams p) {
   constexpr int NW = 4, NT = BN / 16;
-  constexpr int NSLOT = BN == 64 ? 3 : 2, AHEAD = NSLOT - 1;
+  constexpr int NSLOT = BN == 64 ? CRIMAC_W4_NSLOT64 : 2, AHEAD = NSLOT - 1;
   constexpr int B_BYTES = BN * RB;                 // weight slot: 8 / 16 KB
   constexpr int NB = (BN / 8) / NW;                // weight wave-instructions per wave and step: 2 / 4
   constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
@@ -250,7 +253,8 @@ void conv3x3_glds_w4_kernel(ConvParams p) {
   const int nsteps = kchunks * 9;
   issue_halo(0);
   issue_b(0, 0, 0);
-  if constexpr (AHEAD == 2) issue_b(0, 1, 1);
+  if constexpr (AHEAD >= 2) issue_b(0, 1, 1);
+  if constexpr (AHEAD >= 3) issue_b(0, 2, 2);
   wait_vmcnt<(AHEAD - 1) * NB>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -296,7 +300,7 @@ int launch_w4(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  const size_t lds = (size_t)A_BYTES + (BN == 64 ? 3 : 2) * BN * RB;
+  const size_t lds = (size_t)A_BYTES + (BN == 64 ? CRIMAC_W4_NSLOT64 : 2) * BN * RB;
   static_assert(BM / EpiPasses<TO>::value * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4 <= A_BYTES + 2 * BN * RB,
                 "epilogue staging must fit");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)

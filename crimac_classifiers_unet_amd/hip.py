@@ -114,7 +114,7 @@ class HipLibraryError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.environ.get("CRIMAC_LIB", _build.LIB_PATH)       # override: kernel experiments only
+    return os.environ.get("CRIMAC_LIB") or _build.LIB_PATH       # override: kernel experiments only
 
 
 def load_library():

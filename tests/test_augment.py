@@ -72,7 +72,7 @@ def test_reference_add_noise_has_the_same_distribution():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["f32x6", "bf16"])
+@pytest.mark.parametrize("prec", ["f32x6", "bf16", "h3p"])
 def test_gpu_augment_equals_oracle(prec):
     import crimac_classifiers_unet_amd as pkg
     rng = np.random.default_rng(5)
@@ -85,9 +85,13 @@ def test_gpu_augment_equals_oracle(prec):
     assert noisy.any() and (~noisy).any() and flipped.any() and (~flipped).any()
     m = pkg.UNet_Baseline(3, 4, precision=prec).cuda()
     x, lab = m.engine.augment_batch(torch.from_numpy(data).cuda(), torch.from_numpy(labels).cuda(), 0xC0FFEE1234)
-    got = x.float().cpu().numpy().reshape(B, H, W, 16)
+    if prec == "h3p":          # fp16 plane pairs: every 8-channel group holds [8 hi][8 lo], value = hi + lo
+        h = x.cpu().view(torch.float16).view(-1, 2, 2, 8).float()
+        got = (h[:, :, 0] + h[:, :, 1]).reshape(B, H, W, 16).numpy()
+    else:
+        got = x.float().cpu().numpy().reshape(B, H, W, 16)
     assert np.abs(got[..., 4:]).max() == 0
-    tol = 0.3 if prec == "bf16" else 2e-5
+    tol = 0.3 if prec == "bf16" else (4e-5 if prec == "h3p" else 2e-5)
     assert np.abs(got[..., :4].transpose(0, 3, 1, 2) - ref).max() < tol
     assert np.array_equal(lab.cpu().numpy(), ref_lab)
     # a training step on raw crops runs and lowers the loss on repetition

@@ -66,7 +66,7 @@ def test_pipeline_builds_the_late_injection_model():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("f32x6", 2e-5), ("bf16", 6e-2)])
+@pytest.mark.parametrize("precision,tol", [("f32x6", 2e-5), ("h3p", 2e-5), ("bf16", 6e-2)])
 def test_late_injection_hip_path_matches_reference_golden(case, precision, tol):
     fix, sd, x, meta, lab = case
     m = pkg.UNet_LateMetInject(3, 4, CM, precision=precision)
@@ -83,8 +83,8 @@ def test_late_injection_hip_path_matches_reference_golden(case, precision, tol):
     loss = crit(logits, lab.long().cuda())
     loss.backward()
     assert rel(logits.detach(), fix["logits_train"]) < tol
-    assert abs(float(loss) - float(fix["loss"])) < (1e-5 if precision == "f32x6" else 2e-2) * abs(float(fix["loss"]))
-    if precision != "f32x6":
+    assert abs(float(loss) - float(fix["loss"])) < (2e-2 if precision == "bf16" else 1e-5) * abs(float(fix["loss"]))
+    if precision == "bf16":
         return
     for k, p in m.named_parameters():
         if "grad/" + k in fix.files:
@@ -97,7 +97,9 @@ def test_late_injection_hip_path_matches_reference_golden(case, precision, tol):
     m2.cuda().train()
     l2 = m2.engine.train_step(x.cuda(), lab.cuda(), crit.weight, lr=0.0, momentum=0.0, meta=meta.cuda())
     assert abs(float(l2) - float(loss)) < 1e-6 * abs(float(loss))
-    g1, g2 = m.engine.G["post_processing_weights.main.2.weight"], m2.engine.G["post_processing_weights.main.2.weight"]
+    # (a loss-scaled precision leaves the flat gradient of the FUSED step scaled: SGD divides it out)
+    g1 = m.engine.G["post_processing_weights.main.2.weight"]
+    g2 = m2.engine.G["post_processing_weights.main.2.weight"] / m2.engine.loss_scale
     assert float((g1 - g2).norm() / g1.norm()) < 1e-3
 
 

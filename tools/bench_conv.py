@@ -31,16 +31,26 @@ def main():
     ap.add_argument("--nostat", action="store_true", help="conv without the fused BatchNorm statistics")
     a = ap.parse_args()
     P = hip.PREC_NAMES[a.prec]
-    dt = torch.bfloat16 if a.prec == "bf16" else torch.float32
+    dt = torch.bfloat16 if a.prec == "bf16" else (torch.float16 if a.prec == "fp16" else torch.float32)
+    hp = a.prec == "h3p"
+
+    def act(M, C):
+        """random activations in the precision's storage format (h3p: fp16 plane pairs [8 hi | 8 lo] per 8 channels)"""
+        v = torch.randn(M, C, device="cuda")
+        if not hp:
+            return v.to(dt)
+        hi = v.half()
+        lo = (v - hi.float()).half()
+        return torch.stack([hi.view(M, C // 8, 8), lo.view(M, C // 8, 8)], 2).contiguous().view(torch.float32).view(M, C)
     sel = [int(i) for i in a.layers.split(",")] if a.layers else range(len(LAYERS))
     B = a.batch
     tot_c = tot_w = 0.0
     for li in sel:
         name, H, Ci, Co = LAYERS[li]
         M = B * H * H
-        x = torch.randn(M, Ci, device="cuda").to(dt)
-        dy = torch.randn(M, Co, device="cuda").to(dt)
-        w_hi = torch.randint(-3000, 3000, (9 * Co * Ci,), dtype=torch.int16, device="cuda")
+        x = act(M, Ci)
+        dy = act(M, Co)
+        w_hi = torch.randint(-3000, 3000, ((2 if hp else 1) * 9 * Co * Ci,), dtype=torch.int16, device="cuda")
         w_lo = torch.randint(-3000, 3000, (9 * Co * Ci,), dtype=torch.int16, device="cuda")
         bias = torch.randn(Co, device="cuda")
         out = torch.empty(M, Co, device="cuda", dtype=dt)
