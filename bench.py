@@ -448,22 +448,32 @@ def run_rank(args):
     if rank == 0:
         sf = args.start_filts
         rl = main["roofline"]
-        pmc = load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json")
-        if pmc and args.precision == "bf16" and sf == 64:
-            sel = [v for k, v in pmc["kernels"].items() if k.startswith("conv3x3")]
-            nl = sum(v["launches"] for v in sel)
-            rl["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
-            rl["traffic_source"] = ("REPLAYED from the committed profile " + pmc.get("_file", "profiles/*_pmc_traffic.json") +
-                                    " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; "
-                                    "not observed in this run): HBM (L2-miss) bytes per launch")
-        util = load_profile_json("r02_mfma_util.json")
+        def replay(roof, roof_w, prec):
+            """HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) and MFMA busy fraction (SQ_VALU_MFMA_BUSY_CYCLES /
+            GRBM_GUI_ACTIVE pass) of the same command, from the committed profiles of this round -- labelled as replayed."""
+            pm = load_profile_json(f"r03_{prec}_pmc_traffic.json")
+            if pm:
+                for r_, pat in ((roof, "conv3x3"), (roof_w, "wgrad")):
+                    sel = [v for k, v in pm["kernels"].items() if k.startswith(pat)]
+                    nl = sum(v["launches"] for v in sel)
+                    r_["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
+                    r_["traffic_source"] = ("REPLAYED from the committed profile " + pm["_file"] + " (rocprofv3 --pmc FETCH_SIZE / "
+                                            "WRITE_SIZE passes of this command on the serialized step; FETCH_SIZE doubled per the "
+                                            "gfx950 correction; not observed in this run): HBM bytes per launch")
+            ut = load_profile_json(f"r03_{prec}_mfma_util.json")
+            if ut:
+                for r_, key in ((roof, "conv3x3"), (roof_w, "wgrad")):
+                    r_["mfma_busy_frac"] = ut.get(key, {}).get("mfma_busy_frac")
+                    r_["util_source"] = "REPLAYED from the committed profile " + ut["_file"] + " (not observed in this run): " + str(ut.get("note"))
+        if sf == 64 and args.precision in ("bf16", "h3p"):
+            replay(rl, main["roofline_wgrad"], args.precision)
+        if parity is not None and args.parity_precision in ("bf16", "h3p"):
+            replay(parity["roofline"], parity["roofline_wgrad"], args.parity_precision)
+        util = load_profile_json("r02_mfma_util.json")       # (round 2: in-kernel clocks of the bf16 kernels, unchanged since)
         if util and args.precision == "bf16" and sf == 64:
-            rl["mfma_busy_frac"] = util.get("conv3x3", {}).get("mfma_busy_frac")
             rl["clock_ghz"] = util.get("conv3x3", {}).get("clock_ghz")
-            rl["util_source"] = ("REPLAYED from the committed profile " + util.get("_file", "profiles/*_mfma_util.json") +
-                                 " (not observed in this run): " + str(util.get("note")))
-            main["roofline_wgrad"]["mfma_busy_frac"] = util.get("wgrad", {}).get("mfma_busy_frac")
             main["roofline_wgrad"]["clock_ghz"] = util.get("wgrad", {}).get("clock_ghz")
+            rl["clock_source"] = "REPLAYED from profiles/r02_inkernel_clock_*.json (diagnostic builds with s_memtime stamps)"
         workload = ("BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, batch 32 x 4x256x256 per GPU"
                     if sf == 64 else
                     f"BASELINE configs[4]: wide U-Net (depth 5, {sf} filters) train step, batch {args.batch} x 4x256x256 "
