@@ -31,6 +31,18 @@ struct EpiParams {
   long pool_ld;           //          nn.MaxPool2d behind the block, unet.py:85-86 -- no second pass over the output)
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0) -- here that means for the
+// ACKNOWLEDGEMENT of the tile's global stores: between the two slices of an fp32 tile (and in front of the statistics
+// flush) every wave of the workgroup sat through a store round trip.  What the staging tile needs is that every wave
+// has READ its part (its ds_reads have returned: the stores that consume them have issued); the stores themselves may
+// stay in flight.  (Phase stamps, 64 -> 64 @256x256 plane pairs: epilogue 16.2 k cycles per workgroup next to 13.8 k of
+// MFMA work.)
+__device__ __forceinline__ void epi_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // Accumulator access for the two MFMA shapes (C/D layouts: cdna_hip_programming.md §3):
 //   32x32x16: acc[MT][NT] of f32x16, row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane & 31
 //   16x16x32: acc[MT][NT] of f32x4,  row = (lane>>4)*4 + r,               col = lane & 15
@@ -84,7 +96,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
   for (int k = 0; k < 8; ++k) { d1[k] = 0.f; d2[k] = 0.f; }
 #pragma unroll
  for (int ps = 0; ps < PASSES; ++ps) {
-  if (ps > 0) __syncthreads();                                           // the previous slice has been stored
+  if (ps > 0) epi_barrier_lds();                                         // the previous slice has been read out (its stores may be in flight)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = wc * (NT * L::TS) + j * L::TS + L::col(lane);
@@ -109,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       }
     }
   }
-  __syncthreads();
+  epi_barrier_lds();
   if (mode == 1 && ps == PASSES - 1) {
     // rows live in registers and in the lane groups above the column lanes: fold with shuffles,
     // then one LDS add per column
@@ -128,7 +140,37 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       }
     }
   }
-  {
+  if constexpr (F32 && MODE != 2) {
+    // 4-byte outputs without the fused BatchNorm-backward sums: one 16-byte store per lane and CONSECUTIVE lanes on
+    // consecutive 16 bytes, so that a wave-instruction writes whole 128-byte lines.  (The 8-channels-per-thread form
+    // below writes a thread's 32 bytes as two instructions of 16 bytes at a 32-byte lane stride: every instruction
+    // touches twice the lines and fills each only half.)  fp32: a lane takes 4 channels; plane pairs: a PAIR of lanes takes
+    // an 8-channel group, the even lane stores its hi plane, the odd lane its lo plane.
+    constexpr int CPR4 = BN / 4;                // 16-byte pieces per row
+    constexpr int RPP4 = NTHREADS / CPR4;       // rows per store round
+    const int c4 = tid % CPR4, r0 = tid / CPR4;
+    TA* outp = reinterpret_cast<TA*>(e.out);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        outp + (((long)b * e.H + y0) * e.W + x0) * e.out_ld + n0, 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int UNR4 = HPO ? 4 : RPASS / RPP4;     // (plane pairs: 8 values + two planes live per row)
+#pragma unroll(UNR4)
+    for (int rr = 0; rr < RPASS / RPP4; ++rr) {
+      const int lrow = r0 + rr * RPP4, row = ps * RPASS + lrow;
+      const int ty = row >> 4, tx = row & 15;
+      const bool ok = FULL || ((y0 + ty < e.H) && (x0 + tx < e.W));
+      const int off = (int)(ok ? (unsigned)((((long)ty * e.W + tx) * e.out_ld + c4 * 4) * 4) : OOB);
+      if constexpr (HPO) {
+        float v[8];
+        load8(reinterpret_cast<const float*>(stage + lrow * STAGE_PITCH) + (c4 >> 1) * 8, v);
+        u32x4 hi, lo;
+        hp_split(v, hi, lo);
+        __builtin_amdgcn_raw_buffer_store_b128((c4 & 1) ? lo : hi, ro, off, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(stage + lrow * STAGE_PITCH) + c4 * 4), ro, off, 0, 0);
+      }
+    }
+  } else {
     constexpr int CPR = BN / 8;                 // 8-channel chunks per row
     constexpr int RPP = NTHREADS / CPR;         // rows per store round
     static_assert(RPP % 16 == 0 || 16 % RPP == 0, "a round covers whole image rows or a fraction of one");
@@ -247,7 +289,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
   }
  }   // passes
   if (mode) {
-    __syncthreads();
+    epi_barrier_lds();
     // thousands of workgroups add to the same N channels: spread them over replicas (the atomic
     // unit serialises same-address adds); the consumer sums the replicas
     const long rep = (long)(blockIdx.x % (unsigned)e.stat_replicas) * e.N;

@@ -7,13 +7,23 @@ from crimac_classifiers_unet_amd import hip
 from crimac_classifiers_unet_amd.hip import call, ptr
 lib = hip.load_library()
 rd = lib.crimac_diag_clock_conv_read; rd.argtypes = [C.c_void_p]; rd.restype = C.c_int
-B, P = 32, hip.PREC_NAMES["bf16"]
-for name, H, Ci, Co in [("e1c1 64->128@128", 128, 64, 128), ("e1c2 128->128@128", 128, 128, 128), ("d2c1 256->128@128", 128, 256, 128),
-                        ("e2c2 256->256@64", 64, 256, 256), ("e3c2 512->512@32", 32, 512, 512), ("d0c1 1024->512@32", 32, 1024, 512)]:
+PREC = sys.argv[1] if len(sys.argv) > 1 else "bf16"          # bf16 | h3p (plane pairs: chunks of 32 real channels)
+B, P = 32, hip.PREC_NAMES[PREC]
+HPM = PREC == "h3p"
+SHAPES = [("e1c1 64->128@128", 128, 64, 128), ("e1c2 128->128@128", 128, 128, 128), ("d2c1 256->128@128", 128, 256, 128),
+          ("e2c2 256->256@64", 64, 256, 256), ("e3c2 512->512@32", 32, 512, 512), ("d0c1 1024->512@32", 32, 1024, 512)]
+if HPM:
+    SHAPES = [("e0c2 64->64@256", 256, 64, 64), ("d3c1 128->64@256", 256, 128, 64)] + SHAPES
+for name, H, Ci, Co in SHAPES:
     M = B * H * H
-    x = torch.randn(M, Ci, device="cuda").bfloat16()
-    w = torch.randint(-3000, 3000, (9 * Co * Ci,), dtype=torch.int16, device="cuda")
-    bias = torch.randn(Co, device="cuda"); out = torch.empty(M, Co, device="cuda", dtype=torch.bfloat16)
+    if HPM:
+        v = torch.randn(M, Ci, device="cuda")
+        hi = v.half(); lo = (v - hi.float()).half()
+        x = torch.stack([hi.view(M, Ci // 8, 8), lo.view(M, Ci // 8, 8)], 2).contiguous().view(torch.float32).view(M, Ci)
+    else:
+        x = torch.randn(M, Ci, device="cuda").bfloat16()
+    w = torch.randint(-3000, 3000, ((2 if HPM else 1) * 9 * Co * Ci,), dtype=torch.int16, device="cuda")
+    bias = torch.randn(Co, device="cuda"); out = torch.empty(M, Co, device="cuda", dtype=torch.float32 if HPM else torch.bfloat16)
     st = torch.zeros(2, 64, Co, dtype=torch.float64, device="cuda")
     fn = lambda: call("crimac_conv3x3", P, ptr(x), Ci, B, H, H, Ci, Co, ptr(w), ptr(w), ptr(bias), ptr(out), Co, 0, 1,
                       ptr(st[0]), ptr(st[1]), 64, None, 0, None, 0)
@@ -27,8 +37,8 @@ for name, H, Ci, Co in [("e1c1 64->128@128", 128, 64, 128), ("e1c2 128->128@128"
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     buf = (C.c_ulonglong * (2 * 4096))(); assert rd(buf) == 0
-    nwg = min(1024, B * (H // 16) ** 2 * (Co // 128))
+    nwg = min(1024, B * (H // 16) ** 2 * max(Co // 128, 1))
     a = np.frombuffer(buf, dtype=np.uint64)[:4096].astype(np.float64).reshape(1024, 4)[:nwg]
-    m = np.median(a, axis=0); k = Ci // 64
+    m = np.median(a, axis=0); k = Ci // (32 if HPM else 64)
     print(f"{name:20s} {us:6.1f} us ({2.0 * 9 * Ci * Co * M / us / 1e6:6.0f} TFLOP/s) workgroup cycles: prologue {m[0]:6.0f} | halo waits {m[1]:6.0f} "
           f"({m[1] / k:5.0f}/chunk) | MFMA {m[2]:7.0f} ({m[2] / k:6.0f}/chunk; alone on the SIMD 9216) | epilogue {m[3]:6.0f} | sum {m.sum():7.0f}", flush=True)
