@@ -228,8 +228,13 @@ void upconv_wch_kernel(UpParams p) {
     constexpr int PASSES = EpiPasses<TO>::value, RPASS = BM / PASSES;
     constexpr int PITCH = BN * (int)sizeof(TS) + 16;
     TO* outp = reinterpret_cast<TO*>(p.out);
-    const int c8 = tid & 15, r0 = tid >> 4;          // 16 chunks of 8 columns per row, 16 rows per round
-    const int n = n0 + c8 * 8;
+    // 16-bit outputs: 16 lanes x 8 columns per row, 16 rows per round.  4-byte outputs (fp32 / plane pairs): 32 lanes
+    // x 16 BYTES per row, 8 rows per round -- consecutive lanes on consecutive 16 bytes (whole lines per wave-instruction,
+    // conv_epilogue.h); plane pairs: the even lane of a pair stores the hi plane of an 8-column group, the odd lane the lo
+    constexpr bool W4 = sizeof(TS) == 4;
+    constexpr int LPR = W4 ? 32 : 16, RPR = 256 / LPR;
+    const int cl = tid % LPR, r0 = tid / LPR;
+    const int n = n0 + (W4 ? (HPO ? (cl >> 1) * 8 : cl * 4) : cl * 8);
     const int ab = n / p.cout, co = n - ab * p.cout;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -247,22 +252,24 @@ void upconv_wch_kernel(UpParams p) {
           }
       }
       __syncthreads();
-#pragma unroll
-      for (int rr = 0; rr < RPASS / 16; ++rr) {
-        const int lrow = r0 + rr * 16, row = ps * RPASS + lrow;
+#pragma unroll(HPO ? 4 : RPASS / RPR)
+      for (int rr = 0; rr < RPASS / RPR; ++rr) {
+        const int lrow = r0 + rr * RPR, row = ps * RPASS + lrow;
         const int y = y0 + (row >> 4), x = x0 + (row & 15);
         if (y < p.H && x < p.W) {
           const long pix = ((long)b * 2 * p.H + 2 * y + (ab >> 1)) * (2 * p.W) + 2 * x + (ab & 1);
-          const TS* sp = reinterpret_cast<const TS*>(smem + lrow * PITCH) + c8 * 8;
           if constexpr (HPO) {
             float v[8];
-            load8(sp, v);
-            store8(outp + pix * p.out_ld + co, v);
-          } else if constexpr (sizeof(TS) == 4) {
-            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) = *reinterpret_cast<const u32x4*>(sp);
-            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co + 4) = *reinterpret_cast<const u32x4*>(sp + 4);
+            load8(reinterpret_cast<const float*>(smem + lrow * PITCH) + (cl >> 1) * 8, v);
+            u32x4 hi, lo;
+            hp_split(v, hi, lo);
+            *(reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) + (cl & 1)) = (cl & 1) ? lo : hi;
+          } else if constexpr (W4) {
+            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) =
+                *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(smem + lrow * PITCH) + cl * 4);
           } else {
-            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) = *reinterpret_cast<const u32x4*>(sp);
+            *reinterpret_cast<u32x4*>(outp + pix * p.out_ld + co) =
+                *reinterpret_cast<const u32x4*>(reinterpret_cast<const TS*>(smem + lrow * PITCH) + cl * 8);
           }
         }
       }

@@ -510,3 +510,37 @@ def test_tiled_inference_and_pipeline_surface_in_h3p():
     ref, _ = torc.predict_chunk(sv, labels, seabed, 0, 440, net)
     out = chunks[0][2]
     assert np.array_equal(out != 0, ref != 0) and np.abs(out - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (2, 16, 16, 16, 64), (1, 32, 32, 64, 32)])
+def test_reproducible_weight_gradients_in_h3p(shape):
+    """crimac_wgrad_partials (one slab per pixel split by plain stores, ordered sum in crimac_unpack_wgrad_layers) with
+    plane-pair operands -- the 8-wave kernel, its first-layer form and the register-staged fallback: two runs
+    bit-identical, equal to the torch reference."""
+    import ctypes
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(41)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g))
+    dy = hp_round(torch.randn(B, Co, H, W, generator=g) * 30)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), dy.double(), padding=1).float()
+    dyn, xn = to_nhwc_hp(dy), to_nhwc_hp(x)
+    lib = hip.load_library()
+    n = 9 * Co * Ci
+    outs = []
+    for target in (0, 6):
+        sp = lib.crimac_wgrad_splits(P, 0, Co, Ci, B, H, W, target)
+        assert sp >= 1
+        stride = n + 64
+        for rep in range(2):
+            slabs = torch.full((sp * stride,), float("nan"), dtype=torch.float32, device="cuda")
+            call("crimac_wgrad_partials", P, 0, ptr(dyn), Co, Co, ptr(xn), Ci, Ci, B, H, W, ptr(slabs), stride, target)
+            grad = torch.zeros(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+            d = (hip.LayerDesc * 1)()
+            d[0].grad, d[0].dw, d[0].kind = grad.data_ptr(), slabs.data_ptr(), 0
+            d[0].Co, d[0].Ci, d[0].Ci_pad = Co, Ci, Ci
+            d[0].dw_splits, d[0].dw_stride = sp, stride
+            call("crimac_unpack_wgrad_layers", ctypes.byref(d), 1)
+            torch.cuda.synchronize()
+            outs.append(grad.cpu())
+        assert torch.equal(outs[-1], outs[-2])
+        assert relerr(outs[-1], ref) < 2 * TOL
