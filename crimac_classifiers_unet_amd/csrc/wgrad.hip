@@ -245,7 +245,14 @@ void wgrad_pp_kernel(WgradParams p) {
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NSI = NARROW ? 1 : 2;                  // S images staged
   constexpr int NDMA = 2 * 16 + NSI * 23;              // DMA wave-instructions per tile
-  constexpr int NI = (NDMA + 7) / 8;                   // ... per wave: 10 (7)
+  // Who moves the tiles.  All 8 waves (DW = 8): after the barrier both waves of a SIMD issue their DMA share and THEN
+  // both contract -- the SIMD's MFMA pipe idles through the issue phase.  Only waves 4-7 (DW = 4, the tap group with 4 of
+  // the 9 taps): while they issue the whole tile's DMA their SIMD partners (waves 0-3, 5 taps) already contract.
+#ifndef CRIMAC_WGRAD_PP_DMA_WAVES
+#define CRIMAC_WGRAD_PP_DMA_WAVES 4
+#endif
+  constexpr int DW = NARROW ? 8 : CRIMAC_WGRAD_PP_DMA_WAVES;
+  constexpr int NI = (NDMA + DW - 1) / DW;             // ... per moving wave
   constexpr int NFW = NARROW ? 2 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -286,7 +293,7 @@ void wgrad_pp_kernel(WgradParams p) {
   };
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int k = wave + 8 * i;
+    const int k = (wave & (DW - 1)) + DW * i;
     bool is_s; int img, row;
     geo(k, is_s, img, row);
     const int u = c ^ (swz16(row) >> 4);                       // logical 16-byte unit this lane's LDS position holds
@@ -320,7 +327,7 @@ void wgrad_pp_kernel(WgradParams p) {
         const_cast<hp_t*>(sp + ((b * p.Hf + y0 - 1) * (long)p.Wf + x0 - 1) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int k = wave + 8 * i;
+      const int k = (wave & (DW - 1)) + DW * i;
       if (k >= NDMA) continue;                       // wave-uniform
       bool is_s; int img, row;
       geo(k, is_s, img, row);
@@ -356,11 +363,12 @@ void wgrad_pp_kernel(WgradParams p) {
     const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
     const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
     const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
-    if (t_begin < t_end) issue_tile(t_begin, 0);
+    const bool mover = DW == 8 || wave >= 4;
+    if (t_begin < t_end && mover) issue_tile(t_begin, 0);
     for (long tile = t_begin; tile < t_end; ++tile) {
       const int cur = (int)((tile - t_begin) & 1);
       __syncthreads();           // vmcnt(0) + barrier: the tile has landed for everyone, the other buffer is free
-      if (tile + 1 < t_end) issue_tile(tile + 1, cur ^ 1);
+      if (tile + 1 < t_end && mover) issue_tile(tile + 1, cur ^ 1);
       const unsigned aF = lds0 + cur * PP_BUF, aS = aF + 2 * PP_F_IMG + sa * PP_S_IMG;
       // (NARROW: this wave's F image and 16-channel fragment -- slots 2 ff, 2 ff + 1 -- ride in the address)
       const unsigned fv0 = aF + (NARROW ? fi * PP_F_IMG : 0) + ((RF * 128 + 8 * pp + swz16(RF)) ^ (NARROW ? ff << 6 : 0));
