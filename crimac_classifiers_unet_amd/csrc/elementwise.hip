@@ -285,13 +285,100 @@ __global__ __launch_bounds__(256) void sum_replicas_kernel(const double* __restr
   if (dst32) dst32[i] = (float)s;
 }
 
+// ---- training-mode BatchNorm statistics finished INSIDE the consumer -------------------------------------------
+// (no bn_finalize / sum_replicas launch between the convolution and the kernel that applies the statistics: 36 launches
+// of a step and their dependency bubbles.)  Every workgroup sums the producer's `nrep` replica accumulators of all C
+// channels itself -- C x nrep x 16 bytes out of L2, the engine keeps C x nrep <= 4096 -- and holds the per-channel
+// constants in LDS; workgroup 0 also writes them out (the backward pass reads them) and updates the running statistics.
+// All workgroups add in the same order: every one of them sees the same constants.
+struct BnFin {
+  const double* sum; const double* sumsq;   // [nrep][C]
+  int nrep;
+  long count;                               // pixels the sums were taken over
+  const float* gamma; const float* beta;
+  float eps, momentum;
+  float* rmean; float* rvar; long long* nbt;   // running statistics (may be null)
+  float* vec; long stride;                  // rows mean | invstd | scale | shift, row stride `stride`
+};
+// sums of two replica arrays for all C channels; every thread of the 256-thread block calls it; `red`: 512 doubles of
+// LDS.  fn(c, s1, s2) runs once per channel (by one thread of the block).
+template <typename F>
+__device__ __forceinline__ void replica_sums_block(const double* __restrict__ a, const double* __restrict__ b, int nrep,
+                                                   int C, double* red, F&& fn) {
+  const int tid = threadIdx.x;
+  const int k = C >= 256 ? 1 : 256 / C;          // threads per channel
+  for (int cb = 0; cb < C; cb += 256) {
+    const int c = cb + (k == 1 ? tid : tid % C), j = k == 1 ? 0 : tid / C;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C && j < k) {
+      // all of a batch's loads are issued before the first add: one memory latency per 8 replicas, not one per replica
+      // (the accumulators were filled by memory-side atomics: these reads miss the L2)
+      constexpr int NB = 8;
+      int r = j;
+      for (; r + (NB - 1) * k < nrep; r += NB * k) {
+        double v1[NB], v2[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { v1[u] = a[(long)(r + u * k) * C + c]; v2[u] = b[(long)(r + u * k) * C + c]; }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { s1 += v1[u]; s2 += v2[u]; }
+      }
+      double w1[NB], w2[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const bool in = r + u * k < nrep;
+        w1[u] = in ? a[(long)(r + u * k) * C + c] : 0.0;
+        w2[u] = in ? b[(long)(r + u * k) * C + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { s1 += w1[u]; s2 += w2[u]; }
+    }
+    if (k > 1) {
+      red[tid] = s1;
+      red[256 + tid] = s2;
+      __syncthreads();
+      if (j == 0 && c < C) {
+        s1 = 0.0; s2 = 0.0;
+        for (int q = 0; q < k; ++q) { s1 += red[q * C + c]; s2 += red[256 + q * C + c]; }
+      }
+    }
+    if (j == 0 && c < C) fn(c, s1, s2);
+  }
+}
+// cst: [4][C] floats of LDS (mean | invstd | scale | shift), valid after the call (it ends with a barrier)
+__device__ __forceinline__ void bn_fin_block(const BnFin& a, int C, float* cst, double* red) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.nbt) *a.nbt += 1;
+  const bool writer = blockIdx.x == 0;
+  replica_sums_block(a.sum, a.sumsq, a.nrep, C, red, [&](int c, double s1, double s2) {
+    const double mean = s1 / (double)a.count;
+    double var = s2 / (double)a.count - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float sc = a.gamma[c] * invstd;
+    const float sh = a.beta[c] - (float)mean * sc;
+    cst[c] = (float)mean; cst[C + c] = invstd; cst[2 * C + c] = sc; cst[3 * C + c] = sh;
+    if (writer) {
+      a.vec[c] = (float)mean; a.vec[a.stride + c] = invstd; a.vec[2 * a.stride + c] = sc; a.vec[3 * a.stride + c] = sh;
+      if (a.rmean) {
+        const double unb = a.count > 1 ? var * ((double)a.count / (double)(a.count - 1)) : var;
+        a.rmean[c] = (1.f - a.momentum) * a.rmean[c] + a.momentum * (float)mean;
+        a.rvar[c] = (1.f - a.momentum) * a.rvar[c] + a.momentum * (float)unb;
+      }
+    }
+  });
+  __syncthreads();
+}
+
 // ---- BN apply (+ReLU) (+2x2 max-pool) -------------------------------------------------------------
 // T: storage type of the convolution output y; TO: of the activation (H3P: fp32 in, fp16 plane pairs out)
-template <typename T, typename TO = T>
+// FIN: scale / shift come from the producer's replica accumulators (bn_fin_block) instead of two finished vectors
+template <typename T, typename TO = T, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, long y_ld,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
-                                                     TO* __restrict__ out, long out_ld, long M, int C) {
+                                                     TO* __restrict__ out, long out_ld, long M, int C, BnFin fin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bn_smem[];
+  float* cst = reinterpret_cast<float*>(bn_smem + 512 * sizeof(double));
+  if constexpr (FIN) bn_fin_block(fin, C, cst, reinterpret_cast<double*>(bn_smem));
   // thread -> fixed 8-channel chunk (its scale/shift live in registers), rows strided over the grid
   const int cpr = C / 8;
   const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
@@ -301,8 +388,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sc[j] = scale ? scale[c0 + j] : 1.f;
-    sh[j] = scale ? shift[c0 + j] : 0.f;
+    if constexpr (FIN) {
+      sc[j] = cst[2 * C + c0 + j];
+      sh[j] = cst[3 * C + c0 + j];
+    } else {
+      sc[j] = scale ? scale[c0 + j] : 1.f;
+      sh[j] = scale ? shift[c0 + j] : 0.f;
+    }
   }
   const long stride = (long)gridDim.x * rpi;
   constexpr int U = 4;
@@ -324,13 +416,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
   }
 }
 
-template <typename T, typename TO = T>
+template <typename T, typename TO = T, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ y, long y_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu,
                                                           TO* __restrict__ out, long out_ld,
                                                           TO* __restrict__ pool, long pool_ld, int B,
-                                                          int H, int W, int C) {
+                                                          int H, int W, int C, BnFin fin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bn_smem[];
+  float* cst = reinterpret_cast<float*>(bn_smem + 512 * sizeof(double));
+  if constexpr (FIN) bn_fin_block(fin, C, cst, reinterpret_cast<double*>(bn_smem));
   const int cpr = C / 8;
   const int Hp = H / 2, Wp = W / 2;
   const long total = (long)B * Hp * Wp * cpr;
@@ -345,8 +440,13 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
     float sc[8], sh[8], mx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      sc[j] = scale ? scale[c0 + j] : 1.f;
-      sh[j] = scale ? shift[c0 + j] : 0.f;
+      if constexpr (FIN) {
+        sc[j] = cst[2 * C + c0 + j];
+        sh[j] = cst[3 * C + c0 + j];
+      } else {
+        sc[j] = scale ? scale[c0 + j] : 1.f;
+        sh[j] = scale ? shift[c0 + j] : 0.f;
+      }
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -577,13 +677,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 // The same without the (never used) pre-BatchNorm bias gradient: a pure streaming kernel like bn_act_kernel --
 // thread-fixed channel chunk, constants in registers, U rows in flight, no LDS, no reduction tail.
-template <typename T, typename TD = T>
+// REP: sum_dz / sum_dzx are the producer's `nrep` replica accumulators [nrep][C] (no sum_replicas launch in between):
+// every workgroup adds them up itself (replica_sums_block), workgroup 0 writes the gamma / beta gradients
+template <typename T, typename TD = T, bool REP = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, long M, long count, int C,
-    TD* __restrict__ dy, long dy_ld, float* dgamma, float* dbeta) {
-  if (blockIdx.x == 0) {
+    TD* __restrict__ dy, long dy_ld, float* dgamma, float* dbeta, int nrep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bn_smem[];
+  float* k12 = reinterpret_cast<float*>(bn_smem + 512 * sizeof(double));      // [2][C]
+  const double invM = 1.0 / (double)count;
+  if constexpr (REP) {
+    const bool writer = blockIdx.x == 0;
+    replica_sums_block(sum_dz, sum_dzx, nrep, C, reinterpret_cast<double*>(bn_smem), [&](int c, double s1, double s2) {
+      k12[c] = (float)(s1 * invM);
+      k12[C + c] = (float)(s2 * invM);
+      if (writer) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+    });
+    __syncthreads();
+  } else if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
       dgamma[c] = (float)sum_dzx[c];
       dbeta[c] = (float)sum_dz[c];
@@ -594,13 +707,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
   const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   if (rl >= rpi) return;
   const int c0 = chunk * 8;
-  const double invM = 1.0 / (double)count;
   float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
-    k1[j] = (float)(sum_dz[c0 + j] * invM);
-    k2[j] = (float)(sum_dzx[c0 + j] * invM);
+    if constexpr (REP) {
+      k1[j] = k12[c0 + j];
+      k2[j] = k12[C + c0 + j];
+    } else {
+      k1[j] = (float)(sum_dz[c0 + j] * invM);
+      k2[j] = (float)(sum_dzx[c0 + j] * invM);
+    }
   }
   const long stride = (long)gridDim.x * rpi;
   constexpr int U = 4;
@@ -1180,19 +1297,20 @@ extern "C" int crimac_bn_finalize(const double* sum, const double* sumsq, int re
 
 static int colreduce_grid(long M, int C);
 
-template <typename T, typename TO = T>
+template <typename T, typename TO = T, bool FIN = false>
 static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, const float* shift,
                               int relu, void* out, long out_ld, void* pool_out, long pool_ld, int B,
-                              int H, int W, int C, hipStream_t st) {
+                              int H, int W, int C, hipStream_t st, BnFin fin = BnFin{}) {
+  const size_t lds = FIN ? 512 * sizeof(double) + 4 * (size_t)C * sizeof(float) : 0;
   if (pool_out) {
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO>), dim3(grid_for(total, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO, FIN>), dim3(grid_for(total, 256)), dim3(256), lds, st,
                        (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, (TO*)pool_out, pool_ld, B,
-                       H, W, C);
+                       H, W, C, fin);
   } else {
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL((bn_act_kernel<T, TO>), dim3(colreduce_grid(M, C)), dim3(256), 0, st,
-                       (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, M, C);
+    hipLaunchKernelGGL((bn_act_kernel<T, TO, FIN>), dim3(colreduce_grid(M, C)), dim3(256), lds, st,
+                       (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, M, C, fin);
   }
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1218,6 +1336,33 @@ extern "C" int crimac_bn_act_pool(int prec, const void* y, long y_ld, const floa
   }
   CRIMAC_FOR_STORAGE(prec, T, return bn_act_pool_launch<T>(y, y_ld, scale, shift, relu, out, out_ld, pool_out, pool_ld,
                                                            B, H, W, C, ST));
+}
+
+// Training-mode BatchNorm + ReLU (+ 2x2 max-pool) straight from the convolution epilogue's replica accumulators:
+// crimac_bn_finalize and crimac_bn_act_pool in one launch (bn_fin_block above).
+extern "C" int crimac_bn_train_act_pool(int prec, const void* y, long y_ld, const double* stat_sum,
+                                        const double* stat_sumsq, int replicas, long count, const float* gamma,
+                                        const float* beta, float eps, float momentum, float* running_mean,
+                                        float* running_var, long long* num_batches_tracked, float* bn_vec,
+                                        long bn_stride, int relu, void* out, long out_ld, void* pool_out,
+                                        long pool_ld, int B, int H, int W, int C, void* stream) {
+  PREC_OK("bn_train_act_pool");
+  CRIMAC_REQUIRE(y && (out || pool_out) && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                 "bn_train_act_pool: bad arguments");
+  CRIMAC_REQUIRE(stat_sum && stat_sumsq && replicas >= 1 && count > 0 && gamma && beta && bn_vec && bn_stride >= C,
+                 "bn_train_act_pool: bad statistics arguments");
+  CRIMAC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_act_pool: running stats");
+  CRIMAC_REQUIRE(y_ld >= C && y_ld % 8 == 0 && (!out || (out_ld >= C && out_ld % 8 == 0)) &&
+                     (!pool_out || (pool_ld >= C && pool_ld % 8 == 0)),
+                 "bn_train_act_pool: bad pixel strides");
+  CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0), "bn_train_act_pool: pooling needs even H, W");
+  const BnFin fin{stat_sum, stat_sumsq, replicas, count, gamma, beta, eps, momentum, running_mean, running_var,
+                  num_batches_tracked, bn_vec, bn_stride};
+  if (prec == CRIMAC_PREC_H3P)
+    return bn_act_pool_launch<float, hp_t, true>(y, y_ld, nullptr, nullptr, relu, out, out_ld, pool_out, pool_ld, B, H, W,
+                                                 C, ST, fin);
+  CRIMAC_FOR_STORAGE(prec, T, return (bn_act_pool_launch<T, T, true>(y, y_ld, nullptr, nullptr, relu, out, out_ld, pool_out,
+                                                                      pool_ld, B, H, W, C, ST, fin)));
 }
 
 static bool bnb_args_ok(const void* y, long y_ld, const float* vec, long stride, double* s0, double* s1, int replicas,
@@ -1290,11 +1435,34 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
   if (!dbias && stream_form && C <= 2048)
     CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD>), dim3(grid), dim3(256), 0, ST,
                                                    (const T*)da, da_ld, (const T*)y, y_ld, scale, shift, mean, invstd,
-                                                   sum_dz, sum_dz_xhat, M, count, C, (TD*)dy, dy_ld, dgamma, dbeta));
+                                                   sum_dz, sum_dz_xhat, M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, 1));
   else
     CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TD>), dim3(grid), dim3(256), lds, ST, (const T*)da,
                                                    da_ld, (const T*)y, y_ld, scale, shift, mean, invstd, sum_dz,
                                                    sum_dz_xhat, M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, dbias));
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+// BatchNorm + ReLU backward straight from the producers' replica accumulators of (sum dz, sum dz*xhat):
+// crimac_sum_replicas and crimac_bn_bwd_apply in one launch.  bn_vec: rows mean | invstd | scale | shift.
+extern "C" int crimac_bn_bwd_apply_replicas(int prec, const void* da, long da_ld, const void* y, long y_ld,
+                                            const float* bn_vec, long bn_stride, const double* sum_dz,
+                                            const double* sum_dz_xhat, int replicas, long M, long count, int C,
+                                            void* dy, long dy_ld, float* dgamma, float* dbeta, void* stream) {
+  PREC_OK("bn_bwd_apply_replicas");
+  CRIMAC_REQUIRE(da && y && bn_vec && bn_stride >= C && sum_dz && sum_dz_xhat && replicas >= 1 && dy && dgamma &&
+                     dbeta && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (count == 0 || count >= M),
+                 "bn_bwd_apply_replicas: bad arguments");
+  if (count == 0) count = M;
+  CRIMAC_REQUIRE(da_ld >= C && y_ld >= C && dy_ld >= C && da_ld % 8 == 0 && y_ld % 8 == 0 && dy_ld % 8 == 0,
+                 "bn_bwd_apply_replicas: bad pixel strides");
+  const int grid = colreduce_grid(M, C);
+  const size_t lds = 512 * sizeof(double) + 2 * (size_t)C * sizeof(float);
+  CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD, true>), dim3(grid), dim3(256), lds,
+                                                 ST, (const T*)da, da_ld, (const T*)y, y_ld, bn_vec + 2 * bn_stride,
+                                                 bn_vec + 3 * bn_stride, bn_vec, bn_vec + bn_stride, sum_dz, sum_dz_xhat,
+                                                 M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, replicas));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

@@ -244,6 +244,22 @@ class UNetEngine:
         o = (b.idx * 4 + k) * self.cmax
         return self.bnf[o:o + b.cout]
 
+    # BatchNorm statistics are finished INSIDE the kernel that applies them (crimac_bn_train_act_pool,
+    # crimac_bn_bwd_apply_replicas): no bn_finalize / sum_replicas launch between a convolution and its consumer (36
+    # launches of a step and their dependency bubbles).  Every consumer workgroup then reads replicas x C fp64 pairs
+    # from L2, so wide layers use fewer replicas (they also have fewer producer workgroups per address): replicas x C <= 4096 is
+    # 16 pairs per thread, one batch of loads.
+    fold_bn_finalize = os.environ.get("CRIMAC_FOLD_BNFIN", "1") != "0"
+
+    def _nrep(self, c):
+        """Replica accumulators a producer spreads the per-channel sums of a c-channel BatchNorm layer over."""
+        if not self.fold_bn_finalize:
+            return STAT_REPLICAS
+        r = STAT_REPLICAS
+        while r > 4 and r * c > 4096:
+            r //= 2
+        return r
+
     # Reproducible weight gradients (opt-in): crimac_wgrad_partials writes one slab per pixel split by plain stores
     # (no atomics, no zero fill) and crimac_unpack_wgrad_layers adds the slabs up in a fixed order, so the 31 M
     # weight gradients are bit-identical run to run.  Measured at B = 32 (profiles/r02_wgrad_partials_ab.txt): the
@@ -507,7 +523,7 @@ class UNetEngine:
     fuse_head_bn = fuse_bn_bwd and os.environ.get("CRIMAC_FUSE_HEADBN", "1") != "0"
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
-                 stats=None, bnb=None, cols=None, out_planes=False):
+                 stats=None, bnb=None, cols=None, out_planes=False, stat_reps=None):
         """3x3 conv (forward planes, or dgrad planes).  ``stats=(sum, sumsq)``: fused statistics of
         the stored output (stat_mode 1).  ``bnb=(block, y)``: the output is the ``da`` of that
         BatchNorm block -> its backward sums are fused in (stat_mode 2, into the block's replica
@@ -519,6 +535,7 @@ class UNetEngine:
         prec = self.prec_bwd if dgrad else self.prec
         if self.conv_impl == "halo":
             mode, s0, s1, by, by_ld, bvec = 0, None, None, None, 0, None
+            reps = stat_reps or self._nrep(cout)      # (BatchNorm sums of the cout-channel layer this output belongs to)
             if stats is not None:
                 mode, s0, s1 = 1, ptr(stats[0]), ptr(stats[1])
             elif bnb is not None and self.fuse_bn_bwd:
@@ -527,11 +544,11 @@ class UNetEngine:
                 by, by_ld, bvec = y.p, y.ld, ptr(self._bnf(blk, 0))
             if cols is not None:                      # a range of the output channels (crimac_conv3x3_cols)
                 call("crimac_conv3x3_cols", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
-                     out.p, out.ld, relu, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
+                     out.p, out.ld, relu, mode, s0, s1, reps, by, by_ld, bvec, self.cmax,
                      cols[0], cols[1], flops=flops * cols[1] / cout)
                 return mode != 0
             call("crimac_conv3x3", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
-                 out.p, out.ld, relu, mode, s0, s1, STAT_REPLICAS, by, by_ld, bvec, self.cmax,
+                 out.p, out.ld, relu, mode, s0, s1, reps, by, by_ld, bvec, self.cmax,
                  flops=flops)
             return mode != 0
         if self.is_hp:
@@ -549,7 +566,7 @@ class UNetEngine:
         if y is None:
             return (None, 0, None, 0, None, None, 1)
         return (y.p, y.ld, ptr(self._bnf(blk, 0)), self.cmax, ptr(self._stat(blk, 0)), ptr(self._stat(blk, 1)),
-                STAT_REPLICAS)
+                self._nrep(blk.cout))
 
     def _upconv_fwd(self, x: Act, u, out: Act, B, H, W):
         pk = self.pk[u.key]
@@ -606,7 +623,7 @@ class UNetEngine:
         if world > 1:
             import torch.distributed as dist
             tmp = self._buf("syncbn.fwd", (2, self.cmax), torch.float64)   # (the backward slots must stay zero)
-            call("crimac_sum_replicas", ptr(self._stat(b, 0)), STAT_REPLICAS, b.cout, b.cout,
+            call("crimac_sum_replicas", ptr(self._stat(b, 0)), self._nrep(b.cout), b.cout, b.cout,
                  ptr(tmp[0]), None, ptr(self._stat(b, 1)), ptr(tmp[1]))
             dist.all_reduce(tmp, group=UNetEngine._bn_group)
             call("crimac_bn_finalize", ptr(tmp[0]), ptr(tmp[1]), 1, M * world, b.cout,
@@ -615,11 +632,24 @@ class UNetEngine:
                  ptr(self.Bf[b.bn_key + ".num_batches_tracked"]), ptr(self._bnf(b, 0)),
                  ptr(self._bnf(b, 1)), ptr(self._bnf(b, 2)), ptr(self._bnf(b, 3)))
             return
-        call("crimac_bn_finalize", ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), STAT_REPLICAS, M, b.cout,
+        call("crimac_bn_finalize", ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), self._nrep(b.cout), M, b.cout,
              ptr(self.P[b.bn_key + ".weight"]), ptr(self.P[b.bn_key + ".bias"]), BN_EPS, BN_MOMENTUM,
              ptr(self.Bf[b.bn_key + ".running_mean"]), ptr(self.Bf[b.bn_key + ".running_var"]),
              ptr(self.Bf[b.bn_key + ".num_batches_tracked"]), ptr(self._bnf(b, 0)),
              ptr(self._bnf(b, 1)), ptr(self._bnf(b, 2)), ptr(self._bnf(b, 3)))
+
+    def _bn_act(self, b, y: Act, out: Act, pool: Act, B, H, W, M):
+        """Train-mode BatchNorm + ReLU (+ max-pool) of the conv output y whose statistics the conv epilogue took."""
+        if not self.fold_bn_finalize or self._sync_world() > 1:
+            self._bn_train(b, y, M)
+            self._act(b, y, out, pool, B, H, W)
+            return
+        call("crimac_bn_train_act_pool", self.prec, y.p, y.ld, ptr(self._stat(b, 0)), ptr(self._stat(b, 1)),
+             self._nrep(b.cout), M, ptr(self.P[b.bn_key + ".weight"]), ptr(self.P[b.bn_key + ".bias"]), BN_EPS,
+             BN_MOMENTUM, ptr(self.Bf[b.bn_key + ".running_mean"]), ptr(self.Bf[b.bn_key + ".running_var"]),
+             ptr(self.Bf[b.bn_key + ".num_batches_tracked"]), ptr(self._bnf(b, 0)), self.cmax, 1,
+             out.p if out is not None else None, out.ld if out is not None else 0,
+             pool.p if pool is not None else None, pool.ld if pool is not None else 0, B, H, W, b.cout)
 
     def _act(self, b, y: Act, out: Act, pool: Act, B, H, W, train=True):
         call("crimac_bn_act_pool", self.prec, y.p, y.ld,
@@ -781,12 +811,10 @@ class UNetEngine:
                 self._conv3x3(cur, self.pk[b1.conv_key], self.P[b1.conv_key + ".bias"], y1, B, h, w,
                               b1.cin_pad, c, relu=False, cin_real=b1.cin,
                               stats=(self._stat(b1, 0), self._stat(b1, 1)))
-                self._bn_train(b1, y1, M)
-                self._act(b1, y1, a1, None, B, h, w)
+                self._bn_act(b1, y1, a1, None, B, h, w, M)
                 self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
                               relu=False, stats=(self._stat(b2, 0), self._stat(b2, 1)))
-                self._bn_train(b2, y2, M)
-                self._act(b2, y2, a2, pool, B, h, w)
+                self._bn_act(b2, y2, a2, pool, B, h, w, M)
                 saved[f"e{i}"] = (cur, y1, a1, y2, a2)
             else:
                 pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
@@ -821,18 +849,17 @@ class UNetEngine:
                 y2 = Act(self._buf(f"d{j}.y2", (M, c)), c)
                 self._conv3x3(catA, self.pk[b1.conv_key], self.P[b1.conv_key + ".bias"], y1, B, h, w,
                               2 * c, c, relu=False, stats=(self._stat(b1, 0), self._stat(b1, 1)))
-                self._bn_train(b1, y1, M)
-                self._act(b1, y1, a1, None, B, h, w)
+                self._bn_act(b1, y1, a1, None, B, h, w, M)
                 self._conv3x3(a1, self.pk[b2.conv_key], self.P[b2.conv_key + ".bias"], y2, B, h, w, c, c,
                               relu=False, stats=(self._stat(b2, 0), self._stat(b2, 1)))
-                self._bn_train(b2, y2, M)
                 if j == D - 2 and self.fuse_head_bn and self.fuse_bn_bwd:
                     # the last block's activation only feeds the 1x1 head: formed on the fly there (forward and
                     # backward) from y2 -- one read + one write of the largest activation saved, twice
+                    self._bn_train(b2, y2, M)
                     head_bn = b2
                     a2 = y2
                 else:
-                    self._act(b2, y2, a2, None, B, h, w)
+                    self._bn_act(b2, y2, a2, None, B, h, w, M)
                 saved[f"d{j}"] = (cur, catA, y1, a1, y2, a2)
             else:
                 pe1, pe2 = self.pk_eval[b1.conv_key], self.pk_eval[b2.conv_key]
@@ -876,15 +903,18 @@ class UNetEngine:
         ``da`` of that block -> fuse ITS sums into the dgrad convolution.  bias_from_stats=(grad, C, level):
         also take the per-channel sums of the first C channels of ``dx_out`` (a transposed-conv bias
         gradient) from the dgrad epilogue.  Returns whether next_bn's sums were fused."""
-        if reduce_done:
-            call("crimac_sum_replicas", ptr(self._stat(b, 0)), STAT_REPLICAS, b.cout, b.cout,
+        world = self._sync_world()
+        folded = reduce_done and self.fold_bn_finalize and world == 1     # the replicas are added up by the apply kernel
+        if folded:
+            pass
+        elif reduce_done:
+            call("crimac_sum_replicas", ptr(self._stat(b, 0)), self._nrep(b.cout), b.cout, b.cout,
                  ptr(self._stat(b, 2)), None, ptr(self._stat(b, 1)), ptr(self._stat(b, 3)))
         else:
             call("crimac_bn_bwd_reduce", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
                  ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
                  ptr(self._stat(b, 2)), ptr(self._stat(b, 3)))
         dy = Act(self._buf(f"{tag}.dy", (M, b.cout)), b.cout)
-        world = self._sync_world()
         dgamma, dbeta = self.G[b.bn_key + ".weight"], self.G[b.bn_key + ".bias"]
         if world > 1:
             # gamma / beta gradients are this rank's LOCAL sums (the gradient exchange adds the ranks up); the
@@ -895,11 +925,16 @@ class UNetEngine:
             dist.all_reduce(self._stat_pair(b), group=UNetEngine._bn_group)
             scr = self._buf("g.syncbn.scratch", (2, self.cmax), torch.float32)
             dgamma, dbeta = scr[0], scr[1]
-        call("crimac_bn_bwd_apply", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
-             ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), ptr(self._stat(b, 2)),
-             ptr(self._stat(b, 3)), M, M * world, b.cout, dy.p, dy.ld, ptr(dgamma), ptr(dbeta),
-             None)      # d(conv bias in front of train-mode BN) = sum dy == 0 exactly: left at the zero fill
-             #            (the reference holds ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
+        # (d(conv bias in front of train-mode BN) = sum dy == 0 exactly: left at the zero fill -- the reference holds
+        # ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
+        if folded:
+            call("crimac_bn_bwd_apply_replicas", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 0)), self.cmax,
+                 ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), self._nrep(b.cout), M, M, b.cout, dy.p, dy.ld,
+                 ptr(dgamma), ptr(dbeta))
+        else:
+            call("crimac_bn_bwd_apply", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
+                 ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), ptr(self._stat(b, 2)),
+                 ptr(self._stat(b, 3)), M, M * world, b.cout, dy.p, dy.ld, ptr(dgamma), ptr(dbeta), None)
         self._wgrad(self.prec_bwd, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w, b.conv_key,
                     flops=2.0 * 9 * b.cin * b.cout * B * h * w)
         fused = False

@@ -66,11 +66,14 @@ SIGNATURES = {
     "crimac_colsum_f32": [_i, _vp, _l, _l, _i, _vp, _vp],
     "crimac_bn_finalize": [_vp, _vp, _i, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "crimac_bn_act_pool": [_i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp],
+    "crimac_bn_train_act_pool": [_i, _vp, _l, _vp, _vp, _i, _l, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _l, _i, _vp, _l,
+                                 _vp, _l, _i, _i, _i, _i, _vp],
     "crimac_unpool_add": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _i,
                           _vp],
     "crimac_bn_bwd_reduce": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp],
     "crimac_bn_bwd_apply": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _vp, _l, _vp,
                             _vp, _vp, _vp],
+    "crimac_bn_bwd_apply_replicas": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _l, _l, _i, _vp, _l, _vp, _vp, _vp],
     "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp,
                         _i, _vp],

@@ -263,6 +263,16 @@ int crimac_bn_finalize(const double* sum, const double* sumsq, int replicas, lon
 int crimac_bn_act_pool(int prec, const void* y, long y_ld, const float* scale, const float* shift,
                        int relu, void* out, long out_ld, void* pool_out, long pool_ld, int B, int H,
                        int W, int C, void* stream);
+/* crimac_bn_finalize + crimac_bn_act_pool in ONE launch (train mode: nn.BatchNorm2d + ReLU [+ MaxPool2d],
+ * unet.py:78-86, :121-122): every workgroup adds up the convolution epilogue's [replicas][C] accumulators itself
+ * (count = pixels they cover) and applies scale / shift; workgroup 0 writes the rows mean | invstd | scale | shift of
+ * bn_vec (row stride bn_stride; the backward pass reads them) and updates the running statistics as
+ * crimac_bn_finalize does.  Keep replicas * C small (<= 4096: one batch of loads per thread): that many fp64 pairs are read per workgroup. */
+int crimac_bn_train_act_pool(int prec, const void* y, long y_ld, const double* stat_sum, const double* stat_sumsq,
+                             int replicas, long count, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float* bn_vec, long bn_stride, int relu, void* out,
+                             long out_ld, void* pool_out, long pool_ld, int B, int H, int W, int C, void* stream);
 /* Backward of [pool ->] (skip add): da = ds + unpool(dp) with first-max tie rule of
  * aten::max_pool2d; `a` is the forward activation that was pooled.  ds may be NULL.
  * stat_sum != NULL: `da` feeds a BatchNorm+ReLU block; its backward sums (as crimac_conv3x3 stat_mode 2:
@@ -289,6 +299,12 @@ int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, lon
                         const float* scale, const float* shift, const float* mean, const float* invstd,
                         const double* sum_dz, const double* sum_dz_xhat, long M, long count, int C, void* dy,
                         long dy_ld, float* dgamma, float* dbeta, float* dbias, void* stream);
+
+/* crimac_sum_replicas + crimac_bn_bwd_apply in ONE launch: sum_dz / sum_dz_xhat are the [replicas][C] accumulators the
+ * producer of `da` filled (stat_mode 2 / crimac_unpool_add / crimac_head_bwd); bn_vec rows mean | invstd | scale | shift. */
+int crimac_bn_bwd_apply_replicas(int prec, const void* da, long da_ld, const void* y, long y_ld, const float* bn_vec,
+                                 long bn_stride, const double* sum_dz, const double* sum_dz_xhat, int replicas, long M,
+                                 long count, int C, void* dy, long dy_ld, float* dgamma, float* dbeta, void* stream);
 
 /* ---- 1x1 head, loss, optimiser --------------------------------------------------------------- */
 

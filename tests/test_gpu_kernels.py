@@ -306,6 +306,90 @@ def test_batchnorm_train_forward_backward_pool(prec, C):
     assert relerr(db.cpu(), br.grad) < (2e-2 if prec in LOWP else 2e-4)
 
 
+@pytest.mark.parametrize("prec", PRECS + ["h3p"])
+@pytest.mark.parametrize("C,R,pooled", [(64, 64, True), (48, 5, False), (256, 32, True), (1024, 8, False), (16, 1, True)])
+def test_batchnorm_statistics_finished_inside_the_consumer(prec, C, R, pooled):
+    """crimac_bn_train_act_pool == crimac_bn_finalize + crimac_bn_act_pool and crimac_bn_bwd_apply_replicas ==
+    crimac_sum_replicas + crimac_bn_bwd_apply, from the same [replicas][C] accumulators: identical tensors."""
+    B, H, W = 3, 8, 12
+    M = B * H * W
+    P = hip.PREC_NAMES[prec]
+    d = "cuda"
+    g = torch.Generator().manual_seed(C + R)
+    hp = prec == "h3p"
+    dt_y = torch.float32 if hp else _dt(prec)
+    y = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dt_y).to(d)
+    # replica accumulators as a producer leaves them: partial sums of disjoint pixel subsets
+    rep = torch.zeros(2, R, C, dtype=torch.float64, device=d)
+    owner = torch.randint(0, R, (M,), generator=g).to(d)
+    yd = y.double()
+    rep[0].index_add_(0, owner, yd)
+    rep[1].index_add_(0, owner, yd * yd)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(d)
+    beta = (torch.randn(C, generator=g) * 0.2).to(d)
+
+    def run(fused):
+        rm, rv = torch.full((C,), 0.25, device=d), torch.full((C,), 1.5, device=d)
+        nbt = torch.zeros((), dtype=torch.int64, device=d)
+        ld = C + 8                                             # (row stride of the vector block > C)
+        vec = torch.zeros(4, ld, dtype=torch.float32, device=d)
+        a = torch.zeros(M, C, dtype=y.dtype, device=d)          # (h3p: fp32-sized plane pairs)
+        pool = torch.zeros(M // 4, C, dtype=a.dtype, device=d) if pooled else None
+        if fused:
+            call("crimac_bn_train_act_pool", P, ptr(y), C, ptr(rep[0]), ptr(rep[1]), R, M, ptr(gamma), ptr(beta), 1e-5,
+                 0.1, ptr(rm), ptr(rv), ptr(nbt), ptr(vec), ld, 1, ptr(a), C, ptr(pool) if pooled else None,
+                 C if pooled else 0, B, H, W, C)
+        else:
+            call("crimac_bn_finalize", ptr(rep[0]), ptr(rep[1]), R, M, C, ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(rm),
+                 ptr(rv), ptr(nbt), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]))
+            call("crimac_bn_act_pool", P, ptr(y), C, ptr(vec[2]), ptr(vec[3]), 1, ptr(a), C,
+                 ptr(pool) if pooled else None, C if pooled else 0, B, H, W, C)
+        torch.cuda.synchronize()
+        return vec[:, :C].clone(), a, pool, rm, rv, int(nbt)
+
+    v0, a0, p0, rm0, rv0, n0 = run(False)
+    v1, a1, p1, rm1, rv1, n1 = run(True)
+    # (the two forms add the replicas in a different order: the fp64 sums may differ in their last bit)
+    assert relerr(v1.cpu(), v0.cpu()) < 1e-6 and n0 == n1 == 1
+    assert relerr(rm1.cpu(), rm0.cpu()) < 1e-6 and relerr(rv1.cpu(), rv0.cpu()) < 1e-6
+    if torch.equal(v1, v0):
+        assert torch.equal(a1.view(torch.uint8), a0.view(torch.uint8))
+        assert not pooled or torch.equal(p1.view(torch.uint8), p0.view(torch.uint8))
+    elif not hp:
+        assert relerr(a1.float().cpu(), a0.float().cpu()) < TOL.get(prec, 1e-5)
+    # backward
+    da = torch.randn(M, C, generator=g).to(dt_y).to(d)
+    repb = torch.zeros(2, R, C, dtype=torch.float64, device=d)
+    act = yd * v0[2].double() + v0[3].double() > 0
+    dz = da.double() * act
+    repb[0].index_add_(0, owner, dz)
+    repb[1].index_add_(0, owner, dz * (yd - v0[0].double()) * v0[1].double())
+    vec = torch.zeros(4, C + 8, dtype=torch.float32, device=d)
+    vec[:, :C] = v0
+    outs = []
+    for fused in (False, True):
+        dy = torch.zeros(M, C, dtype=torch.float32 if hp else dt_y, device=d)
+        dg, db = torch.zeros(C, device=d), torch.zeros(C, device=d)
+        if fused:
+            call("crimac_bn_bwd_apply_replicas", P, ptr(da), C, ptr(y), C, ptr(vec), C + 8, ptr(repb[0]), ptr(repb[1]),
+                 R, M, 0, C, ptr(dy), C, ptr(dg), ptr(db))
+        else:
+            s2 = torch.zeros(2, C, dtype=torch.float64, device=d)
+            call("crimac_sum_replicas", ptr(repb[0]), R, C, C, ptr(s2[0]), None, ptr(repb[1]), ptr(s2[1]))
+            call("crimac_bn_bwd_apply", P, ptr(da), C, ptr(y), C, ptr(vec[2]), ptr(vec[3]), ptr(vec[0]), ptr(vec[1]),
+                 ptr(s2[0]), ptr(s2[1]), M, 0, C, ptr(dy), C, ptr(dg), ptr(db), None)
+        torch.cuda.synchronize()
+        outs.append((dy, dg, db))
+    (dy0, dg0, db0), (dy1, dg1, db1) = outs
+    assert relerr(dg1.cpu(), dg0.cpu()) < 1e-6 and relerr(db1.cpu(), db0.cpu()) < 1e-6
+    if hp:
+        hi0, lo0 = dy0.view(torch.float16).view(M, C // 8, 2, 8).float().unbind(2)
+        hi1, lo1 = dy1.view(torch.float16).view(M, C // 8, 2, 8).float().unbind(2)
+        assert relerr((hi1 + lo1).cpu(), (hi0 + lo0).cpu()) < 1e-5
+    else:
+        assert relerr(dy1.float().cpu(), dy0.float().cpu()) < TOL.get(prec, 1e-5)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_unpool_first_max_tie_rule(prec):
     """Ties inside a 2x2 window: gradient goes to the FIRST maximum in scan order (aten max_pool2d)."""
