@@ -7,6 +7,7 @@ launches on random data the median over workgroups of d_memtime / d_memrealtime 
 holds inside the kernel.  usage (one process per library, CRIMAC_LIB selects it):
     CRIMAC_LIB=$PWD/gpurun_exp_diagconv.so  python tools/diag_clock.py conv  out.json
     CRIMAC_LIB=$PWD/gpurun_exp_diagwgrad.so python tools/diag_clock.py wgrad out.json
+A fourth argument selects the precision (bf16 default; h3p: the plane-pair form of the convolution kernel).
 """
 import ctypes as C
 import json
@@ -34,15 +35,28 @@ def main():
     reader = getattr(lib, f"crimac_diag_clock_{what}_read")
     reader.argtypes = [C.c_void_p]
     reader.restype = C.c_int
-    B, P = 32, hip.PREC_NAMES["bf16"]
+    prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+    hp = prec == "h3p"
+    if hp and what != "conv":
+        raise SystemExit("h3p: the convolution kernel carries the stamps")
+    B, P = 32, hip.PREC_NAMES[prec]
     res = {}
     for name, H, Ci, Co in SHAPES[what]:
         M = B * H * H
-        x = torch.randn(M, Ci, device="cuda").to(torch.bfloat16)
+        if hp:
+            if "persistent" in name:
+                name = "e0c2 64->64@256 (2 x 2 wave form)"
+            v = torch.randn(M, Ci, device="cuda")
+            hi = v.half(); lo = (v - hi.float()).half()       # fp16 plane pairs: [8 hi][8 lo] per 8-channel group
+            x = torch.stack([hi.view(M, Ci // 8, 8), lo.view(M, Ci // 8, 8)], 2).contiguous().view(torch.float32).view(M, Ci)
+            w_hi = torch.randn(2 * 9 * Co * Ci, device="cuda").half().view(torch.int16)
+            out = torch.empty(M, Co, device="cuda", dtype=torch.float32)
+        else:
+            x = torch.randn(M, Ci, device="cuda").to(torch.bfloat16)
+            w_hi = torch.randn(9 * Co * Ci, device="cuda").to(torch.bfloat16).view(torch.int16)
+            out = torch.empty(M, Co, device="cuda", dtype=torch.bfloat16)
         dy = torch.randn(M, Co, device="cuda").to(torch.bfloat16)
-        w_hi = torch.randn(9 * Co * Ci, device="cuda").to(torch.bfloat16).view(torch.int16)
         bias = torch.randn(Co, device="cuda")
-        out = torch.empty(M, Co, device="cuda", dtype=torch.bfloat16)
         dw = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
         if what == "conv":
             fn = lambda: call("crimac_conv3x3", P, ptr(x), Ci, B, H, H, Ci, Co, ptr(w_hi), ptr(w_hi), ptr(bias),
@@ -79,7 +93,7 @@ def main():
         print(f"{what:5s} {name:22s} clock {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz, 10):.3f}, p90 "
               f"{np.percentile(ghz, 90):.3f}), {us:7.1f} us, {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
     json.dump({"what": what, "method": "s_memtime / s_memrealtime x 100 MHz around the kernel's main loop, median over "
-               "workgroups, after >= 2 s of back-to-back launches on random bf16 data (diagnostic build; stamps "
+               "workgroups, after >= 2 s of back-to-back launches on random data (diagnostic build; stamps "
                "cost wave cycles, read the clock, not the run time)", "shapes": res}, open(out_path, "w"), indent=1)
 
 
