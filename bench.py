@@ -465,6 +465,13 @@ def run_rank(args):
                 for r_, key in ((roof, "conv3x3"), (roof_w, "wgrad")):
                     r_["mfma_busy_frac"] = ut.get(key, {}).get("mfma_busy_frac")
                     r_["util_source"] = "REPLAYED from the committed profile " + ut["_file"] + " (not observed in this run): " + str(ut.get("note"))
+            ck = load_profile_json(f"r03_inkernel_clock_conv_{prec}.json")
+            if ck:
+                ghz = sorted(v["clock_ghz_median"] for v in ck["shapes"].values())
+                roof["clock_ghz"] = ghz[len(ghz) // 2]
+                roof["clock_source"] = ("REPLAYED from the committed profile " + ck["_file"] + " (diagnostic build with s_memtime / "
+                                        "s_memrealtime stamps around the convolution's main loop, median over the shapes; not "
+                                        "observed in this run)")
         if sf == 64 and args.precision in ("bf16", "h3p"):
             replay(rl, main["roofline_wgrad"], args.precision)
         if parity is not None and args.parity_precision in ("bf16", "h3p"):
