@@ -376,10 +376,13 @@ struct WchFrags {
 };
 // NQ: groups of 4 image rows per wave (4: the wave covers all 16 rows of the tile; 2: the 2 x 2 form for 64-channel
 // tiles, waves = 2 pixel halves x 2 channel halves, the half's row offset rides in the address registers)
-template <int H, int NQ = 4>
+// ILV (tall form): the wave's second half of row groups lies 2 NQ image rows further down -- a wave owns rows
+// [8 wp, 8 wp + 8) and [16 + 8 wp, 16 + 8 wp + 8) of the 32-row tile, so that each 16-row slice of the epilogue holds half of
+// EVERY wave's accumulators (with 16 contiguous rows per wave one wave pair stages a slice while the other idles)
+template <int H, int NQ = 4, bool ILV = false>
 __device__ __forceinline__ void wch_issue(const unsigned (&av)[3][2], WchFrags& f) {
   constexpr int t = H / (2 * NQ), ks2 = (H / NQ) % 2, q = H % NQ;
-  constexpr int base = (t / 3 + 4 * q) * (HP * RB);
+  constexpr int base = (t / 3 + 4 * q + (ILV && q >= NQ / 2 ? 2 * NQ : 0)) * (HP * RB);
   f.a[H & 1][0] = lds_read128_asm<base + 0 * (HP * RB)>(av[t % 3][ks2]);
   f.a[H & 1][1] = lds_read128_asm<base + 1 * (HP * RB)>(av[t % 3][ks2]);
   f.a[H & 1][2] = lds_read128_asm<base + 2 * (HP * RB)>(av[t % 3][ks2]);
@@ -398,7 +401,7 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
 // PP (plane pairs): k-step 0 of a chunk is the hi plane of 32 channels, k-step 1 their lo plane, in both operands: the
 // hi fragments of A meet both weight planes (hi*lo, then hi*hi), the lo fragments the hi weights only -- 3 MFMAs per
 // fragment pair, 16 + 8 per pair of groups, on the same reads and weight loads as the 16-bit kernel's 8 + 8.
-template <typename T16, bool PP, int H, int NQ = 4, typename ACC>
+template <typename T16, bool PP, int H, int NQ = 4, bool ILV = false, typename ACC>
 __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsigned short* wtap, long w_tap, long w_nb,
                                            const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
   constexpr int t = H / (2 * NQ), ks2 = (H / NQ) % 2, q = H % NQ, NH = 18 * NQ;
@@ -418,7 +421,7 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
     }
   }
   if constexpr (H + 1 < NH) {
-    wch_issue<H + 1, NQ>(av, f);
+    wch_issue<H + 1, NQ, ILV>(av, f);
     wch_release<false>(f, H & 1);
   } else {
     wch_release<true>(f, H & 1);
@@ -436,16 +439,28 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
     for (int nb = 0; nb < 2; ++nb)
       acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][(PP ? 0 : ks2 * 2) + nb],
                                                                     acc[4 * q + j][nb]);
-  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1, NQ>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
+  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1, NQ, ILV>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
-// S22: the 2 x 2 form for 64-channel tiles: waves = 2 pixel halves (8 image rows each) x 2 channel halves (32 channels
-// each); the wave's weight fragments still come straight from global memory (each half is fetched by two waves).
-template <typename T16, int MODE, typename TO = T16, bool PP = false, bool S22 = false>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2, S22 ? 3 : 2))) void conv3x3_wch_kernel(ConvParams p) {
+// FORM 1 ("S22"): the 2 x 2 form for 64-channel tiles: waves = 2 pixel halves (8 image rows each) x 2 channel halves (32
+// channels each); the wave's weight fragments still come straight from global memory (each half is fetched by two waves).
+// FORM 2 ("tall"): 64 output channels of a 32 x 16-pixel tile: waves = 2 pixel halves of SIXTEEN image rows x 2 channel
+// halves -- every wave is exactly the wave of the 128-channel form (16 M tiles x 32 channels, the same reads, weight
+// loads and MFMAs per tap), so a weight fragment feeds as many MFMAs as there; what differs is the halo (34 x 18 pixels,
+// 76.5 KB per chunk: 1.9x the bytes per MFMA, which is what 64 output channels cost) -- two workgroups per CU.
+// Why: in FORM 1 a wave's tap is 48 MFMAs (plane pairs) between two weight-fragment waits and a workgroup's prologue,
+// halo waits and epilogue (28 k cycles) stand against 13.8 k cycles of MFMA work per SIMD: MFMA busy 0.45 (PMC) where the
+// 128-channel form reaches 0.77.
+template <typename T16, int MODE, typename TO = T16, bool PP = false, int FORM = 0>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? 3 : 2, FORM == 1 ? 3 : 2))) void conv3x3_wch_kernel(ConvParams p) {
+  constexpr bool S22 = FORM != 0;                  // waves = pixel halves x channel halves
   constexpr int BN = S22 ? 64 : 128, NW = 4;
-  constexpr int NQ = S22 ? 2 : 4, WR = 4 * NQ;       // image rows (16-pixel M tiles) per wave
-  constexpr int NH = (HALO_INSTR + NW - 1) / NW;   // 11
+  constexpr int NQ = FORM == 1 ? 2 : 4, WR = 4 * NQ;       // image rows (16-pixel M tiles) per wave
+  constexpr int TRK = FORM == 2 ? 32 : TR;                 // image rows of the workgroup's tile
+  constexpr bool ILV = FORM == 2;                          // the wave's rows: two blocks of WR / 2 (wch_issue)
+  constexpr int HALO_ROWS_K = (TRK + 2) * HP;              // 324 (612)
+  constexpr int HALO_INSTR_K = (HALO_ROWS_K + 7) / 8;      // 41 (77) wave-instructions of 8 rows
+  constexpr int NH = (HALO_INSTR_K + NW - 1) / NW;         // 11 (20)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef CRIMAC_DIAG_PHASES
   unsigned long long wph[4] = {0, 0, 0, 0}, wph_t;
@@ -469,29 +484,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2
   tile_m /= p.tiles_x;
   const int tyi = tile_m % p.tiles_y;
   const int b = tile_m / p.tiles_y;
-  const int y0 = tyi * TR, x0 = txi * TC;
+  const int y0 = tyi * TRK, x0 = txi * TC;
   const int n0 = p.n_first + blockIdx.y * BN;
 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.in), 0, (int)((((long)p.B * p.H * p.W - 1) * p.in_ld + p.Cin) * 2), 0x00020000);
-  unsigned h_off[NH];
-#pragma unroll
-  for (int i = 0; i < NH; ++i) {
+  // per-lane source offset of halo DMA instruction i (8 halo rows each): a table in registers; the tall form (20
+  // instructions per wave, and the accumulators of the 128-channel form) recomputes it at every chunk instead -- ~12
+  // integer operations per instruction next to 864 MFMAs, against 20 registers that the epilogue would spill
+  auto halo_off = [&](int i) -> unsigned {
     const int k = wave + NW * i;
-    const int row = 8 * k + sub;
-    const int hy = row / HP, hx = row - hy * HP;
+    int row = 8 * k + sub;
+    if constexpr (FORM == 2) asm volatile("" : "+v"(row));          // (recomputed where it is used, not hoisted back into a table)
+    const int hy = (row * 3641) >> 16, hx = row - hy * HP;          // row / 18 (exact for row < 4096)
     const unsigned y = (unsigned)(y0 + hy - 1), x = (unsigned)(x0 + hx - 1);
-    const bool ok = k < HALO_INSTR && row < HALO_ROWS && y < (unsigned)p.H && x < (unsigned)p.W;
-    h_off[i] = ok ? (unsigned)(((((long)b * p.H + y) * p.W + x) * p.in_ld + src_unit<PP>(c8 ^ halo_swz(hx)) * 8) * 2)
-                  : 0x80000000u;
+    const bool ok = k < HALO_INSTR_K && row < HALO_ROWS_K && y < (unsigned)p.H && x < (unsigned)p.W;
+    // (the launcher guarantees 32-bit byte offsets: `small`)
+    return ok ? (unsigned)((((b * p.H + (int)y) * p.W + (int)x) * (int)p.in_ld + src_unit<PP>(c8 ^ halo_swz(hx)) * 8) * 2)
+              : 0x80000000u;
+  };
+  constexpr bool HTAB = FORM != 2;
+  unsigned h_off[HTAB ? NH : 1];
+  if constexpr (HTAB) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) h_off[i] = halo_off(i);
   }
   auto issue_halo = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NH; ++i)
-      if (wave + NW * i < HALO_INSTR)
+      if (wave + NW * i < HALO_INSTR_K) {
+        unsigned off;
+        if constexpr (HTAB) off = h_off[i]; else off = halo_off(i);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc, (__attribute__((address_space(3))) void*)(sA + (wave + NW * i) * 1024), 16, (int)h_off[i],
+            rsrc, (__attribute__((address_space(3))) void*)(sA + (wave + NW * i) * 1024), 16, (int)off,
             kc * BK * 2, 0, CRIMAC_WCH_HALO_AUX);
+      }
   };
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -507,7 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2)
-        av[kx][ks2] = a_lds + (wp * WR * HP + fr + kx) * RB + (((4 * ks2 + fq) ^ halo_swz(fr + kx)) << 4);
+        av[kx][ks2] = a_lds + (wp * (ILV ? WR / 2 : WR) * HP + fr + kx) * RB + (((4 * ks2 + fq) ^ halo_swz(fr + kx)) << 4);
   }
 
   f32x4 acc[WR][2];
@@ -535,8 +562,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2
     CRIMAC_CPH(1)
     const unsigned short* wtap = wrow + kc * BK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
-    wch_issue<0, NQ>(av, f);
-    wch_step<T16, PP, 0, NQ>(av, wtap, w_tap, w_nb, wnext, f, acc);
+    wch_issue<0, NQ, ILV>(av, f);
+    wch_step<T16, PP, 0, NQ, ILV>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(2)
@@ -545,7 +572,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2
 #ifndef CRIMAC_DIAG_PHASES
   CRIMAC_DIAG_STORE(crimac_diag_clock_conv, dg_t0, dg_r0, dg_t1, dg_r1)
 #endif
-  conv_epilogue<TO, BN, BM, 256, WR, 2, f32x4, MODE, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TR, wp, wc);
+  // (tall form, 16-bit output: two slices of 256 rows like the other forms' whole tile -- 16 fully unrolled store rounds
+  // spill ~60 registers in the statistics mode)
+  constexpr int EPASS = EpiPasses<TO>::value * (FORM == 2 && sizeof(TO) == 2 ? 2 : 1);
+  conv_epilogue<TO, BN, TRK * TC, 256, WR, 2, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc);
 #ifdef CRIMAC_DIAG_PHASES
   // cycles of wave 0: prologue | waiting for the halo chunks | MFMA steps | epilogue (stores issued)
   CRIMAC_CPH(3)
@@ -555,15 +585,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S22 ? 3 : 2
 #endif
 }
 
-template <typename T16, typename TO = T16, bool PP = false, bool S22 = false>
+template <typename T16, typename TO = T16, bool PP = false, int S22 = 0>      // S22: the kernel's FORM
 int launch_wch(ConvParams p, hipStream_t st) {
   constexpr int BN = S22 ? 64 : 128;
-  p.tiles_y = cdiv(p.H, TR);
+  constexpr int TRK = S22 == 2 ? 32 : TR;
+  constexpr int HALO_BYTES = ((TRK + 2) * HP + 7) / 8 * 1024;      // one halo buffer, padded to whole DMA instructions
+  p.tiles_y = cdiv(p.H, TRK);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t stage = (size_t)(BM / EpiPasses<TO>::value) * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4;
-  const size_t lds = stage > (size_t)A_BYTES ? stage : (size_t)A_BYTES;
-  static_assert(stage <= 72 * 1024, "two workgroups per CU");
+  constexpr int EPASS = EpiPasses<TO>::value * (S22 == 2 && sizeof(TO) == 2 ? 2 : 1);      // (as in the kernel)
+  constexpr size_t stage = (size_t)(TRK * TC / EPASS) * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4;
+  const size_t lds = stage > (size_t)HALO_BYTES ? stage : (size_t)HALO_BYTES;
+  static_assert(stage <= 80 * 1024 && HALO_BYTES <= 80 * 1024, "two workgroups per CU");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP, S22>),
@@ -1285,6 +1318,12 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
   // Measured per layer at B = 32 (tools/bench_conv.py): wch 1.1-1.6 PFLOP/s vs 1.0-1.25 (W4<128>); on the two
   // HBM-heavy N = 64 shapes W4<64> (305 / 423 us) beats a 2x2-wave channel split (319 / 458 us).
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
+  // N = 64: the tall form of the channel-split kernel (CRIMAC_CONV_TALL16: 0 off, 1 every shape but 64 -> 64, 2 every N = 64
+  // shape).  Measured at B = 32, 256 x 256: 128 -> 64  274-276 us (pixel-split kernel with the LDS weight ring: 373-379);
+  // 64 -> 64  231-238 us against 175-190 of the persistent kernel below, which keeps that shape.
+  static const int tall = getenv("CRIMAC_CONV_TALL16") ? atoi(getenv("CRIMAC_CONV_TALL16")) : 1;
+  const bool small64 = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
+  if (N == 64 && small64 && (tall == 2 || (tall == 1 && Cin != 64))) return launch_wch<T16, T16, false, 2>(p, st);
   // 64 -> 64 with many tiles: persistent kernel with LDS-resident weights (CRIMAC_CONV_P64=0: W4 for A/B runs)
   static const int p64 = getenv("CRIMAC_CONV_P64") ? atoi(getenv("CRIMAC_CONV_P64")) : 1;
   if (p64 && N == 64 && Cin == 64 && H % TR == 0 && W % TC == 0 && (long)B * (H / TR) * (W / TC) >= 512)
@@ -1313,9 +1352,13 @@ int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int 
                  "multiples of 64", n_first, n_count);
   if (n_count % 128 == 0 && n_first % 128 == 0)
     return out_planes ? launch_w4<128, half_t, hp_t, true>(p, st) : launch_w4<128, half_t, float, true>(p, st);
-  static const int s22 = getenv("CRIMAC_CONV_S22") ? atoi(getenv("CRIMAC_CONV_S22")) : 1;
+  // 64-channel ranges: CRIMAC_CONV_S22 = 2 (default) the tall 32 x 16-pixel form, 1 the 2 x 2 form on 16 x 16 pixels,
+  // 0 the pixel-split kernel with the LDS weight ring
+  static const int s22 = getenv("CRIMAC_CONV_S22") ? atoi(getenv("CRIMAC_CONV_S22")) : 2;
+  if (s22 == 2 && small)
+    return out_planes ? launch_wch<half_t, hp_t, true, 2>(p, st) : launch_wch<half_t, float, true, 2>(p, st);
   if (s22 && small)
-    return out_planes ? launch_wch<half_t, hp_t, true, true>(p, st) : launch_wch<half_t, float, true, true>(p, st);
+    return out_planes ? launch_wch<half_t, hp_t, true, 1>(p, st) : launch_wch<half_t, float, true, 1>(p, st);
   return out_planes ? launch_w4<64, half_t, hp_t, true>(p, st) : launch_w4<64, half_t, float, true>(p, st);
 }
 

@@ -69,7 +69,10 @@ template <> struct AccLayout<f32x4> {
 // TA: storage type of the OUTPUT (bf16_t / half_t / float, or hp_t: fp16 plane pairs, staged as fp32 and split when
 // the tile is stored).  PASSES > 1: the tile goes through the staging area in PASSES slices of BM / PASSES rows (fp32
 // staging of a 256 x 128 tile would need 135 KB of LDS: one workgroup per CU instead of two).
-template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, bool FULL, typename ACC, int PASSES = 1>
+// ILV: M tile i of wave row group wr (two groups) is tile row  wr * MT/2 + i  (i < MT/2)  or  MT + wr * MT/2 + i - MT/2:
+// every slice of MT tile rows then holds half of each wave's accumulators (conv3x3_glds.hip, tall form).
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, bool FULL, typename ACC, int PASSES = 1,
+          bool ILV = false>
 __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], const EpiParams& e,
                                                    unsigned char* smem, int b, int y0, int x0, int n0,
                                                    int wr, int wc) {
@@ -94,16 +97,48 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
   float d1[8], d2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { d1[k] = 0.f; d2[k] = 0.f; }
+  // (mode 2) BatchNorm constants of this thread's 8-channel chunk c8 = tid % (BN / 8): loaded once, as the bias below
+  float sc[8], sh[8], mu[8], is[8];
+  if (mode == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = n0 + (tid % (BN / 8)) * 8 + k;
+      mu[k] = e.bnb_vec[c];
+      is[k] = e.bnb_vec[e.bnb_stride + c];
+      sc[k] = e.bnb_vec[2 * e.bnb_stride + c];
+      sh[k] = e.bnb_vec[3 * e.bnb_stride + c];
+    }
+  }
+  // the bias is loaded ONCE, in front of the first slice: a load inside the slice loop would sit behind the previous
+  // slice's global stores in the (in-order) vector-memory counter -- its wait is a wait for their acknowledgement
+#ifdef CRIMAC_EPI_NO_HOIST              // (A/B builds: the bias load inside the slice loop, as before)
+  constexpr bool HOIST = false;
+#else
+  constexpr bool HOIST = PASSES > 1;
+#endif
+  float bvs[NT];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bvs[j] = e.bias ? e.bias[n0 + wc * (NT * L::TS) + j * L::TS + L::col(lane)] : 0.f;
+  }
 #pragma unroll
  for (int ps = 0; ps < PASSES; ++ps) {
   if (ps > 0) epi_barrier_lds();                                         // the previous slice has been read out (its stores may be in flight)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = wc * (NT * L::TS) + j * L::TS + L::col(lane);
-    const float bv = e.bias ? e.bias[n0 + col] : 0.f;
+    float bv;
+    if constexpr (HOIST) {
+      bv = bvs[j];
+      asm volatile("" : "+v"(bv));     // (keeps this slice's bias / ReLU / rounding arithmetic behind the barrier above: hoisted
+                                       // in front of it, hipcc holds both slices' results and spills ~80 registers)
+    } else {
+      bv = e.bias ? e.bias[n0 + col] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int row0 = wr * (MT * L::TS) + i * L::TS;                    // (wave-uniform: an M tile lies in one pass)
+      const int row0 = ILV ? ((i < MT / 2 ? wr * (MT / 2) + i : MT + wr * (MT / 2) + i - MT / 2) * L::TS)
+                           : wr * (MT * L::TS) + i * L::TS;              // (wave-uniform: an M tile lies in one pass)
       if (PASSES > 1 && row0 / RPASS != ps) continue;
 #pragma unroll
       for (int r = 0; r < L::NR; ++r) {
@@ -190,20 +225,9 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
     const unsigned q0 = mode == 2 ? (unsigned)((((long)ty0 * e.W + tx) * e.bnb_y_ld + c8 * 8) * (int)sizeof(TA)) : 0u;
     const unsigned q_step = mode == 2 ? (unsigned)(((long)(RPP >> 4) * e.W * e.bnb_y_ld + (RPP & 15) * e.bnb_y_ld) * (int)sizeof(TA)) : 0u;
     static_assert(RPP >= 16, "rows of one thread differ by whole image rows");
-    float sc[8], sh[8], mu[8], is[8];
-    if (mode == 2) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int c = n0 + c8 * 8 + k;
-        mu[k] = e.bnb_vec[c];
-        is[k] = e.bnb_vec[e.bnb_stride + c];
-        sc[k] = e.bnb_vec[2 * e.bnb_stride + c];
-        sh[k] = e.bnb_vec[3 * e.bnb_stride + c];
-      }
-    }
-    // (fp32 tiles with the fused BatchNorm-backward sums: 16 registers of y and g per row next to the accumulators of
-    // the slices still to come -- fully unrolled, hipcc hoists every load and spills ~100 registers)
-    constexpr int UNR = (MODE == 2 && F32 && PASSES > 1) ? 2 : RPASS / RPP;
+    // (sliced tiles with the fused BatchNorm-backward sums: the registers of y and g per row stand next to the accumulators
+    // of the slices still to come -- fully unrolled, hipcc hoists every load and spills 70-100 registers)
+    constexpr int UNR = (MODE == 2 && PASSES > 1) ? 2 : RPASS / RPP;
 #pragma unroll(UNR)
     for (int rr = 0; rr < RPASS / RPP; ++rr) {
       const int lrow = r0 + rr * RPP, row = ps * RPASS + lrow;
@@ -301,7 +325,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
 }
 
 // Dispatch on the (workgroup-uniform) tile position and, when MODE < 0, on the runtime statistics mode.
-template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC, int MODE = -1, int PASSES = 1>
+template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename ACC, int MODE = -1, int PASSES = 1,
+          bool ILV = false>
 __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
                                               unsigned char* smem, int b, int y0, int x0, int n0,
                                               int tile_rows, int wr, int wc) {
@@ -309,8 +334,8 @@ __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const Ep
   const int mode = MODE >= 0 ? MODE : (e.stat_sum ? e.stat_mode : 0);
 #define CRIMAC_EPI(M)                                                                                      \
   do {                                                                                                     \
-    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC, PASSES>(acc, e, smem, b, y0, x0, n0, wr, wc);   \
-    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC, PASSES>(acc, e, smem, b, y0, x0, n0, wr, wc);       \
+    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC, PASSES, ILV>(acc, e, smem, b, y0, x0, n0, wr, wc);   \
+    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC, PASSES, ILV>(acc, e, smem, b, y0, x0, n0, wr, wc);       \
   } while (0)
   if constexpr (MODE >= 0) {
     CRIMAC_EPI(MODE);
