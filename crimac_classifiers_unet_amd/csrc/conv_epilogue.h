@@ -225,6 +225,44 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
     const unsigned q0 = mode == 2 ? (unsigned)((((long)ty0 * e.W + tx) * e.bnb_y_ld + c8 * 8) * (int)sizeof(TA)) : 0u;
     const unsigned q_step = mode == 2 ? (unsigned)(((long)(RPP >> 4) * e.W * e.bnb_y_ld + (RPP & 15) * e.bnb_y_ld) * (int)sizeof(TA)) : 0u;
     static_assert(RPP >= 16, "rows of one thread differ by whole image rows");
+#ifdef CRIMAC_EPI_BNB_INLINE            // (A/B builds: the y load of a row right behind that row's store, as before)
+    constexpr bool YFIRST = false;
+#else
+    constexpr bool YFIRST = MODE == 2;
+#endif
+    if constexpr (YFIRST) {
+      // Mode 2, the saved forward outputs FIRST: all y loads of the slice (YB rows in flight) and the sums, then the
+      // stores.  Vector-memory operations retire in issue order: a y load issued behind a row's store is a wait for that
+      // store's acknowledgement -- 8-16 serialised round trips per slice (128 -> 128 @128x128 plane pairs: the input
+      // gradient with the fused sums took 351 us, the same convolution with statistics 288).
+      constexpr int NR = RPASS / RPP, YB = NR < 4 ? NR : 4, YV = F32 ? 2 : 1;
+#pragma unroll 1
+      for (int rb = 0; rb < NR; rb += YB) {
+        u32x4 t[YB][YV];
+        bool okb[YB];
+#pragma unroll
+        for (int u = 0; u < YB; ++u) {
+          const int rr = rb + u, row = ps * RPASS + r0 + rr * RPP;
+          okb[u] = FULL || ((y0 + (row >> 4) < e.H) && (x0 + tx < e.W));
+          const int yoff = (int)(okb[u] ? q0 + rr * q_step : OOB);
+#pragma unroll
+          for (int h = 0; h < YV; ++h) t[u][h] = __builtin_amdgcn_raw_buffer_load_b128(ry, yoff, 16 * h, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < YB; ++u) {
+          const TS* sp = reinterpret_cast<const TS*>(stage + (r0 + (rb + u) * RPP) * STAGE_PITCH) + c8 * 8;
+          float g[8], yv[8];
+          load8(sp, g);
+          load8(reinterpret_cast<const TS*>(t[u]), yv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float dz = (okb[u] && (yv[k] * sc[k] + sh[k]) > 0.f) ? g[k] : 0.f;
+            d1[k] += dz;
+            d2[k] += dz * (yv[k] - mu[k]) * is[k];
+          }
+        }
+      }
+    }
     // (sliced tiles with the fused BatchNorm-backward sums: the registers of y and g per row stand next to the accumulators
     // of the slices still to come -- fully unrolled, hipcc hoists every load and spills 70-100 registers)
     constexpr int UNR = (MODE == 2 && PASSES > 1) ? 2 : RPASS / RPP;
@@ -247,7 +285,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       } else {
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp), ro, off, 0, 0);
       }
-      if (mode == 2) {
+      if (mode == 2 && !YFIRST) {
         float g[8], yv[8];
         load8(sp, g);
         const int yoff = (int)(ok ? q0 + rr * q_step : OOB);
