@@ -199,20 +199,23 @@ __global__ __launch_bounds__(256) void unpack_layers_kernel(Table tb) {
   const int T = g.taps, run = TILE * T;
   const int nin = g.inner - i0 < TILE ? (g.inner - i0 > 0 ? g.inner - i0 : 0) : TILE;
   // packed side: dw[t][outer][inner_pad] (conv3x3: [t][co][ci_pad], upconv: [ab][ci][co]), inner fastest
+#pragma unroll 2
   for (int idx = threadIdx.x; idx < T * TILE * TILE; idx += 256) {
     const int il = idx % TILE, ol = (idx / TILE) % TILE, t = idx / (TILE * TILE);
     if (il < nin) {
       const float* src = d.dw + ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il;
-#if CRIMAC_STREAM_NT
-      float v = __builtin_nontemporal_load(src);
+      // slabs: four independent partial sums (four loads in flight: one load per loop iteration made this pass a chain of
+      // memory latencies), added up in a FIXED order -- reproducible run to run
       const int nsl = d.dw_splits < kFold ? d.dw_splits : kFold;                       // (folded by fold_slabs_kernel)
-      for (int sp = 1; sp < nsl; ++sp) v += __builtin_nontemporal_load(src + (long)sp * d.dw_stride);   // fixed order: reproducible
-#else
-      float v = src[0];
-      const int nsl = d.dw_splits < kFold ? d.dw_splits : kFold;                       // (folded by fold_slabs_kernel)
-      for (int sp = 1; sp < nsl; ++sp) v += src[(long)sp * d.dw_stride];              // fixed order: reproducible
-#endif
-      tile[ol][il * T + t] = v;
+      float v0 = src[0], v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      int sp = 1;
+      for (; sp + 3 < nsl; sp += 4) {
+        const float a = src[(long)sp * d.dw_stride], b = src[(long)(sp + 1) * d.dw_stride];
+        const float c = src[(long)(sp + 2) * d.dw_stride], e = src[(long)(sp + 3) * d.dw_stride];
+        v0 += a; v1 += b; v2 += c; v3 += e;
+      }
+      for (; sp < nsl; ++sp) v0 += src[(long)sp * d.dw_stride];
+      tile[ol][il * T + t] = (v0 + v1) + (v2 + v3);
     }
   }
   __syncthreads();

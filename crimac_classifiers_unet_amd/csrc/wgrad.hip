@@ -178,6 +178,19 @@ constexpr int PP_F_IMG = 128 * 128;                 // one F image: 8 x 16 pixel
 constexpr int PP_S_IMG = 184 * 128;                 // one S image: (8 + 2) x 18 = 180 halo rows, padded to 184
 constexpr int PP_BUF = 2 * PP_F_IMG + 2 * PP_S_IMG;   // 79,872 bytes per tile buffer
 
+// Slab form of the flush (partial_stride > 0): a 64 x 64 x taps accumulator tile staged in LDS as [tap][row][kFlushPitch]
+// floats goes out as 16-byte stores, 16 consecutive lanes per 256-byte tile row: whole lines per wave-instruction.
+constexpr int kFlushPitch = 68;        // 64 + 4: the MFMA layout's lane blocks (4 rows apart) land 16 banks apart
+template <int NTHR>
+__device__ __forceinline__ void flush_staged_tile(const float* stg, float* slab, int ntaps, int CF, int CS, int cf0, int cs0,
+                                                  int t_id) {
+  for (int i = t_id; i < ntaps * 64 * 16; i += NTHR) {
+    const int R = i >> 4, c4 = i & 15, t = R >> 6, row = R & 63;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + R * kFlushPitch + c4 * 4);
+    *reinterpret_cast<f32x4*>(slab + ((long)t * CF + cf0 + row) * CS + cs0 + c4 * 4) = v;
+  }
+}
+
 struct PpFrags {
   bf16x4 a[8][2];         // [F plane fragment: image * 4 + slot][read]
   bf16x4 b[2][2][2];      // [step parity][S fragment: hi, lo][read]
@@ -383,6 +396,25 @@ void wgrad_pp_kernel(WgradParams p) {
       }
       wg_rd_b<0, TG, 0, false>(sv, f);
       pp_step<TG, 0, NFW>(fv0, sv, f, acc);
+    }
+    if constexpr (!NARROW) {
+      if (p.partial_stride > 0) {                 // slab form: through LDS, whole lines (flush_staged_tile)
+        float* stg = reinterpret_cast<float*>(smem);
+        __syncthreads();                          // every wave has left its tile loop: the tile buffers are dead
+        float* sl = stg + (G::T0 * 64 + (lane >> 4) * 4) * kFlushPitch + sa * 32 + ws * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < G::N; ++t) {
+          float* st_ = sl + t * 64 * kFlushPitch;
+          asm volatile("" : "+v"(st_));
+#pragma unroll
+          for (int fr = 0; fr < NFR; ++fr)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_[(fr * 16 + r) * kFlushPitch] = acc[t][fr][r];
+        }
+        __syncthreads();
+        flush_staged_tile<512>(stg, p.dw + (long)split * p.partial_stride, 9, p.CF, p.CS, cf0, cs0, tid);
+        return;
+      }
     }
     // dw[t][cf][cs] += acc: F rows cf0 + 16 fr .. +15, S columns cs0 + 32 sa + 16 ws .. +15, this wave's taps
     float* dwp = p.dw + (p.partial_stride > 0 ? (long)split * p.partial_stride : 0);
@@ -811,6 +843,30 @@ void wgrad_kernel(WgradParams p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc2[t][fh][sh][r] += o[r];
             }
+      }
+      if constexpr (TEAMS == 2) {
+        if (p.partial_stride > 0 && cf0 + 64 <= p.CF && cs0 + 64 <= p.CS) {      // (workgroup-uniform)
+          // slab form, whole tile: accumulators -> LDS [tap][row][68] -> 16-byte stores, 16 lanes per 256-byte tile row
+          // (straight from the MFMA layout a wave-instruction writes four 64-byte half lines)
+          float* stg = reinterpret_cast<float*>(smem);
+          __syncthreads();                          // the exchange area above has been read
+          // (one base per tap + immediates: the offsets of a tap fit the 16-bit immediate of ds_write)
+          float* sl = stg + (G::T0 * 64 + (lane >> 4) * 4) * kFlushPitch + ws * 32 + (lane & 15);
+#pragma unroll
+          for (int t = 0; t < G::N; ++t) {
+            float* st_ = sl + t * 64 * kFlushPitch;
+            asm volatile("" : "+v"(st_));
+#pragma unroll
+            for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+              for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_[(fh * 16 + r) * kFlushPitch + sh * 16] = acc2[t][fh][sh][r];
+          }
+          __syncthreads();
+          flush_staged_tile<256>(stg, p.dw + (long)split * p.partial_stride, NTAPS, p.CF, p.CS, cf0, cs0, tid & 255);
+          return;
+        }
       }
       // dw[t][cf][cs] += acc: this wave holds F rows cf0 .. cf0+63 x S columns cs0 + 32*ws .. +31 of its taps.
       // partial_stride > 0: every (channel tile, split) workgroup OWNS its tile of slab `split` -- plain stores, no

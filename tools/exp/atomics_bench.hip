@@ -12,6 +12,19 @@ __global__ __launch_bounds__(512) void flush(float* base, const int* tile_of, in
   if (by_xcc) t += (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) * ntiles_per_slab;
   float* dst = base + (long)t * TILE;
   const float v = 1.0f;
+  if (mode >= 2) {
+    // the weight-gradient kernels' flush shape: a wave-instruction = 4 rows x 16 floats (four 64-byte half lines, rows of
+    // 64 floats); mode 3: the same elements as 2 rows x 32 floats (two whole 128-byte lines)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ws = wave & 1, row0 = (wave >> 1) * 144;             // a wave: one 32-column half of 144 of the 576 rows
+    for (int k = 0; k < 72; ++k) {                                 // 72 wave-instructions either way
+      int row, col;
+      if (mode == 2) { row = row0 + (k >> 1) * 4 + (lane >> 4); col = ws * 32 + (k & 1) * 16 + (lane & 15); }
+      else { row = row0 + k * 2 + (lane >> 5); col = ws * 32 + (lane & 31); }
+      atomicAdd(dst + row * 64 + col, v);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < TILE; i += 512) {
     if (mode == 0) atomicAdd(dst + i, v);
     else dst[i] = v;
@@ -55,5 +68,11 @@ int main() {
   for (int i = 0; i < NWG; ++i) t[i] = i;
   run("atomics: private tiles (no sharing)", t, 0, 0, 0);
   run("plain stores: private tiles", t, 1, 0, 0);
+  for (int i = 0; i < NWG; ++i) t[i] = i / 4;
+  run("atomics, 64 tiles x 4 sharers, 4 x 64-byte half lines per instruction", t, 2, 0, 0);
+  run("atomics, 64 tiles x 4 sharers, 2 x 128-byte lines per instruction", t, 3, 0, 0);
+  for (int i = 0; i < NWG; ++i) t[i] = 0;
+  run("atomics, ONE tile, 4 x 64-byte half lines per instruction", t, 2, 0, 0);
+  run("atomics, ONE tile, 2 x 128-byte lines per instruction", t, 3, 0, 0);
   return 0;
 }
