@@ -679,8 +679,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // thread-fixed channel chunk, constants in registers, U rows in flight, no LDS, no reduction tail.
 // REP: sum_dz / sum_dzx are the producer's `nrep` replica accumulators [nrep][C] (no sum_replicas launch in between):
 // every workgroup adds them up itself (replica_sums_block), workgroup 0 writes the gamma / beta gradients
+#ifndef CRIMAC_BNB_APPLY_WAVES
+#define CRIMAC_BNB_APPLY_WAVES 2     // waves per SIMD the kernel is compiled for (4: at most 128 registers, two rows in flight)
+#endif
+// Tried (CRIMAC_BNB_APPLY_WAVES=4): at most 128 registers, so that a wave of this kernel fits BESIDE the two waves per SIMD
+// of the plane-pair weight-gradient kernel (2 x 192 registers; it needs no LDS) and this HBM-bound pass could run on the same
+// CUs as the MFMA-bound weight gradient of the previous block on the two-stream step: 26.25 vs 26.13 ms -- no gain, the
+// streams do not put the two kernels on the chip at the same time often enough.
 template <typename T, typename TD = T, bool REP = false>
-__global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRIMAC_BNB_APPLY_WAVES)))
+void bn_bwd_apply_stream_kernel(
     const T* __restrict__ da, long da_ld, const T* __restrict__ y, long y_ld, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, long M, long count, int C,
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_stream_kernel(
     }
   }
   const long stride = (long)gridDim.x * rpi;
-  constexpr int U = 4;
+  constexpr int U = CRIMAC_BNB_APPLY_WAVES >= 4 ? 2 : 4;      // rows in flight per thread (two fit the 128-register budget)
   for (long m = (long)blockIdx.x * rpi + rl; m < M; m += U * stride) {
     float g[U][8], yv[U][8];
 #pragma unroll
