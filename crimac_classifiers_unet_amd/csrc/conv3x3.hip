@@ -313,6 +313,8 @@ int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int 
 int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
                           const EpiParams& epi, hipStream_t st, int fp16);
 // conv3x3_glds.hip: plane-pair input (CRIMAC_PREC_H3P), Cin % 32 == 0; out_planes: plane-pair output, else fp32
+int crimac_conv3x3_c16_hp(const void* in, long in_ld, int B, int H, int W, int N, const void* w, const EpiParams& epi,
+                          hipStream_t st, int out_planes);
 int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w,
                            const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes);
 
@@ -358,6 +360,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   p.w_hi = (const unsigned short*)w_hi; p.w_lo = (const unsigned short*)w_lo;
   EpiParams& e = p.epi;
   const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
+  const int cin4 = (relu & CRIMAC_EPI_CIN4) != 0;
   relu &= CRIMAC_EPI_RELU;
   CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode != 2),
                  "conv3x3: plane-pair output is an H3P option (never with the fused BatchNorm-backward sums)");
@@ -392,6 +395,10 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     if (Cin % 32 == 0 && use_glds)
       return crimac_conv3x3_glds_hp(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, out_planes);
     CRIMAC_REQUIRE(!pool_out, "conv3x3_pool (plane pairs): Cin %% 32 == 0 only");
+    // first layer (4 input channels padded to 16): the persistent 16-channel kernel on hi / lo pseudo-channels
+    static const int c16hp = getenv("CRIMAC_CONV_C16HP") ? atoi(getenv("CRIMAC_CONV_C16HP")) : 1;
+    if (c16hp && cin4 && Cin == 16 && N == 64 && use_glds && stat_mode != 2 && in_ld >= 8)
+      return crimac_conv3x3_c16_hp(in, in_ld, B, H, W, N, w_hi, e, st, out_planes);
     if (Cin % 32 == 0) {
       if (out_planes) return n128 ? launch<hp_t, 2, 128, 32, 8, half_t, hp_t>(p, st) : launch<hp_t, 2, 64, 32, 8, half_t, hp_t>(p, st);
       return n128 ? launch<hp_t, 2, 128, 32, 8, half_t, float>(p, st) : launch<hp_t, 2, 64, 32, 8, half_t, float>(p, st);

@@ -636,12 +636,21 @@ int launch_wch(ConvParams p, hipStream_t st) {
 //   * wave w owns image rows 4w .. 4w+3 x all 64 channels and writes them through a private LDS slab, one
 //     16-pixel row (2 KB contiguous in HBM) at a time -- no workgroup barrier in the epilogue;
 //   * the statistics stay in registers across tiles and are flushed once per workgroup.
-template <typename T16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 registers: 4 workgroups/CU
+// PP (plane pairs, CRIMAC_PREC_H3P): the SAME 16-channel fp16 convolution on sixteen PSEUDO-channels per pixel and tap,
+//   input  [x_hi(4) | x_lo(4) | x_hi(4) | 0(4)]   (the four real channels' hi / lo planes, assembled while the halo is staged
+//                                                  from the [8 hi][8 lo] groups in memory),
+//   weight [w_hi(4) | w_hi(4) | w_lo(4) | 0(4)]   (assembled when the weights go to LDS, from the interleaved [16 hi | 16 lo] rows),
+// whose sum over the sixteen "channels" is x_hi w_hi + x_lo w_hi + x_hi w_lo -- the three products of the plane-pair kernels
+// in the k-steps the 16-bit first layer already runs (the generic register-staged kernel took 232 us forward, 291 us in
+// inference).  TO: output storage (PP: float = the training forward's y, hp_t = plane pairs for inference).
+template <typename T16, typename TO = T16, bool PP = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(TO) == 2 ? 4 : 3, sizeof(TO) == 2 ? 4 : 3)))      // <= 128 (168) registers: 4 (3) workgroups/CU
 void conv3x3_c16_kernel(ConvParams p, int ntiles) {
+  constexpr bool HPO = __is_same(TO, hp_t);
+  using TS = typename std::conditional<HPO, float, TO>::type;      // element type of the output slabs
   constexpr int BN = 64, CB = 32;                 // bytes per halo pixel
   constexpr int NHU = (HALO_ROWS * 2 + 255) / 256;   // halo 16-byte units per thread: 3
-  constexpr int SLAB_PITCH = BN * 2 + 16, SLAB = 16 * SLAB_PITCH;
+  constexpr int SLAB_PITCH = BN * (int)sizeof(TS) + 16, SLAB = 16 * SLAB_PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -650,15 +659,23 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   unsigned char* wlds = smem + HALO_ROWS * CB + 4 * SLAB + 2 * BN * 4;
   const EpiParams& e = p.epi;
   const T16* inp = reinterpret_cast<const T16*>(p.in);
-  T16* outp = reinterpret_cast<T16*>(e.out);
+  TO* outp = reinterpret_cast<TO*>(e.out);
   const bool stats = e.stat_sum != nullptr && e.stat_mode == 1;
   if (tid < 2 * BN) sstat[tid] = 0.f;
 
   // weights [tap][n][16] (18 KB) -> LDS once per workgroup; fragment (s, j) of a lane = row j*16 + fr of tap
   // 2s + (fq >> 1), channels (fq & 1)*8 .. +8 (same 32-byte pitch as the halo: conflict-free ds_read_b128)
   const int fr = lane & 15, fq = lane >> 4;
-  for (int u = tid; u < 9 * BN * 2; u += 256)
-    *reinterpret_cast<u32x4*>(wlds + u * 16) = *reinterpret_cast<const u32x4*>(p.w_hi + (long)u * 8);
+  for (int u = tid; u < 9 * BN * 2; u += 256) {
+    if constexpr (PP) {
+      // row (tap, n) in memory: [16 hi | 16 lo] halves; unit 0 of its LDS row = [hi 0-3 | hi 0-3], unit 1 = [lo 0-3 | 0]
+      const unsigned short* wr = p.w_hi + (long)(u >> 1) * 32;
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(wr), lo = *reinterpret_cast<const u32x2*>(wr + 16);
+      *reinterpret_cast<u32x4*>(wlds + u * 16) = (u & 1) ? u32x4{lo[0], lo[1], 0u, 0u} : u32x4{hi[0], hi[1], hi[0], hi[1]};
+    } else {
+      *reinterpret_cast<u32x4*>(wlds + u * 16) = *reinterpret_cast<const u32x4*>(p.w_hi + (long)u * 8);
+    }
+  }
   int b_off[5];
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
@@ -701,8 +718,21 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
       const int hy = row / HP, hx = row - hy * HP;
       const int y = y0 + hy - 1, x = x0 + hx - 1;
       hreg[i] = u32x4{0, 0, 0, 0};
-      if (u < HALO_ROWS * 2 && y >= 0 && y < p.H && x >= 0 && x < p.W)
-        hreg[i] = *reinterpret_cast<const u32x4*>(inp + (((long)b * p.H + y) * p.W + x) * p.in_ld + half * 8);
+      if (u < HALO_ROWS * 2 && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+        if constexpr (PP) {
+          // pixel in memory (in_ld halves): [8 hi | 8 lo] of channels 0-7 first; unit 0 = [hi 0-3 | lo 0-3], unit 1 = [hi 0-3 | 0]
+          const T16* px = inp + (((long)b * p.H + y) * p.W + x) * p.in_ld;
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(px);
+          if (half == 0) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(px + 8);
+            hreg[i] = u32x4{hi[0], hi[1], lo[0], lo[1]};
+          } else {
+            hreg[i] = u32x4{hi[0], hi[1], 0u, 0u};
+          }
+        } else {
+          hreg[i] = *reinterpret_cast<const u32x4*>(inp + (((long)b * p.H + y) * p.W + x) * p.in_ld + half * 8);
+        }
+      }
     }
   };
 
@@ -757,22 +787,43 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int px = (lane >> 4) * 4 + r;
-            float v = acc[i][j][r] + bv[j];
+            float v = (PP ? acc[i][j][r] * e.acc_scale : acc[i][j][r]) + bv[j];
             if (e.relu) v = fmaxf(v, 0.f);
-            const T16 q = (T16)v;
-            *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
-            const float vs = (float)q;            // statistics of the value as STORED
+            const TS q = (TS)v;
+            *reinterpret_cast<TS*>(slab + px * SLAB_PITCH + (j * 16 + fr) * (int)sizeof(TS)) = q;
+            const float vs = HPO ? storage_round<hp_t>(v) : (float)q;            // statistics of the value as STORED
             const bool ok = y < p.H && x0 + px < p.W;
             cs1[j] += ok ? vs : 0.f;
             cs2[j] += ok ? vs * vs : 0.f;
           }
         // (wave-private slab: LDS operations of one wave execute in order, no barrier)
+        if constexpr (sizeof(TS) == 2) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int u = lane + k * 64, px = u >> 3, c8 = u & 7;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(slab + px * SLAB_PITCH + c8 * 16);
-          if (y < p.H && x0 + px < p.W)
-            *reinterpret_cast<u32x4*>(outp + (((long)b * p.H + y) * p.W + x0 + px) * e.out_ld + c8 * 8) = v;
+          for (int k = 0; k < 2; ++k) {
+            const int u = lane + k * 64, px = u >> 3, c8 = u & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(slab + px * SLAB_PITCH + c8 * 16);
+            if (y < p.H && x0 + px < p.W)
+              *reinterpret_cast<u32x4*>(outp + (((long)b * p.H + y) * p.W + x0 + px) * e.out_ld + c8 * 8) = v;
+          }
+        } else {
+          // 4-byte outputs: 16 lanes per pixel (256 bytes), one 16-byte store each: whole lines per wave-instruction; plane
+          // pairs: a PAIR of lanes takes an 8-channel group, the even lane stores its hi plane, the odd lane its lo plane
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int u = lane + k * 64, px = u >> 4, c4 = u & 15;
+            const bool ok = y < p.H && x0 + px < p.W;
+            TO* dst = outp + (((long)b * p.H + y) * p.W + x0 + px) * e.out_ld + c4 * 4;
+            if constexpr (HPO) {
+              float v8[8];
+              load8(reinterpret_cast<const float*>(slab + px * SLAB_PITCH) + (c4 >> 1) * 8, v8);
+              u32x4 hi, lo;
+              hp_split(v8, hi, lo);
+              if (ok) *reinterpret_cast<u32x4*>(dst) = (c4 & 1) ? lo : hi;
+            } else {
+              const u32x4 v = *reinterpret_cast<const u32x4*>(slab + px * SLAB_PITCH + c4 * 16);
+              if (ok) *reinterpret_cast<u32x4*>(dst) = v;
+            }
+          }
         }
       }
     }
@@ -797,14 +848,16 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   }
 }
 
-template <typename T16>
+template <typename T16, typename TO = T16, bool PP = false>
 int launch_c16(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t lds = (size_t)HALO_ROWS * 32 + 4 * 16 * (64 * 2 + 16) + 2 * 64 * 4 + 9 * 64 * 32;   // 38.6 KB
-  const long grid = ntiles < 1024 ? ntiles : 1024;          // 4 workgroups per CU
-  hipLaunchKernelGGL(conv3x3_c16_kernel<T16>, dim3((unsigned)grid), dim3(256), lds, st, p, (int)ntiles);
+  constexpr int OB = sizeof(TO) == 2 ? 2 : 4;               // bytes per staged output element
+  constexpr size_t lds = (size_t)HALO_ROWS * 32 + 4 * 16 * (64 * OB + 16) + 2 * 64 * 4 + 9 * 64 * 32;   // 38.6 KB (46.7 KB)
+  const long cap = OB == 2 ? 1024 : 768;                    // 4 (3) workgroups per CU
+  const long grid = ntiles < cap ? ntiles : cap;
+  hipLaunchKernelGGL((conv3x3_c16_kernel<T16, TO, PP>), dim3((unsigned)grid), dim3(256), lds, st, p, (int)ntiles);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }
@@ -1296,6 +1349,18 @@ int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N
   p.epi = epi;
   p.n_first = 0; p.n_count = N;
   return fp16 ? launch_c16<half_t>(p, st) : launch_c16<bf16_t>(p, st);
+}
+
+// first layer, plane pairs (CRIMAC_PREC_H3P): in = [pixels][in_ld channels] of hp_t (in_ld >= 8), w = interleaved planes
+// [9][N][16 hi | 16 lo]; output fp32 or (out_planes) plane pairs
+int crimac_conv3x3_c16_hp(const void* in, long in_ld, int B, int H, int W, int N, const void* w, const EpiParams& epi,
+                          hipStream_t st, int out_planes) {
+  ConvParams p;
+  p.in = in; p.in_ld = 2 * in_ld; p.B = B; p.H = H; p.W = W; p.Cin = 16; p.N = N;
+  p.w_hi = (const unsigned short*)w;
+  p.epi = epi;
+  p.n_first = 0; p.n_count = N;
+  return out_planes ? launch_c16<half_t, hp_t, true>(p, st) : launch_c16<half_t, float, true>(p, st);
 }
 
 namespace {

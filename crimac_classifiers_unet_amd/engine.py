@@ -531,6 +531,8 @@ class UNetEngine:
         instead of fp32.  Returns True if the requested fusion ran inside the conv kernel."""
         flops = 2.0 * 9 * (cin_real or cin) * cout * B * H * W
         relu = (hip.EPI_RELU if relu else 0) | (hip.EPI_OUT_PLANES if (out_planes and self.is_hp) else 0)
+        if self.is_hp and cin_real is not None and cin_real <= 4 and cin == CIN_PAD and not dgrad:
+            relu |= hip.EPI_CIN4          # (the network input: channels 4 .. 15 of the padded pixel are zero)
         w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
         prec = self.prec_bwd if dgrad else self.prec
         if self.conv_impl == "halo":

@@ -93,6 +93,10 @@ extern "C" {
  * reduction) = store the output as fp16 plane pairs (it feeds another contraction) instead of fp32. */
 #define CRIMAC_EPI_RELU 1
 #define CRIMAC_EPI_OUT_PLANES 2
+/* bit 2 (CRIMAC_PREC_H3P, Cin == 16): a promise that only the first FOUR input channels are non-zero (the network input,
+ * unet.py:77 with in_channels <= 4) -- selects the persistent first-layer kernel, which contracts their hi / lo planes as
+ * sixteen pseudo-channels.  Without it the generic kernel runs. */
+#define CRIMAC_EPI_CIN4 4
 
 /* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
  * struct passed by pointer (crimac_layer_desc), the meaning of an argument or the set of precisions changes, and a

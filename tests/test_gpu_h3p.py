@@ -159,6 +159,43 @@ def test_conv3x3_forward_fp32_and_plane_pair_outputs(shape):
     assert relerr(s1, y.sum((0, 2, 3))) < 1e-5 and relerr(s2, (y * y).sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 4), (3, 21, 37, 4), (1, 40, 24, 3), (20, 128, 128, 4), (2, 256, 256, 4)])
+def test_first_layer_on_the_persistent_pseudo_channel_kernel(shape):
+    """CRIMAC_EPI_CIN4: the network input (<= 4 real channels of the padded 16) through the persistent first-layer kernel
+    (hi / lo planes as sixteen pseudo-channels) == F.conv2d, == the generic kernel to rounding; fp32 output with fused
+    statistics (training) and ReLU + plane-pair output (inference); partial tiles and persistent tile loops (> 768 tiles)."""
+    B, H, W, Ci = shape
+    Co = 64
+    g = torch.Generator().manual_seed(2)
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g) * 3)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    fh, fl, _, _ = pack_conv(w, 16, dgrad=False)
+    ref = F.conv2d(x.double(), w_round(w).double(), b.double(), padding=1).float()
+    xin = to_nhwc_hp(x, ld=16)
+    bd = b.cuda()
+    M = B * H * W
+
+    def run(flags, stats=None):
+        out = torch.full((M, Co), 7.0, dtype=torch.float32, device="cuda")
+        mode, s0, s1 = (1, ptr(stats[0]), ptr(stats[1])) if stats is not None else (0, None, None)
+        call("crimac_conv3x3", P, ptr(xin), 16, B, H, W, 16, Co, ptr(fh), ptr(fl), ptr(bd), ptr(out), Co, flags, mode, s0, s1, 4,
+             None, 0, None, 0)
+        torch.cuda.synchronize()
+        return out
+
+    st = [torch.zeros(4 * Co, dtype=torch.float64, device="cuda") for _ in range(2)]
+    out = run(hip.EPI_CIN4, st)
+    y = from_nhwc(out, B, H, W)
+    assert relerr(y, ref) < TOL
+    assert relerr(from_nhwc(run(0), B, H, W), y) < 2e-6                      # the generic kernel
+    yd = y.double()
+    s1, s2 = st[0].view(4, Co).sum(0).cpu(), st[1].view(4, Co).sum(0).cpu()
+    assert relerr(s1, yd.sum((0, 2, 3))) < 1e-5 and relerr(s2, (yd * yd).sum((0, 2, 3))) < 1e-5
+    got = from_nhwc_hp(run(hip.EPI_CIN4 | hip.EPI_RELU | hip.EPI_OUT_PLANES), B, H, W)
+    assert relerr(got, torch.relu(ref)) < TOL
+
+
 def test_conv3x3_strided_io_and_channel_ranges():
     """Input and output in channel slices of wider buffers (the concat buffers), and crimac_conv3x3_cols: the two halves
     of a decoder input gradient, the first as plane pairs with column sums, the second as fp32 -- in ONE buffer."""

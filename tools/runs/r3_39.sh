@@ -1,0 +1,12 @@
+#!/bin/bash
+set -e
+mkdir -p gpurun_out/r3_39
+timeout -k 10 900 python -m pytest tests/test_gpu_h3p.py tests/test_lmi.py -q -x -m gpu > gpurun_out/r3_39/t1.log 2>&1 || { tail -60 gpurun_out/r3_39/t1.log; exit 1; }
+tail -1 gpurun_out/r3_39/t1.log
+BA="--steps 20 --warmup 5 --no-cpu-baseline --no-tiled --no-parity-mode --no-wide"
+for i in 1 2; do
+for V in 1 0; do
+CRIMAC_CONV_C16HP=$V timeout -k 10 200 python bench.py --precision h3p $BA 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('h3p c16hp=$V', d['value'], d['ms_per_step'], d['infer_patches_per_s'])"
+done; done
