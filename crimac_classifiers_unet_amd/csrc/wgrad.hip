@@ -436,6 +436,181 @@ void wgrad_pp_kernel(WgradParams p) {
   else run(std::integral_constant<int, 1>{});
 }
 
+// ---- plane pairs, transposed convolution 2x2 / stride 2: 128 F x 64 S REAL channels x 4 taps per workgroup of 8 waves ----
+// dW[ab][ci][co] = sum_p X[p][ci] dY[(2y + a, 2x + b)][co]: F = X on the coarse grid, S = dY on the fine grid.  Four taps
+// give a staged byte a quarter of the MFMAs the 3x3 kernel gets out of it, so the launch is its tile traffic: with 64 x 64
+// tiles every shape of the network moves 1.34 GB through the LDS-DMA path (F is re-read CS / 64 times, S CF / 64 times);
+// 128 x 64 tiles move 0.8 GB.  Tile = 2 x 16 coarse pixels (one k-step of 32 pixels): F as four 32-channel images of 32
+// rows, S as two images of 128 rows ordered [fine row][column parity][x] (48 KB per buffer, two buffers); rows, slots and
+// the swizzle as in wgrad_pp_kernel.  Waves = S image x S slot pair x tap group (a = 0 | a = 1); every wave holds all 128
+// F channels (16 plane fragments), 2 taps x 8 accumulator tiles; per tile 40 transposing reads, one wait, 48 MFMAs.
+constexpr int UP_F_IMG = 32 * 128, UP_S_IMG = 128 * 128;
+constexpr int UP_BUF = 4 * UP_F_IMG + 2 * UP_S_IMG;          // 49,152 bytes per tile buffer
+struct UpFrags {
+  bf16x4 a[16][2];        // [F plane fragment: image * 4 + slot][read]
+  bf16x4 b[2][2][2];      // [tap of the group][S fragment: hi, lo][read]
+};
+template <int FH>
+__device__ __forceinline__ void up_rd_a(unsigned fv0, UpFrags& f) {
+  f.a[FH][0] = lds_tr16_asm<(FH >> 2) * UP_F_IMG>(fv0 ^ ((FH & 3) << 5));
+  f.a[FH][1] = lds_tr16_asm<(FH >> 2) * UP_F_IMG + 8 * 128>(fv0 ^ ((FH & 3) << 5));
+  if constexpr (FH + 1 < 16) up_rd_a<FH + 1>(fv0, f);
+}
+template <int A, int L>          // tap (a = A, b = L): S rows A * 32 + L * 16 + (this lane's row)
+__device__ __forceinline__ void up_rd_b(unsigned s0, UpFrags& f) {
+  constexpr int c = A * 32 + L * 16;
+  f.b[L][0][0] = lds_tr16_asm<c * 128>(s0);
+  f.b[L][0][1] = lds_tr16_asm<(c + 8) * 128>(s0);
+  f.b[L][1][0] = lds_tr16_asm<c * 128>(s0 ^ 32);
+  f.b[L][1][1] = lds_tr16_asm<(c + 8) * 128>(s0 ^ 32);
+}
+template <int L, int FH, typename ACC>
+__device__ __forceinline__ void up_mfma(UpFrags& f, ACC& acc) {
+  const bf16x8 af = __builtin_shufflevector(f.a[FH][0], f.a[FH][1], 0, 1, 2, 3, 4, 5, 6, 7);
+  const bf16x8 b_hi = __builtin_shufflevector(f.b[L][0][0], f.b[L][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+  if constexpr ((FH & 1) == 0) {
+    const bf16x8 b_lo = __builtin_shufflevector(f.b[L][1][0], f.b[L][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[L][FH >> 1] = E16<half_t>::mfma16(af, b_lo, acc[L][FH >> 1]);
+  }
+  acc[L][FH >> 1] = E16<half_t>::mfma16(af, b_hi, acc[L][FH >> 1]);
+  if constexpr (FH + 1 < 16) up_mfma<L, FH + 1>(f, acc);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wgrad_up_pp_kernel(WgradParams p) {
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NDMA = 4 * 4 + 2 * 16;                 // DMA wave-instructions (8 rows = 1 KiB each) per tile
+  constexpr int NI = NDMA / 4;                         // ... per moving wave (waves 4-7, as in wgrad_pp_kernel)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ws = wave & 1, sa = (wave >> 1) & 1, tg = wave >> 2;
+  const int cs_tiles = p.CS / 64;
+  const int ch_tiles = (p.CF / 128) * cs_tiles;
+  int qt, split;
+  if (p.nsplits % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    qt = j % ch_tiles;
+    split = xcd + 8 * (j / ch_tiles);
+  } else if (ch_tiles % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, R = ch_tiles >> 3;
+    qt = xcd * R + j % R;
+    split = j / R;
+  } else {
+    qt = blockIdx.x % ch_tiles;
+    split = blockIdx.x / ch_tiles;
+  }
+  const int cf0 = (qt / cs_tiles) * 128, cs0 = (qt % cs_tiles) * 64;
+  const hp_t* fp = reinterpret_cast<const hp_t*>(p.f);
+  const hp_t* sp = reinterpret_cast<const hp_t*>(p.s);
+  const int Ws = 2 * p.Wf;
+
+  // DMA plan of a moving wave: instruction k = (wave & 3) + 4 i; k in [0,16): F image k / 4, rows 8 (k % 4) ..; [16,48): S image
+  const int sub = lane >> 3, c = lane & 7;
+  unsigned rel[NI];
+  int lds_at[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = (wave & 3) + 4 * i;
+    const bool is_s = k >= 16;
+    const int kk = is_s ? k - 16 : k;
+    const int img = is_s ? kk >> 4 : kk >> 2;
+    const int row = 8 * (is_s ? (kk & 15) : (kk & 3)) + sub;
+    const int u = c ^ (swz16(row) >> 4);                       // logical 16-byte unit this lane's LDS position holds
+    const int su = (((u >> 2) * 2 + (u & 1)) << 1) | ((u >> 1) & 1);   // its source unit: group (2 fh + half), plane
+    lds_at[i] = is_s ? 4 * UP_F_IMG + img * UP_S_IMG + (row - sub) * 128 : img * UP_F_IMG + (row - sub) * 128;
+    if (!is_s) {
+      rel[i] = (unsigned)((((row >> 4) * (long)p.Wf + (row & 15)) * p.f_ld + cf0 + 32 * img) * 4 + su * 16);
+    } else {
+      const int fy = row >> 5, b = (row >> 4) & 1, x = row & 15;            // fine pixel (fy, 2 x + b) of the tile
+      rel[i] = (unsigned)(((fy * (long)Ws + 2 * x + b) * p.s_ld + cs0 + 32 * img) * 4 + su * 16);
+    }
+  }
+  auto issue_tile = [&](long tile, int buf) {
+    const int txi = (int)(tile % p.tiles_x);
+    const long tt = tile / p.tiles_x;
+    const int y0 = (int)(tt % p.tiles_y) * 2, x0 = txi * 16;
+    const long b = tt / p.tiles_y;
+    unsigned char* base = smem + buf * UP_BUF;
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<hp_t*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<hp_t*>(sp + ((b * 2 * p.Hf + 2 * y0) * (long)Ws + 2 * x0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = (wave & 3) + 4 * i;
+      const bool is_s = k >= 16;
+      const int kk = is_s ? k - 16 : k;
+      const int row = 8 * (is_s ? (kk & 15) : (kk & 3)) + sub;
+      // coarse pixel of the row: F (row >> 4, row & 15); S fine row row >> 5 -> coarse row (row >> 6), column row & 15
+      const int cy = is_s ? (row >> 6) : (row >> 4), cx = row & 15;
+      const bool ok = (y0 + cy) < p.Hf && (x0 + cx) < p.Wf;
+      if (!is_s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + lds_at[i]), 16,
+                                                 (int)(ok ? rel[i] : OOB), 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(base + lds_at[i]), 16,
+                                                 (int)(ok ? rel[i] : OOB), 0, 0, 0);
+    }
+  };
+
+  const long t_begin = (long)split * p.tiles_per_block;
+  const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;        // F row of this lane's k-group (coarse row g / 2)
+  const int RSl = (g >> 1) * 64 + 4 * (g & 1) + q;       // S row: coarse row y -> fine rows 2 y, 2 y + 1 = 64 rows further
+  const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
+  const bool mover = wave >= 4;
+  auto run = [&](auto tgc) {
+    constexpr int A = decltype(tgc)::value;              // this wave's taps: (a = A, b = 0), (a = A, b = 1)
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][fr][r] = 0.f;
+    if (t_begin < t_end && mover) issue_tile(t_begin, 0);
+    for (long tile = t_begin; tile < t_end; ++tile) {
+      const int cur = (int)((tile - t_begin) & 1);
+      __syncthreads();           // vmcnt(0) + barrier: the tile has landed for everyone, the other buffer is free
+      if (tile + 1 < t_end && mover) issue_tile(tile + 1, cur ^ 1);
+      const unsigned aF = lds0 + cur * UP_BUF, aS = aF + 4 * UP_F_IMG + sa * UP_S_IMG;
+      const unsigned fv0 = aF + RF * 128 + 8 * pp + swz16(RF);
+      const unsigned s0 = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(RSl));
+      UpFrags f;
+      up_rd_a<0>(fv0, f);
+      up_rd_b<A, 0>(s0, f);
+      up_rd_b<A, 1>(s0, f);
+      wait_lgkm<0>();
+#pragma unroll
+      for (int fh = 0; fh < 16; ++fh) { tie(f.a[fh][0]); tie(f.a[fh][1]); }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) { tie(f.b[t][sh][0]); tie(f.b[t][sh][1]); }
+      up_mfma<0, 0>(f, acc);
+      up_mfma<1, 0>(f, acc);
+    }
+    // dw[ab][ci][co] += acc: F rows cf0 + 16 fr .. +15, S columns cs0 + 32 sa + 16 ws .. +15, taps 2 A, 2 A + 1
+    float* dwp = p.dw + (p.partial_stride > 0 ? (long)split * p.partial_stride : 0);
+    const int col = cs0 + sa * 32 + ws * 16 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int fr = 0; fr < 8; ++fr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = cf0 + fr * 16 + (lane >> 4) * 4 + r;
+          float* dst = dwp + ((long)(2 * A + t) * p.CF + row) * p.CS + col;
+          if (p.partial_stride > 0) *dst = acc[t][fr][r];
+          else atomicAdd(dst, acc[t][fr][r]);
+        }
+  };
+  if (tg == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
 // MODE 0: conv3x3 (TR = 8, halo 10 x 18);  MODE 1: upconv 2x2 (TR = 4, fine patch 8 x 32)
 //
 // bf16 path: tiles go global -> LDS directly (LDS-DMA through a buffer resource rebased on the tile origin,
@@ -1042,6 +1217,32 @@ int launch_pp(WgradParams p, int target_blocks, hipStream_t st) {
   return CRIMAC_OK;
 }
 
+// plane pairs, transposed convolution: the 128 x 64 kernel above (CRIMAC_WGRAD_UP_PP=0: the register-staged kernel)
+bool up_pp_ok(int prec, int mode, int CF, int CS, long f_ld, long s_ld, int Wf, long partial_stride) {
+  static const int off = getenv("CRIMAC_WGRAD_UP_PP") ? atoi(getenv("CRIMAC_WGRAD_UP_PP")) == 0 : 0;
+  return !off && prec == CRIMAC_PREC_H3P && mode == 1 && partial_stride == 0 && CF % 128 == 0 && CS % 64 == 0 &&
+         (2L * Wf + 16) * f_ld * 4 < (1L << 31) && (8L * Wf + 32) * s_ld * 4 < (1L << 31);
+}
+int launch_up_pp(WgradParams p, int target_blocks, hipStream_t st) {
+  p.tiles_y = cdiv(p.Hf, 2);
+  p.tiles_x = cdiv(p.Wf, 16);
+  p.ntiles = (long)p.B * p.tiles_y * p.tiles_x;
+  const int ch_tiles = (p.CF / 128) * (p.CS / 64);
+  const int target = target_blocks > 0 ? target_blocks : 256;       // one workgroup of 8 waves per CU
+  long splits = target / ch_tiles;
+  if (splits < 1) splits = 1;
+  if (splits > p.ntiles) splits = p.ntiles;
+  p.tiles_per_block = cdiv(p.ntiles, splits);
+  p.nsplits = cdiv(p.ntiles, p.tiles_per_block);
+  static unsigned long long attr_devs = 0;
+  if (crimac_first_use_on_device(&attr_devs))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_up_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  hipLaunchKernelGGL(wgrad_up_pp_kernel, dim3(ch_tiles * p.nsplits), dim3(512), 2 * (size_t)UP_BUF, st, p);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
 // 16-bit storage, conv3x3: the two-team kernel (CRIMAC_WGRAD_TEAMS=1 selects the 4-wave kernel for A/B runs)
 // plane pairs, conv3x3, whole 64-channel tiles both ways, 32-bit DMA offsets inside a tile: the 8-wave kernel above
 bool pp_ok(int prec, int mode, int CF, int CS, long f_ld, long s_ld, int Wf) {
@@ -1088,6 +1289,7 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
     return mode == 0 ? launch<float, 2, 0>(p, target_blocks, st) : launch<float, 2, 1>(p, target_blocks, st);
   if (prec == CRIMAC_PREC_H3P) {    // both operands are fp16 plane pairs (activation x loss-scaled output gradient)
     if (pp_ok(prec, mode, CF, CS, f_ld, s_ld, Wf)) return launch_pp(p, target_blocks, st);
+    if (up_pp_ok(prec, mode, CF, CS, f_ld, s_ld, Wf, p.partial_stride)) return launch_up_pp(p, target_blocks, st);
     return mode == 0 ? launch<hp_t, 2, 0>(p, target_blocks, st) : launch<hp_t, 2, 1>(p, target_blocks, st);
   }
   return mode == 0 ? launch<float, 3, 0>(p, target_blocks, st) : launch<float, 3, 1>(p, target_blocks, st);

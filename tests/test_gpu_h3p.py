@@ -265,7 +265,8 @@ def test_conv3x3_with_fused_maxpool_plane_pairs():
     assert torch.equal(from_nhwc_hp(pool, B, H // 2, W // 2), F.max_pool2d(a, 2))     # pool of the values as stored, exactly
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 4, 8, 256, 128), (2, 24, 40, 128, 64), (2, 64, 64, 256, 128)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 4, 8, 256, 128), (2, 24, 40, 128, 64), (2, 64, 64, 256, 128),
+                                   (3, 5, 7, 128, 64), (32, 16, 16, 1024, 512), (1, 8, 8, 384, 128)])
 def test_upconv2x2_forward_dgrad_wgrad(shape):
     B, H, W, Ci, Co = shape
     g = torch.Generator().manual_seed(5)
