@@ -241,10 +241,10 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
            "train_tflops": world * B * steps / elapsed * TRAIN_GFLOP_PER_PATCH * scale_f / 1e3,
            "final_loss": final_loss, "loss_scale": eng.loss_scale, "skipped_steps": skipped,
            "roofline": roofline("crimac_conv3x3", CONV_KERNELS if precision in ("bf16", "fp16") else
-                                ("crimac_conv3x3: conv3x3_wch_kernel + conv3x3_glds_w4_kernel (plane-pair forms: 3 MFMAs per "
-                                 "fragment pair) + conv3x3_kernel (first layer)" if precision == "h3p" else
+                                ("crimac_conv3x3: conv3x3_wch_kernel (plane-pair forms: 3 MFMAs per fragment pair) + conv3x3_c16_kernel "
+                                 "(first layer, pseudo-channels)" if precision == "h3p" else
                                  "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)")),
-           "roofline_wgrad": roofline("crimac_wgrad", "wgrad_pp_kernel + wgrad_kernel (weight gradient, all shapes)"
+           "roofline_wgrad": roofline("crimac_wgrad", "wgrad_pp_kernel + wgrad_up_pp_kernel + wgrad_kernel (weight gradient, all shapes)"
                                       if precision == "h3p" else "wgrad_kernel (weight gradient, all shapes)")}
     if infer:
         model.eval()
