@@ -117,9 +117,13 @@ template <bool PP> __device__ __forceinline__ int src_unit(int u) { return PP ? 
 
 // SCATTER: forward (output on the fine grid, column group (a,b) -> pixel (2y+a, 2x+b)); else dense dgrad tile.
 // PP: plane-pair input (p.K / p.in_ld count halves); TO: output storage type (T16, float, or hp_t plane pairs)
-template <bool SCATTER, typename T16, typename TO = T16, bool PP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NWV: waves per workgroup = 32-column groups sharing the A tile: 4 (128 columns, two workgroups per CU) or 8 (256 columns,
+// one workgroup per CU: an experiment, see launch()).  Every column group of a pixel tile stages the same A chunks
+// (plane pairs, 1024 -> 512 forward: 16 column groups x 33.5 MB = 0.54 GB through the LDS-DMA path in 105 us).
+template <bool SCATTER, typename T16, typename TO = T16, bool PP = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void upconv_wch_kernel(UpParams p) {
+  constexpr int BN = 32 * NWV, NW = NWV, NA = A_BYTES / 1024 / NWV, NTHR = 64 * NWV;      // (shadow the 4-wave constants)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
@@ -218,7 +222,7 @@ void upconv_wch_kernel(UpParams p) {
   __syncthreads();                       // staging below reuses the A buffers
 
   if constexpr (!SCATTER) {
-    conv_epilogue<TO, BN, BM, 256, 16, 2, f32x4, -1, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
+    conv_epilogue<TO, BN, BM, NTHR, 16, 2, f32x4, -1, EpiPasses<TO>::value>(acc, p.epi, smem, b, y0, x0, n0, TP, 0, wave);
   } else {
     // bias, then the tile through LDS: [256 rows][128 cols + pad] (16-bit types: all rows at once; fp32 / plane pairs:
     // two slices of 128 rows, staged as fp32), then 16-byte stores scattered to the fine grid: column
@@ -232,7 +236,7 @@ void upconv_wch_kernel(UpParams p) {
     // x 16 BYTES per row, 8 rows per round -- consecutive lanes on consecutive 16 bytes (whole lines per wave-instruction,
     // conv_epilogue.h); plane pairs: the even lane of a pair stores the hi plane of an 8-column group, the odd lane the lo
     constexpr bool W4 = sizeof(TS) == 4;
-    constexpr int LPR = W4 ? 32 : 16, RPR = 256 / LPR;
+    constexpr int LPR = W4 ? BN / 4 : BN / 8, RPR = NTHR / LPR;       // lanes per row; rows per round: 8 (4-byte), 16 (16-bit)
     const int cl = tid % LPR, r0 = tid / LPR;
     const int n = n0 + (W4 ? (HPO ? (cl >> 1) * 8 : cl * 4) : cl * 8);
     const int ab = n / p.cout, co = n - ab * p.cout;
@@ -277,21 +281,33 @@ void upconv_wch_kernel(UpParams p) {
   }
 }
 
-template <bool SCATTER, typename T16, typename TO = T16, bool PP = false>
-int launch(UpParams p, hipStream_t st) {
+template <bool SCATTER, typename T16, typename TO, bool PP, int NWV>
+int launch_n(UpParams p, hipStream_t st) {
+  constexpr int BNK = 32 * NWV;
   p.tiles_y = cdiv(p.H, TP);
   p.tiles_x = cdiv(p.W, TP);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t stage = (size_t)(BM / EpiPasses<TO>::value) * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4;
+  constexpr size_t stage = (size_t)(BM / EpiPasses<TO>::value) * (BNK * EpiPasses<TO>::kStageBytes + 16) + 2 * BNK * 4;
+  static_assert(stage <= 160 * 1024, "epilogue staging");
   const size_t lds = stage > 2 * (size_t)A_BYTES ? stage : 2 * (size_t)A_BYTES;
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER, T16, TO, PP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wch_kernel<SCATTER, T16, TO, PP, NWV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER, T16, TO, PP>), dim3((unsigned)ntiles, p.N / BN), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((upconv_wch_kernel<SCATTER, T16, TO, PP, NWV>), dim3((unsigned)ntiles, p.N / BNK), dim3(64 * NWV), lds, st,
+                     p);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
+}
+// CRIMAC_UPCONV_W8=1: 256 columns per workgroup where the column count allows it.  Measured (B = 32, same box): it halves
+// the A-tile traffic, but one 8-wave workgroup per CU has no second workgroup to cover its chunk barriers and epilogue:
+// plane pairs 25.56 vs 25.32 ms per step (inference +0.6 %), bf16 equal (inference -2 %) -- off by default.
+template <bool SCATTER, typename T16, typename TO = T16, bool PP = false>
+int launch(UpParams p, hipStream_t st) {
+  static const int w8 = getenv("CRIMAC_UPCONV_W8") ? atoi(getenv("CRIMAC_UPCONV_W8")) : 0;
+  if (w8 && p.N % 256 == 0) return launch_n<SCATTER, T16, TO, PP, 8>(p, st);
+  return launch_n<SCATTER, T16, TO, PP, 4>(p, st);
 }
 
 }  // namespace
