@@ -547,6 +547,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
 
   const int kchunks = p.Cin / BK;
   WchFrags f;
+#ifndef CRIMAC_WCH_NO_BIAS_PRE
+  // this lane's two bias values, requested here and used by the epilogue (conv_epilogue.h: bias_pre)
+  float bias_pre[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) bias_pre[nb] = p.epi.bias ? p.epi.bias[n0 + wc * 32 + nb * 16 + (lane & 15)] : 0.f;
+#endif
   issue_halo(0);                         // (in flight together with the first weight fragments: one latency, not two)
   wch_load_b(wrow, wrow + w_nb, f.b[1]);
   wch_land_b(f.b[1]);                    // vmcnt(0): the fragments and the first halo chunk
@@ -575,7 +581,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   // (tall form, 16-bit output: two slices of 256 rows like the other forms' whole tile -- 16 fully unrolled store rounds
   // spill ~60 registers in the statistics mode)
   constexpr int EPASS = EpiPasses<TO>::value * (FORM == 2 && sizeof(TO) == 2 ? 2 : 1);
+#ifndef CRIMAC_WCH_NO_BIAS_PRE
+  conv_epilogue<TO, BN, TRK * TC, 256, WR, 2, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc, bias_pre);
+#else
   conv_epilogue<TO, BN, TRK * TC, 256, WR, 2, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc);
+#endif
 #ifdef CRIMAC_DIAG_PHASES
   // cycles of wave 0: prologue | waiting for the halo chunks | MFMA steps | epilogue (stores issued)
   CRIMAC_CPH(3)

@@ -75,7 +75,7 @@ template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, b
           bool ILV = false>
 __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], const EpiParams& e,
                                                    unsigned char* smem, int b, int y0, int x0, int n0,
-                                                   int wr, int wc) {
+                                                   int wr, int wc, const float* bias_pre = nullptr) {
   using L = AccLayout<ACC>;
   constexpr bool HPO = __is_same(TA, hp_t);
   using TS = typename std::conditional<HPO, float, TA>::type;           // element type of the staging tile
@@ -116,8 +116,13 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
 #else
   constexpr bool HOIST = PASSES > 1;
 #endif
+  // bias_pre: the caller loaded this lane's NT bias values before its main loop (the load's L2 round trip at the head of
+  // the epilogue is ~1.5 k cycles in which the whole workgroup does nothing)
   float bvs[NT];
-  if constexpr (HOIST) {
+  if (bias_pre) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bvs[j] = bias_pre[j];
+  } else if constexpr (HOIST) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) bvs[j] = e.bias ? e.bias[n0 + wc * (NT * L::TS) + j * L::TS + L::col(lane)] : 0.f;
   }
@@ -128,7 +133,10 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
   for (int j = 0; j < NT; ++j) {
     const int col = wc * (NT * L::TS) + j * L::TS + L::col(lane);
     float bv;
-    if constexpr (HOIST) {
+    if (bias_pre) {
+      bv = bvs[j];
+      asm volatile("" : "+v"(bv));
+    } else if constexpr (HOIST) {
       bv = bvs[j];
       asm volatile("" : "+v"(bv));     // (keeps this slice's bias / ReLU / rounding arithmetic behind the barrier above: hoisted
                                        // in front of it, hipcc holds both slices' results and spills ~80 registers)
@@ -367,13 +375,13 @@ template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, typename AC
           bool ILV = false>
 __device__ __forceinline__ void conv_epilogue(const ACC (&acc)[MT][NT], const EpiParams& e,
                                               unsigned char* smem, int b, int y0, int x0, int n0,
-                                              int tile_rows, int wr, int wc) {
+                                              int tile_rows, int wr, int wc, const float* bias_pre = nullptr) {
   const bool full = (y0 + tile_rows <= e.H) && (x0 + 16 <= e.W);
   const int mode = MODE >= 0 ? MODE : (e.stat_sum ? e.stat_mode : 0);
 #define CRIMAC_EPI(M)                                                                                      \
   do {                                                                                                     \
-    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC, PASSES, ILV>(acc, e, smem, b, y0, x0, n0, wr, wc);   \
-    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC, PASSES, ILV>(acc, e, smem, b, y0, x0, n0, wr, wc);       \
+    if (full) conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, true, ACC, PASSES, ILV>(acc, e, smem, b, y0, x0, n0, wr, wc, bias_pre);   \
+    else conv_epilogue_body<TA, BN, BM, NTHREADS, MT, NT, M, false, ACC, PASSES, ILV>(acc, e, smem, b, y0, x0, n0, wr, wc, bias_pre);       \
   } while (0)
   if constexpr (MODE >= 0) {
     CRIMAC_EPI(MODE);
