@@ -24,6 +24,11 @@
 #include "conv_epilogue.h"
 
 CRIMAC_DIAG_DECLARE(crimac_diag_clock_conv)
+#ifdef CRIMAC_DIAG_EPI
+extern "C" int crimac_diag_epi_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(crimac_epi_buf), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 #ifndef CRIMAC_P64_HALO_AUX
 #define CRIMAC_P64_HALO_AUX 0      // cache policy of the halo loads (2: non-temporal)
 #endif

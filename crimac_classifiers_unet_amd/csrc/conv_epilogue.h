@@ -43,6 +43,18 @@ __device__ __forceinline__ void epi_barrier_lds() {
   asm volatile("" ::: "memory");
 }
 
+// -DCRIMAC_DIAG_EPI (diagnostic builds of ONE translation unit, tools/diag_epi_phases.py): s_memtime at the phase
+// boundaries of the epilogue, wave 0 of each workgroup -> crimac_epi_buf[workgroup % 1024][8]
+#ifdef CRIMAC_DIAG_EPI
+__device__ unsigned long long crimac_epi_buf[1024 * 8];
+#define CRIMAC_EPI_STAMP(k)                                                                                   \
+  { unsigned long long tn_; __builtin_amdgcn_sched_barrier(0);                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    if (threadIdx.x == 0) crimac_epi_buf[((blockIdx.y * gridDim.x + blockIdx.x) % 1024) * 8 + (k)] = tn_; }
+#else
+#define CRIMAC_EPI_STAMP(k) {}
+#endif
+
 // Accumulator access for the two MFMA shapes (C/D layouts: cdna_hip_programming.md §3):
 //   32x32x16: acc[MT][NT] of f32x16, row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane & 31
 //   16x16x32: acc[MT][NT] of f32x4,  row = (lane>>4)*4 + r,               col = lane & 15
@@ -76,6 +88,7 @@ template <typename TA, int BN, int BM, int NTHREADS, int MT, int NT, int MODE, b
 __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], const EpiParams& e,
                                                    unsigned char* smem, int b, int y0, int x0, int n0,
                                                    int wr, int wc, const float* bias_pre = nullptr) {
+  CRIMAC_EPI_STAMP(0)
   using L = AccLayout<ACC>;
   constexpr bool HPO = __is_same(TA, hp_t);
   using TS = typename std::conditional<HPO, float, TA>::type;           // element type of the staging tile
@@ -164,7 +177,9 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       }
     }
   }
+  if (ps == 0) { CRIMAC_EPI_STAMP(1) }        // slice 0 staged
   epi_barrier_lds();
+  if (ps == 0) { CRIMAC_EPI_STAMP(2) }        // ... and visible
   if (mode == 1 && ps == PASSES - 1) {
     // rows live in registers and in the lane groups above the column lanes: fold with shuffles,
     // then one LDS add per column
@@ -333,6 +348,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       }
     }
   }
+  if (ps == 0) { CRIMAC_EPI_STAMP(3) }        // slice 0's stores issued
   if (e.pool_out) {
     // the staged slice still holds the values as stored (plane pairs: the fp32 values, rounding is monotone so the
     // maximum of the stored values is the stored maximum): 2x2 windows never straddle tiles or slices (y0, x0 even)
@@ -358,6 +374,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
     }
   }
  }   // passes
+  CRIMAC_EPI_STAMP(4)                         // all slices stored
   if (mode) {
     epi_barrier_lds();
     // thousands of workgroups add to the same N channels: spread them over replicas (the atomic
@@ -368,6 +385,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
       atomicAdd(&e.stat_sumsq[rep + n0 + c], (double)sstat[BN + c]);
     }
   }
+  CRIMAC_EPI_STAMP(5)
 }
 
 // Dispatch on the (workgroup-uniform) tile position and, when MODE < 0, on the runtime statistics mode.
