@@ -64,6 +64,11 @@ def parse_args(argv=None):
                     help="h3p: fp16 plane pairs split by the producer (fp32-class logits, identical argmax masks) at 3 MFMAs "
                          "per product on the LDS-DMA kernels; f32h3: the same arithmetic forward with fp32 storage (split "
                          "while staging) and a bf16-plane backward; f32x6: 6 MFMAs, fp32-equivalent gradients too")
+    ap.add_argument("--roofline-steps", type=int, default=30, help="serialized steps of the per-kernel (roofline) pass")
+    ap.add_argument("--roofline-warmup", type=int, default=10, help="serialized warm-up steps in front of that pass")
+    ap.add_argument("--loop-iters", type=int, default=60, help="iterations of the train_loop leg (SegPipe.train_model + DataLoader)")
+    ap.add_argument("--loop-workers", type=int, default=4, help="DataLoader workers of the train_loop leg (yaml default 4)")
+    ap.add_argument("--no-train-loop", action="store_true")
     ap.add_argument("--tiled-pings", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -185,12 +190,25 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
         loss = step()
     barrier()
     hip.PROFILE = []                 # HIP-event instrumentation of the conv / wgrad launches inside the timed region
+    if world > 1:
+        eng.exchange_probe = []      # (event after the backward pass, event after the last collective) per step
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     prof_timed, hip.PROFILE = hip.PROFILE, None
+    exchange = None
+    if world > 1:
+        ex = [a.elapsed_time(b) for a, b in eng.exchange_probe]
+        eng.exchange_probe = None
+        exchange = {"exchange_ms_exposed": max_over_ranks(statistics.median(ex)) if ex else None,
+                    "exchange_ms_exposed_worst_step": max_over_ranks(max(ex)) if ex else None,
+                    "what": "per step, time on the training stream between the end of the backward pass and the moment the "
+                            "last gradient collective has been waited for (the part of the 124 MB exchange the backward "
+                            "pass did not hide); median over the timed steps, max over ranks",
+                    "algo": getattr(grad_sync, "algo", None), "bucket_mb": grad_sync.bucket_elems * 4 / (1 << 20),
+                    "per_range_optimiser_step": bool(eng.early_sgd and eng.early_sgd_multi)}
     final_loss = float(loss)
     assert final_loss == final_loss, "training diverged (NaN loss)"
     skipped = eng.skipped_steps()
@@ -201,51 +219,82 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
 
     # Per-kernel durations: in the timed region the weight gradients run on a side stream CONCURRENTLY with the
     # input-gradient convolutions, so their HIP-event intervals overlap.  The roofline figures come from a second,
-    # serialized pass (same steps, side stream off) right after the timed region.
-    prof, serialized = prof_timed, False
+    # serialized pass (same steps, side stream off) right after the timed region: >= 30 steps after >= 10 warm-ups,
+    # every launch of the step reduced to the MEDIAN (and minimum) over the steps, and an MFMA-only calibration launch
+    # (crimac_mfma_calibrate: rate + in-kernel shader clock) before and after it -- a pass taken on a throttled box
+    # shows in the line itself.
+    prof, serialized, n_ser, calib = prof_timed, False, steps, None
     if eng.wgrad_side_streams > 0:
         saved_cfg = (eng.wgrad_side_streams, eng._side)
         eng.wgrad_side_streams, eng._side = 0, None
-        for _ in range(2):
+        for _ in range(args.roofline_warmup):
             step()
         barrier()
+        calib = {"before": mfma_calibration(dev)}
+        n_ser = max(3, args.roofline_steps)
         hip.PROFILE = []
-        for _ in range(max(3, min(steps, 10))):
+        for _ in range(n_ser):
             step()
         barrier()
         prof, hip.PROFILE = hip.PROFILE, None
+        calib["after"] = mfma_calibration(dev)
         eng.wgrad_side_streams, eng._side = saved_cfg
         serialized = True
 
-    def kernel_rate(kname, records):
-        sel = [(f, s.elapsed_time(e)) for n, f, s, e in records if n.startswith(kname)]   # (crimac_wgrad[_partials])
-        fl, ms_ = sum(f for f, _ in sel), sum(m for _, m in sel)
-        return (fl / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0), ms_, len(sel)
+    def per_launch(records, n_steps):
+        """[(name, flops, median ms, min ms, mean ms)] per launch POSITION of the step, over the n_steps repetitions."""
+        n = len(records) // max(n_steps, 1)
+        if n == 0 or n * n_steps != len(records):
+            raise RuntimeError(f"profile records ({len(records)}) are not a multiple of the steps ({n_steps})")
+        out = []
+        for p in range(n):
+            ts = [records[k * n + p][2].elapsed_time(records[k * n + p][3]) for k in range(n_steps)]
+            assert all(records[k * n + p][0] == records[p][0] for k in range(n_steps))
+            out.append((records[p][0], records[p][1], statistics.median(ts), min(ts), sum(ts) / len(ts)))
+        return out
 
+    pl_ser, pl_timed = per_launch(prof, n_ser), per_launch(prof_timed, steps)
     peak = MFMA_PEAK_TFLOPS[precision]
     scale_f = (sf / 64.0) ** 2        # conv FLOPs scale with the square of the width (first / last layer aside)
 
     def roofline(kname, label):
-        ach, ms, n = kernel_rate(kname, prof)
-        _, ms_t, n_t = kernel_rate(kname, prof_timed)
-        return {"bound": "mfma", "kernel": label, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None,
-                "algorithmic_flops_per_launch": (ach * 1e12) * (ms * 1e-3) / max(n, 1), "launches": n,
-                "avg_launch_us": 1e3 * ms / max(n, 1),
-                "measured": ("serialized pass after the timed region (weight-gradient side stream off); in the "
-                             "timed region these launches overlap the weight gradients" if serialized else "timed region"),
-                "avg_launch_us_timed_region_overlapped": 1e3 * ms_t / max(n_t, 1)}
+        sel = [r for r in pl_ser if r[0].startswith(kname)]            # (crimac_wgrad[_partials])
+        sel_t = [r for r in pl_timed if r[0].startswith(kname)]
+        n = max(len(sel), 1)
+        fl = sum(r[1] for r in sel)
+        med, mn, mean = (sum(r[i] for r in sel) for i in (2, 3, 4))
+        ach = fl / (med * 1e-3) / 1e12 if med > 0 else 0.0
+        r = {"bound": "mfma", "kernel": label, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+             "frac": ach / peak, "traffic": None,
+             "algorithmic_flops_per_launch": fl / n, "launches_per_step": len(sel), "steps_measured": n_ser,
+             "median_launch_us": 1e3 * med / n, "min_launch_us": 1e3 * mn / n, "avg_launch_us": 1e3 * mean / n,
+             "frac_from_min": (fl / (mn * 1e-3) / 1e12 / peak) if mn > 0 else 0.0,
+             "frac_from_mean": (fl / (mean * 1e-3) / 1e12 / peak) if mean > 0 else 0.0,
+             "measured": ((f"serialized pass after the timed region (weight-gradient side stream off), {n_ser} steps after "
+                           f"{args.roofline_warmup} warm-ups; achieved = algorithmic FLOPs of one step's launches / the sum of "
+                           "their per-launch MEDIAN HIP-event durations over the steps (avg_launch_us = the mean, what "
+                           "rocprofv3 --stats averages); in the timed region these launches overlap the weight gradients")
+                          if serialized else "timed region"),
+             "median_launch_us_timed_region_overlapped": 1e3 * sum(r[2] for r in sel_t) / max(len(sel_t), 1)}
+        if calib is not None:
+            r["mfma_calibration"] = calib
+        return r
 
     res = {"precision": precision, "dtype": DTYPE_LABEL[precision],
            "train_patches_per_s": world * B * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
            "train_tflops": world * B * steps / elapsed * TRAIN_GFLOP_PER_PATCH * scale_f / 1e3,
-           "final_loss": final_loss, "loss_scale": eng.loss_scale, "skipped_steps": skipped,
+           "final_loss": final_loss, "loss_scale": eng.loss_scale, "skipped_steps": skipped, "exchange": exchange,
            "roofline": roofline("crimac_conv3x3", CONV_KERNELS if precision in ("bf16", "fp16") else
                                 ("crimac_conv3x3: conv3x3_wch_kernel (plane-pair forms: 3 MFMAs per fragment pair) + conv3x3_c16_kernel "
                                  "(first layer, pseudo-channels)" if precision == "h3p" else
                                  "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)")),
            "roofline_wgrad": roofline("crimac_wgrad", "wgrad_pp_kernel + wgrad_up_pp_kernel + wgrad_kernel (weight gradient, all shapes)"
                                       if precision == "h3p" else "wgrad_kernel (weight gradient, all shapes)")}
+    if world == 1 and not args.no_train_loop and sf == 64 and not args.gpu_augment:
+        res["train_loop"] = measure_train_loop(args, precision, dev, log, res["train_patches_per_s"])
+        if precision == args.precision:               # (the reference's in-line copy, for comparison: main mode only)
+            res["train_loop"]["inline_copy"] = measure_train_loop(args, precision, dev, log, res["train_patches_per_s"],
+                                                                  pin_batches=False)
     if infer:
         model.eval()
         with torch.no_grad():
@@ -260,6 +309,38 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
         res["infer_patches_per_s"] = world * B * steps / ti
         res["infer_tflops"] = res["infer_patches_per_s"] * FWD_GFLOP_PER_PATCH * scale_f / 1e3
     return res, model
+
+
+_CALIB = {}
+
+
+def mfma_calibration(dev, iters=15000, blocks=512):
+    """One MFMA-only launch (crimac_mfma_calibrate, ~2 ms: 512 workgroups x 4 waves x iters x 8 MFMAs 16x16x32 bf16 on
+    register operands) timed with HIP events, median of 3 after one warm-up: the dense-MFMA rate the chip delivers at
+    this moment and the shader clock its workgroups saw (s_memtime / s_memrealtime, median over the workgroups)."""
+    import numpy as np
+    import torch
+    from crimac_classifiers_unet_amd import hip
+    if "stamps" not in _CALIB:
+        _CALIB["stamps"] = torch.zeros(2 * blocks, dtype=torch.int64, device=dev)
+        _CALIB["sink"] = torch.zeros(4, dtype=torch.float32, device=dev)
+    st, sink = _CALIB["stamps"], _CALIB["sink"]
+    ts = []
+    for k in range(4):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        hip.call("crimac_mfma_calibrate", iters, blocks, hip.ptr(st), hip.ptr(sink))
+        e_.record()
+        e_.synchronize()
+        if k:
+            ts.append(s_.elapsed_time(e_))
+    ms = statistics.median(ts)
+    v = st.cpu().numpy().reshape(blocks, 2).astype(np.float64)
+    ghz = float(np.median(v[:, 0] / np.maximum(v[:, 1], 1.0)) * 0.1)
+    flop = 2.0 * 16 * 16 * 32 * 8 * iters * 4 * blocks
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"tflops": tf, "frac_of_nominal_peak": tf / 2500.0, "shader_clock_ghz": ghz, "launch_ms": ms,
+            "what": "MFMA-only launch (register operands, no memory traffic), observed in this run"}
 
 
 def golden_parity(precision, dev, log):
@@ -320,7 +401,9 @@ def measure_tiled(model, args, log, world=1):
     log(f"tiled: synthetic survey 4 x {n_pings} x {n_range} built in {time.perf_counter() - t0:.1f} s")
     pipe = types.SimpleNamespace(model=model, device=next(model.parameters()).device, frequencies=[18, 38, 120, 200])
     import numpy as np
-    f16 = dict(out_dtype=np.float16)                     # what the reference stores (save_predict.py:212)
+    # float16: what the reference stores (save_predict.py:212); N > 1: every rank keeps its own ping ranges (the
+    # zero-communication form; predict_survey's default hands the chunks to rank 0 in ping order for a sequential writer)
+    f16 = dict(out_dtype=np.float16, ordered_to_rank0=False)
     for _ in ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, **f16):
         pass                                             # warm-up: one untimed pass over the survey
     torch.cuda.synchronize()
@@ -355,6 +438,71 @@ def measure_tiled(model, args, log, world=1):
             "written_frac_sampled": written / (n_range * ((n_pings + 63) // 64))}
 
 
+def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_batches=True):
+    """The loop the reference actually runs (pipeline.py:161-181): ``SegPipeUNet.train_model`` fed by a
+    ``torch.utils.data.DataLoader`` (default collate, worker processes) over an in-memory synthetic Dataset that yields
+    the reference's batch dict -- ``data`` float32 [4, 256, 256], ``labels`` int16 [256, 256], ``center_coordinates``
+    int64 [2] per sample -- so the timed region contains the collate, the worker -> parent hand-over,
+    the H2D copy (pinned ring + copy stream, staging.py) and the step.  One untimed pass over the DataLoader first
+    (worker start-up, pinned / device allocations), then one timed pass; workers persist between the two."""
+    import numpy as np
+    import torch
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+
+    B, iters = args.batch, max(args.loop_iters, 30)
+    n_distinct = 2 * B
+    data = synth.synth_echogram_batch(n_distinct, 4, 256, 256, seed=300)
+    labels = synth.synth_labels(n_distinct, 256, 256, seed=301)
+
+    class SyntheticCrops(torch.utils.data.Dataset):
+        def __len__(self):
+            return iters * B
+
+        def __getitem__(self, i):
+            k = i % n_distinct
+            return {"data": data[k], "labels": labels[k], "center_coordinates": np.array([128, 128 + i], dtype=np.int64)}
+
+    nw = max(int(args.loop_workers), 0)
+    dl = torch.utils.data.DataLoader(SyntheticCrops(), batch_size=B, shuffle=False, num_workers=nw, drop_last=True,
+                                     persistent_workers=nw > 0)
+    pipe = pkg.SegPipeUNet(checkpoint_dir=None, data_mode="zarr", frequencies=[18, 38, 120, 200], patch_size=[256, 256],
+                           loss_type="CE", lr=0.005, lr_reduction=0.5, lr_step=1000, momentum=0.95, batch_size=B,
+                           num_workers=nw, iterations=iters, test_iter=10, log_step=10 ** 9, save_model_params=False,
+                           meta_channels=[], late_meta_inject=False, eval_mode="all", experiment_name="bench",
+                           precision=precision, infer_precision=precision, pin_batches=pin_batches,
+                           loss_flush=10 ** 9)
+    pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+
+    class LastLoss:
+        last = None
+
+        def add_scalar(self, tag, scalar_value, global_step):
+            if tag == "train/loss":
+                self.last = scalar_value
+
+    import contextlib
+    lg = LastLoss()
+    with contextlib.redirect_stdout(sys.stderr):      # (train_model prints "Training complete" like the reference)
+        pipe.train_model(dl, None, logger=lg)         # untimed: workers, allocations, first-touch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.train_model(dl, None, logger=lg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    del dl
+    pps = iters * B / dt
+    assert lg.last is not None and lg.last == lg.last, "train_loop: NaN loss"
+    log(f"{precision}: train_loop ({'pinned ring' if pin_batches else 'in-line copy'}, {nw} workers): {pps:.0f} patches/s "
+        f"= {pps / resident_patches_per_s:.3f} of the resident-batch figure")
+    return {"patches_per_s": pps, "ms_per_step": 1e3 * dt / iters, "iterations": iters, "batch": B,
+            "dataloader_workers": nw, "input_staging": "pinned ring + copy stream (staging.BatchStager)" if pin_batches
+            else "in-line .to(device) as the reference (pipeline.py:163-164)",
+            "vs_resident_batch": pps / resident_patches_per_s, "final_loss": lg.last,
+            "timed": "SegPipeUNet.train_model over a DataLoader (default collate, batch dict of the reference): collate + "
+                     "hand-over + H2D + step, one full pass of the DataLoader after one untimed pass"}
+
+
 def load_profile_json(name):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -383,11 +531,30 @@ def run_rank(args):
         t = torch.ones(1)
         if torch.cuda.is_available():
             t = t.cuda(local % max(torch.cuda.device_count(), 1))
+        gs_ok = None
         if world > 1:
             dist.all_reduce(t)
+            # the gradient exchange itself at this world size: four ranges handed over in backward order, 32 MB-style
+            # buckets scaled down, all-reduce and reduce-scatter + all-gather spellings, per-range completion
+            gs_ok = True
+            n = 8 * 4096 + 64
+            bounds = [(n - 9000, n), (n - 20000, n - 9000), (4000, n - 20000), (0, 4000)]
+            expect = torch.arange(n, dtype=torch.float32) * (world * (world + 1) // 2)
+            for algo in ("all_reduce", "rs_ag"):
+                flat = (torch.arange(n, dtype=torch.float32) * (rank + 1)).to(t.device)
+                gs = parallel.GradSync(bucket_mb=4096 * 4 / (1 << 20), algo=algo)
+                for lo, hi in bounds:
+                    gs.launch(flat, lo, hi)
+                for lo, hi in bounds:
+                    gs.finish_range(lo, hi)
+                    gs_ok = gs_ok and bool(torch.equal(flat[lo:hi].cpu(), expect[lo:hi]))
+                gs_ok = gs_ok and abs(gs.finish() - 1.0 / world) < 1e-12
+            ok_t = torch.tensor([1.0 if gs_ok else 0.0]).to(t.device)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)          # (every rank saw the right sums)
+            gs_ok = bool(ok_t.item() == 1.0)
         if rank == 0:
             print(json.dumps({"selftest": True, "n_gpus": world, "ranks_counted": int(t.item()),
-                              "backend": dist.get_backend() if world > 1 else None,
+                              "backend": dist.get_backend() if world > 1 else None, "gradsync_ok": gs_ok,
                               "self_launched": os.environ.get("CRIMAC_SELF_LAUNCHED") == "1"}), flush=True)
         if world > 1:
             dist.barrier()
@@ -451,7 +618,7 @@ def run_rank(args):
         def replay(roof, roof_w, prec):
             """HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) and MFMA busy fraction (SQ_VALU_MFMA_BUSY_CYCLES /
             GRBM_GUI_ACTIVE pass) of the same command, from the committed profiles of this round -- labelled as replayed."""
-            pm = load_profile_json(f"r03_{prec}_pmc_traffic.json")
+            pm = load_profile_json(f"r04_{prec}_pmc_traffic.json") or load_profile_json(f"r03_{prec}_pmc_traffic.json")
             if pm:
                 for r_, pat in ((roof, "conv3x3"), (roof_w, "wgrad")):
                     sel = [v for k, v in pm["kernels"].items() if k.startswith(pat)]
@@ -460,27 +627,17 @@ def run_rank(args):
                     r_["traffic_source"] = ("REPLAYED from the committed profile " + pm["_file"] + " (rocprofv3 --pmc FETCH_SIZE / "
                                             "WRITE_SIZE passes of this command on the serialized step; FETCH_SIZE doubled per the "
                                             "gfx950 correction; not observed in this run): HBM bytes per launch")
-            ut = load_profile_json(f"r03_{prec}_mfma_util.json")
+            ut = load_profile_json(f"r04_{prec}_mfma_util.json") or load_profile_json(f"r03_{prec}_mfma_util.json")
             if ut:
                 for r_, key in ((roof, "conv3x3"), (roof_w, "wgrad")):
                     r_["mfma_busy_frac"] = ut.get(key, {}).get("mfma_busy_frac")
                     r_["util_source"] = "REPLAYED from the committed profile " + ut["_file"] + " (not observed in this run): " + str(ut.get("note"))
-            ck = load_profile_json(f"r03_inkernel_clock_conv_{prec}.json")
-            if ck:
-                ghz = sorted(v["clock_ghz_median"] for v in ck["shapes"].values())
-                roof["clock_ghz"] = ghz[len(ghz) // 2]
-                roof["clock_source"] = ("REPLAYED from the committed profile " + ck["_file"] + " (diagnostic build with s_memtime / "
-                                        "s_memrealtime stamps around the convolution's main loop, median over the shapes; not "
-                                        "observed in this run)")
+            # (no replayed clocks: the shader clock under a dense MFMA stream is OBSERVED in this run, before and after
+            # the serialized pass -- roofline.mfma_calibration)
         if sf == 64 and args.precision in ("bf16", "h3p"):
             replay(rl, main["roofline_wgrad"], args.precision)
         if parity is not None and args.parity_precision in ("bf16", "h3p"):
             replay(parity["roofline"], parity["roofline_wgrad"], args.parity_precision)
-        util = load_profile_json("r02_mfma_util.json")       # (round 2: in-kernel clocks of the bf16 kernels, unchanged since)
-        if util and args.precision == "bf16" and sf == 64:
-            rl["clock_ghz"] = util.get("conv3x3", {}).get("clock_ghz")
-            main["roofline_wgrad"]["clock_ghz"] = util.get("wgrad", {}).get("clock_ghz")
-            rl["clock_source"] = "REPLAYED from profiles/r02_inkernel_clock_*.json (diagnostic builds with s_memtime stamps)"
         workload = ("BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, batch 32 x 4x256x256 per GPU"
                     if sf == 64 else
                     f"BASELINE configs[4]: wide U-Net (depth 5, {sf} filters) train step, batch {args.batch} x 4x256x256 "
@@ -507,6 +664,10 @@ def run_rank(args):
             "golden_parity": main["golden_parity"],
             "roofline": rl, "roofline_wgrad": main["roofline_wgrad"],
         }
+        if main.get("train_loop") is not None:
+            out["train_loop"] = main["train_loop"]
+        if main.get("exchange") is not None:
+            out["exchange"] = main["exchange"]
         if parity is not None:
             out["parity_mode"] = parity
         if tiled is not None:
@@ -528,9 +689,18 @@ def run_rank(args):
                 diff = got.argmax(1) != ref_logits.argmax(1)
                 top2 = ref_logits.topk(2, dim=1).values
                 margins = (top2[:, 0] - top2[:, 1])[diff]
+                # the criterion of tests/test_gpu_h3p.py (test_network_batch32_full_size_matches_oracle, which runs these
+                # very crops as its seed-1 case): every flipped pixel sits where the oracle's own two top logits are
+                # closer than its fp32 round-off, and such ties are rare
+                tie, frac = 2e-6, 1e-5
+                ok = bool((margins < tie).all()) and int(diff.sum()) <= frac * diff.numel()
                 return {"precision": args.parity_precision, "crops": "32 x 4 x 256 x 256 (synthetic, seed 1) vs the CPU oracle",
                         "pixels": int(diff.numel()), "logits_rel": float((got - ref_logits).abs().max() / ref_logits.abs().max()),
-                        "argmax_flips": int(diff.sum()), "oracle_top2_margin_at_flips": [float(v) for v in margins[:8]]}
+                        "argmax_flips": int(diff.sum()), "oracle_top2_margin_at_flips": [float(v) for v in margins[:8]],
+                        "max_oracle_margin_at_flips": float(margins.max()) if margins.numel() else 0.0,
+                        "criterion": f"every flip at an oracle top-2 margin < {tie:g} and flips <= {frac:g} of the pixels "
+                                     "(the assertion of tests/test_gpu_h3p.py on the same crops)",
+                        "identical_masks_up_to_oracle_ties": ok}
             cb = cpu_baseline(parity32 if (parity is not None and args.start_filts == 64) else None)
             p32 = cb.pop("parity_batch32")
             if p32 is not None:

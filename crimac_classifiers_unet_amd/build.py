@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libcrimac_unet_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["conv3x3.hip", "conv3x3_glds.hip", "igemm.hip", "upconv.hip", "wgrad.hip", "elementwise.hip", "pack.hip", "tiling.hip", "augment.hip", "labels.hip", "meta.hip"]
+SOURCES = ["conv3x3.hip", "conv3x3_glds.hip", "igemm.hip", "upconv.hip", "wgrad.hip", "elementwise.hip", "pack.hip", "tiling.hip", "augment.hip", "labels.hip", "meta.hip", "calib.hip"]
 def _headers():
     """Every header a source may include: csrc/*.h plus the public C-ABI header."""
     import glob

@@ -69,11 +69,19 @@ class _UpConv:
 
 
 class UNetEngine:
-    def __init__(self, module, precision="bf16"):
+    def __init__(self, module, precision="bf16", leader=None):
+        """``leader``: another engine of the SAME module that owns the flat parameter / gradient / momentum buffers.
+        A follower engine runs eval-mode forwards in its own precision on the leader's parameters (its own packed
+        operands and activation buffers): the inference precision of a model that trains in another one
+        (``UNet_Baseline(infer_precision=...)``)."""
         if precision not in hip.PREC_NAMES:
             raise ValueError(f"precision must be one of {list(hip.PREC_NAMES)}, got {precision!r}")
         hip.load_library()       # fail loudly before anything else if the HIP library is missing
         self.module = module
+        self.leader = leader
+        self._followers = []
+        if leader is not None:
+            leader._followers.append(self)
         self.precision = precision
         self.prec = hip.PREC_NAMES[precision]
         self.act_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision, torch.float32)
@@ -144,6 +152,17 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     def bind(self):
         """(Re)point every module parameter at a slice of the flat fp32 buffer on the module's GPU."""
+        if self.leader is not None:
+            L = self.leader
+            L.bind()
+            if getattr(self, "flat_p", None) is not L.flat_p:          # (first use, or the leader re-bound: new device)
+                self.device, self.layout, self.n_flat = L.device, L.layout, L.n_flat
+                self.flat_p, self.flat_g, self.flat_v = L.flat_p, L.flat_g, L.flat_v
+                self.P, self.G, self.Bf = L.P, L.G, L.Bf
+                self._alloc_static()
+                self._train_pack_dirty = self._eval_pack_dirty = True
+                self._bufs = {}
+            return
         params = list(self.module.named_parameters())
         dev = params[0][1].device
         if dev.type != "cuda":
@@ -313,6 +332,9 @@ class UNetEngine:
     def mark_dirty(self):
         self._train_pack_dirty = self._eval_pack_dirty = True
         self._packed_groups = set()       # layer groups whose train-mode planes were re-packed after this change
+        for f in self._followers:         # (engines of other precisions on the same parameters)
+            f._train_pack_dirty = f._eval_pack_dirty = True
+            f._packed_groups = set()
 
     def _check_versions(self):
         """Detect in-place edits made through torch (load_state_dict, manual init, optimizers)."""
@@ -387,6 +409,14 @@ class UNetEngine:
     wgrad_side_streams = int(os.environ.get("CRIMAC_WGRAD_STREAM", "1"))
     unpack_on_side = os.environ.get("CRIMAC_UNPACK_SIDE", "1") != "0"
     early_sgd = os.environ.get("CRIMAC_EARLY_SGD", "1") != "0"
+    # N > 1: apply SGD / re-pack per gradient range behind GradSync.finish_range instead of one optimiser step behind
+    # finish().  OPT-IN until it has run on a multi-GPU node: its RCCL branches (stream-ordered waits, chained
+    # reduce-scatter + all-gather, per-range re-pack) are covered by a single-rank nccl test and a 2-rank test that
+    # needs two GPUs (tests/test_gpu_unet.py), not yet by hardware with N > 1
+    early_sgd_multi = os.environ.get("CRIMAC_EARLY_SGD_MULTI", "0") != "0"
+    # bench.py (N > 1): list that receives (event after the backward pass, event after the last collective was waited
+    # for) per step -- the part of the gradient exchange the step could not hide
+    exchange_probe = None
     early_pack = os.environ.get("CRIMAC_EARLY_PACK", "1") != "0"
     split_skip_dgrad = os.environ.get("CRIMAC_SPLIT_SKIP", "1") != "0"    # skip half of decoder dgrads on the side stream
     # launch the gradient collectives from the side stream too (they then never hold up the caller's stream)
@@ -678,6 +708,9 @@ class UNetEngine:
         """Logits [B,n_classes,H,W] fp32 (NCHW).  Train mode keeps what backward needs.
         ``meta`` [B,Cm,H,W]: the metadata planes of UNet_LateMetInject.forward(x, meta_tensor) (unet.py:372)."""
         self.bind()
+        if training and self.leader is not None:
+            raise RuntimeError("this engine only runs eval-mode forwards (it shares the parameters of the model's training "
+                               "engine); train-mode passes go through model.engine")
         if self.lmi:
             meta = self._meta(meta, x)
         elif meta is not None:
@@ -788,8 +821,15 @@ class UNetEngine:
         geo = self._geom(B, H, W)
         D = self.depth
         if training:
+            if self.leader is not None:
+                raise RuntimeError("follower engine: eval-mode forwards only (train through model.engine)")
             self._pack_train()
             self.stat.zero_()
+            # the BatchNorm running statistics change with every train-mode forward: eval-mode operands (BN folded into
+            # the convolution) of this engine and of its followers are stale from here on
+            self._eval_pack_dirty = True
+            for f in self._followers:
+                f._eval_pack_dirty = True
         else:
             self._pack_eval()
         cur = Act(xin, CIN_PAD)
@@ -1251,13 +1291,26 @@ class UNetEngine:
         self.last_loss_sums = sums.clone()
         dl = self.ce_backward(logits, labels, class_w, sums, ls, ignore_index)
         scale = 1.0
-        single = grad_sync is None or (hasattr(grad_sync, "world") and grad_sync.world() == 1)
+        single = grad_sync is None or (hasattr(grad_sync, "world") and grad_sync.world() == 1
+                                       and not getattr(grad_sync, "force", False))
+
+        def finish_exchange():
+            """grad_sync.finish() bracketed by the exchange probe's events."""
+            if self.exchange_probe is None:
+                return grad_sync.finish()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sc = grad_sync.finish()
+            e1.record()
+            self.exchange_probe.append((e0, e1))
+            return sc
+
         if ls != 1.0:
             # loss-scaled step: all ranges are applied together behind ONE overflow check (a step is applied
             # whole or not at all), so the per-range early updates of the unscaled path are not used
             if grad_sync is not None and hasattr(grad_sync, "launch"):
                 self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
-                scale = grad_sync.finish()
+                scale = finish_exchange()
             else:
                 self.backward(dl)
                 if grad_sync is not None:
@@ -1273,22 +1326,30 @@ class UNetEngine:
             return (sums[0] / sums[1]).float()
         if grad_sync is not None and hasattr(grad_sync, "launch"):
             self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))
-            if not single and self.early_sgd and hasattr(grad_sync, "finish_range"):
+            if not single and self.early_sgd and self.early_sgd_multi and hasattr(grad_sync, "finish_range"):
                 # N > 1: the gradient ranges were handed to the exchange in the order the backward pass completed them
                 # (decoder first, shallow encoder blocks last).  Each range is applied, and its weight planes re-packed
                 # for the next step, as soon as ITS collectives are done -- the update of the decoder (40 % of the
                 # parameters) runs while the later ranges are still on the links, instead of the whole optimiser step
                 # and the whole re-pack queuing behind the last collective.
                 self.mark_dirty()
-                for g, (lo, hi) in enumerate(self.grad_ranges()):
+                probe = self.exchange_probe is not None
+                if probe:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rngs = self.grad_ranges()
+                for g, (lo, hi) in enumerate(rngs):
                     scale = grad_sync.finish_range(lo, hi)
+                    if probe and g == len(rngs) - 1:
+                        e1.record()                   # (the last range's collectives have been waited for)
+                        self.exchange_probe.append((e0, e1))
                     self._sgd_range(lo, hi, lr, momentum, scale)
                     if self.early_pack:
                         self._pack_group(g)
                         self._packed_groups.add(g)
                 grad_sync.finish()
                 return (sums[0] / sums[1]).float()
-            scale = grad_sync.finish()
+            scale = finish_exchange()
         else:
             self.backward(dl)
             if grad_sync is not None:

@@ -60,9 +60,14 @@ class GradSync:
     launched yet, waits for everything and returns the 1/world averaging scale (folded into SGD).
     """
 
-    def __init__(self, bucket_mb=32.0, group=None, algo=None):
+    def __init__(self, bucket_mb=32.0, group=None, algo=None, force=False):
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.group = group
+        # force: issue the collectives even in a process group of ONE rank (they are identities there).  A single GPU
+        # can then drive every multi-rank code path of the step -- RCCL's stream-ordered waits, the chained
+        # reduce-scatter + all-gather, the exchange launched from the side stream, the per-range optimiser step --
+        # and must reproduce the plain single-rank step bit for bit (tests/test_gpu_unet.py)
+        self.force = bool(force)
         # 'all_reduce' (default): one RCCL all-reduce per bucket.  'rs_ag': the same sum spelled out as
         # reduce-scatter + all-gather per bucket (SURVEY.md §8e) -- what RCCL's ring all-reduce does internally; the
         # explicit form lets the two halves be scheduled as separate collectives on the process group's stream.
@@ -87,8 +92,10 @@ class GradSync:
         return dist.get_backend(self.group) == "nccl"
 
     def launch(self, flat_grad, lo, hi):
-        if self.world() == 1 or hi <= lo:
+        if (self.world() == 1 and not self.force) or hi <= lo:
             return
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradSync(force=True) needs an initialised process group (world size 1 is enough)")
         for a, b in self._done:
             if lo < b and a < hi:
                 raise RuntimeError(f"GradSync: range [{lo},{hi}) overlaps [{a},{b}) already in flight")
@@ -130,7 +137,7 @@ class GradSync:
         [lo, hi) only, so that the optimiser step of that range can run while later ranges are still being exchanged.
         Returns the 1/world averaging scale."""
         rng = (lo, hi)
-        if rng not in self._done and self.world() > 1:
+        if rng not in self._done and (self.world() > 1 or self.force):
             raise RuntimeError(f"GradSync.finish_range: [{lo},{hi}) was not launched")
         keep = []
         for g in self._gathers:
@@ -157,7 +164,7 @@ class GradSync:
         return 1.0 / self.world()
 
     def __call__(self, flat_grad):
-        if self.world() == 1:
+        if self.world() == 1 and not self.force:
             return 1.0
         for lo, hi in self.pending_ranges(flat_grad.numel()):
             self.launch(flat_grad, lo, hi)

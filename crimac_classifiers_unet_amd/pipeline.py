@@ -8,8 +8,10 @@ the same ``state_dict`` checkpoints (``best.pt`` / ``last.pt``).
 
 The compute behind ``train_model`` / ``predict_batch`` is the HIP engine; with ``torch.distributed``
 initialised (one process per GPU) ``train_model`` all-reduces gradients over RCCL.
-New optional keywords (all defaulted, so the baseline yaml still works): ``precision``
-('bf16' | 'fp16' | 'f32x3' | 'f32x6'), ``loss_flush`` (how often queued train losses are handed to the logger).
+New optional keywords (all defaulted, so the baseline yaml still works): ``precision`` -- the TRAINING precision
+('bf16' | 'fp16' | 'h3p' | 'f32h3' | 'f32x3' | 'f32x6'), ``infer_precision`` -- the precision of every eval-mode forward
+(``predict_batch``, validation, ``save_predict`` / ``evaluate`` flows; default 'h3p': logits within 1e-5 of the reference's,
+identical argmax masks), ``loss_flush`` (how often queued train losses are handed to the logger).
 """
 from __future__ import annotations
 
@@ -48,8 +50,8 @@ class SegPipe:
     def __init__(self, checkpoint_dir, data_mode, frequencies, patch_size, loss_type, lr, lr_reduction,
                  lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
-                 precision="bf16", loss_flush=50, gpu_augment=False, random_seed=0, gpu_metrics=False,
-                 gpu_label_transform=False, sync_bn=False, **kwargs):
+                 precision="bf16", infer_precision="h3p", loss_flush=50, gpu_augment=False, random_seed=0,
+                 gpu_metrics=False, gpu_label_transform=False, sync_bn=False, pin_batches=True, **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -78,7 +80,16 @@ class SegPipe:
         self.eval_mode = eval_mode
         self.best_F1_val = -np.inf
 
+        # training runs in `precision` (default bf16: throughput); everything that PREDICTS -- predict_batch, the
+        # validation loops, the save_predict / evaluate flows -- runs in `infer_precision` (default h3p: the precision
+        # that meets the parity bar of the reference's fp32 path, pipeline.py:205-219).  Asking for a 16-bit inference
+        # precision is allowed (2.2x the throughput) and announced once, see _warn_infer_precision
         self.precision = precision
+        self.infer_precision = infer_precision or precision
+        self._warned_infer = False
+        # pin_batches: train_model stages the DataLoader's batches through a pinned ring on a copy stream (H2D of step
+        # i + 1 under step i); False = the reference's in-line `.to(device)` (pipeline.py:163-164)
+        self.pin_batches = bool(pin_batches)
         self.loss_flush = max(int(loss_flush), 1)
         # gpu_augment: the train Dataset hands RAW linear-sv crops (augmentation_function=None,
         # data_transform_function=None) and add_noise / flip_x_axis / remove_nan_inf / db_with_limits
@@ -99,8 +110,20 @@ class SegPipe:
         self.gpu_metrics = bool(gpu_metrics)
 
     # ------------------------------------------------------------------------------------------
+    def _warn_infer_precision(self):
+        """One line, once, when predictions are about to be made in a precision that does not reproduce the
+        reference's argmax masks."""
+        why = UNet_Baseline.PARITY_FAILING.get(self.infer_precision)
+        if why and not self._warned_infer:
+            import warnings
+            warnings.warn(f"infer_precision={self.infer_precision!r}: predicted class masks differ from the fp32 reference "
+                          f"pipeline at {why} of the golden crop; use infer_precision='h3p' (the default) for "
+                          "reference-identical masks", stacklevel=3)
+        self._warned_infer = True
+
     def load_model_params(self, checkpoint_path=None):
         """Load a ``state_dict`` checkpoint (reference pipeline.py:109-130)."""
+        self._warn_infer_precision()
         if self.model_is_loaded:
             return
         assert self.model is not None
@@ -155,10 +178,23 @@ class SegPipe:
                         logger.add_scalar(tag="train/loss", scalar_value=v, global_step=step)
             pending.clear()
 
-        for i, batch in _tqdm(enumerate(dataloader_train), desc="Training model",
-                              total=len(dataloader_train), disable=not is_rank0):
-            inputs_train = batch["data"].float().to(self.device, non_blocking=True)
-            labels_train = batch["labels"].to(self.device, non_blocking=True)
+        def batches():
+            """(i, data float32 on the device, labels on the device): the reference's in-step ``.float().to(device)``
+            (pipeline.py:163-164), staged one batch ahead through pinned memory and a copy stream (staging.py) so that
+            the upload of step i + 1 runs under step i; ``pin_batches: False`` keeps the in-line copy."""
+            if self.pin_batches and self.device.type == "cuda":
+                from .staging import BatchStager
+                for i, x, lab, _ in BatchStager(dataloader_train, self.device):
+                    yield i, x, lab
+                return
+            for i, batch in enumerate(dataloader_train):
+                x = batch["data"]
+                if x.dtype != torch.float32:
+                    x = x.float()
+                yield i, x.to(self.device, non_blocking=True), batch["labels"].to(self.device, non_blocking=True)
+
+        for i, inputs_train, labels_train in _tqdm(batches(), desc="Training model",
+                                                   total=len(dataloader_train), disable=not is_rank0):
             self.model.train()
             meta_train = None
             if self.late_meta_inject:            # pipeline.py:170-174: data planes | metadata planes
@@ -430,12 +466,14 @@ class SegPipeUNet(SegPipe):
         if not self.late_meta_inject:
             self.model = UNet_Baseline(n_classes=3, in_channels=4 + get_in_channels(self.meta_channels),
                                        late_meta_inject=False, depth=depth, start_filts=start_filts,
-                                       up_mode="transpose", merge_mode="concat", precision=self.precision)
+                                       up_mode="transpose", merge_mode="concat", precision=self.precision,
+                                       infer_precision=self.infer_precision)
         else:
             self.model = UNet_LateMetInject(n_classes=3, in_channels=4,
                                             meta_in_channels=get_in_channels(self.meta_channels),
                                             late_meta_inject=True, depth=depth, start_filts=start_filts,
-                                            up_mode="transpose", merge_mode="concat", precision=self.precision)
+                                            up_mode="transpose", merge_mode="concat", precision=self.precision,
+                                            infer_precision=self.infer_precision)
 
 
 def get_in_channels(meta_channels):

@@ -103,7 +103,7 @@ class ChunkPredictor:
 
     def __init__(self, model, n_range, patch_size=(256, 256), patch_overlap=20, batch_size=32, out_f16=False):
         self.model = model
-        self.engine = model.engine
+        self.engine = model.infer_engine        # (eval-mode forwards: the model's inference precision)
         self.n_range = n_range
         self.patch_size = tuple(int(v) for v in patch_size)
         self.patch_overlap = int(patch_overlap)
@@ -238,6 +238,62 @@ def seabed_vector_or_mask(reader, s, e, n_range, sb, sb_ping0):
     return sb, np.ascontiguousarray(below.astype(np.uint8))
 
 
+class _OrderedHandoff:
+    """Chunk-sharded inference, one writer: ranks r > 0 send each finished chunk to rank 0, which yields the whole survey
+    in ping order (``predict_survey(ordered_to_rank0=True)``).  Point-to-point only: ``isend`` / ``irecv`` of one
+    ``[2, n_range, pings]`` tensor per chunk -- under RCCL ("nccl") the DEVICE tensor the scatter kernel wrote (device to
+    device over xGMI; the sender does no D2H copy at all), under gloo a host tensor.  Chunk i belongs to rank i % N, so
+    rank 0 walks the survey in rounds of N chunks: it posts the N - 1 receives of a round, runs its own chunk of the
+    round (its pipeline already works on the next one), then takes the received chunks in rank order."""
+
+    MAX_IN_FLIGHT = 2          # sends a rank keeps outstanding before it waits for the oldest (back-pressure)
+
+    def __init__(self, rank, world, all_chunks, n_range, out_dtype):
+        self.rank, self.world, self.all_chunks, self.n_range = rank, world, all_chunks, n_range
+        self.device_tensors = torch.distributed.get_backend() == "nccl"
+        self.tdtype = torch.float16 if out_dtype == np.float16 else torch.float32
+        self.inflight = []
+        self.bufs = {}
+
+    # -- ranks r > 0 --------------------------------------------------------------------------------------------
+    def send(self, out):
+        t = out if self.device_tensors else out.cpu()       # (cp.out is a fresh tensor per chunk: safe to keep)
+        self.inflight.append((torch.distributed.isend(t.contiguous(), dst=0), t))
+        while len(self.inflight) > self.MAX_IN_FLIGHT:
+            self.inflight.pop(0)[0].wait()
+
+    def flush(self):
+        for req, _ in self.inflight:
+            req.wait()
+        self.inflight = []
+        if self.device_tensors:
+            torch.cuda.current_stream().synchronize()
+
+    # -- rank 0 -------------------------------------------------------------------------------------------------
+    def _buf(self, r, n_pings, device):
+        key = (r, n_pings)
+        if key not in self.bufs:
+            self.bufs[key] = torch.empty((2, self.n_range, n_pings), dtype=self.tdtype,
+                                         device=device if self.device_tensors else "cpu")
+        return self.bufs[key]
+
+    def merge(self, own):
+        """``own``: rank 0's generator over ITS chunks (0, N, 2N, ...) -> every chunk of the survey in ping order."""
+        device = torch.device("cuda", torch.cuda.current_device()) if self.device_tensors else None
+        own = iter(own)
+        for k0 in range(0, len(self.all_chunks), self.world):
+            reqs = []
+            for r in range(1, self.world):
+                if k0 + r < len(self.all_chunks):
+                    s, e = self.all_chunks[k0 + r]
+                    buf = self._buf(r, e - s, device)
+                    reqs.append((s, e, buf, torch.distributed.irecv(buf, src=r)))
+            yield next(own)
+            for s, e, buf, req in reqs:
+                req.wait()
+                yield s, e, buf.cpu().numpy().copy() if self.device_tensors else buf.numpy().copy()
+
+
 _STAGING = {}          # (device, sizes) -> pinned / device staging buffers of predict_survey
 
 
@@ -249,13 +305,22 @@ def release_staging():
 
 def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, preload_n_pings,
                    start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, predict_fn=None,
-                   shard="chunk", **kwargs):
+                   shard="chunk", ordered_to_rank0=None, **kwargs):
     """Generator over chunks: yields ``(start_ping, end_ping, out[2, n_range, end-start] numpy)``.
 
-    Multi-GPU (torch.distributed initialised, one process per GPU):
-      ``shard="chunk"`` (default) -- rank r owns chunks r, r + N, r + 2N, ...: every rank reads, uploads, predicts and
-          returns only ITS ping ranges (disjoint regions of the output array / zarr store) -- no collective anywhere,
-          the reader I/O and the PCIe traffic scale with the ranks too; each rank's generator yields its own chunks;
+    Multi-GPU (torch.distributed initialised, one process per GPU).  EVERY rank must iterate the
+    generator to its end.
+      ``shard="chunk"`` (default) -- rank r owns chunks r, r + N, r + 2N, ...: every rank reads, uploads and predicts
+          only ITS ping ranges; the reader I/O and the PCIe traffic scale with the ranks too.  What the generators yield
+          is set by ``ordered_to_rank0``:
+            True (the default under torch.distributed) -- the finished float16 / float32 chunks are handed to rank 0
+              point-to-point (one send per chunk, 16.8 MB as float16; RCCL: device to device over xGMI, off the compute
+              stream; gloo: host tensors) and RANK 0 YIELDS EVERY CHUNK OF THE SURVEY IN PING ORDER, the other ranks
+              yield nothing: the reference's strictly sequential writer (``append_to_zarr`` with
+              ``append_dim='ping_time'`` and resume by ``sizes['ping_time']``, save_predict.py:107-134) runs unchanged on
+              rank 0, and a caller that writes on rank 0 only loses nothing;
+            False -- no communication at all: each rank yields its OWN chunks only (disjoint ping ranges); for callers
+              that write regions themselves.
       ``shard="patch"`` -- every rank walks every chunk, takes patches p = rank (mod N) of it and the per-rank float16
           outputs are summed (one all-reduce of the chunk per chunk): every rank yields every chunk.
 
@@ -278,10 +343,20 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
     if shard not in ("chunk", "patch"):
         raise ValueError(f"predict_survey: shard must be 'chunk' or 'patch', got {shard!r}")
     share_patches = shard == "patch"
-    if not share_patches and torch.distributed.is_available() and torch.distributed.is_initialized():
-        chunks = chunks[torch.distributed.get_rank()::torch.distributed.get_world_size()]
-        if not chunks:
-            return
+    dist = torch.distributed
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if ordered_to_rank0 and share_patches:
+        raise ValueError("predict_survey: ordered_to_rank0 belongs to shard='chunk' (with shard='patch' every rank already "
+                         "yields every chunk)")
+    ordered = multi and not share_patches and (ordered_to_rank0 is None or bool(ordered_to_rank0))
+    all_chunks = chunks
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    if multi and not share_patches:
+        chunks = chunks[rank::world]
+    sender = ordered and rank != 0
+    hand = _OrderedHandoff(rank, world, all_chunks, n_range, np.dtype(out_dtype)) if ordered else None
+    if not chunks:
+        return
     n_freq = len(segpipe.frequencies)
     widest = max(e - s for s, e in chunks)
     halo = patch_size[1]
@@ -404,6 +479,10 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                     ev1.record()
                     stats.setdefault("gpu_events", []).append((ev0, ev1))
                 computed[slot].record()
+                if sender:                            # ordered hand-off: the chunk goes to rank 0, nothing comes back here
+                    hand.send(out)
+                    note("enqueue_s", t0)
+                    continue
                 pinned[slot][:out.numel()].view(out.shape).copy_(out, non_blocking=True)
                 events[slot].record()
                 note("enqueue_s", t0)
@@ -417,12 +496,18 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
                     note("copy_out_s", t0)
                     yield ps, pe, res
                 pending = (s, e, slot)
+            if sender:
+                hand.flush()
+                return
             ps, pe, pslot = pending
             events[pslot].synchronize()
             yield ps, pe, pinned[pslot][:2 * n_range * (pe - ps)].view(2, n_range, pe - ps).numpy().copy()
 
     try:
-        yield from _loop()
+        if ordered and rank == 0:
+            yield from hand.merge(_loop())
+        else:
+            yield from _loop()
     finally:
         torch.cuda.current_stream().synchronize()     # (nothing of this survey still reads or writes the staging)
         bufs["busy"] = False

@@ -470,6 +470,16 @@ int crimac_refine_labels(const void* labels_in, int label_bytes, const unsigned 
                          const float* data, int thr_channel, float thr_lo, float thr_hi, int mode,
                          short* labels_out, int B, int C, int H, int W, void* stream);
 
+/* ---- measurement support (bench.py only, not on the product path) --------------------------- */
+
+/* MFMA-only calibration launch: `blocks` workgroups of 4 waves each issue iters x 8 v_mfma_f32_16x16x32_bf16 on
+ * register operands (no memory traffic): 2 * 16*16*32 * 8 * iters * 4 * blocks FLOP.  stamps (device, 2 x blocks
+ * uint64, or NULL) receives per workgroup the s_memtime (shader cycles) and s_memrealtime (100 MHz) differences
+ * around the loop: shader clock = stamps[2i] / stamps[2i+1] x 100 MHz.  sink: any device float (never written).
+ * The reference has no counterpart (it never measures the device); this exists so that a roofline pass taken on a
+ * throttled box is visible in the bench line itself. */
+int crimac_mfma_calibrate(int iters, int blocks, unsigned long long* stamps, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

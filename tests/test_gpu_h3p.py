@@ -456,24 +456,40 @@ def test_network_eval_and_train_step_match_reference_golden(golden_dir):
     assert m.engine.skipped_steps() == 0
 
 
-def test_network_batch32_full_size_matches_oracle():
+# A pixel whose argmax differs from the oracle's counts as a parity failure UNLESS the oracle's own two top logits are
+# closer than its fp32 round-off at that pixel (two fp32 evaluations of the reference -- another thread count, another
+# oneDNN blocking -- disagree there too): the criterion is the MARGIN, never a count fitted to one seed.
+TIE_MARGIN = 2e-6          # logits are O(1): 2e-6 is ~16 fp32 ulps of the oracle's own summation noise
+MAX_TIE_FRACTION = 1e-5    # and such ties must stay rare (a systematic error would show as many small-margin flips)
+
+
+def assert_masks_identical_up_to_oracle_ties(out, ref, what):
+    diff = out.argmax(1) != ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[diff]
+    n = int(diff.sum())
+    print(f"{what}: argmax flips={n}/{ref[:, 0].numel()} oracle margins at flips={[f'{v:.1e}' for v in margin.tolist()[:8]]}")
+    assert bool((margin < TIE_MARGIN).all()), (what, margin.max())
+    assert n <= MAX_TIE_FRACTION * ref[:, 0].numel(), (what, n)
+
+
+@pytest.mark.parametrize("seed", [100, 1])
+def test_network_batch32_full_size_matches_oracle(seed):
     """BASELINE configs[1] size (32 x 4 x 256 x 256) in the fast parity precision against the CPU oracle: every kernel at
     the dispatch the benchmark uses.  Identical argmax masks except where the oracle's own two top logits tie to fp32
-    round-off; the number of such pixels is printed (the bench line records the golden-crop count)."""
+    round-off (margin criterion above).  seed 1 = the crops bench.py's ``batch32_vs_oracle`` runs on."""
     from oracle import unet_oracle as orc
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     sd = synth.synth_state_dict(seed=0)
-    x = torch.from_numpy(synth.synth_echogram_batch(32, 4, 256, 256, seed=100))
+    x = torch.from_numpy(synth.synth_echogram_batch(32, 4, 256, 256, seed=seed))
     ref = orc.predict(sd, x)
     m = _model().eval()
     with torch.no_grad():
         out = m(x.cuda()).cpu()
     r = _rel(out, ref)
-    diff = out.argmax(1) != ref.argmax(1)
-    top2 = ref.topk(2, dim=1).values
-    margin = (top2[:, 0] - top2[:, 1])[diff]
-    print(f"B=32 eval h3p: rel={r:.3e} argmax flips={int(diff.sum())}/{ref[:, 0].numel()} margins={margin.tolist()}")
+    print(f"B=32 eval h3p seed {seed}: rel={r:.3e}")
     assert r < 1e-5
-    assert int(diff.sum()) <= 2 and bool((margin < 2e-6).all())
+    assert_masks_identical_up_to_oracle_ties(out, ref, f"B=32 eval h3p seed {seed}")
 
 
 def test_training_trajectory_and_loss_scale_bookkeeping():

@@ -266,8 +266,9 @@ def test_batch32_full_size_f32x6_matches_oracle():
     margin = (top2[:, 0] - top2[:, 1])[diff]
     print(f"B=32 eval f32x6: rel={r:.3e} argmax flips={int(diff.sum())}/{ref[:, 0].numel()} margins={margin.tolist()}")
     assert r < 1e-5
-    # identical masks except where the reference's own two top logits tie to fp32 round-off
-    assert int(diff.sum()) <= 2 and bool((margin < 2e-6).all())
+    # identical masks except where the reference's own two top logits tie to fp32 round-off: the criterion is the
+    # oracle's margin at the flipped pixel, not a count (tests/test_gpu_h3p.py: assert_masks_identical_up_to_oracle_ties)
+    assert bool((margin < 2e-6).all()) and int(diff.sum()) <= 1e-5 * diff.numel()
     # the 3-MFMA parity mode (fp16 planes forward) at the same size: same bar
     mh = make_model("f32h3").eval()
     with torch.no_grad():
@@ -276,7 +277,7 @@ def test_batch32_full_size_f32x6_matches_oracle():
     diffh = outh.argmax(1).cpu() != ref.argmax(1)
     marginh = (top2[:, 0] - top2[:, 1])[diffh]
     print(f"B=32 eval f32h3: rel={rh:.3e} argmax flips={int(diffh.sum())}/{ref[:, 0].numel()} margins={marginh.tolist()}")
-    assert rh < 1e-5 and int(diffh.sum()) <= 2 and bool((marginh < 2e-5).all())
+    assert rh < 1e-5 and bool((marginh < 2e-6).all()) and int(diffh.sum()) <= 1e-5 * diffh.numel()
     del mh
     ref_loss, ref_logits, ref_grads, ref_stats = orc.loss_and_grads(sd, x, lab)
     m.train()

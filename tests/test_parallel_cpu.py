@@ -71,7 +71,7 @@ def _worker(rank, world, port, results):
     # inference: 7 "patches", each rank computes its shard, all-gather restores patch order
     n = 7
     idx = parallel.shard_indices(n, rank, world)
-    local = torch.tensor([[10.0 * i, 10.0 * i + 1] for i in idx])
+    local = torch.tensor([[10.0 * i, 10.0 * i + 1] for i in idx]).reshape(-1, 2)        # (a rank may own no patch)
     full = parallel.gather_shards(local, n)
     ok_gather = bool(torch.equal(full, torch.tensor([[10.0 * i, 10.0 * i + 1] for i in range(n)])))
     sums = parallel.all_reduce_scalars(torch.tensor([1.0 + rank, 2.0]))
@@ -81,8 +81,10 @@ def _worker(rank, world, port, results):
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_world_size_n_gloo(world):
+    """world 8 = the node the scaling bench runs on (one rank per GPU): rendezvous, bucketed exchange in both spellings,
+    out-of-order ranges, per-range completion, patch gather with ranks that own nothing."""
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
@@ -91,9 +93,9 @@ def test_world_size_2_gloo():
         for p in procs:
             p.start()
         for p in procs:
-            p.join(120)
+            p.join(240)
             assert p.exitcode == 0
-        assert dict(results) == {0: (True, True, True), 1: (True, True, True)}
+        assert dict(results) == {r: (True, True, True) for r in range(world)}
 
 
 def test_single_process_is_a_noop():

@@ -394,8 +394,12 @@ def _tiled_rank_worker(rank, world, port, out):
     if rank == 0:
         out["chunks"] = [(s, e, o.copy()) for s, e, o in chunks]
     # chunk sharding: rank r owns chunks r, r + N, ...; no collective; together the ranks cover the survey once
-    mine = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16))
+    mine = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16, ordered_to_rank0=False))
     out[f"own{rank}"] = [(s, e, o.copy()) for s, e, o in mine]
+    # the default under torch.distributed: chunk-sharded compute, ordered hand-off -- rank 0 yields the WHOLE survey in
+    # ping order (what a sequential append_to_zarr writer on rank 0 needs), the other ranks yield nothing
+    ordered = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 175, out_dtype=np.float16))
+    out[f"ordered{rank}"] = [(s, e, o.copy()) for s, e, o in ordered]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -430,11 +434,18 @@ def test_two_ranks_share_the_patches_of_a_chunk_and_merge_exactly():
             assert p.exitcode == 0
         multi = out["chunks"]
         own = [out["own0"], out["own1"]]
+        ordered = [out["ordered0"], out["ordered1"]]
     for (s0, e0, o0), (s1, e1, o1) in zip(single, multi):
         assert (s0, e0) == (s1, e1) and np.array_equal(o0, o1) and (o0 != 0).any()
     # chunk sharding: rank 0 produced chunk 0, rank 1 chunk 1, each bit-identical to the single-process result
     assert [c[:2] for c in own[0]] == [single[0][:2]] and [c[:2] for c in own[1]] == [single[1][:2]]
     assert np.array_equal(own[0][0][2], single[0][2]) and np.array_equal(own[1][0][2], single[1][2])
+    # ordered hand-off (4 chunks over 2 ranks): rank 0 got all four, in ping order, bit-identical; rank 1 nothing
+    single4 = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 175, out_dtype=np.float16))
+    assert len(single4) == 4 and ordered[1] == []
+    assert [c[:2] for c in ordered[0]] == [c[:2] for c in single4]
+    for (_, _, a), (_, _, b) in zip(ordered[0], single4):
+        assert a.dtype == np.float16 and np.array_equal(a, b)
 
 
 # ---- metadata planes (late metadata injection) --------------------------------------------------------------
