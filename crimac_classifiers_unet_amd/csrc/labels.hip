@@ -19,20 +19,41 @@ constexpr int kThreads = 1024;
 // 7x7 disk (refine_label_boundary.py:50-58): half-width of the row at vertical offset dy
 __device__ __forceinline__ int disk_hw(int dy) { return dy == 0 ? 3 : (dy == 1 || dy == -1) ? 3 : (dy == 2 || dy == -2) ? 2 : 1; }
 
-__device__ __forceinline__ long load_label(const void* p, int bytes, long i) {
+__device__ __forceinline__ long load_label_raw(const void* p, int bytes, long i) {
   if (bytes == 8) return ((const long long*)p)[i];
   if (bytes == 4) return ((const int*)p)[i];
   return ((const short*)p)[i];
 }
 
+// Test-time chain (define_label_transform_test, batch/transforms.py:81-99): the labels refine_label_boundary sees
+// have already been through convert_label_indexing_unused_species (convert_label_indexing.py:37-47):
+// 0 / 27 / 1 -> 0 / 1 / 2, other species (> 0) -> -10, everything else -> -100.
+template <bool TEST>
+__device__ __forceinline__ long load_label(const void* p, int bytes, long i) {
+  const long l = load_label_raw(p, bytes, i);
+  if (!TEST) return l;
+  return l == 0 ? 0 : l == 27 ? 1 : l == 1 ? 2 : l > 0 ? -10 : -100;
+}
+
+// What mask_label_seabed (mask_label_seabed.py:24-68) and mask_label_overlap (mask_label_overlap.py:23-48) need.
+struct TestChain {
+  const long long* centres;             // [B][2] (range idx, GLOBAL ping idx) of the patch centres
+  const int* seabed;                    // per-ping seabed index, pings [seabed_ping0, +seabed_pings) -- or
+  int seabed_ping0, seabed_pings;
+  const unsigned char* seabed_mask;     // the reader's 2-D mask [mask_pings][n_range] (1 below the seabed)
+  int mask_ping0, mask_pings;
+  int n_range, seabed_pad, seabed_rule, overlap;
+};
+
 // One workgroup per (patch, band of BAND rows): it scans the whole patch for the bounding box (a few reads
 // per thread, L2-resident) and then works on its rows plus the 3 + 3 halo rows the two morphology passes need.
 constexpr int BAND = 32;
 
+template <bool TEST>
 __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
     const void* __restrict__ labels_in, int label_bytes, const unsigned char* __restrict__ aux,
     const float* __restrict__ data, int thr_channel, float thr_lo, float thr_hi, int mode,
-    short* __restrict__ labels_out, int C, int H, int W) {
+    short* __restrict__ labels_out, int C, int H, int W, TestChain tc) {
   extern __shared__ unsigned char smem[];
   const int HW = H * W;
   const int r0 = blockIdx.y * BAND;                     // first output row of this band
@@ -49,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
   // ---- bounding box of label != -100 over the whole patch -------------------------------------------
   int y0 = H, y1 = 0, x0 = W, x1 = 0;
   for (int i = tid; i < HW; i += kThreads) {
-    if (load_label(labels_in, label_bytes, base + i) != -100) {
+    if (load_label<TEST>(labels_in, label_bytes, base + i) != -100) {
       const int y = i / W, x = i - y * W;
       y0 = min(y0, y); y1 = max(y1, y + 1); x0 = min(x0, x); x1 = max(x1, x + 1);
     }
@@ -64,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
     bool hit = false;
     if (!empty && y >= y0 && y < y1 && x >= x0 && x < x1) {
       const long gi = base + (long)y * W + x;
-      if (load_label(labels_in, label_bytes, gi) > 0) {
+      if (load_label<TEST>(labels_in, label_bytes, gi) > 0) {
         if (aux) hit = aux[gi] & 1;
         else {
           const float d = data[((long)b * C + thr_channel) * HW + (long)y * W + x];
@@ -97,7 +118,7 @@ __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
   for (int i = tid; i < rows * W; i += kThreads) {
     const int ry = i / W, x = i - ry * W, y = r0 + ry;
     const long gi = base + (long)y * W + x;
-    long l = load_label(labels_in, label_bytes, gi);
+    long l = load_label<TEST>(labels_in, label_bytes, gi);
     if (!empty && l > 0) {        // label > 0 implies inside the crop
       bool closed = true;
       for (int dy = -3; dy <= 3 && closed; ++dy) {
@@ -109,7 +130,32 @@ __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
       }
       if (!closed) l = -30;
     }
-    if (mode == 1) {
+    if (TEST) {
+      // mask_label_seabed: background pixels below the (padded) seabed -> -50; boundary / fish labels take precedence
+      const int cy = (int)tc.centres[2 * b], cx = (int)tc.centres[2 * b + 1];
+      const int yd = cy - H / 2 + 1 + y, xd = cx - W / 2 + 1 + x;            // data coordinates of this patch pixel
+      if (l == 0 && yd >= 0 && yd < tc.n_range) {
+        // zarr reader: the pad shifts the mask down INSIDE the slice the patch asks for (rows from y_top); Echogram:
+        // absolute rows >= seabed + pad
+        const int y_top = tc.seabed_rule == 0 ? max(cy - H / 2 + 1, 0) : 0;
+        if (yd - y_top >= tc.seabed_pad) {
+          bool below = false;
+          if (tc.seabed) {
+            const int xs = xd - tc.seabed_ping0;
+            below = xs >= 0 && xs < tc.seabed_pings && (yd - tc.seabed_pad) >= tc.seabed[xs];
+          } else if (tc.seabed_mask) {
+            const int xm = xd - tc.mask_ping0;
+            below = xm >= 0 && xm < tc.mask_pings && tc.seabed_mask[(long)xm * tc.n_range + (yd - tc.seabed_pad)];
+          }
+          if (below) l = -50;
+        }
+      }
+      // mask_label_overlap: the rim shared with the neighbouring patches -> -70, except where the crop left the data
+      const int o = tc.overlap;
+      if (o > 0 && (y < o || y >= H - o || x < o || x >= W - o) && l != -100) l = -70;
+      // remove_nan_inf's label rule (the data transform runs after the label transform)
+      if (!isfinite(data[(long)b * C * HW + (long)y * W + x])) l = -100;
+    } else if (mode == 1) {
       l = l == 0 ? 0 : l == 27 ? 1 : l == 1 ? 2 : -100;
       bool bad;
       if (aux) bad = aux[gi] & 2;
@@ -135,12 +181,43 @@ extern "C" int crimac_refine_labels(const void* labels_in, int label_bytes, cons
   CRIMAC_REQUIRE(mode == 0 || mode == 1, "refine_labels: bad mode %d", mode);
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_labels_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_labels_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const size_t lds = (size_t)(((2 * BAND + 18) * W + 15) & ~15) + 16;
-  hipLaunchKernelGGL(refine_labels_kernel, dim3(B, cdiv(H, BAND)), dim3(kThreads), lds, (hipStream_t)stream, labels_in,
-                     label_bytes, aux_mask, data, thr_channel, thr_lo, thr_hi, mode, labels_out, C, H, W);
+  hipLaunchKernelGGL(refine_labels_kernel<false>, dim3(B, cdiv(H, BAND)), dim3(kThreads), lds, (hipStream_t)stream,
+                     labels_in, label_bytes, aux_mask, data, thr_channel, thr_lo, thr_hi, mode, labels_out, C, H, W,
+                     TestChain{});
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_labels_test_transform(const void* labels_in, int label_bytes, const float* data, int thr_channel,
+                                            float thr_lo, float thr_hi, const long long* centres, const int* seabed,
+                                            int seabed_ping0, int seabed_pings, const unsigned char* seabed_mask,
+                                            int mask_ping0, int mask_pings, int n_range, int seabed_pad,
+                                            int seabed_rule, int overlap, short* labels_out, int B, int C, int H,
+                                            int W, void* stream) {
+  CRIMAC_REQUIRE(labels_in && labels_out && data && centres && (label_bytes == 2 || label_bytes == 4 || label_bytes == 8),
+                 "labels_test_transform: bad arguments (label_bytes=%d)", label_bytes);
+  CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && W <= 1024 && H % 2 == 0 && W % 2 == 0 && (long)H * W < (1L << 30),
+                 "labels_test_transform: patch of %d x %d (even sizes, W <= 1024)", H, W);
+  CRIMAC_REQUIRE(C > 0 && thr_channel >= 0 && thr_channel < C, "labels_test_transform: bad channel %d of %d", thr_channel, C);
+  CRIMAC_REQUIRE(!(seabed && seabed_mask), "labels_test_transform: give the seabed vector OR the seabed mask");
+  CRIMAC_REQUIRE(seabed_rule == 0 || seabed_rule == 1, "labels_test_transform: seabed_rule=%d", seabed_rule);
+  CRIMAC_REQUIRE(overlap >= 0 && 2 * overlap < H && 2 * overlap < W && n_range > 0 && seabed_pad >= 0,
+                 "labels_test_transform: overlap %d / n_range %d / pad %d", overlap, n_range, seabed_pad);
+  static unsigned long long attr_devs = 0;
+  if (crimac_first_use_on_device(&attr_devs)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_labels_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const size_t lds = (size_t)(((2 * BAND + 18) * W + 15) & ~15) + 16;
+  TestChain tc{centres, seabed, seabed_ping0, seabed_pings, seabed_mask, mask_ping0, mask_pings, n_range, seabed_pad,
+               seabed_rule, overlap};
+  hipLaunchKernelGGL(refine_labels_kernel<true>, dim3(B, cdiv(H, BAND)), dim3(kThreads), lds, (hipStream_t)stream,
+                     labels_in, label_bytes, (const unsigned char*)nullptr, data, thr_channel, thr_lo, thr_hi, 2, labels_out,
+                     C, H, W, tc);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

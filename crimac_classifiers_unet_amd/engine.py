@@ -1249,6 +1249,7 @@ class UNetEngine:
                  float(lr), float(momentum), float(grad_scale), 1 if zero_grad else 0)
         self.mark_dirty()
 
+    min_loss_scale = 2.0 ** 4        # floor of the dynamic loss scale (update_loss_scale warns when it is reached)
     loss_scale_check_every = 25      # guarded steps between two host reads of the skip counter inside train_step (0: never)
 
     def skipped_steps(self):
@@ -1259,12 +1260,24 @@ class UNetEngine:
         """Dynamic loss scale, evaluated only where the caller synchronises anyway (the pipeline's loss flush):
         halve the scale if a step was skipped since the last call, double it after ``growth_interval`` clean
         calls (up to 2^24).  Returns the scale now in force."""
-        if not self.dynamic_loss_scale or self.loss_scale == 1.0:
+        if not self.dynamic_loss_scale:
             return self.loss_scale
         n = self.skipped_steps()
         if n > self._skipped_seen:
             self._skipped_seen, self._good_checks = n, 0
-            self.loss_scale = max(self.loss_scale / 2.0, 1.0)
+            if self.loss_scale / 2.0 < self.min_loss_scale:
+                # a scale this low means the gradients overflow fp16 however they are scaled (diverged weights, inf / NaN
+                # in the input): say so once; the guarded step keeps skipping such steps, the scale stays at the floor and
+                # grows again from there once steps succeed
+                if not getattr(self, "_warned_scale_floor", False):
+                    import warnings
+                    warnings.warn(f"loss scale reached its floor ({self.min_loss_scale:g}) after {n} skipped steps: the "
+                                  "gradients overflow fp16 storage whatever the scale (diverging training or non-finite "
+                                  "inputs?)", RuntimeWarning, stacklevel=2)
+                    self._warned_scale_floor = True
+                self.loss_scale = self.min_loss_scale
+            else:
+                self.loss_scale = self.loss_scale / 2.0
         else:
             self._good_checks += 1
             if self._good_checks >= growth_interval and self.loss_scale < 2.0 ** 24:
@@ -1305,8 +1318,10 @@ class UNetEngine:
             self.exchange_probe.append((e0, e1))
             return sc
 
-        if ls != 1.0:
-            # loss-scaled step: all ranges are applied together behind ONE overflow check (a step is applied
+        if self.dynamic_loss_scale or ls != 1.0:
+            # loss-scaled step (selected by the MODE, not by the current value of the scale: fp16 / plane-pair gradient
+            # storage needs the overflow guard whatever the scale has decayed to): all ranges are applied together
+            # behind ONE overflow check (a step is applied
             # whole or not at all), so the per-range early updates of the unscaled path are not used
             if grad_sync is not None and hasattr(grad_sync, "launch"):
                 self.backward(dl, on_ready=None if single else (lambda lo, hi: grad_sync.launch(self.flat_g, lo, hi)))

@@ -97,6 +97,8 @@ SIGNATURES = {
     "crimac_refine_labels": [_vp, _i, _vp, _vp, _i, _f, _f, _i, _vp, _i, _i, _i, _i, _vp],
     "crimac_pr_histogram": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_mfma_calibrate": [_i, _i, _vp, _vp],
+    "crimac_labels_test_transform": [_vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i,
+                                     _i, _i],
     "crimac_scatter_patches": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i,
                                _i, _vp, _vp],
 }

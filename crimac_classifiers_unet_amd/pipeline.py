@@ -251,6 +251,62 @@ class SegPipe:
                 return self.model.predict_softmax(inputs)
             return self.model(inputs)
 
+    # -- test-time transforms on the GPU (the validation / evaluate flows) ---------------------
+    _test_source = None
+
+    def use_gpu_test_transform(self, reader, patch_overlap=0, seabed_pad=10):
+        """From here on the validation / test DataLoaders hand RAW crops: the reference ``Dataset`` built with
+        ``label_transform_function=None`` and ``data_transform_function=None`` (batch/dataset.py:89-103 then applies
+        nothing), i.e. ``data`` = linear sv, ``labels`` = raw annotation ids (-100 outside the data),
+        ``center_coordinates`` = (range idx, ping idx).  ``define_label_transform_test`` (batch/transforms.py:81-99) and
+        ``define_data_transform`` (:49-55) run on the GPU instead: ``crimac_labels_test_transform`` +
+        ``crimac_augment_db_nhwc`` (remove_nan_inf + db_with_limits, straight into the first convolution's layout).
+        ``reader``: the survey's zarr reader (``shape``, ``get_seabed``, ``get_seabed_mask``) the crops come from -- its
+        seabed is uploaded once.  ``None`` switches back to host-transformed batches."""
+        if reader is None:
+            self._test_source = None
+            return
+        if getattr(reader, "data_format", "zarr") != "zarr":
+            raise NotImplementedError("use_gpu_test_transform: zarr readers only (the memmap flow's set_data_border_value "
+                                      "lives in the tiled path, tiled_inference.predict_echogram_memm)")
+        from .tiled_inference import seabed_vector_or_mask
+        n_pings, n_range = reader.shape
+        sb = np.asarray(reader.get_seabed(0, n_pings, return_numpy=True)).astype(np.int32)
+        sb, mask = seabed_vector_or_mask(reader, 0, n_pings, n_range, sb, 0)
+        dev = self.device
+        self._test_source = {
+            "seabed": None if mask is not None else torch.from_numpy(np.ascontiguousarray(sb)).to(dev),
+            "mask": None if mask is None else torch.from_numpy(mask).to(dev),
+            "n_pings": int(n_pings), "n_range": int(n_range), "overlap": int(patch_overlap), "pad": int(seabed_pad)}
+
+    def _predict_raw_batch(self, batch):
+        """(logits, transformed int16 labels on the device) of one batch of RAW crops (``use_gpu_test_transform``)."""
+        from .hip import call, ptr
+        src, dev = self._test_source, self.device
+        if self.late_meta_inject:
+            raise NotImplementedError("use_gpu_test_transform with late metadata injection")
+        self.model.eval()
+        data = batch["data"].to(dev)
+        if data.dtype != torch.float32:
+            data = data.float()
+        data = data.contiguous()
+        labels = batch["labels"].to(dev)
+        if labels.dtype not in (torch.int16, torch.int32, torch.int64):
+            labels = labels.long()
+        labels = labels.contiguous()
+        cen = torch.as_tensor(batch["center_coordinates"]).to(dev).long().contiguous()
+        B, C, H, W = data.shape
+        out = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+        eng = self.model.infer_engine
+        with torch.no_grad(), torch.cuda.device(dev):
+            call("crimac_labels_test_transform", ptr(labels), labels.element_size(), ptr(data), len(self.frequencies) - 1,
+                 1e-7, 1e-4, ptr(cen), ptr(src["seabed"]), 0, src["n_pings"] if src["seabed"] is not None else 0,
+                 ptr(src["mask"]), 0, src["n_pings"] if src["mask"] is not None else 0, src["n_range"], src["pad"], 0,
+                 src["overlap"], ptr(out), B, C, H, W)
+            x, _ = eng.augment_batch(data, None, 0, do_noise=False, do_flip=False)     # remove_nan_inf + db_with_limits
+            logits = eng.forward_nhwc(x, B, H, W, training=False)
+        return logits, out
+
     def set_label_ignore_val(self, labels):
         """Reference pipeline.py:222-239 (in place, like the reference)."""
         labels[labels == LABEL_OVERLAP_VAL] = LABEL_IGNORE_VAL
@@ -312,11 +368,14 @@ class SegPipe:
                                              disable=disable_tqdm)):
                 if bi % world != rank:            # batches are dealt round-robin to the ranks
                     continue
-                logits = self.predict_batch(batch, return_softmax=False)
-                labels = batch["labels"].to(dev)
-                if labels.dtype not in (torch.int16, torch.int32, torch.int64):
-                    labels = labels.long()
-                labels = labels.contiguous()
+                if self._test_source is not None:      # RAW crops: label + data transforms on the GPU
+                    logits, labels = self._predict_raw_batch(batch)
+                else:
+                    logits = self.predict_batch(batch, return_softmax=False)
+                    labels = batch["labels"].to(dev)
+                    if labels.dtype not in (torch.int16, torch.int32, torch.int64):
+                        labels = labels.long()
+                    labels = labels.contiguous()
                 if criterion is not None:
                     loss = criterion(logits, self.set_label_ignore_val(labels.clone().long()))
                     sum_loss = loss if sum_loss is None else sum_loss + loss

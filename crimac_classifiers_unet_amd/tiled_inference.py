@@ -215,9 +215,11 @@ def seabed_vector_or_mask(reader, s, e, n_range, sb, sb_ping0):
     reader derives that vector as ``argmax(range)`` of the stored mask (data_reader.py:864-865), so the two agree only
     where the mask of a ping is exactly "zeros, then ones to the end": a ping with NO detected bottom has an all-zero
     mask (``fillna(0)``) and argmax 0 -- the vector rule would mask its whole water column, the reference masks
-    nothing -- and a mask with holes is not a threshold at all.  Checked here per chunk on the reader's own mask for
-    the pings [s, e) the chunk writes: no-bottom pings get seabed = n_range (nothing below it), and a mask the vector
-    cannot express is returned as uint8 [e - s, n_range] to be uploaded instead (``ChunkPredictor.load_chunk``).
+    nothing -- a mask with holes is not a threshold at all, and a reader whose ``get_seabed`` is independent of its mask
+    (the memmap reader's seabed.npy) may simply disagree with it.  Checked here per chunk, EXACTLY, on the reader's own
+    mask (read once) for the pings [s, e) the chunk writes: the mask must equal ``arange(n_range) >= vector`` element for
+    element; no-bottom pings get seabed = n_range (nothing below it); anything the vector cannot express is returned as
+    uint8 [e - s, n_range] to be uploaded instead (``ChunkPredictor.load_chunk``).
 
     Returns (seabed vector to upload, mask or None).  ``sb`` covers pings [sb_ping0, sb_ping0 + len(sb))."""
     if not hasattr(reader, "get_seabed_mask"):
@@ -227,13 +229,13 @@ def seabed_vector_or_mask(reader, s, e, n_range, sb, sb_ping0):
     if m.shape != (e - s, n_range):
         raise ValueError(f"get_seabed_mask returned {m.shape}, expected {(e - s, n_range)}")
     below = m != 0
-    cnt = np.count_nonzero(below, axis=1)
-    vec = sb[s - sb_ping0:e - sb_ping0]
-    none = cnt == 0
-    if np.array_equal(np.where(none, 0, n_range - vec), cnt):      # every column: zeros, then ones from seabed[ping] on
+    vec = np.asarray(sb[s - sb_ping0:e - sb_ping0]).astype(np.int64)
+    none = ~below.any(axis=1)
+    vec_eff = np.where(none, n_range, vec)                   # no bottom detected: nothing lies below it
+    if np.array_equal(below, np.arange(n_range)[None, :] >= vec_eff[:, None]):
         if none.any():
             sb = sb.copy()
-            sb[s - sb_ping0:e - sb_ping0][none] = n_range
+            sb[s - sb_ping0:e - sb_ping0] = vec_eff
         return sb, None
     return sb, np.ascontiguousarray(below.astype(np.uint8))
 
@@ -403,10 +405,16 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
     def fetch(i, s, e):
         t0 = tick()
         k = i % NS
-        seabed = np.asarray(reader.get_seabed(s, e - s, return_numpy=True)).astype(np.int32)
+        # ping extent of the data a patch of the chunk can touch (dataset.py:175-177): the patch columns depend on
+        # (s, e) only, so the seabed of [lo, hi) -- which contains [s, e) -- is read ONCE (the zarr reader derives it from
+        # the full 2-D mask every time, data_reader.py:864-865)
+        xs = np.arange(s - (patch_overlap + 1), e - (patch_overlap + 1), patch_size[0] - 2 * patch_overlap) + patch_size[0] // 2
+        lo = max(0, int(xs[0]) - patch_size[1] // 2)
+        hi = min(n_pings, int(xs[-1]) + patch_size[1] // 2)
+        sb = np.asarray(reader.get_seabed(lo, hi - lo, return_numpy=True)).astype(np.int32)
+        seabed = sb[max(s - lo, 0):e - lo] if lo <= s else np.asarray(reader.get_seabed(s, e - s, return_numpy=True)).astype(np.int32)
         grid = plan_grid(n_range, int(seabed.max()), s, e, patch_size, patch_overlap)
-        lo = max(0, int(grid[0, 1]) - patch_size[1] // 2)              # dataset.py:175-177
-        hi = min(n_pings, int(grid[-1, 1]) + patch_size[1] // 2)
+        assert lo == max(0, int(grid[0, 1]) - patch_size[1] // 2) and hi == min(n_pings, int(grid[-1, 1]) + patch_size[1] // 2)
         uploaded[k].synchronize()                                        # (no-op until the slot has been used)
         data = reader.get_data_slice(idx_ping=lo, n_pings=hi - lo, frequencies=segpipe.frequencies,
                                      return_numpy=True)
@@ -418,7 +426,6 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
             l_t = stage_lab[k][:e - s]
             np.copyto(l_t.numpy(), lab, casting="unsafe")
         # the seabed of every ping a patch of the chunk can touch (the scatter kernel evaluates the mask from it)
-        sb = np.asarray(reader.get_seabed(lo, hi - lo, return_numpy=True)).astype(np.int32)
         sb, mask = seabed_vector_or_mask(reader, s, e, n_range, sb, lo)
         P = len(grid)
         assert (hi - lo) + 4 * P <= n_misc, "misc staging too small"

@@ -86,7 +86,7 @@ class SGDMomentum:
         eng.bind()
         g = self.param_groups[0]
         # loss-scaled precision (fp16): a step whose gradients overflowed is skipped, as torch.cuda.amp.GradScaler does
-        eng.sgd_step(g["lr"], g["momentum"], guarded=eng.loss_scale != 1.0)
+        eng.sgd_step(g["lr"], g["momentum"], guarded=eng.dynamic_loss_scale or eng.loss_scale != 1.0)
 
     def state_dict(self):
         g = self.param_groups[0]

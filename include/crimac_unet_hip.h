@@ -470,6 +470,25 @@ int crimac_refine_labels(const void* labels_in, int label_bytes, const unsigned 
                          const float* data, int thr_channel, float thr_lo, float thr_hi, int mode,
                          short* labels_out, int B, int C, int H, int W, void* stream);
 
+/* define_label_transform_test (batch/transforms.py:81-99, label_masks = 'all') + remove_nan_inf's label rule
+ * (remove_nan_inf.py:30-32) on a batch of RAW crops -- the label chain of the validation / evaluate flows
+ * (pipeline.py:242-341; evaluate.py:39-117): convert_label_indexing_unused_species (convert_label_indexing.py:37-47),
+ * refine_label_boundary on the converted labels and the raw linear-sv crop (refine_label_boundary.py:35-104),
+ * mask_label_seabed (mask_label_seabed.py:24-68: background below seabed + pad -> -50), mask_label_overlap
+ * (mask_label_overlap.py:23-48: rim of `overlap` pixels -> -70 except where the crop left the data).
+ *   labels_in [B][H][W] raw annotation ids (-100 outside the data), data [B][C][H][W] fp32 linear sv,
+ *   centres [B][2] int64 (range idx, GLOBAL ping idx) -- the batch's `center_coordinates`; the seabed as in
+ *   crimac_scatter_patches_ex: per-ping vector seabed[seabed_pings] from global ping seabed_ping0, OR the reader's mask
+ *   [mask_pings][n_range] from global ping mask_ping0; seabed_rule 0 = zarr reader (pad applied inside the requested
+ *   slice, data_reader.py:837-841), 1 = Echogram (absolute rows, data_reader.py:407-431); H, W even, W <= 1024.
+ *   labels_out int16 [B][H][W] in {-100, -70, -50, -30, -10, 0, 1, 2}.  Bit-exact against the reference's output
+ *   (tests/golden/labels_test.npz). */
+int crimac_labels_test_transform(const void* labels_in, int label_bytes, const float* data, int thr_channel,
+                                 float thr_lo, float thr_hi, const long long* centres, const int* seabed,
+                                 int seabed_ping0, int seabed_pings, const unsigned char* seabed_mask, int mask_ping0,
+                                 int mask_pings, int n_range, int seabed_pad, int seabed_rule, int overlap,
+                                 short* labels_out, int B, int C, int H, int W, void* stream);
+
 /* ---- measurement support (bench.py only, not on the product path) --------------------------- */
 
 /* MFMA-only calibration launch: `blocks` workgroups of 4 waves each issue iters x 8 v_mfma_f32_16x16x32_bf16 on

@@ -93,3 +93,66 @@ def train_label_transform(data, labels, thr_channel_idx, threshold_val=(1e-7, 1e
             lab[~np.isfinite(data[b, 0])] = LABEL_IGNORE_VAL       # remove_nan_inf.py:30-32
         out[b] = lab.astype(np.int16)
     return out
+
+
+# ---- test-time chain (validation / evaluate flows) -------------------------------------------------------------------
+LABEL_OVERLAP_VAL = -70            # constants.py:27
+LABEL_SEABED_MASK_VAL = -50        # constants.py:28
+LABEL_UNUSED_SPECIES = -10         # constants.py:30
+SEABED_PAD = 10                    # mask_label_seabed.py:50-52
+
+
+def convert_label_indexing_unused_species(labels):
+    """convert_label_indexing.py:37-47: convert_label_indexing, then foreign species (> 0, not 1 / 27) -> -10."""
+    out = convert_label_indexing(labels)
+    out[(labels > 0) & (labels != 1) & (labels != 27)] = LABEL_UNUSED_SPECIES
+    return out
+
+
+def test_label_transform(data, labels, centre, thr_channel_idx, seabed, n_range, patch_overlap=0, seabed_rule="zarr",
+                         seabed_mask=None, threshold_val=(1e-7, 1e-4), nan_rule=True):
+    """define_label_transform_test (batch/transforms.py:81-99, label_masks='all') followed by remove_nan_inf's label rule
+    (remove_nan_inf.py:30-32), for ONE patch: convert_label_indexing_unused_species -> refine_label_boundary (on the
+    converted labels and the RAW linear-sv crop: the label transform runs before the data transform, batch/dataset.py:
+    89-103) -> mask_label_seabed (mask_label_seabed.py:24-68) -> mask_label_overlap (mask_label_overlap.py:23-48).
+
+    data [C,H,W] linear sv crop, labels [H,W] raw annotation ids (-100 outside the data), centre (range idx, GLOBAL ping
+    idx) of the patch, ``seabed`` per-ping seabed index vector indexed by global ping (``seabed_mask`` [n_pings, n_range],
+    zarr rule only: the reader's own 2-D mask instead).  seabed_rule: 'zarr' -- the reader shifts the mask down by the pad
+    INSIDE the slice it is asked for (data_reader.py:837-841) -- or 'memm' -- ``Echogram.get_seabed_mask``: absolute rows
+    >= seabed + pad (data_reader.py:407-431).  H and W even (the reference's own coordinate helpers disagree by one pixel
+    for odd sizes).  Returns int16 labels in {-100, -70, -50, -30, -10, 0, 1, 2}."""
+    H, W = labels.shape
+    assert H % 2 == 0 and W % 2 == 0
+    lab = convert_label_indexing_unused_species(np.asarray(labels).astype(np.int64))
+    lab = refine_label_boundary(np.asarray(data)[thr_channel_idx], lab, threshold_val)
+    cy, cx = int(centre[0]), int(centre[1])
+    y_data = cy - H // 2 + 1 + np.arange(H)                 # patch pixel p <-> data coordinate centre - n/2 + 1 + p
+    x_data = cx - W // 2 + 1 + np.arange(W)
+    y_top = max(cy - H // 2 + 1, 0)
+    below = np.zeros((H, W), dtype=bool)
+    ok_rows = (y_data >= 0) & (y_data < n_range)
+    n_pings = len(seabed) if seabed_mask is None else np.asarray(seabed_mask).shape[0]
+    for j, x in enumerate(x_data):
+        if x < 0 or x >= n_pings:
+            continue
+        if seabed_rule == "zarr" and seabed_mask is not None:
+            src = np.clip(y_data - SEABED_PAD, 0, n_range - 1)
+            below[:, j] = ok_rows & (y_data - y_top >= SEABED_PAD) & (np.asarray(seabed_mask)[x, src] != 0)
+        elif seabed_rule == "zarr":
+            below[:, j] = ok_rows & (y_data - y_top >= SEABED_PAD) & ((y_data - SEABED_PAD) >= seabed[x])
+        else:
+            below[:, j] = ok_rows & ((y_data - SEABED_PAD) >= seabed[x])
+    lab[below & (lab == BACKGROUND)] = LABEL_SEABED_MASK_VAL          # boundary / fish labels take precedence
+    if patch_overlap > 0:
+        o = patch_overlap
+        out = np.full(lab.shape, LABEL_OVERLAP_VAL, dtype=np.int64)
+        out[o:-o, o:-o] = lab[o:-o, o:-o]
+        out[lab == LABEL_BOUNDARY_VAL] = LABEL_BOUNDARY_VAL
+        lab = out
+    if nan_rule:
+        lab[~np.isfinite(np.asarray(data)[0])] = LABEL_IGNORE_VAL
+    return lab.astype(np.int16)
+
+
+test_label_transform.__test__ = False      # (not a pytest test: the name mirrors define_label_transform_test)

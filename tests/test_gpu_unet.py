@@ -465,6 +465,51 @@ def test_train_model_loop_with_logger_and_lr_schedule(tmp_path):
     assert list(sd.keys()) == list(synth.unet_state_shapes().keys())
 
 
+class _CropDataset(torch.utils.data.Dataset):
+    """In-memory Dataset yielding the reference's per-sample dict (batch/dataset.py: data float64 on the zarr path,
+    labels int16, centre coordinates)."""
+
+    def __init__(self, n, hw=64, dtype=np.float64):
+        self.x = synth.synth_echogram_batch(n, 4, hw, hw, seed=70).astype(dtype)
+        self.y = synth.synth_labels(n, hw, hw, seed=71)
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        return {"data": self.x[i], "labels": self.y[i], "center_coordinates": np.array([i, i], dtype=np.int64)}
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_train_model_pinned_input_ring_equals_the_inline_copy(workers):
+    """train_model's input staging (staging.BatchStager: DataLoader pulled one batch ahead by a host thread, pinned ring,
+    copy stream; float64 -> float32 on the way like the reference's ``.float()``, pipeline.py:163) feeds the steps
+    exactly what the reference's in-line ``.float().to(device)`` feeds them: same logged losses, same parameters --
+    with DataLoader worker processes and without."""
+    logs, params = {}, {}
+    for pin in (True, False):
+        pipe = pkg.SegPipeUNet(experiment_name="t", **_pipe_cfg(precision="f32x6", pin_batches=pin, loss_flush=3,
+                                                                 num_workers=workers))
+        pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+        dl = torch.utils.data.DataLoader(_CropDataset(14), batch_size=2, shuffle=False, num_workers=workers)
+
+        class Logger:
+            def __init__(self):
+                self.v = []
+
+            def add_scalar(self, tag, scalar_value, global_step):
+                if tag == "train/loss":
+                    self.v.append((int(global_step), float(scalar_value)))
+        lg = Logger()
+        pipe.train_model(dl, None, lg)
+        torch.cuda.synchronize()
+        logs[pin], params[pin] = lg.v, pipe.model.engine.flat_p.clone()
+    assert [s for s, _ in logs[True]] == [s for s, _ in logs[False]] == list(range(1, 8))
+    for (_, a), (_, b) in zip(logs[True], logs[False]):
+        assert abs(a - b) <= 2e-4 * abs(b), (logs[True], logs[False])     # (fp32 atomics order; 7 steps)
+    assert l2rel(params[True], params[False]) < 1e-5
+
+
 def test_validation_f1_matches_cpu_reference_path():
     """The 'F1 vs CPU ref' half of the metric (pipeline.py:242-341): get_predictions_dataloader +
     compute_evaluation_metrics through the GPU pipeline vs the same steps on the CPU oracle."""
@@ -786,6 +831,52 @@ def test_fp16_loss_scale_overflow_skips_the_step_and_adapts():
     p1 = eng.flat_p.clone()
     opt.step()
     assert torch.equal(eng.flat_p, p1) and eng.skipped_steps() == 2
+    # the scale has a floor: repeated overflows stop halving at 2^4 with a warning, the step stays guarded there (the
+    # guard is selected by the mode, not by the value of the scale), and clean intervals let it grow again
+    eng.loss_scale = 2.0 ** 5
+    eng._skipped_seen = eng.skipped_steps() - 1
+    assert eng.update_loss_scale() == 2.0 ** 4
+    eng._skipped_seen = eng.skipped_steps() - 1
+    with pytest.warns(RuntimeWarning, match="loss scale reached its floor"):
+        assert eng.update_loss_scale() == 2.0 ** 4
+    eng.loss_scale = 1.0                          # (even at 1 an fp16-storage mode runs the guarded step)
+    n_before = eng.skipped_steps()
+    eng.train_step(x, lab, cw, lr=0.0, momentum=0.0)
+    assert eng._scale_state is not None and eng.skipped_steps() >= n_before
+    eng.loss_scale = 2.0 ** 4
+    for _ in range(4):
+        eng.update_loss_scale()
+    assert eng.loss_scale == 2.0 ** 5
+
+
+def test_bn_finalize_folded_into_the_consumers_equals_the_separate_launches():
+    """CRIMAC_FOLD_BNFIN (the BatchNorm statistics finished inside bn_train_act_pool / bn_bwd_apply_replicas)
+    against the separate bn_finalize / sum_replicas launches: running statistics, num_batches_tracked and every gradient
+    of one training step agree -- on a net whose channel counts (192, 384) are not powers of two and use a reduced
+    replica count."""
+    x = torch.from_numpy(synth.synth_echogram_batch(3, 4, 32, 48, seed=61)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(3, 32, 48, seed=62)).cuda()
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    res = {}
+    for fold in (True, False):
+        m = pkg.UNet_Baseline(3, 4, depth=2, start_filts=192, precision="bf16")
+        m.load_state_dict(synth.synth_state_dict(depth=2, start_filts=192, seed=3))
+        m.cuda().train()
+        eng = m.engine
+        eng.fold_bn_finalize = fold
+        assert eng._nrep(192) == (16 if fold else 64)
+        loss = eng.train_step(x, lab, cw, lr=0.0, momentum=0.0)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        res[fold] = (float(loss), eng.flat_g.clone(), sd)
+    (l1, g1, s1), (l0, g0, s0) = res[True], res[False]
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    for k in s0:
+        if "num_batches" in k:
+            assert int(s1[k]) == int(s0[k]) == 1, k
+        else:
+            assert rel(s1[k], s0[k]) < 1e-6, k
+    assert l2rel(g1, g0) < 1e-4          # (same arithmetic; fp32 atomics of the weight gradients order differently)
 
 
 def test_wide_net_fp16_full_size_with_gpu_augment_properties():

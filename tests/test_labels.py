@@ -80,3 +80,103 @@ def test_refine_labels_kernel_matches_oracle(golden_dir):
     torch.cuda.synchronize()
     ref0 = np.stack([orc.refine_label_boundary(data[b, 3], labels[b]) for b in range(B)])
     assert np.array_equal(out.cpu().numpy(), ref0)
+
+
+# ---- test-time chain (validation / evaluate flows): define_label_transform_test --------------------------------------
+def _test_cases(golden_dir):
+    fix = np.load(os.path.join(golden_dir, "labels_test.npz"))
+    sv03, labels, seabed, mask = fix["sv03"], fix["labels"], fix["seabed"], fix["holey_mask"]
+    sv = np.zeros((4,) + sv03.shape[1:], dtype=np.float32)
+    sv[0], sv[3] = sv03[0], sv03[1]
+    from oracle import tiling_oracle as torc
+    for i, (flav, size, overlap, cy, cx) in enumerate(fix["cases"].tolist()):
+        lab = torc.crop(np.ascontiguousarray(labels.T), (cy, cx), (size, size), -100).astype(np.int64)
+        data = torc.crop(np.ascontiguousarray(sv.transpose(0, 2, 1)), (cy, cx), (size, size), 0).astype(np.float32)
+        yield i, ("zarr", "zarrmask", "memm")[flav], size, overlap, (cy, cx), data, lab, seabed, mask, fix[f"c{i}/final"]
+
+
+def test_oracle_matches_reference_test_label_transform(golden_dir):
+    """oracle/labels_oracle.test_label_transform == the reference's define_label_transform_test + remove_nan_inf on 63
+    crops: zarr reader (vector-expressible mask), zarr reader with a holey stored mask, memmap Echogram; three patch
+    sizes / overlaps; centres at the survey corners, across the seabed, below the water column."""
+    seen = set()
+    n_range = None
+    for i, flav, size, overlap, centre, data, lab, seabed, mask, final in _test_cases(golden_dir):
+        n_range = mask.shape[1]
+        got = orc.test_label_transform(data, lab, centre, 3, seabed, n_range, overlap,
+                                       "memm" if flav == "memm" else "zarr", mask if flav == "zarrmask" else None)
+        assert np.array_equal(got, final), f"case {i} ({flav}, {size}, {overlap}, {centre}): {np.argwhere(got != final)[:5]}"
+        seen |= set(np.unique(final).tolist())
+    assert seen == {-100, -70, -50, -30, -10, 0, 1, 2}
+
+
+@pytest.mark.gpu
+def test_labels_test_transform_kernel_matches_reference_golden(golden_dir):
+    """crimac_labels_test_transform (batched: every case of one size in ONE launch) is bit-exact against the reference."""
+    import torch
+    from crimac_classifiers_unet_amd.hip import call, ptr
+    cases = list(_test_cases(golden_dir))
+    mask = cases[0][8]
+    n_pings, n_range = mask.shape
+    for flav in ("zarr", "zarrmask", "memm"):
+        for size in (64, 96, 128):
+            grp = [c for c in cases if c[1] == flav and c[2] == size]
+            overlap = grp[0][3]
+            data = torch.from_numpy(np.stack([c[5] for c in grp])).cuda()
+            cen = torch.tensor([c[4] for c in grp], dtype=torch.int64).cuda()
+            sb = torch.from_numpy(grp[0][7].astype(np.int32)).cuda()
+            mk = torch.from_numpy(np.ascontiguousarray(mask)).cuda() if flav == "zarrmask" else None
+            for dt in (torch.int16, torch.int64):
+                lab = torch.from_numpy(np.stack([c[6] for c in grp])).to(dt).cuda()
+                out = torch.full((len(grp), size, size), 7, dtype=torch.int16, device="cuda")
+                call("crimac_labels_test_transform", ptr(lab), lab.element_size(), ptr(data), 3, 1e-7, 1e-4, ptr(cen),
+                     None if mk is not None else ptr(sb), 0, n_pings, ptr(mk), 0, n_pings if mk is not None else 0, n_range, 10,
+                     1 if flav == "memm" else 0, overlap, ptr(out), len(grp), 4, size, size)
+                torch.cuda.synchronize()
+                for k, c in enumerate(grp):
+                    assert np.array_equal(out[k].cpu().numpy(), c[9]), (flav, size, c[4], dt)
+
+
+@pytest.mark.gpu
+def test_validation_histograms_from_raw_crops_equal_the_host_transformed_batches(golden_dir):
+    """SegPipe.use_gpu_test_transform: a validation DataLoader that hands RAW crops (linear sv, raw annotation ids, centre
+    coordinates) gives the same PR histograms and loss as one that hands the REFERENCE-transformed labels (the golden
+    `final` arrays, i.e. define_label_transform_test + remove_nan_inf as the reference ran them) and dB data."""
+    import torch
+    import yaml
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    from oracle import tiling_oracle as torc
+    from tools.fake_reader import FakeZarrReader
+    fix = np.load(os.path.join(golden_dir, "labels_test.npz"))
+    sv = np.zeros((4,) + fix["sv03"].shape[1:], dtype=np.float32)
+    sv[0], sv[3] = fix["sv03"][0], fix["sv03"][1]
+    sv[1], sv[2] = sv[3] * 0.5, sv[0] * 2.0                     # (channels 1 / 2 are not in the fixture: any finite data)
+    sv[1][~np.isfinite(sv[1])] = 1e-5
+    sv[2][~np.isfinite(sv[2])] = 1e-5
+    reader = FakeZarrReader(sv, fix["labels"].astype(np.int64), fix["seabed"].astype(np.int64))
+    cases = [c for c in _test_cases(golden_dir) if c[1] == "zarr" and c[2] == 96]
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(save_model_params=False, data_mode="zarr")
+    pipe = pkg.SegPipeUNet(experiment_name="t", **cfg)
+    pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+    pipe.model.to(pipe.device)
+    crit = pipe.get_criterion()
+    raw, host = [], []
+    for k in range(0, len(cases) - 1, 2):
+        grp = cases[k:k + 2]
+        lin = np.stack([torc.crop(np.ascontiguousarray(sv.transpose(0, 2, 1)), c[4], (96, 96), 0).astype(np.float32) for c in grp])
+        cen = torch.tensor([c[4] for c in grp], dtype=torch.int64)
+        raw.append({"data": torch.from_numpy(lin), "labels": torch.from_numpy(np.stack([c[6] for c in grp]).astype(np.int16)),
+                    "center_coordinates": cen})
+        db = np.stack([torc.data_transform(x)[0] for x in lin])
+        host.append({"data": torch.from_numpy(db), "labels": torch.from_numpy(np.stack([c[9] for c in grp])),
+                     "center_coordinates": cen})
+    hp0, hn0, loss0 = pipe.get_pr_histograms_dataloader(host, criterion=crit)
+    pipe.use_gpu_test_transform(reader, patch_overlap=20)
+    hp1, hn1, loss1 = pipe.get_pr_histograms_dataloader(raw, criterion=crit)
+    assert hp0.sum() + hn0.sum() > 1000
+    assert np.array_equal(hp0, hp1) and np.array_equal(hn0, hn1)
+    assert abs(loss0 - loss1) <= 1e-6 * abs(loss0)
+    pipe.use_gpu_test_transform(None)
+    assert pipe._test_source is None
