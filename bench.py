@@ -586,7 +586,7 @@ def run_rank(args):
     parity = None
     if world == 1 and not args.no_parity_mode and args.precision != args.parity_precision and args.start_filts == 64:
         torch.cuda.empty_cache()
-        parity, pm = measure_mode(args, args.parity_precision, max(3, args.steps // 2), 2, world, rank, dev,
+        parity, pm = measure_mode(args, args.parity_precision, max(3, args.steps), max(2, args.warmup), world, rank, dev,
                                   grad_sync, infer=not args.no_infer, log=log)
         if not args.no_tiled:
             parity["tiled"] = measure_tiled(pm, args, log)       # configs[3] in the parity precision as well

@@ -2,9 +2,11 @@
 
 The reference moves every batch to the device inside the step (``batch['data'].float().to(device)``): the DataLoader
 hands PAGEABLE tensors, so that copy is synchronous -- 37.7 MB (32 x 4 x 256 x 256 fp32) in front of a 12 ms step.
-Here a host thread pulls the DataLoader one batch ahead and copies ``data`` (converted to float32 on the way, the
-reference's ``.float()``) and ``labels`` into a ring of PINNED buffers; the upload runs on a copy stream into a ring of
-device buffers, and the training stream waits for the upload's event only -- the H2D of step i + 1 runs under step i.
+Here a host thread pulls the DataLoader one batch ahead and copies ``data`` and ``labels`` -- in the dtype they arrive in,
+one plain memcpy each (numpy, GIL released; a torch CPU copy would start an OpenMP team per calling thread, one thread per
+VISIBLE core: 256 on a GPU box whose cgroup grants 16 -- measured 43 ms per batch) -- into a ring of PINNED buffers; the
+upload runs on a copy stream into a ring of device buffers, the reference's ``.float()`` happens on the device, and the
+training stream waits for the upload's event only -- the H2D of step i + 1 runs under step i.
 The same structure feeds the tiled-inference path (tiled_inference.predict_survey: reader thread -> pinned staging ->
 copy stream -> two resident chunk buffers).
 """
@@ -13,6 +15,7 @@ from __future__ import annotations
 import queue
 import threading
 
+import numpy as np
 import torch
 
 RING = 3          # slots: one being filled by the host thread, one uploading, one being consumed by the step
@@ -29,7 +32,7 @@ class _Slot:
 
 
 class BatchStager:
-    """Iterate ``dataloader`` yielding ``(index, data_dev float32 [B,C,H,W], labels_dev [B,H,W], batch)`` with the
+    """Iterate ``dataloader`` yielding ``(index, data_dev [B,C,H,W] float32, labels_dev [B,H,W], batch)`` with the
     tensors already (asynchronously) on ``device``; the caller's CURRENT stream is made to wait for the upload.
 
     The yielded device tensors belong to the ring: they stay valid until RING - 1 further batches have been yielded
@@ -51,9 +54,9 @@ class BatchStager:
 
     # -- host thread: DataLoader -> pinned ------------------------------------------------------------------------
     def _ensure(self, slot, data, labels):
-        if (slot.data_pin is None or slot.data_pin.shape != data.shape):
-            slot.data_pin = torch.empty(data.shape, dtype=torch.float32).pin_memory()
-            slot.data_dev = torch.empty(data.shape, dtype=torch.float32, device=self.device)
+        if (slot.data_pin is None or slot.data_pin.shape != data.shape or slot.data_pin.dtype != data.dtype):
+            slot.data_pin = torch.empty(data.shape, dtype=data.dtype).pin_memory()
+            slot.data_dev = torch.empty(data.shape, dtype=data.dtype, device=self.device)
         if labels is not None and (slot.lab_pin is None or slot.lab_pin.shape != labels.shape
                                    or slot.lab_pin.dtype != labels.dtype):
             slot.lab_pin = torch.empty(labels.shape, dtype=labels.dtype).pin_memory()
@@ -75,9 +78,9 @@ class BatchStager:
                 if slot.used:
                     slot.uploaded.synchronize()          # the previous upload out of this pinned slot has finished
                 self._ensure(slot, data, labels)
-                slot.data_pin.copy_(data)                 # (dtype conversion to float32 rides on the copy)
+                np.copyto(slot.data_pin.numpy(), data.contiguous().numpy())      # memcpy, GIL released
                 if labels is not None:
-                    slot.lab_pin.copy_(labels)
+                    np.copyto(slot.lab_pin.numpy(), labels.contiguous().numpy())
                 self._q.put((i, k, batch, labels is not None))
                 if self._stop:
                     return
@@ -116,7 +119,10 @@ class BatchStager:
                 slot.used = True
                 main.wait_event(slot.uploaded)
                 prev = k
-                yield i, slot.data_dev, (slot.lab_dev if has_lab else None), batch
+                x = slot.data_dev
+                if x.dtype != torch.float32:              # the reference's `.float()` (pipeline.py:163), on the device
+                    x = x.float()
+                yield i, x, (slot.lab_dev if has_lab else None), batch
         finally:
             self._stop = True
             try:                                          # unblock a producer waiting for a free slot

@@ -510,7 +510,8 @@ def test_training_trajectory_and_loss_scale_bookkeeping():
 
 
 @pytest.mark.parametrize("cfg", [dict(in_channels=11), dict(depth=3), dict(depth=4, in_channels=6, start_filts=128),
-                                 dict(batch=1, hw=(16, 48)), dict(batch=5, hw=(80, 32))])
+                                 dict(batch=1, hw=(16, 48)), dict(batch=5, hw=(80, 32)),
+                                 dict(depth=6, hw=(64, 96))])       # BASELINE configs[4] "deeper": 2048-channel bottleneck
 def test_other_architectures_and_ragged_shapes_match_oracle(cfg):
     """Away from the benchmark shape (metadata planes as input channels, shallower / wider nets, odd batches, the smallest
     legal crop, non-square crops): eval logits and one training step against the oracle."""

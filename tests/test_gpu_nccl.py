@@ -56,7 +56,10 @@ def _forced_worker(port, out):
     x = torch.from_numpy(synth.synth_echogram_batch(4, 4, 64, 64, seed=1)).cuda()
     lab = torch.from_numpy(synth.synth_labels(4, 64, 64, seed=2)).cuda()
     res = {}
-    for precision in ("bf16", "h3p"):              # (unscaled step / loss-scaled step: two branches of the engine)
+    # f32x6: the unscaled step (per-range optimiser step available); h3p: the loss-scaled step (one guarded update).
+    # Both are fp32-class precisions: two runs differ by the order of fp32 atomics only.  (bf16 would not do: its
+    # 16-bit storage amplifies that noise to O(10 %) of a gradient within one step)
+    for precision in ("f32x6", "h3p"):
         m0 = _make(precision)
         p0 = m0.engine
         p0.bind()
@@ -97,11 +100,11 @@ def test_single_rank_nccl_drives_every_multi_rank_branch_of_the_step():
     for key, (r1, r2, got_l, ref_l, upd) in res.items():
         print(f"{key}: update L2-rel after step 1 {r1:.2e}, after step 2 {r2:.2e}; losses {got_l} vs {ref_l}")
         assert upd > 0
-        # step 1 starts from identical parameters: only the order of the fp32 atomics of the weight gradients differs
-        assert r1 < 1e-4, (key, r1)
-        # step 2 runs on re-packed operands (per-range re-pack included); 16-bit storage amplifies step-1 noise
-        assert r2 < 5e-2, (key, r2)
-        assert abs(got_l[0] - ref_l[0]) <= 1e-6 * abs(ref_l[0]) and abs(got_l[1] - ref_l[1]) < 2e-3 * abs(ref_l[1])
+        # step 1 starts from identical parameters: only the order of the fp32 atomics (statistics, weight gradients) differs
+        assert r1 < 2e-3, (key, r1)
+        # step 2 runs on re-packed operands (per-range re-pack included)
+        assert r2 < 2e-2, (key, r2)
+        assert abs(got_l[0] - ref_l[0]) <= 1e-5 * abs(ref_l[0]) and abs(got_l[1] - ref_l[1]) < 1e-3 * abs(ref_l[1])
 
 
 def _two_rank_worker(rank, world, port, x, lab, algo, per_range, out):

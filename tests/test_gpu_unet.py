@@ -1131,7 +1131,8 @@ def test_f32h3_eval_is_fp32_class_and_train_step_matches_golden(full_case):
 
 
 @pytest.mark.parametrize("cfg", [dict(in_channels=11), dict(depth=3), dict(depth=4, in_channels=6, start_filts=128),
-                                 dict(batch=1, hw=(16, 48)), dict(batch=5, hw=(80, 32))])
+                                 dict(batch=1, hw=(16, 48)), dict(batch=5, hw=(80, 32)),
+                                 dict(depth=6, hw=(64, 96))])       # BASELINE configs[4] "deeper": 2048-channel bottleneck
 def test_other_architectures_and_ragged_shapes_match_oracle(cfg):
     """Parity away from the benchmark shape: metadata planes as extra INPUT channels (pipeline.py:392: 4 + 7 = 11),
     shallower nets, odd batch sizes, the smallest legal crop (16 px for depth 5) and non-square crops -- eval logits

@@ -175,8 +175,16 @@ def test_validation_histograms_from_raw_crops_equal_the_host_transformed_batches
     hp0, hn0, loss0 = pipe.get_pr_histograms_dataloader(host, criterion=crit)
     pipe.use_gpu_test_transform(reader, patch_overlap=20)
     hp1, hn1, loss1 = pipe.get_pr_histograms_dataloader(raw, criterion=crit)
+    # labels decide which pixels are counted and on which side: those totals are exact.  The probabilities behind the
+    # bins come from two dB transforms (numpy log10 on the host, the GPU's in the raw flow) that may differ in the last
+    # bit, so a few pixels may land in a neighbouring float16 bin
     assert hp0.sum() + hn0.sum() > 1000
-    assert np.array_equal(hp0, hp1) and np.array_equal(hn0, hn1)
-    assert abs(loss0 - loss1) <= 1e-6 * abs(loss0)
+    assert hp0.sum() == hp1.sum() and hn0.sum() == hn1.sum()
+    moved = np.abs(np.cumsum(hp0) - np.cumsum(hp1)).sum() + np.abs(np.cumsum(hn0) - np.cumsum(hn1)).sum()
+    assert moved <= 0.01 * (hp0.sum() + hn0.sum()), moved
+    f0 = pipe.compute_evaluation_metrics_from_histograms(hp0, hn0)["F1"].max()
+    f1 = pipe.compute_evaluation_metrics_from_histograms(hp1, hn1)["F1"].max()
+    assert abs(f0 - f1) <= 1e-3 * max(f0, 1e-6)
+    assert abs(loss0 - loss1) <= 1e-5 * abs(loss0)
     pipe.use_gpu_test_transform(None)
     assert pipe._test_source is None
