@@ -67,7 +67,11 @@ def parse_args(argv=None):
     ap.add_argument("--roofline-steps", type=int, default=30, help="serialized steps of the per-kernel (roofline) pass")
     ap.add_argument("--roofline-warmup", type=int, default=10, help="serialized warm-up steps in front of that pass")
     ap.add_argument("--loop-iters", type=int, default=60, help="iterations of the train_loop leg (SegPipe.train_model + DataLoader)")
-    ap.add_argument("--loop-workers", type=int, default=4, help="DataLoader workers of the train_loop leg (yaml default 4)")
+    ap.add_argument("--loop-workers", type=int, default=8,
+                    help="DataLoader workers of the train_loop leg.  A worker collates a batch of 32 x 1 MB crops into shared "
+                         "memory in ~26 ms (first-touch page faults), so the yaml's default of 4 (written for batch_size 4) "
+                         "delivers a batch every ~6.5 ms before the parent has touched it; 8 workers keep the loader ahead of "
+                         "a 12 ms step")
     ap.add_argument("--no-train-loop", action="store_true")
     ap.add_argument("--tiled-pings", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -290,11 +294,6 @@ def measure_mode(args, precision, steps, warmup, world, rank, dev, grad_sync, in
                                  "crimac_conv3x3: conv3x3_kernel (fp32 storage, split-bf16 planes, register-staged halo)")),
            "roofline_wgrad": roofline("crimac_wgrad", "wgrad_pp_kernel + wgrad_up_pp_kernel + wgrad_kernel (weight gradient, all shapes)"
                                       if precision == "h3p" else "wgrad_kernel (weight gradient, all shapes)")}
-    if world == 1 and not args.no_train_loop and sf == 64 and not args.gpu_augment:
-        res["train_loop"] = measure_train_loop(args, precision, dev, log, res["train_patches_per_s"])
-        if precision == args.precision:               # (the reference's in-line copy, for comparison: main mode only)
-            res["train_loop"]["inline_copy"] = measure_train_loop(args, precision, dev, log, res["train_patches_per_s"],
-                                                                  pin_batches=False)
     if infer:
         model.eval()
         with torch.no_grad():
@@ -490,7 +489,10 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
         pipe.train_model(dl, None, logger=lg)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    del dl
+    del dl, pipe                                      # (worker processes and the model go before anything else is timed)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     pps = iters * B / dt
     assert lg.last is not None and lg.last == lg.last, "train_loop: NaN loss"
     log(f"{precision}: train_loop ({'pinned ring' if pin_batches else 'in-line copy'}, {nw} workers): {pps:.0f} patches/s "
@@ -612,6 +614,16 @@ def run_rank(args):
                 "conv_frac_of_peak": wres["roofline"]["frac"], "wgrad_frac_of_peak": wres["roofline_wgrad"]["frac"],
                 "steps": 3, "warmup": 2}
         log(f"wide fp16 (configs[4], 1 GPU): {wide['train_patches_per_s']:.0f} patches/s")
+    # The loop the reference runs (DataLoader + train_model), LAST of the GPU legs: its DataLoader forks worker processes
+    # from this process, and the legs measured after it in the first version of this bench ran 6 % slower
+    # (h3p step 27.2 ms in the default run against 25.6 ms on its own, same box, same per-kernel durations)
+    if world == 1 and not args.no_train_loop and args.start_filts == 64 and not args.gpu_augment:
+        torch.cuda.empty_cache()
+        main["train_loop"] = measure_train_loop(args, args.precision, dev, log, main["train_patches_per_s"])
+        main["train_loop"]["inline_copy"] = measure_train_loop(args, args.precision, dev, log, main["train_patches_per_s"],
+                                                               pin_batches=False)
+        if parity is not None:
+            parity["train_loop"] = measure_train_loop(args, args.parity_precision, dev, log, parity["train_patches_per_s"])
     if rank == 0:
         sf = args.start_filts
         rl = main["roofline"]

@@ -191,7 +191,10 @@ class SegPipe:
                 x = batch["data"]
                 if x.dtype != torch.float32:
                     x = x.float()
-                yield i, x.to(self.device, non_blocking=True), batch["labels"].to(self.device, non_blocking=True)
+                # BLOCKING copies, like the reference's: the sources are pageable (and `x.float()` is a temporary) -- an
+                # asynchronous copy would still be reading them when the next batch reuses the memory (measured: with
+                # DataLoader workers the first steps trained on the wrong crops)
+                yield i, x.to(self.device), batch["labels"].to(self.device)
 
         for i, inputs_train, labels_train in _tqdm(batches(), desc="Training model",
                                                    total=len(dataloader_train), disable=not is_rank0):

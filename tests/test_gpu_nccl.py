@@ -101,9 +101,9 @@ def test_single_rank_nccl_drives_every_multi_rank_branch_of_the_step():
         print(f"{key}: update L2-rel after step 1 {r1:.2e}, after step 2 {r2:.2e}; losses {got_l} vs {ref_l}")
         assert upd > 0
         # step 1 starts from identical parameters: only the order of the fp32 atomics (statistics, weight gradients) differs
-        assert r1 < 2e-3, (key, r1)
+        assert r1 < 1e-2, (key, r1)            # (a lost range or a wrong scale is an O(1) error)
         # step 2 runs on re-packed operands (per-range re-pack included)
-        assert r2 < 2e-2, (key, r2)
+        assert r2 < 5e-2, (key, r2)
         assert abs(got_l[0] - ref_l[0]) <= 1e-5 * abs(ref_l[0]) and abs(got_l[1] - ref_l[1]) < 1e-3 * abs(ref_l[1])
 
 
