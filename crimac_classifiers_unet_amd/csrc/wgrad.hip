@@ -1149,6 +1149,441 @@ void wgrad_kernel(WgradParams p) {
   }
 }
 
+// ---- grouped launch: ONE persistent kernel for the conv3x3 weight gradients of several layers ---------------------------
+// Every launch of wgrad_kernel ends with all 256 workgroups flushing their 147 KB of accumulators by fp32 atomics AT THE
+// SAME TIME: 37.5 MB at the memory-side atomic rate (~1.2 TB/s whoever shares an address) = ~30 us in which no MFMA
+// runs, 22 times per step (skipping the flush in an ablation build took 0.44 ms off the 12.0 ms bf16 step).  Here the work
+// of several layers -- items (layer, 64 x 64 channel tile, pixel split) -- goes through per-XCD queues that persistent
+// workgroups (one of two teams per CU, as in wgrad_kernel<.., TEAMS = 2>) pull from: a workgroup that has finished an
+// item issues its atomics and goes on to the next item, whose tiles team 1 is already contracting, so the flushes of the
+// 256 workgroups drift apart and drain under the other workgroups' MFMAs; only the last items' flushes are a tail.
+// Since the queue balances the load, a layer no longer needs exactly one resident round of splits: the plan uses
+// ~half as many (half the atomic volume per step).  16-bit storage, conv3x3, Cin >= 64 only (the first layer and the
+// transposed convolutions keep their own launches).
+constexpr int kGroupMaxLayers = CRIMAC_WGRAD_GROUP_MAX_LAYERS;
+using GroupLayer = crimac_wgrad_group_layer;       // (include/crimac_unet_hip.h)
+struct GroupParams {
+  GroupLayer layer[kGroupMaxLayers];
+  int B;
+  const int* items;          // [8][cap][2]: (layer, channel-tile pair * 65536 + split) in the order of XCD x's queue
+  int cap;
+  int count[8];
+  unsigned* counter;         // [8], zeroed by the caller before the launch
+};
+
+// barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the ACKNOWLEDGEMENT of the
+// atomics a team-0 wave has just issued -- the very wait this kernel exists to avoid
+__device__ __forceinline__ void group_barrier_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// a queue word, read as LDS (through a generic pointer a volatile read is a FLAT load: it counts in vmcnt, and the wait the
+// compiler puts behind it is a wait for every vector-memory operation outstanding -- the flush included)
+__device__ __forceinline__ unsigned lds_word(const unsigned* p) {
+  return *(volatile LDS_PTR(unsigned))(LDS_PTR(unsigned))(p);
+}
+
+template <typename TA>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wgrad_group_kernel(GroupParams gp) {
+  constexpr int MODE = 0, TR = 8, NTAPS = 9;
+  constexpr int F_ROWS = TR * 16;
+  constexpr int S_ROWS = (TR + 2) * 18;
+  constexpr int S_ROWS_PAD = (S_ROWS + 7) / 8 * 8;
+  constexpr int F_BYTES = F_ROWS * 128;
+  constexpr int S_BYTES = S_ROWS_PAD * 128;
+  constexpr int BUF_BYTES = F_BYTES + S_BYTES;
+  constexpr int NF = F_ROWS / 8 / 4;
+  constexpr int NS = (S_ROWS_PAD / 8 + 3) / 4;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int ws = wave & 1, tg = wave >> 1;
+  const int g = lane >> 4, li = lane & 15;
+  const int q = li >> 2, pp = li & 3;
+  const int sub = lane >> 3, c = lane & 7;
+  const int xcd = blockIdx.x & 7;
+  // queue words behind the four tile buffers: tq[0..1] team barrier counters, tq[2] next tile of the item, tq[4..7] the
+  // tile each team takes next (one iteration ahead), tq[8 + 4 * parity ..]: this workgroup's current / next ITEM:
+  // (index in the XCD's queue, layer, channel-tile pair * 65536 + split).
+  // The item is fetched by ONE lane of team 1 -- a team-0 wave has its flush outstanding, and any vector-memory load it
+  // issued would return behind those atomics (in-order retirement): the whole workgroup would sit through the flush.
+  unsigned* tq = reinterpret_cast<unsigned*>(smem + 4 * BUF_BYTES);
+  const int n_items = gp.count[xcd];
+  auto fetch_item = [&](int par) {
+    const unsigned k = __hip_atomic_fetch_add(gp.counter + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned a = 0, b = 0;
+    if (k < (unsigned)n_items) {
+      const int* it = gp.items + 2 * ((long)xcd * gp.cap + k);
+      a = (unsigned)it[0];
+      b = (unsigned)it[1];
+    }
+    tq[8 + 4 * par] = k;
+    tq[9 + 4 * par] = a;
+    tq[10 + 4 * par] = b;
+  };
+  if (tid == 256) fetch_item(0);
+  __syncthreads();
+  int ipar = 0;
+
+  auto run = [&](auto tgc) {
+    constexpr int TG = decltype(tgc)::value;
+    using G = WgTaps<MODE, TG>;
+    f32x4 acc2[G::N][4][2];
+    const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
+    const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
+    const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem)) + team * 2 * BUF_BYTES;
+    const int tt = tid & 255;
+    unsigned* tcnt = tq + team;
+    for (;;) {
+      const int k = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 8 + 4 * ipar));
+      if (k >= n_items) break;
+      const int li_ = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 9 + 4 * ipar));
+      const int qs = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 10 + 4 * ipar));
+      const GroupLayer& p = gp.layer[li_];
+      const int qt = qs >> 16, split = qs & 0xFFFF;
+      const int cs_tiles = (p.CS + 63) / 64;
+      const int cf0 = (qt / cs_tiles) * 64, cs0 = (qt % cs_tiles) * 64;
+      const TA* fp = reinterpret_cast<const TA*>(p.f);
+      const TA* sp = reinterpret_cast<const TA*>(p.s);
+      const int Hs = p.Hf, Ws = p.Wf;
+#pragma unroll
+      for (int t = 0; t < G::N; ++t)
+#pragma unroll
+        for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[t][fh][sh][r] = 0.f;
+      // per-lane DMA offsets relative to the tile origin (as in wgrad_kernel)
+      unsigned f_rel[NF], s_rel[NS];
+      auto f_geo = [&](int i, int& ry, int& rx) {
+        const int row = 8 * (wave + 4 * i) + sub;
+        ry = row >> 4;
+        rx = row & 15;
+      };
+      auto s_geo = [&](int i, int& ry, int& rx) {
+        const int row = 8 * (wave + 4 * i) + sub;
+        ry = (row * 3641) >> 16;
+        rx = row - ry * 18;
+      };
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int row = 8 * (wave + 4 * i) + sub;
+        const int u = c ^ (swz16(row) >> 4);
+        int ry, rx;
+        f_geo(i, ry, rx);
+        f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * 2) : OOB;
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int kk = wave + 4 * i;
+        const int row = 8 * kk + sub;
+        const int u = c ^ (swz16(row) >> 4);
+        int ry, rx;
+        s_geo(i, ry, rx);
+        const bool ok = kk < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
+        s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * 2) : OOB;
+      }
+      auto issue_tile = [&](long tile, int buf) {
+        const int txi = (int)(tile % p.tiles_x);
+        const long ttl = tile / p.tiles_x;
+        const int tyi = (int)(ttl % p.tiles_y);
+        const long b = ttl / p.tiles_y;
+        const int y0 = tyi * TR, x0 = txi * 16;
+        unsigned char* base = smem + (team * 2 + buf) * BUF_BYTES;
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<TA*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          int ry, rx;
+          f_geo(i, ry, rx);
+          const bool ok = (y0 + ry) < p.Hf && (x0 + rx) < p.Wf;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + (wave + 4 * i) * 1024),
+                                                   16, (int)(ok ? f_rel[i] : OOB), 0, 0, 0);
+        }
+        unsigned char* sbase = base + F_BYTES;
+        const int sy0 = y0 - 1, sx0 = x0 - 1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<TA*>(sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int kk = wave + 4 * i;
+          if (kk >= S_ROWS_PAD / 8) continue;          // wave-uniform
+          int ry, rx;
+          s_geo(i, ry, rx);
+          const unsigned y = (unsigned)(sy0 + ry), x = (unsigned)(sx0 + rx);
+          const bool ok = y < (unsigned)Hs && x < (unsigned)Ws;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sbase + kk * 1024), 16,
+                                                   (int)(ok ? s_rel[i] : OOB), 0, 0, 0);
+        }
+      };
+      auto contract_tile = [&](int cur) {
+        const unsigned aF = lds0 + cur * BUF_BYTES, aS = aF + F_BYTES;
+        const unsigned fv0 = aF + RF * 128 + 8 * pp + swz16(RF);
+        unsigned sv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) sv[kk] = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(kk + RSl));
+        WgFrags f;
+        wg_rd_a<0, 0>(fv0, f);
+        wg_rd_a<0, 1>(fv0, f);
+        wg_rd_a<0, 2>(fv0, f);
+        wg_rd_a<0, 3>(fv0, f);
+        wg_rd_b<MODE, TG, 0, false>(sv, f);
+        wg_step<typename PlaneOf<TA>::type, MODE, TG, 0, false>(fv0, sv, f, acc2);
+      };
+      const long t_begin = (long)split * p.tiles_per_block;
+      const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
+      // ---- the two-team tile loop of wgrad_kernel<.., TEAMS = 2> on this item's pixel range --------------------------
+      if (tid < 3) tq[tid] = tid == 2 ? 2u : 0u;
+      group_barrier_lds();
+      unsigned ttarget = 0;
+      long cur_tile = t_begin + team;
+      bool have = cur_tile < t_end;
+      if (have) issue_tile(cur_tile, 0);
+      if (tt == 0) tq[4 + 2 * team] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // the NEXT item is requested now (two dependent round trips to L2, hidden behind this item's first tile)
+      if (tid == 256) fetch_item(ipar ^ 1);
+      int cur = 0, par = 0;
+      while (have) {
+        // this wave's share of the tile has landed -- for a team-0 wave this is also where the atomics of the PREVIOUS
+        // item are acknowledged (vector-memory operations retire in issue order); team 1 contracts tiles meanwhile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ttarget += 4;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(tcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ttarget) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const long nxt = t_begin + __builtin_amdgcn_readfirstlane((int)lds_word(tq + 4 + 2 * team + par));
+        par ^= 1;
+        if (tt == 0) tq[4 + 2 * team + par] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool has_next = nxt < t_end;
+        if (has_next) issue_tile(nxt, cur ^ 1);
+        contract_tile(cur);
+        cur ^= 1;
+        cur_tile = nxt;
+        have = has_next;
+      }
+      // team 1's accumulators -> LDS (the tile buffers are dead once every wave has left its loop) -> added to team 0's
+      constexpr int N0 = WgTaps<MODE, 0>::N, N1 = WgTaps<MODE, 1>::N;
+      static_assert((2 * N0 + 2 * N1) * 8192 <= 4 * BUF_BYTES, "accumulator exchange area");
+      unsigned char* xa = smem + (TG == 0 ? ws * N0 : 2 * N0 + ws * N1) * 8192 + lane * 16;
+      group_barrier_lds();
+      if (team == 1) {
+#pragma unroll
+        for (int t = 0; t < G::N; ++t)
+#pragma unroll
+          for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) *reinterpret_cast<f32x4*>(xa + ((t * 4 + fh) * 2 + sh) * 1024) = acc2[t][fh][sh];
+      }
+      group_barrier_lds();
+      if (team == 0) {
+#pragma unroll
+        for (int t = 0; t < G::N; ++t)
+#pragma unroll
+          for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(xa + ((t * 4 + fh) * 2 + sh) * 1024);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc2[t][fh][sh][r] += o[r];
+            }
+      }
+      // the exchange area has been read: the tile buffers (and the queue words) belong to the next item from here on
+      group_barrier_lds();
+      ipar ^= 1;
+      if (team == 0) {
+        // dw[t][cf][cs] += acc, fire and forget: nothing below waits for these (the next tile wait of THIS wave does,
+        // in issue order; team 1 keeps the SIMDs busy until then)
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          const int col = cs0 + ws * 32 + sh * 16 + (lane & 15);
+          if (col < p.CS) {
+#pragma unroll
+            for (int t = 0; t < G::N; ++t)
+#pragma unroll
+              for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int row = cf0 + fh * 16 + (lane >> 4) * 4 + r;
+                  if (row < p.CF) atomicAdd(p.dw + ((long)(G::T0 + t) * p.CF + row) * p.CS + col, acc2[t][fh][sh][r]);
+                }
+          }
+        }
+      }
+    }
+  };
+  if (tg == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
+// The same for plane pairs (CRIMAC_PREC_H3P): wgrad_pp_kernel<false>'s tile loop -- one team of 8 waves, waves 4-7 move
+// the tiles -- inside the item loop.  All 8 waves flush, so the workgroup does sit through ITS OWN flush (the first tile
+// barrier of the next item waits for vmcnt(0)); but that is 147 KB against a memory side that the other 255 workgroups
+// are not hitting at the same moment, and the next item's first tile is requested before the flush is issued.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void wgrad_pp_group_kernel(GroupParams gp) {
+  constexpr int TR = 8;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NDMA = 2 * 16 + 2 * 23;
+  constexpr int DW = 4;
+  constexpr int NI = (NDMA + DW - 1) / DW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ws = wave & 1, sa = (wave >> 1) & 1, tg = wave >> 2;
+  const int sub = lane >> 3, c = lane & 7;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int xcd = blockIdx.x & 7;
+  unsigned* tq = reinterpret_cast<unsigned*>(smem + 2 * PP_BUF);      // tq[8 + 4 * parity ..]: (item index, layer, tile pair / split)
+  const int n_items = gp.count[xcd];
+  auto fetch_item = [&](int par) {
+    const unsigned k = __hip_atomic_fetch_add(gp.counter + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned a = 0, b = 0;
+    if (k < (unsigned)n_items) {
+      const int* it = gp.items + 2 * ((long)xcd * gp.cap + k);
+      a = (unsigned)it[0];
+      b = (unsigned)it[1];
+    }
+    tq[8 + 4 * par] = k;
+    tq[9 + 4 * par] = a;
+    tq[10 + 4 * par] = b;
+  };
+  if (tid == 256) fetch_item(0);
+  __syncthreads();
+  int ipar = 0;
+  const bool mover = wave >= 4;
+
+  auto run = [&](auto tgc) {
+    constexpr int TG = decltype(tgc)::value;
+    using G = WgTaps<0, TG>;
+    f32x4 acc[G::N][4];
+    const int RF = (g >> 1) * 16 + 4 * (g & 1) + q;
+    const int RSl = (g >> 1) * G::RS + 4 * (g & 1) + q;
+    const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem));
+    bool have_prev = false;
+    float* prev_dw = nullptr;
+    int prev_CF = 0, prev_CS = 0, prev_cf0 = 0, prev_cs0 = 0;
+    for (;;) {
+      const int k = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 8 + 4 * ipar));
+      const bool valid = k < n_items;
+      const int li_ = valid ? __builtin_amdgcn_readfirstlane((int)lds_word(tq + 9 + 4 * ipar)) : 0;
+      const int qs = valid ? __builtin_amdgcn_readfirstlane((int)lds_word(tq + 10 + 4 * ipar)) : 0;
+      const GroupLayer& p = gp.layer[li_];
+      const int qt = qs >> 16, split = qs & 0xFFFF;
+      const int cs_tiles = p.CS / 64;
+      const int cf0 = (qt / cs_tiles) * 64, cs0 = (qt % cs_tiles) * 64;
+      const hp_t* fp = reinterpret_cast<const hp_t*>(p.f);
+      const hp_t* sp = reinterpret_cast<const hp_t*>(p.s);
+      unsigned rel[NI];
+      int lds_at[NI];
+      auto geo = [&](int kk_, bool& is_s, int& img, int& row) {
+        is_s = kk_ >= 32;
+        const int kk = is_s ? kk_ - 32 : kk_;
+        img = is_s ? (kk >= 23 ? 1 : 0) : (kk >> 4);
+        row = 8 * (is_s ? kk - 23 * img : (kk & 15)) + sub;
+      };
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int kk = (wave & (DW - 1)) + DW * i;
+        bool is_s; int img, row;
+        geo(kk, is_s, img, row);
+        const int u = c ^ (swz16(row) >> 4);
+        const int su = (((u >> 2) * 2 + (u & 1)) << 1) | ((u >> 1) & 1);
+        lds_at[i] = kk < NDMA ? (is_s ? 2 * PP_F_IMG + img * PP_S_IMG + (row - sub) * 128 : img * PP_F_IMG + (row - sub) * 128) : -1;
+        if (!is_s) {
+          const int ry = row >> 4, rx = row & 15;
+          rel[i] = (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + 32 * img) * 4 + su * 16);
+        } else {
+          const int ry = (row * 3641) >> 16, rx = row - ry * 18;
+          rel[i] = row < 180 ? (unsigned)(((ry * (long)p.Wf + rx) * p.s_ld + cs0 + 32 * img) * 4 + su * 16) : OOB;
+        }
+      }
+      auto issue_tile = [&](long tile, int buf) {
+        const int txi = (int)(tile % p.tiles_x);
+        const long ttl = tile / p.tiles_x;
+        const int tyi = (int)(ttl % p.tiles_y);
+        const long b = ttl / p.tiles_y;
+        const int y0 = tyi * TR, x0 = txi * 16;
+        unsigned char* base = smem + buf * PP_BUF;
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<hp_t*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<hp_t*>(sp + ((b * p.Hf + y0 - 1) * (long)p.Wf + x0 - 1) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int kk = (wave & (DW - 1)) + DW * i;
+          if (kk >= NDMA) continue;                       // wave-uniform
+          bool is_s; int img, row;
+          geo(kk, is_s, img, row);
+          if (!is_s) {
+            const bool ok = (y0 + (row >> 4)) < p.Hf && (x0 + (row & 15)) < p.Wf;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rf, (__attribute__((address_space(3))) void*)(base + lds_at[i]), 16,
+                                                     (int)(ok ? rel[i] : OOB), 0, 0, 0);
+          } else {
+            const int ry = (row * 3641) >> 16, rx = row - ry * 18;
+            const unsigned y = (unsigned)(y0 - 1 + ry), x = (unsigned)(x0 - 1 + rx);
+            const bool ok = y < (unsigned)p.Hf && x < (unsigned)p.Wf;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(base + lds_at[i]), 16,
+                                                     (int)(ok ? rel[i] : OOB), 0, 0, 0);
+          }
+        }
+      };
+      const long t_begin = (long)split * p.tiles_per_block;
+      const long t_end = t_begin + p.tiles_per_block < p.ntiles ? t_begin + p.tiles_per_block : p.ntiles;
+      // the next item's first tile is on its way before the finished item's flush is issued
+      if (valid && mover && t_begin < t_end) issue_tile(t_begin, 0);
+      if (have_prev) {
+        // dw[t][cf][cs] += acc of the item just finished: F rows cf0 + 16 fr .. +15, S columns cs0 + 32 sa + 16 ws .. +15
+        const int col = prev_cs0 + sa * 32 + ws * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < G::N; ++t)
+#pragma unroll
+          for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = prev_cf0 + fr * 16 + (lane >> 4) * 4 + r;
+              atomicAdd(prev_dw + ((long)(G::T0 + t) * prev_CF + row) * prev_CS + col, acc[t][fr][r]);
+            }
+      }
+      if (!valid) break;
+#pragma unroll
+      for (int t = 0; t < G::N; ++t)
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][fr][r] = 0.f;
+      if (tid == 256) fetch_item(ipar ^ 1);          // (a moving wave: its wait is the first tile barrier's anyway)
+      for (long tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (int)((tile - t_begin) & 1);
+        __syncthreads();           // vmcnt(0) + barrier: the tile has landed for everyone, the other buffer is free
+        if (tile + 1 < t_end && mover) issue_tile(tile + 1, cur ^ 1);
+        const unsigned aF = lds0 + cur * PP_BUF, aS = aF + 2 * PP_F_IMG + sa * PP_S_IMG;
+        const unsigned fv0 = aF + (RF * 128 + 8 * pp + swz16(RF));
+        unsigned sv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) sv[kk] = aS + RSl * 128 + 8 * pp + ((ws * 64) ^ swz16(kk + RSl));
+        PpFrags f;
+        pp_rd_a<0, 0>(fv0, f); pp_rd_a<0, 1>(fv0, f); pp_rd_a<0, 2>(fv0, f); pp_rd_a<0, 3>(fv0, f);
+        pp_rd_a<0, 4>(fv0, f); pp_rd_a<0, 5>(fv0, f); pp_rd_a<0, 6>(fv0, f); pp_rd_a<0, 7>(fv0, f);
+        wg_rd_b<0, TG, 0, false>(sv, f);
+        pp_step<TG, 0, 8>(fv0, sv, f, acc);
+      }
+      group_barrier_lds();         // every wave has read the item's last tile: both buffers belong to the next item
+      prev_dw = p.dw; prev_CF = p.CF; prev_CS = p.CS; prev_cf0 = cf0; prev_cs0 = cs0;
+      have_prev = true;
+      ipar ^= 1;
+    }
+  };
+  if (tg == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
 // Pixel-range split of a shape: fills tiles_y/x, ntiles, tiles_per_block, nsplits (same for every precision).
 // teams: 2 for the 8-wave kernel (one workgroup per CU), 1 for the 4-wave kernel (two per CU).
 void plan_splits(WgradParams& p, int mode, int target_blocks, int teams) {
@@ -1296,6 +1731,137 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
 }
 
 }  // namespace
+
+// ---- grouped launch: plan (host) and launch ------------------------------------------------------------------------------
+static int group_check(int prec, const crimac_wgrad_group_layer* L, int n, int B) {
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16 || prec == CRIMAC_PREC_H3P,
+                 "wgrad_group: 16-bit storage precisions and plane pairs only (prec=%d)", prec);
+  const bool hp = prec == CRIMAC_PREC_H3P;
+  CRIMAC_REQUIRE(L && n >= 1 && n <= CRIMAC_WGRAD_GROUP_MAX_LAYERS && B > 0, "wgrad_group: 1..%d layers", CRIMAC_WGRAD_GROUP_MAX_LAYERS);
+  for (int i = 0; i < n; ++i) {
+    CRIMAC_REQUIRE(L[i].CF > 0 && L[i].CF % 8 == 0 && L[i].CS >= 64 && L[i].CS % 8 == 0, "wgrad_group: layer %d: CF=%d CS=%d "
+                   "(CS >= 64: the first layer keeps its own launch)", i, L[i].CF, L[i].CS);
+    CRIMAC_REQUIRE(L[i].f_ld >= L[i].CF && L[i].s_ld >= L[i].CS && L[i].f_ld % 8 == 0 && L[i].s_ld % 8 == 0 && L[i].Hf > 0 && L[i].Wf > 0,
+                   "wgrad_group: layer %d: bad strides / sizes", i);
+    CRIMAC_REQUIRE((10L * L[i].Wf + 18) * (L[i].f_ld > L[i].s_ld ? L[i].f_ld : L[i].s_ld) * (hp ? 4 : 2) < (1L << 31),
+                   "wgrad_group: layer %d: a tile's DMA offsets exceed 32 bits", i);
+    CRIMAC_REQUIRE(!hp || (L[i].CF % 64 == 0 && L[i].CS % 64 == 0), "wgrad_group: layer %d: plane pairs need whole 64-channel "
+                   "tiles (CF=%d CS=%d)", i, L[i].CF, L[i].CS);
+  }
+  return CRIMAC_OK;
+}
+
+extern "C" int crimac_wgrad_group_layer_size(void) { return (int)sizeof(crimac_wgrad_group_layer); }
+
+extern "C" int crimac_wgrad_group_plan(int prec, crimac_wgrad_group_layer* layers, int n_layers, int B, int items_per_layer,
+                                       int* items, int cap, int* counts) {
+  if (int rc = group_check(prec, layers, n_layers, B)) return rc;
+  CRIMAC_REQUIRE(counts, "wgrad_group_plan: counts is NULL");
+  static const int env_items = getenv("CRIMAC_WGRAD_GROUP_ITEMS") ? atoi(getenv("CRIMAC_WGRAD_GROUP_ITEMS")) : 0;
+  // 128 items per layer: half the splits (and half the atomic volume) of one launch per layer, whose 256 splits were
+  // there to fill the chip; measured equal to 256 within noise (bf16 step 11.73 vs 11.78 ms), 384 slower (11.91)
+  const int target = items_per_layer > 0 ? items_per_layer : (env_items > 0 ? env_items : 128);
+  int order[CRIMAC_WGRAD_GROUP_MAX_LAYERS];
+  for (int i = 0; i < n_layers; ++i) {
+    crimac_wgrad_group_layer& l = layers[i];
+    l.tiles_y = cdiv(l.Hf, 8);
+    l.tiles_x = cdiv(l.Wf, 16);
+    l.ntiles = (long)B * l.tiles_y * l.tiles_x;
+    const int ch_tiles = cdiv(l.CF, 64) * cdiv(l.CS, 64);
+    long splits = target / ch_tiles;
+    // every split costs one atomic pass over its 64 x 64 x 9 tile: keep ~4096 contraction pixels per split unless that
+    // leaves the layer with too few items to spread over the chip
+    const long pix = (long)B * l.Hf * l.Wf;
+    long max_splits = pix / 4096 > 1 ? pix / 4096 : 1;
+    while (max_splits * ch_tiles < target / 2 && max_splits * 2 <= pix / 1024) max_splits *= 2;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > l.ntiles) splits = l.ntiles;
+    if (splits >= 8) splits = splits / 8 * 8;               // whole rounds of the 8 XCDs
+    l.tiles_per_block = cdiv(l.ntiles, splits);
+    l.nsplits = cdiv(l.ntiles, l.tiles_per_block);
+    CRIMAC_REQUIRE(ch_tiles < 65536 && l.nsplits < 65536, "wgrad_group_plan: layer %d does not fit the item encoding", i);
+    order[i] = i;
+  }
+  // longest items first (a queue of unequal items balances best that way); equal shapes keep their order
+  for (int a = 1; a < n_layers; ++a)
+    for (int b = a; b > 0 && layers[order[b]].tiles_per_block > layers[order[b - 1]].tiles_per_block; --b) {
+      const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+    }
+  int n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long rr = 0;
+  for (int oi = 0; oi < n_layers; ++oi) {
+    const int li = order[oi];
+    const crimac_wgrad_group_layer& l = layers[li];
+    const int ch_tiles = cdiv(l.CF, 64) * cdiv(l.CS, 64);
+    auto put = [&](int x, int qt, int split) {
+      if (items && n[x] < cap) {
+        items[2 * ((long)x * cap + n[x])] = li;
+        items[2 * ((long)x * cap + n[x]) + 1] = qt * 65536 + split;
+      }
+      ++n[x];
+    };
+    if (l.nsplits % 8 == 0) {
+      // split-major as in wgrad_kernel: XCD x owns the pixel ranges x, x + 8, ... and runs ALL channel-tile pairs on
+      // them back to back, so a staged F / S tile is fetched into that XCD's L2 once
+      for (int x = 0; x < 8; ++x)
+        for (int sp = x; sp < l.nsplits; sp += 8)
+          for (int qt = 0; qt < ch_tiles; ++qt) put(x, qt, sp);
+    } else {
+      for (int sp = 0; sp < l.nsplits; ++sp)
+        for (int qt = 0; qt < ch_tiles; ++qt) put((int)(rr++ % 8), qt, sp);
+    }
+  }
+  int need = 0;
+  for (int x = 0; x < 8; ++x) { counts[x] = n[x]; if (n[x] > need) need = n[x]; }
+  if (items) CRIMAC_REQUIRE(need <= cap, "wgrad_group_plan: %d items per queue, room for %d", need, cap);
+  return need;              // (>= 0: the queue capacity this plan needs; sizing call: items == NULL)
+}
+
+extern "C" int crimac_wgrad_group(int prec, const crimac_wgrad_group_layer* layers, int n_layers, int B, const int* items,
+                                  int cap, const int* counts, unsigned int* counters, void* stream) {
+  if (int rc = group_check(prec, layers, n_layers, B)) return rc;
+  CRIMAC_REQUIRE(items && counts && counters && cap > 0, "wgrad_group: bad queue arguments");
+  GroupParams gp;
+  for (int i = 0; i < n_layers; ++i) {
+    gp.layer[i] = layers[i];
+    CRIMAC_REQUIRE(layers[i].f && layers[i].s && layers[i].dw, "wgrad_group: layer %d: NULL tensor", i);
+    CRIMAC_REQUIRE(layers[i].tiles_per_block > 0 && layers[i].nsplits > 0 && layers[i].ntiles == (long)B * layers[i].tiles_y * layers[i].tiles_x &&
+                       layers[i].tiles_y == cdiv(layers[i].Hf, 8) && layers[i].tiles_x == cdiv(layers[i].Wf, 16),
+                   "wgrad_group: layer %d was not planned for this geometry (crimac_wgrad_group_plan)", i);
+  }
+  gp.B = B; gp.items = items; gp.cap = cap; gp.counter = counters;
+  long total = 0;
+  for (int x = 0; x < 8; ++x) {
+    CRIMAC_REQUIRE(counts[x] >= 0 && counts[x] <= cap, "wgrad_group: queue %d holds %d items, capacity %d", x, counts[x], cap);
+    gp.count[x] = counts[x];
+    total += counts[x];
+  }
+  if (total == 0) return CRIMAC_OK;
+  constexpr size_t lds = 4 * (size_t)((8 * 16 + ((8 + 2) * 18 + 7) / 8 * 8) * 128) + 64;
+  hipStream_t st = (hipStream_t)stream;
+  int ncu = crimac_cu_count();
+  ncu = ncu / 8 * 8;                       // (equal shares of the 8 XCD queues)
+  if (ncu < 8) ncu = 8;
+  if (prec == CRIMAC_PREC_H3P) {
+    static unsigned long long attr_devs = 0;
+    if (crimac_first_use_on_device(&attr_devs))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pp_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(wgrad_pp_group_kernel, dim3(ncu), dim3(512), 2 * (size_t)PP_BUF + 64, st, gp);
+  } else if (prec == CRIMAC_PREC_BF16) {
+    static unsigned long long attr_devs = 0;
+    if (crimac_first_use_on_device(&attr_devs))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(wgrad_group_kernel<bf16_t>, dim3(ncu), dim3(512), lds, st, gp);
+  } else {
+    static unsigned long long attr_devs = 0;
+    if (crimac_first_use_on_device(&attr_devs))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(wgrad_group_kernel<half_t>, dim3(ncu), dim3(512), lds, st, gp);
+  }
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
 
 extern "C" int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s,
                             long s_ld, int CS, int B, int Hf, int Wf, float* dw, int target_blocks,

@@ -243,8 +243,12 @@ class UNetEngine:
         self.stat = torch.zeros(2 + nb * (2 * STAT_REPLICAS + 2) * cmax, dtype=torch.float64, device=dev)
         self.cmax = cmax
         # transposed-conv bias gradients come out of the dgrad epilogue of the block above: [level][2][R][2*cmax]
-        self.bias_scr = torch.zeros(max(self.depth - 1, 1) * 2 * STAT_REPLICAS * 2 * cmax, dtype=torch.float64,
+        # (+ 128 doubles at the end: the 8 queue counters of up to 32 grouped weight-gradient launches per backward pass,
+        # uint32 -- zeroed by the same fill)
+        self.bias_scr = torch.zeros(max(self.depth - 1, 1) * 2 * STAT_REPLICAS * 2 * cmax + 128, dtype=torch.float64,
                                     device=dev)
+        self._wg_counters = self.bias_scr[-128:].view(torch.int32)
+        self._wg_plans = {}
         # fp32 per BN layer: mean, invstd, scale, shift
         self.bnf = torch.zeros(nb * 4 * cmax, dtype=torch.float32, device=dev)
         self.class_w = None
@@ -435,16 +439,71 @@ class UNetEngine:
         return (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
                 and dist.get_backend() == "gloo")
 
-    def _wgrad(self, prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, key, flops=None):
-        dwt, sp, stride = self._dw(key)
-        if self.use_wgrad_partials:
-            name, args = "crimac_wgrad_partials", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt), stride,
-                                                   self.wgrad_target_blocks)
-        else:
-            name, args = "crimac_wgrad", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt),
-                                          self.wgrad_target_blocks)
+    # Grouped weight gradients (crimac_wgrad_group): the conv3x3 layers of a backward group are contracted by ONE
+    # persistent launch instead of one launch each -- their atomic flushes then drain under each other's MFMAs instead of
+    # ending every launch (0.44 ms of the 12.0 ms bf16 step in the no-flush ablation).  The layers are collected while the
+    # backward pass walks them (their dy buffers stay alive: one per block) and launched where the group's gradient range
+    # is handed on (_unpack_group), or earlier once `wgrad_group_layers` of them are waiting.
+    # CRIMAC_WGRAD_GROUP=0: one launch per layer (crimac_wgrad), as before.
+    wgrad_group = os.environ.get("CRIMAC_WGRAD_GROUP", "1") != "0"
+    wgrad_group_layers = int(os.environ.get("CRIMAC_WGRAD_GROUP_LAYERS", str(hip.WGRAD_GROUP_MAX_LAYERS)))
+    wgrad_group_items = int(os.environ.get("CRIMAC_WGRAD_GROUP_ITEMS", "0"))      # items per layer (0: the library's default)
+    _wg_pending = None
+
+    def _groupable(self, prec, mode, cf, cs):
+        if not (self.wgrad_group and mode == 0 and cs >= 64 and not self.use_wgrad_partials and self._wg_pending is not None):
+            return False
+        if prec == hip.PREC_H3P:                      # plane pairs: whole 64 x 64 channel tiles
+            return cf % 64 == 0 and cs % 64 == 0
+        return prec in hip.PREC_16BIT
+
+    def _group_plan(self, B, shapes):
+        """Planned layer array, device copy of the 8 item queues, their lengths -- cached per geometry."""
+        key = (self.prec_bwd, B, self.wgrad_group_items, shapes)
+        plan = self._wg_plans.get(key)
+        if plan is None:
+            lib = hip.load_library()
+            arr = (hip.WgradGroupLayer * len(shapes))()
+            for d, (cf, cs, h, w, f_ld, s_ld) in zip(arr, shapes):
+                d.CF, d.CS, d.Hf, d.Wf, d.f_ld, d.s_ld = cf, cs, h, w, f_ld, s_ld
+            counts = (C.c_int * 8)()
+            cap = lib.crimac_wgrad_group_plan(self.prec_bwd, arr, len(shapes), B, self.wgrad_group_items, None, 0, counts)
+            if cap < 0:
+                raise hip.HipLibraryError("crimac_wgrad_group_plan failed: " + lib.crimac_last_error().decode(errors="replace"))
+            items = torch.zeros(8 * max(cap, 1) * 2, dtype=torch.int32)
+            rc = lib.crimac_wgrad_group_plan(self.prec_bwd, arr, len(shapes), B, self.wgrad_group_items,
+                                             C.c_void_p(items.data_ptr()), max(cap, 1), counts)
+            if rc < 0:
+                raise hip.HipLibraryError("crimac_wgrad_group_plan failed: " + lib.crimac_last_error().decode(errors="replace"))
+            plan = (arr, items.to(self.device), counts, max(cap, 1))
+            self._wg_plans[key] = plan
+        return plan
+
+    def _flush_wgrad_group(self):
+        pend = self._wg_pending
+        if not pend:
+            return
+        self._wg_pending = []
+        B = pend[0]["B"]
+        shapes = tuple((q["cf"], q["cs"], q["h"], q["w"], q["f_ld"], q["s_ld"]) for q in pend)
+        planned, items_dev, counts, cap = self._group_plan(B, shapes)
+        arr = (hip.WgradGroupLayer * len(pend))()
+        for d, pl, q in zip(arr, planned, pend):
+            C.memmove(C.byref(d), C.byref(pl), C.sizeof(hip.WgradGroupLayer))
+            d.f, d.s, d.dw = q["f"].value, q["s"].value, q["dw"].data_ptr()
+        if self._wg_launches >= self._wg_counters.numel() // 8:
+            raise RuntimeError("more grouped weight-gradient launches in one backward pass than queue counters")
+        ctr = ptr(self._wg_counters, 8 * self._wg_launches)
+        self._wg_launches += 1
+        flops = sum(q["flops"] for q in pend)
+        args = (self.prec_bwd, C.byref(arr), len(pend), B, ptr(items_dev), cap, C.byref(counts), ctr)
+        self._on_side(lambda: call("crimac_wgrad_group", *args, flops=flops))
+
+    def _on_side(self, fn):
+        """Run ``fn`` (kernel launches) on the weight-gradient side stream, ordered after everything queued on the
+        caller's stream so far; on the caller's stream when the side stream is off (or under gloo rehearsals)."""
         if self.wgrad_side_streams <= 0 or self._gloo_ranks():
-            call(name, *args, flops=flops)
+            fn()
             return
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(self.wgrad_side_streams)]
@@ -453,10 +512,26 @@ class UNetEngine:
         ev = self._side_events[self._side_i % len(self._side_events)]
         side = self._side[self._side_i % len(self._side)]
         self._side_i += 1
-        ev.record()                                   # everything wgrad reads has been queued on this stream
+        ev.record()                                   # everything the launch reads has been queued on this stream
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            call(name, *args, flops=flops)
+            fn()
+
+    def _wgrad(self, prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, key, flops=None):
+        dwt, sp, stride = self._dw(key)
+        if self._groupable(prec, mode, cf, cs):
+            self._wg_pending.append(dict(f=f, f_ld=f_ld, cf=cf, s=s_, s_ld=s_ld, cs=cs, B=B, h=h, w=w, dw=dwt,
+                                         flops=flops or 0.0))
+            if len(self._wg_pending) >= min(self.wgrad_group_layers, hip.WGRAD_GROUP_MAX_LAYERS):
+                self._flush_wgrad_group()
+            return
+        if self.use_wgrad_partials:
+            name, args = "crimac_wgrad_partials", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt), stride,
+                                                   self.wgrad_target_blocks)
+        else:
+            name, args = "crimac_wgrad", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt),
+                                          self.wgrad_target_blocks)
+        self._on_side(lambda: call(name, *args, flops=flops))
 
     def _join_wgrad(self):
         if self._side is not None:
@@ -468,6 +543,7 @@ class UNetEngine:
         ``on_ready(*rng)`` (the gradient exchange of that range).  With ONE side stream both are queued behind
         the weight gradients on that stream -- the caller's stream is not held up (it joins at the end of the
         backward pass); a collective launched there orders itself after the side stream."""
+        self._flush_wgrad_group()                     # the group's conv3x3 weight gradients: one persistent launch
         arr, bounds = self._layer_table()
         first, n = bounds[gi]
         side = self._side[0] if (self._side is not None and len(self._side) == 1 and self.unpack_on_side) else None
@@ -1098,6 +1174,7 @@ class UNetEngine:
         D = self.depth
         self._skip_done = {}
         self._unpacked = {}
+        self._wg_pending, self._wg_launches = [], 0
         self._plan_dw(B, H, W)
         self.flat_g.zero_()
         if not self.use_wgrad_partials:
@@ -1190,6 +1267,8 @@ class UNetEngine:
             g = self._enc_group(i)
             if i == 0 or self._enc_group(i - 1) != g:        # last (shallowest) block of its group
                 self._unpack_group(g, on_ready, ranges[g] if ranges else None)
+        self._flush_wgrad_group()                     # (nothing left by construction: every group was flushed at its hand-over)
+        self._wg_pending = None
         if before_join is not None:
             before_join()                             # the caller's stream has nothing left of the backward pass
         self._join_wgrad()

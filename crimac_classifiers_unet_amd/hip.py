@@ -36,7 +36,7 @@ EPI_RELU, EPI_OUT_PLANES, EPI_CIN4 = 1, 2, 4      # `relu` argument of the convo
 PREC_BACKWARD = {PREC_F32H3: PREC_F32X3}
 PREC_16BIT = (PREC_BF16, PREC_FP16)
 
-ABI_VERSION = 3          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
+ABI_VERSION = 4          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "crimac_sum_replicas": [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_wgrad": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _i, _vp],
     "crimac_wgrad_partials": [_i, _i, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp],
+    "crimac_wgrad_group": [_i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp],
     "crimac_pack_conv3x3": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_pack_upconv2x2": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "crimac_unpack_wgrad_conv3x3": [_vp, _i, _i, _i, _vp, _vp],
@@ -112,6 +113,14 @@ class LayerDesc(C.Structure):
                 ("dw_stride", _l)]
 
 
+class WgradGroupLayer(C.Structure):
+    """crimac_wgrad_group_layer (include/crimac_unet_hip.h): one conv3x3 layer of a grouped weight-gradient launch."""
+    _fields_ = [("f", _vp), ("f_ld", _l), ("CF", _i), ("s", _vp), ("s_ld", _l), ("CS", _i), ("Hf", _i), ("Wf", _i),
+                ("dw", _vp), ("tiles_y", _i), ("tiles_x", _i), ("ntiles", _l), ("tiles_per_block", _i), ("nsplits", _i)]
+
+
+WGRAD_GROUP_MAX_LAYERS = 16      # CRIMAC_WGRAD_GROUP_MAX_LAYERS
+
 _lib = None
 
 
@@ -151,6 +160,13 @@ def load_library():
                               f"{C.sizeof(LayerDesc)} in this binding")
     lib.crimac_wgrad_splits.restype = C.c_int          # (returns a count, not a status; no stream argument)
     lib.crimac_wgrad_splits.argtypes = [_i, _i, _i, _i, _i, _i, _i, _i]
+    lib.crimac_wgrad_group_layer_size.restype = C.c_int
+    lib.crimac_wgrad_group_layer_size.argtypes = []
+    if lib.crimac_wgrad_group_layer_size() != C.sizeof(WgradGroupLayer):
+        raise HipLibraryError(f"{path}: crimac_wgrad_group_layer is {lib.crimac_wgrad_group_layer_size()} bytes in the "
+                              f"library, {C.sizeof(WgradGroupLayer)} in this binding")
+    lib.crimac_wgrad_group_plan.restype = C.c_int      # (host-only planner: returns the queue capacity, no stream)
+    lib.crimac_wgrad_group_plan.argtypes = [_i, _vp, _i, _i, _i, _vp, _i, _vp]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = C.c_int

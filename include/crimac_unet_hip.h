@@ -103,7 +103,7 @@ extern "C" {
  * binding must refuse a library whose version differs from the header it was written against (an older build that
  * happens to export every symbol would walk a descriptor array with the wrong stride).  crimac_layer_desc_size() is
  * sizeof(crimac_layer_desc) as the library was compiled. */
-#define CRIMAC_ABI_VERSION 3
+#define CRIMAC_ABI_VERSION 4
 int crimac_version(void);
 int crimac_layer_desc_size(void);
 const char* crimac_last_error(void);
@@ -190,6 +190,35 @@ int crimac_conv3x3_pool(int prec, const void* in, long in_ld, int B, int H, int 
  *   one atomic pass). */
 int crimac_wgrad(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld,
                  int CS, int B, int Hf, int Wf, float* dw, int target_blocks, void* stream);
+
+/* The conv3x3 weight gradients of SEVERAL layers in one persistent launch (16-bit storage precisions and plane pairs,
+ * Cin >= 64; plane pairs: whole 64-channel tiles): the
+ * same contraction and the same fp32-atomic accumulation into each layer's dw as crimac_wgrad(mode 0), but the (layer,
+ * 64 x 64 channel tile, pixel split) items of all layers go through per-XCD queues that persistent workgroups pull
+ * from, so the atomic flush of a finished item drains under the MFMAs of the next one instead of ending every launch
+ * with all workgroups flushing at once (~30 us x 22 launches per step).  The reference computes these gradients inside
+ * aten::convolution_backward, one layer at a time (loss.backward(), pipeline.py:177).
+ *   crimac_wgrad_group_plan (HOST ONLY, no stream): fills the planned fields of layers[] and the queues -- items
+ *     [8][cap][2] int32 host array (NULL: sizing call), counts[8]; returns the queue capacity the plan needs (>= 0) or a
+ *     negative error.  items_per_layer <= 0: default (128, CRIMAC_WGRAD_GROUP_ITEMS overrides).  The plan depends on the
+ *     shapes and B only, not on the pointers.
+ *   crimac_wgrad_group: layers[] as planned (f, s, dw set), items = the DEVICE copy of the planned queues, counters =
+ *     8 device uint32 ZEROED by the caller before every launch. */
+#define CRIMAC_WGRAD_GROUP_MAX_LAYERS 16
+typedef struct crimac_wgrad_group_layer {
+  const void* f; long f_ld; int CF;      /* dY  [B][Hf][Wf][CF = Cout] */
+  const void* s; long s_ld; int CS;      /* X   [B][Hf][Wf][CS = Cin]  */
+  int Hf, Wf;
+  float* dw;                             /* [9][CF][CS] fp32, accumulated into (caller zeroes) */
+  int tiles_y, tiles_x;                  /* planned fields */
+  long ntiles;
+  int tiles_per_block, nsplits;
+} crimac_wgrad_group_layer;
+int crimac_wgrad_group_layer_size(void);   /* sizeof(crimac_wgrad_group_layer) as the library was compiled */
+int crimac_wgrad_group_plan(int prec, crimac_wgrad_group_layer* layers, int n_layers, int B, int items_per_layer,
+                            int* items, int cap, int* counts);
+int crimac_wgrad_group(int prec, const crimac_wgrad_group_layer* layers, int n_layers, int B, const int* items, int cap,
+                       const int* counts, unsigned int* counters, void* stream);
 /* The same contraction WITHOUT atomics: the pixel range is split into crimac_wgrad_splits(...) parts and the
  * workgroups of part k store their finished 64 x 64 x taps tiles into slab k = partials + k * slab_stride (plain
  * stores; every element of every slab is written, no zero fill needed).  crimac_unpack_wgrad_layers adds the slabs

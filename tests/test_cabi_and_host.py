@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
     # and the binding table covers the header exactly (plus version / last_error)
-    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error", "crimac_wgrad_splits",
-                                  "crimac_layer_desc_size"} == set(syms)
+    assert set(hip.SIGNATURES) | {"crimac_version", "crimac_last_error", "crimac_wgrad_splits", "crimac_layer_desc_size",
+                                  "crimac_wgrad_group_plan", "crimac_wgrad_group_layer_size"} == set(syms)
     # the split planner is a host-only query (no GPU): the level-0 shape fills one resident round
     lib2 = hip.load_library()
     assert lib2.crimac_wgrad_splits(0, 0, 64, 64, 32, 256, 256, 0) == 256        # bf16: one 8-wave workgroup per CU
@@ -43,6 +43,48 @@ def test_library_exports_every_declared_symbol():
     assert int(re.search(r"#define CRIMAC_ABI_VERSION (\d+)", header).group(1)) == hip.ABI_VERSION
     assert lib2.crimac_version() == hip.ABI_VERSION
     assert lib2.crimac_layer_desc_size() == ctypes.sizeof(hip.LayerDesc)
+    assert lib2.crimac_wgrad_group_layer_size() == ctypes.sizeof(hip.WgradGroupLayer)
+
+
+def test_grouped_weight_gradient_plan_covers_every_item_exactly_once():
+    """crimac_wgrad_group_plan (host only): for the encoder shapes of the benchmark and for ragged tiny shapes, every
+    (layer, channel-tile pair, pixel split) appears in exactly one of the 8 queues; whole rounds of 8 splits put split s
+    in queue s % 8 (the XCD that keeps its pixel range in L2); longest items come first."""
+    lib = hip.load_library()
+    cases = [(32, [(64, 64, 256, 256), (128, 64, 128, 128), (128, 128, 128, 128), (256, 128, 64, 64), (1024, 512, 16, 16)]),
+             (2, [(64, 64, 32, 48), (128, 128, 16, 24), (512, 256, 4, 6)]), (1, [(64, 128, 8, 16)])]
+    for B, shapes in cases:
+        arr = (hip.WgradGroupLayer * len(shapes))()
+        for d, (cf, cs, h, w) in zip(arr, shapes):
+            d.CF, d.CS, d.f_ld, d.s_ld, d.Hf, d.Wf = cf, cs, cf, cs, h, w
+        counts = (ctypes.c_int * 8)()
+        cap = lib.crimac_wgrad_group_plan(0, arr, len(shapes), B, 0, None, 0, counts)
+        assert cap > 0 and max(counts) == cap
+        items = (ctypes.c_int * (8 * cap * 2))()
+        assert lib.crimac_wgrad_group_plan(0, arr, len(shapes), B, 0, items, cap, counts) == cap
+        seen = set()
+        for x in range(8):
+            last_cost = None
+            for k in range(counts[x]):
+                li, qs = items[2 * (x * cap + k)], items[2 * (x * cap + k) + 1]
+                qt, sp = qs >> 16, qs & 0xFFFF
+                d = arr[li]
+                assert 0 <= sp < d.nsplits and 0 <= qt < ((d.CF + 63) // 64) * ((d.CS + 63) // 64)
+                if d.nsplits % 8 == 0:
+                    assert sp % 8 == x
+                assert (li, qt, sp) not in seen
+                seen.add((li, qt, sp))
+                assert last_cost is None or d.tiles_per_block <= last_cost
+                last_cost = d.tiles_per_block
+        total = sum(d.nsplits * ((d.CF + 63) // 64) * ((d.CS + 63) // 64) for d in arr)
+        assert len(seen) == total == sum(counts)
+        for d in arr:
+            assert d.ntiles == B * d.tiles_y * d.tiles_x and d.tiles_per_block * d.nsplits >= d.ntiles
+            assert d.tiles_per_block * (d.nsplits - 1) < d.ntiles          # no empty split
+    # the first layer (4 channels padded to 16) is refused: it keeps its own launch
+    arr = (hip.WgradGroupLayer * 1)()
+    arr[0].CF, arr[0].CS, arr[0].f_ld, arr[0].s_ld, arr[0].Hf, arr[0].Wf = 64, 16, 64, 16, 64, 64
+    assert lib.crimac_wgrad_group_plan(0, arr, 1, 2, 0, None, 0, (ctypes.c_int * 8)()) < 0
 
 
 def test_binding_refuses_a_library_with_another_abi_version(monkeypatch):

@@ -340,6 +340,46 @@ def test_wgrad_conv3x3(shape, target):
     assert relerr(grad.cpu(), ref) < 2 * TOL
 
 
+@pytest.mark.parametrize("items", [0, 16])
+def test_grouped_weight_gradients_plane_pairs(items):
+    """crimac_wgrad_group in the plane-pair precision: several conv3x3 layers (full tiles, ragged images, an operand in a
+    channel slice of a wider buffer, few-split layers) through one persistent launch == torch's conv2d_weight in fp64."""
+    import ctypes
+    lib = hip.load_library()
+    g = torch.Generator().manual_seed(43)
+    B = 2
+    specs = [(128, 128, 64, 64, 0), (100, 120, 64, 128, 0), (20, 24, 128, 64, 256), (16, 16, 256, 128, 0), (32, 32, 512, 256, 0)]
+    keep, arr = [], (hip.WgradGroupLayer * len(specs))()
+    for d, (H, W, Ci, Co, ldx) in zip(arr, specs):
+        x = hp_round(torch.randn(B, Ci, H, W, generator=g))
+        dy = hp_round(torch.randn(B, Co, H, W, generator=g) * 40)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), dy.double(), padding=1).float()
+        xn = to_nhwc_hp(x, ld=ldx or Ci, off=(ldx - Ci) if ldx else 0)
+        dyn = to_nhwc_hp(dy)
+        dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+        keep.append((xn, dyn, dwp, ref, Ci, Co))
+        d.f, d.f_ld, d.CF = dyn.data_ptr(), Co, Co
+        d.s, d.s_ld, d.CS = xn.data_ptr() + 4 * ((ldx - Ci) if ldx else 0), ldx or Ci, Ci
+        d.Hf, d.Wf, d.dw = H, W, dwp.data_ptr()
+    counts = (ctypes.c_int * 8)()
+    cap = lib.crimac_wgrad_group_plan(P, arr, len(specs), B, items, None, 0, counts)
+    assert cap > 0, lib.crimac_last_error()
+    host = torch.zeros(8 * cap * 2, dtype=torch.int32)
+    assert lib.crimac_wgrad_group_plan(P, arr, len(specs), B, items, ctypes.c_void_p(host.data_ptr()), cap, counts) == cap
+    dev_items = host.cuda()
+    ctr = torch.zeros(8, dtype=torch.int32, device="cuda")
+    call("crimac_wgrad_group", P, ctypes.byref(arr), len(specs), B, ptr(dev_items), cap, ctypes.byref(counts), ptr(ctr))
+    torch.cuda.synchronize()
+    for (xn, dyn, dwp, ref, Ci, Co), sp in zip(keep, specs):
+        grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+        call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+        torch.cuda.synchronize()
+        assert relerr(grad.cpu(), ref) < 2 * TOL, sp
+    # channel counts that are not whole 64 x 64 tiles are refused for plane pairs (they keep crimac_wgrad)
+    arr[0].CS = 96
+    assert lib.crimac_wgrad_group_plan(P, arr, 1, B, 0, None, 0, counts) < 0
+
+
 def test_wgrad_operands_in_channel_slices():
     """F and S living in slices of wider buffers (the decoder's first convolution reads the concat buffer)."""
     B, H, W, Ci, Co = 2, 32, 32, 128, 64

@@ -930,3 +930,99 @@ def test_wgrad_two_teams_long_tile_queue(prec, target):
         assert relerr(outs[-1], ref) < 1e-4
     # (the queue makes the tile -> team assignment timing dependent: equal up to the order of fp32 additions)
     assert relerr(outs[0], outs[1]) < 1e-5
+
+
+@pytest.mark.parametrize("prec", LOWP)
+@pytest.mark.parametrize("items", [0, 24])
+def test_grouped_weight_gradients_equal_the_torch_reference(prec, items):
+    """crimac_wgrad_group: the conv3x3 weight gradients of several layers through ONE persistent launch with per-XCD item
+    queues -- full-size tiles with hundreds of items per queue, ragged images (partial tiles on both edges), channel
+    counts that are not multiples of the 64 x 64 tile, a layer that lives in a channel slice of a wider buffer (ld > C),
+    layers with fewer splits than XCDs -- each against torch's conv2d_weight on the same (16-bit exact) operands.
+    items = 24: a plan with few, long items per layer (every workgroup runs several tiles per item and several items)."""
+    import ctypes
+    lib = hip.load_library()
+    P = hip.PREC_NAMES[prec]
+    g = torch.Generator().manual_seed(41)
+    #        B,  H,   W,  Ci,  Co, ld_x (0: Ci)
+    specs = [(2, 128, 128, 64, 64, 0), (2, 100, 120, 64, 128, 0), (2, 20, 24, 128, 64, 256), (2, 16, 16, 256, 96, 0),
+             (2, 8, 48, 72, 64, 0), (2, 32, 32, 512, 256, 0)]
+    B = 2
+    keep, arr = [], (hip.WgradGroupLayer * len(specs))()
+    for d, (_, H, W, Ci, Co, ldx) in zip(arr, specs):
+        x = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+        dy = _round(torch.randn(B, Co, H, W, generator=g), prec)
+        ref = torch.nn.grad.conv2d_weight(x, (Co, Ci, 3, 3), dy, padding=1)
+        xn = to_nhwc(x, prec, ld=ldx or Ci)
+        dyn = to_nhwc(dy, prec)
+        dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+        keep.append((xn, dyn, dwp, ref, Ci, Co))
+        d.f, d.f_ld, d.CF = dyn.data_ptr(), Co, Co
+        d.s, d.s_ld, d.CS = xn.data_ptr(), ldx or Ci, Ci
+        d.Hf, d.Wf, d.dw = H, W, dwp.data_ptr()
+    counts = (ctypes.c_int * 8)()
+    cap = lib.crimac_wgrad_group_plan(P, arr, len(specs), B, items, None, 0, counts)
+    assert cap > 0, lib.crimac_last_error()
+    host = torch.zeros(8 * cap * 2, dtype=torch.int32)
+    assert lib.crimac_wgrad_group_plan(P, arr, len(specs), B, items, ctypes.c_void_p(host.data_ptr()), cap, counts) == cap
+    dev_items = host.cuda()
+    ctr = torch.zeros(8, dtype=torch.int32, device="cuda")
+    call("crimac_wgrad_group", P, ctypes.byref(arr), len(specs), B, ptr(dev_items), cap, ctypes.byref(counts), ptr(ctr))
+    torch.cuda.synchronize()
+    assert ctr.cpu().tolist() >= list(counts)          # every queue was drained (workgroups overshoot by their last fetch)
+    for (xn, dyn, dwp, ref, Ci, Co), sp in zip(keep, specs):
+        grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+        call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+        torch.cuda.synchronize()
+        assert relerr(grad.cpu(), ref) < 2e-4, sp
+    # a second launch on the same queues needs fresh counters: with the old ones nothing runs (and nothing hangs)
+    before = keep[0][2].clone()
+    call("crimac_wgrad_group", P, ctypes.byref(arr), len(specs), B, ptr(dev_items), cap, ctypes.byref(counts), ptr(ctr))
+    torch.cuda.synchronize()
+    assert torch.equal(before, keep[0][2])
+
+
+@pytest.mark.parametrize("prec", LOWP + ["h3p"])
+def test_backward_with_grouped_weight_gradients_equals_the_ungrouped_backward(prec):
+    """The engine's backward pass with the conv3x3 weight gradients grouped per gradient range (the default), grouped three
+    layers at a time, and with one launch per layer (CRIMAC_WGRAD_GROUP=0) -- on the SAME saved forward pass (two forward
+    passes of a 16-bit net differ at rounding level and their gradients by O(10 %)): every gradient equal up
+    to the order of the fp32 atomics."""
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+    x = torch.from_numpy(synth.synth_echogram_batch(3, 4, 64, 96, seed=81)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(3, 64, 96, seed=82)).cuda()
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    m = pkg.UNet_Baseline(3, 4, precision=prec)
+    m.load_state_dict(synth.synth_state_dict(seed=0))
+    m.cuda().train()
+    eng = m.engine
+    logits = eng.forward(x, training=True)
+    sums, labels = eng.ce_forward(logits, lab, cw)
+    dl = eng.ce_backward(logits, labels, cw, sums, float(eng.loss_scale))
+    res = {}
+    for tag, grouped, nlayers in (("base", False, 16), ("again", False, 16), ("range", True, 16), ("three", True, 3)):
+        eng.wgrad_group, eng.wgrad_group_layers = grouped, nlayers
+        eng.backward(dl)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(eng.flat_g).all())
+        res[tag] = eng.flat_g.clone()
+        assert eng._wg_launches == {"base": 0, "again": 0, "range": 4, "three": 7}[tag]
+    base = res["base"]
+    assert float(base.abs().max()) > 0
+
+    def dist(a):
+        return float((a - base).double().norm() / base.double().norm())
+    # two runs of the SAME backward pass already differ: the BatchNorm-backward sums are added up by fp32 atomics in
+    # arrival order, an output gradient that lands on the other side of a 16-bit rounding boundary moves by an ulp
+    # (bf16: 0.4 %), and the layers below see it.  The grouped launches must sit inside that noise.
+    noise = dist(res["again"])
+    print(f"{prec}: run-to-run {noise:.2e}, grouped per range {dist(res['range']):.2e}, three at a time {dist(res['three']):.2e}")
+    for k in ("range", "three"):
+        assert dist(res[k]) < max(3 * noise, 1e-3), (k, dist(res[k]), noise)
+    # and the weight gradient of the LAST decoder convolution -- the first dy of the backward pass, computed before any
+    # such rounding difference exists -- agrees to the order of its fp32 atomics
+    o, n, _ = eng.layout[f"up_convs.{eng.depth - 2}.conv2.weight"]
+    for k in ("range", "three"):
+        a, b = res[k][o:o + n].double(), base[o:o + n].double()
+        assert float((a - b).norm() / b.norm()) < 3e-4, k
