@@ -1169,6 +1169,7 @@ struct GroupParams {
   int cap;
   int count[8];
   unsigned* counter;         // [8], zeroed by the caller before the launch
+  int max_items;             // items a workgroup takes before it exits and gives its CU back (<= 0: until the queue is empty)
 };
 
 // barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the ACKNOWLEDGEMENT of the
@@ -1239,7 +1240,7 @@ void wgrad_group_kernel(GroupParams gp) {
     const unsigned lds0 = (unsigned)(unsigned long)((LDS_PTR(unsigned char))(smem)) + team * 2 * BUF_BYTES;
     const int tt = tid & 255;
     unsigned* tcnt = tq + team;
-    for (;;) {
+    for (int taken = 0;; ++taken) {
       const int k = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 8 + 4 * ipar));
       if (k >= n_items) break;
       const int li_ = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 9 + 4 * ipar));
@@ -1346,8 +1347,14 @@ void wgrad_group_kernel(GroupParams gp) {
       bool have = cur_tile < t_end;
       if (have) issue_tile(cur_tile, 0);
       if (tt == 0) tq[4 + 2 * team] = __hip_atomic_fetch_add(tq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      // the NEXT item is requested now (two dependent round trips to L2, hidden behind this item's first tile)
-      if (tid == 256) fetch_item(ipar ^ 1);
+      // the NEXT item is requested now (two dependent round trips to L2, hidden behind this item's first tile) -- unless
+      // this was the workgroup's last one: it then exits and a fresh workgroup (or one of another stream's kernels) gets
+      // the CU; a persistent workgroup would hold it until its queue is empty and block every other kernel meanwhile
+      const bool last = gp.max_items > 0 && taken + 1 >= gp.max_items;
+      if (tid == 256) {
+        if (last) tq[8 + 4 * (ipar ^ 1)] = 0x7FFFFFFFu;
+        else fetch_item(ipar ^ 1);
+      }
       int cur = 0, par = 0;
       while (have) {
         // this wave's share of the tile has landed -- for a team-0 wave this is also where the atomics of the PREVIOUS
@@ -1469,7 +1476,7 @@ void wgrad_pp_group_kernel(GroupParams gp) {
     bool have_prev = false;
     float* prev_dw = nullptr;
     int prev_CF = 0, prev_CS = 0, prev_cf0 = 0, prev_cs0 = 0;
-    for (;;) {
+    for (int taken = 0;; ++taken) {
       const int k = __builtin_amdgcn_readfirstlane((int)lds_word(tq + 8 + 4 * ipar));
       const bool valid = k < n_items;
       const int li_ = valid ? __builtin_amdgcn_readfirstlane((int)lds_word(tq + 9 + 4 * ipar)) : 0;
@@ -1558,7 +1565,10 @@ void wgrad_pp_group_kernel(GroupParams gp) {
         for (int fr = 0; fr < 4; ++fr)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[t][fr][r] = 0.f;
-      if (tid == 256) fetch_item(ipar ^ 1);          // (a moving wave: its wait is the first tile barrier's anyway)
+      if (tid == 256) {                              // (a moving wave: its wait is the first tile barrier's anyway)
+        if (gp.max_items > 0 && taken + 1 >= gp.max_items) tq[8 + 4 * (ipar ^ 1)] = 0x7FFFFFFFu;      // last item: exit next
+        else fetch_item(ipar ^ 1);
+      }
       for (long tile = t_begin; tile < t_end; ++tile) {
         const int cur = (int)((tile - t_begin) & 1);
         __syncthreads();           // vmcnt(0) + barrier: the tile has landed for everyone, the other buffer is free
@@ -1843,6 +1853,21 @@ extern "C" int crimac_wgrad_group(int prec, const crimac_wgrad_group_layer* laye
   int ncu = crimac_cu_count();
   ncu = ncu / 8 * 8;                       // (equal shares of the 8 XCD queues)
   if (ncu < 8) ncu = 8;
+  // Workgroups take `wg_items` items each and exit: the launch is then as many workgroups as that takes (the hardware
+  // keeps one per CU resident and starts the next as one retires), and kernels of OTHER streams get CUs in between -- a
+  // fully persistent grid (CRIMAC_WGRAD_GROUP_WGITEMS=0) holds every CU until its queue is empty, which blocks the input-
+  // gradient chain on the caller's stream for the whole launch.  Measured, bf16 step / serialized sum of the weight-
+  // gradient launches: persistent 11.79 ms / 2.90 ms, 3 items 11.70 / 3.65 (the last round of workgroups is ragged --
+  // in the step the other stream's kernels fill it, alone it is idle CUs), 2 items 11.80 / 3.13, 1 item 11.77 / 2.93;
+  // one launch per layer 11.93 / 3.19.  One item per workgroup: nothing left of "persistent" but the shared queue -- the
+  // flush of a finished workgroup still drains under its neighbours' MFMAs, which is what the grouping is for.
+  static const int wg_items = getenv("CRIMAC_WGRAD_GROUP_WGITEMS") ? atoi(getenv("CRIMAC_WGRAD_GROUP_WGITEMS")) : 1;
+  gp.max_items = wg_items;
+  if (wg_items > 0) {
+    int per_xcd = 0;
+    for (int x = 0; x < 8; ++x) { const int n = cdiv(counts[x], wg_items); if (n > per_xcd) per_xcd = n; }
+    ncu = 8 * per_xcd;
+  }
   if (prec == CRIMAC_PREC_H3P) {
     static unsigned long long attr_devs = 0;
     if (crimac_first_use_on_device(&attr_devs))

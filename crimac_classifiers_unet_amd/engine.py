@@ -445,7 +445,12 @@ class UNetEngine:
     # backward pass walks them (their dy buffers stay alive: one per block) and launched where the group's gradient range
     # is handed on (_unpack_group), or earlier once `wgrad_group_layers` of them are waiting.
     # CRIMAC_WGRAD_GROUP=0: one launch per layer (crimac_wgrad), as before.
+    # Plane pairs (h3p): measured SLOWER grouped (step 25.34 ms with one launch per layer; 25.6 grouped with one item per
+    # workgroup, 25.8-26.1 with persistent workgroups) although the launches themselves get faster alone (6.54 -> 6.3 ms
+    # serialized): the long plane-pair items leave the input-gradient chain on the caller's stream waiting for CUs.  Off
+    # for h3p unless CRIMAC_WGRAD_GROUP_H3P=1.
     wgrad_group = os.environ.get("CRIMAC_WGRAD_GROUP", "1") != "0"
+    wgrad_group_h3p = os.environ.get("CRIMAC_WGRAD_GROUP_H3P", "0") != "0"
     wgrad_group_layers = int(os.environ.get("CRIMAC_WGRAD_GROUP_LAYERS", str(hip.WGRAD_GROUP_MAX_LAYERS)))
     wgrad_group_items = int(os.environ.get("CRIMAC_WGRAD_GROUP_ITEMS", "0"))      # items per layer (0: the library's default)
     _wg_pending = None
@@ -454,7 +459,7 @@ class UNetEngine:
         if not (self.wgrad_group and mode == 0 and cs >= 64 and not self.use_wgrad_partials and self._wg_pending is not None):
             return False
         if prec == hip.PREC_H3P:                      # plane pairs: whole 64 x 64 channel tiles
-            return cf % 64 == 0 and cs % 64 == 0
+            return self.wgrad_group_h3p and cf % 64 == 0 and cs % 64 == 0
         return prec in hip.PREC_16BIT
 
     def _group_plan(self, B, shapes):

@@ -130,7 +130,8 @@ def test_layout_conversion_writes_plane_pairs():
 # (B, H, W, Cin, Cout): channel-split kernel (Cout % 128 == 0), pixel-split kernel (Cout = 64), first layer (Cin = 4 -> 16),
 # partial tiles, many workgroups
 CONV_SHAPES = [(2, 16, 16, 64, 128), (1, 16, 32, 128, 128), (3, 8, 8, 256, 64), (2, 16, 16, 4, 64), (1, 24, 40, 64, 192),
-               (2, 21, 37, 32, 64), (1, 19, 23, 96, 256), (4, 64, 64, 128, 256), (8, 64, 64, 64, 64)]
+               (2, 21, 37, 32, 64), (1, 19, 23, 96, 256), (4, 64, 64, 128, 256), (8, 64, 64, 64, 64),
+               (5, 250, 200, 32, 128), (3, 120, 136, 64, 256)]       # (channel-split kernel, more than two resident rounds, ragged)
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)

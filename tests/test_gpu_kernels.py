@@ -568,7 +568,9 @@ def conv3x3_halo(prec, x_nhwc, in_ld, B, H, W, Cin, Cout, w_hi, w_lo, bias, relu
                                    (2, 16, 16, 4, 64), (1, 24, 40, 64, 192), (2, 12, 20, 32, 128),
                                    (1, 32, 32, 576, 128), (5, 100, 120, 128, 64), (3, 256, 256, 64, 64),
                                    (2, 64, 64, 256, 256), (3, 21, 37, 4, 64), (2, 256, 256, 4, 64),
-                                   (10, 100, 120, 64, 64)])       # (the last: persistent 64->64 kernel, ragged tiles)
+                                   (10, 100, 120, 64, 64),        # (persistent 64->64 kernel, ragged tiles)
+                                   (5, 250, 200, 64, 128), (3, 120, 136, 128, 256)])   # (channel-split kernel, more than
+                                   # two resident rounds of workgroups: 1040 / 432 tiles, ragged on both edges, 1 and 2 chunks)
 def test_conv3x3_halo_forward_stats(prec, shape):
     """Forward incl. fused bias/ReLU and fused BatchNorm statistics; partial tiles (H%8, W%16 != 0);
     odd number of (chunk, tap) steps (Cin = 64, 576) and even (Cin = 128); the last two shapes have more
@@ -618,7 +620,8 @@ def test_conv3x3_halo_strided_io_and_dgrad(prec):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 24, 40, 128, 64), (2, 32, 32, 128, 256),
-                                   (3, 256, 256, 64, 64), (5, 256, 256, 64, 64), (7, 120, 100, 64, 64)])     # (persistent 64->64 kernel: 768 / 1280 tiles)
+                                   (3, 256, 256, 64, 64), (5, 256, 256, 64, 64), (7, 120, 100, 64, 64),     # (persistent 64->64 kernel: 768 / 1280 tiles)
+                                   (5, 250, 200, 128, 64), (3, 120, 136, 256, 128)])     # (dgrad to 128 / 256 channels, > 2 resident rounds)
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(prec, shape):
     """stat_mode 2: the dgrad convolution also produces sum dz / sum dz*xhat of the BatchNorm block its
     output feeds (== crimac_bn_bwd_reduce on (da, y))."""
@@ -982,7 +985,7 @@ def test_grouped_weight_gradients_equal_the_torch_reference(prec, items):
     assert torch.equal(before, keep[0][2])
 
 
-@pytest.mark.parametrize("prec", LOWP + ["h3p"])
+@pytest.mark.parametrize("prec", list(LOWP) + ["h3p"])
 def test_backward_with_grouped_weight_gradients_equals_the_ungrouped_backward(prec):
     """The engine's backward pass with the conv3x3 weight gradients grouped per gradient range (the default), grouped three
     layers at a time, and with one launch per layer (CRIMAC_WGRAD_GROUP=0) -- on the SAME saved forward pass (two forward
@@ -1001,6 +1004,7 @@ def test_backward_with_grouped_weight_gradients_equals_the_ungrouped_backward(pr
     sums, labels = eng.ce_forward(logits, lab, cw)
     dl = eng.ce_backward(logits, labels, cw, sums, float(eng.loss_scale))
     res = {}
+    eng.wgrad_group_h3p = True                    # (off by default for plane pairs: slower in the step; still tested)
     for tag, grouped, nlayers in (("base", False, 16), ("again", False, 16), ("range", True, 16), ("three", True, 3)):
         eng.wgrad_group, eng.wgrad_group_layers = grouped, nlayers
         eng.backward(dl)
