@@ -97,8 +97,14 @@ class UNetEngine:
         # gradients (1e-5 .. 1e-8 unscaled) sit in fp16's normal range; SGD divides it out again and skips the
         # step when a gradient overflowed (crimac_grad_overflow_flag / crimac_sgd_momentum_guarded)
         # (h3p: the output gradients dy are fp16 PLANE PAIRS -- same range, 11 more bits -- and travel scaled likewise)
-        self.loss_scale = 2.0 ** 16 if precision in ("fp16", "h3p") else 1.0
-        self.dynamic_loss_scale = precision in ("fp16", "h3p")
+        self.loss_scale = 2.0 ** 16 if precision in ("fp16", "h3p", "h3f") else 1.0
+        self.dynamic_loss_scale = precision in ("fp16", "h3p", "h3f")
+        # h3f: forward = h3p (plane pairs, 3 MFMAs per product: the logits, the loss and the BatchNorm statistics are h3p's,
+        # bit for bit); backward = the fp16 mode's (loss-scaled fp16 storage, 1 MFMA per product) on fp16 COPIES of the
+        # tensors the forward pass saved (crimac_shadow_fp16).  The parity bar of the north star is on the forward pass;
+        # gradients are held to the reference's own fp32-vs-fp64 noise (a few 1e-3), which an 11-bit backward pass on an
+        # exact forward pass meets -- at a third of the MFMAs and half the bytes of the plane-pair backward pass.
+        self.bwd16 = precision == "h3f"
         self._scale_state = None            # int32[2] on the GPU: [overflow this step, steps skipped]
         self._skipped_seen = 0
         self._good_checks = 0
@@ -134,6 +140,8 @@ class UNetEngine:
         self.meta_channels = int(getattr(module, "meta_in_channels", 0)) if self.lmi else 0
         if self.lmi and not 1 <= self.meta_channels <= 8:
             raise ValueError(f"late metadata injection supports 1..8 metadata channels, got {self.meta_channels}")
+        if self.lmi and self.bwd16:
+            raise NotImplementedError("precision 'h3f' with late metadata injection (use 'h3p')")
         self.blocks = [b for pair in self.enc for b in pair] + [b for pair in self.dec for b in pair]
         for k, b in enumerate(self.blocks):
             b.idx = k
@@ -236,6 +244,20 @@ class UNetEngine:
                               "fwd_lo": torch.empty(8 if il else n_lo * n, dtype=i16, device=dev),
                               "dg_hi": torch.empty(m_hi * n, dtype=i16, device=dev),
                               "dg_lo": torch.empty(8 if il else n_lo * n, dtype=i16, device=dev)}
+        self.pk16 = {}     # h3f: the fp16 personality's operand planes (input-gradient planes are what it uses)
+        self._ltab16 = None
+        if self.bwd16:
+            for b in self.blocks:
+                n_f = 9 * b.cout * b.cin_pad
+                has_dg = b.cin_pad == b.cin
+                self.pk16[b.conv_key] = {
+                    "fwd_hi": torch.empty(n_f, dtype=i16, device=dev), "fwd_lo": torch.empty(8, dtype=i16, device=dev),
+                    "dg_hi": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
+                    "dg_lo": torch.empty(8, dtype=i16, device=dev) if has_dg else None}
+            for u in self.ups:
+                n = 4 * u.cin * u.cout
+                self.pk16[u.key] = {"fwd_hi": torch.empty(n, dtype=i16, device=dev), "fwd_lo": torch.empty(8, dtype=i16, device=dev),
+                                    "dg_hi": torch.empty(n, dtype=i16, device=dev), "dg_lo": torch.empty(8, dtype=i16, device=dev)}
         cmax = self.sf * 2 ** (self.depth - 1)
         nb = len(self.blocks)
         # fp64 scratch: [0:2] loss sums, then per BN layer (2*R + 2) x cmax:
@@ -384,13 +406,28 @@ class UNetEngine:
             bounds.append((pos, len(g)))
             pos += len(g)
         self._ltab = (arr, bounds)
+        if self.bwd16:                                # the same layers with the fp16 personality's planes
+            arr16 = (hip.LayerDesc * len(layers))()
+            for d16, d, l in zip(arr16, arr, layers):
+                C.memmove(C.byref(d16), C.byref(d), C.sizeof(hip.LayerDesc))
+                pk = self.pk16[l.key if isinstance(l, _UpConv) else l.conv_key]
+                d16.fwd_hi, d16.fwd_lo = pk["fwd_hi"].data_ptr(), pk["fwd_lo"].data_ptr()
+                d16.dg_hi = pk["dg_hi"].data_ptr() if pk["dg_hi"] is not None else None
+                d16.dg_lo = pk["dg_lo"].data_ptr() if pk["dg_lo"] is not None else None
+            self._ltab16 = arr16
         return self._ltab
 
     def _pack_group(self, gi):
         arr, bounds = self._layer_table()
         first, n = bounds[gi]
         if n:
-            call("crimac_pack_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n, self.planes_arg)
+            call("crimac_pack_layers", C.byref(arr, first * C.sizeof(hip.LayerDesc)), n, self._fwd_planes_arg())
+            if self.bwd16:
+                call("crimac_pack_layers", C.byref(self._ltab16, first * C.sizeof(hip.LayerDesc)), n, hip.PLANES_FP16)
+
+    def _fwd_planes_arg(self):
+        """`planes` of the forward personality (inside an h3f backward pass self.planes_arg is the fp16 personality's)."""
+        return hip.PREC_PLANES_ARG[hip.PREC_NAMES[self.precision]]
 
     def _pack_train(self):
         if not self._train_pack_dirty:
@@ -402,7 +439,9 @@ class UNetEngine:
                 if gi not in done:
                     self._pack_group(gi)
         else:
-            call("crimac_pack_layers", C.byref(arr), len(arr), self.planes_arg)
+            call("crimac_pack_layers", C.byref(arr), len(arr), self._fwd_planes_arg())
+            if self.bwd16:
+                call("crimac_pack_layers", C.byref(self._ltab16), len(arr), hip.PLANES_FP16)
         self._packed_groups = set()
         self._train_pack_dirty = False
 
@@ -1009,10 +1048,70 @@ class UNetEngine:
                  ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
                  ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
         saved["head_in"] = cur if head_bn is None else None
+        if training and self.bwd16:
+            saved = self._shadow_saved(saved)
         self.saved = saved if training else None
         if training:
             self.forward_generation += 1
         return logits
+
+    # ------------------------------------------------------------------------------------------
+    # h3f: fp16 copies of the saved forward tensors, and the fp16 personality of the backward pass
+    # ------------------------------------------------------------------------------------------
+    def _shadow_saved(self, saved):
+        """The ``saved`` dictionary of a plane-pair training forward with every tensor replaced by its fp16 copy (one
+        crimac_shadow_fp16 launch): conv outputs y (fp32) are rounded, activations (plane pairs) give their hi plane."""
+        ys = set()
+        for k, v in saved.items():
+            if isinstance(v, tuple):
+                idx = (1, 3) if k.startswith("e") else (2, 4)
+                for i in idx:
+                    ys.add(id(v[i].t))
+        twins, descs = {}, []
+
+        def twin(a):
+            if a is None:
+                return None
+            t = a.t
+            if id(t) not in twins:
+                if not t.is_contiguous() or t.dtype != torch.float32 or t.numel() % 8:
+                    raise RuntimeError("h3f: a saved forward tensor is not a contiguous 4-byte-addressed buffer")
+                t16 = self._buf(f"s16.{len(twins)}", tuple(t.shape), torch.float16)
+                twins[id(t)] = t16
+                descs.append((t, t16, 0 if id(t) in ys else 1))
+            return Act(twins[id(t)], a.C, a.off, a.ld)
+        out = {}
+        for k, v in saved.items():
+            if isinstance(v, tuple):
+                out[k] = tuple(twin(a) for a in v)
+            elif isinstance(v, Act):
+                out[k] = twin(v)
+            else:
+                out[k] = v
+        arr = (hip.ShadowDesc * len(descs))()
+        for d, (t, t16, kind) in zip(arr, descs):
+            d.src, d.dst, d.n_elems, d.kind = t.data_ptr(), t16.data_ptr(), t.numel(), kind
+        call("crimac_shadow_fp16", C.byref(arr), len(descs))
+        return out
+
+    def _as_fp16_engine(self):
+        """Context manager: inside it this engine has the attributes of an fp16 engine (kernel precision, storage type of
+        new buffers, operand planes) -- the backward pass of 'h3f' is literally the fp16 mode's."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            names = ("prec", "prec_bwd", "act_dtype", "planes", "planes_arg", "is16", "is_hp", "lds_dma", "pk")
+            old = {n: getattr(self, n) for n in names}
+            self.prec = self.prec_bwd = hip.PREC_FP16
+            self.act_dtype, self.planes, self.planes_arg = torch.float16, 1, hip.PLANES_FP16
+            self.is16, self.is_hp, self.lds_dma, self.pk = True, False, True, self.pk16
+            try:
+                yield
+            finally:
+                for n, v in old.items():
+                    setattr(self, n, v)
+        return ctx()
 
     # ------------------------------------------------------------------------------------------
     # backward
@@ -1170,6 +1269,12 @@ class UNetEngine:
 
         on_ready(lo, hi): called when flat_g[lo:hi] is final (see grad_ranges) so that the gradient
         exchange of that range can start while the rest of the backward pass runs."""
+        if self.bwd16 and self.prec != hip.PREC_FP16:
+            with self._as_fp16_engine():
+                return self._backward(dlogits, on_ready, before_join)
+        return self._backward(dlogits, on_ready, before_join)
+
+    def _backward(self, dlogits, on_ready=None, before_join=None):
         ranges = self.grad_ranges() if on_ready is not None else None
         s = self.saved
         if s is None:

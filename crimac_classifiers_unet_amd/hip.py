@@ -19,8 +19,11 @@ PREC_F32X6 = 2
 PREC_FP16 = 3
 PREC_F32H3 = 4
 PREC_H3P = 5             # pre-split fp16 plane pairs (CRIMAC_PREC_H3P): F32H3's arithmetic on the LDS-DMA kernels
+# 'h3f': the forward pass of 'h3p' (same kernels, same bits) with the BACKWARD pass on the fp16 kernels -- an engine-level
+# mode (engine.py), not a kernel precision: forward launches carry PREC_H3P, backward launches PREC_FP16
 PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16, "f32h3": PREC_F32H3,
-              "h3p": PREC_H3P}
+              "h3p": PREC_H3P, "h3f": PREC_H3P}
+MFMAS_PER_PRODUCT = {PREC_BF16: 1, PREC_FP16: 1, PREC_F32X3: 3, PREC_F32H3: 3, PREC_H3P: 3, PREC_F32X6: 6}
 PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1, PREC_F32H3: 2, PREC_H3P: 2}   # 16-bit planes per operand
 # `planes` argument of the packing entry points (CRIMAC_PLANES_* of the header): bits 0-3 planes, bit 4 / 5 forward /
 # input-gradient planes in IEEE half, bits 8-15 log2 of the scale on the forward planes
@@ -98,6 +101,7 @@ SIGNATURES = {
     "crimac_refine_labels": [_vp, _i, _vp, _vp, _i, _f, _f, _i, _vp, _i, _i, _i, _i, _vp],
     "crimac_pr_histogram": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_mfma_calibrate": [_i, _i, _vp, _vp],
+    "crimac_shadow_fp16": [_vp, _i, _vp],
     "crimac_labels_test_transform": [_vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i,
                                      _i, _i],
     "crimac_scatter_patches": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i,
@@ -120,6 +124,11 @@ class WgradGroupLayer(C.Structure):
 
 
 WGRAD_GROUP_MAX_LAYERS = 16      # CRIMAC_WGRAD_GROUP_MAX_LAYERS
+
+
+class ShadowDesc(C.Structure):
+    """crimac_shadow_desc: one tensor of a crimac_shadow_fp16 call."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("n_elems", _l), ("kind", _i)]
 
 _lib = None
 
@@ -218,13 +227,16 @@ class Act:
 PROFILE = None
 
 
-def call(name: str, *args, flops=None):
+def call(name: str, *args, flops=None, mfmas=1):
+    """``flops``: algorithmic FLOPs of the launch (profiled launches only); ``mfmas``: MFMAs the kernel spends per
+    algorithmic product (1 for 16-bit operands, 3 for plane pairs ...): flops * mfmas is what the MFMA pipe executes, the
+    figure a roofline against the dense 16-bit peak needs when one step mixes precisions ('h3f')."""
     lib = load_library()
     if PROFILE is not None and flops is not None:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         _check(getattr(lib, name)(*args, _stream()), name)
         e.record()
-        PROFILE.append((name, flops, s, e))
+        PROFILE.append((name, flops, s, e, mfmas))
         return
     _check(getattr(lib, name)(*args, _stream()), name)

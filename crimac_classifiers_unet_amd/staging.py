@@ -39,7 +39,8 @@ class BatchStager:
     (the ring records an event on the caller's stream when the next batch is asked for, i.e. after the step that used
     them was enqueued)."""
 
-    def __init__(self, dataloader, device, keys=("data", "labels")):
+    def __init__(self, dataloader, device, keys=("data", "labels"), stats=None):
+        self.stats = stats                   # dict: seconds spent per phase (diagnostics: tools/diag_train_loop.py)
         self.dataloader = dataloader
         self.device = torch.device(device)
         self.keys = keys
@@ -54,18 +55,42 @@ class BatchStager:
 
     # -- host thread: DataLoader -> pinned ------------------------------------------------------------------------
     def _ensure(self, slot, data, labels):
-        if (slot.data_pin is None or slot.data_pin.shape != data.shape or slot.data_pin.dtype != data.dtype):
-            slot.data_pin = torch.empty(data.shape, dtype=data.dtype).pin_memory()
-            slot.data_dev = torch.empty(data.shape, dtype=data.dtype, device=self.device)
-        if labels is not None and (slot.lab_pin is None or slot.lab_pin.shape != labels.shape
-                                   or slot.lab_pin.dtype != labels.dtype):
-            slot.lab_pin = torch.empty(labels.shape, dtype=labels.dtype).pin_memory()
-            slot.lab_dev = torch.empty(labels.shape, dtype=labels.dtype, device=self.device)
+        # The device buffers are allocated ON THE COPY STREAM: the caching allocator hands a block that was freed on a
+        # stream back to allocations on that stream at once (later work of the stream is ordered behind its last use).
+        # Allocated on the default stream, a ring buffer could be the block of a temporary the training stream's kernels
+        # were still reading (the `.float()` copy of a float64 batch) -- and the upload, which runs on the copy stream,
+        # is NOT ordered behind them: the first steps trained on half-overwritten crops (caught by
+        # tests/test_gpu_unet.py::test_train_model_pinned_input_ring_equals_the_inline_copy with DataLoader workers).
+        with torch.cuda.stream(self.copy_stream):
+            if (slot.data_pin is None or slot.data_pin.shape != data.shape or slot.data_pin.dtype != data.dtype):
+                slot.data_pin = torch.empty(data.shape, dtype=data.dtype).pin_memory()
+                slot.data_dev = torch.empty(data.shape, dtype=data.dtype, device=self.device)
+            if labels is not None and (slot.lab_pin is None or slot.lab_pin.shape != labels.shape
+                                       or slot.lab_pin.dtype != labels.dtype):
+                slot.lab_pin = torch.empty(labels.shape, dtype=labels.dtype).pin_memory()
+                slot.lab_dev = torch.empty(labels.shape, dtype=labels.dtype, device=self.device)
+
+    def _note(self, key, t0):
+        if self.stats is not None:
+            import time
+            self.stats[key] = self.stats.get(key, 0.0) + time.perf_counter() - t0
 
     def _producer(self):
+        import time
         try:
-            for i, batch in enumerate(self.dataloader):
+            it = iter(self.dataloader)
+            i = -1
+            while True:
+                t0 = time.perf_counter()
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    break
+                i += 1
+                self._note("producer_next_s", t0)
+                t0 = time.perf_counter()
                 k = self._free.get()
+                self._note("producer_wait_slot_s", t0)
                 if self._stop:
                     return
                 slot = self.slots[k]
@@ -78,10 +103,14 @@ class BatchStager:
                 if slot.used:
                     slot.uploaded.synchronize()          # the previous upload out of this pinned slot has finished
                 self._ensure(slot, data, labels)
+                t0 = time.perf_counter()
                 np.copyto(slot.data_pin.numpy(), data.contiguous().numpy())      # memcpy, GIL released
                 if labels is not None:
                     np.copyto(slot.lab_pin.numpy(), labels.contiguous().numpy())
+                self._note("producer_copy_s", t0)
+                t0 = time.perf_counter()
                 self._q.put((i, k, batch, labels is not None))
+                self._note("producer_wait_queue_s", t0)
                 if self._stop:
                     return
         except BaseException as e:                        # surfaced in the consumer
@@ -96,8 +125,11 @@ class BatchStager:
         main = torch.cuda.current_stream(self.device)
         prev = None
         try:
+            import time
             while True:
+                t0 = time.perf_counter()
                 item = self._q.get()
+                self._note("consumer_wait_batch_s", t0)
                 if prev is not None:
                     # the step that used the previous slot has been enqueued on the caller's stream by now
                     self.slots[prev].consumed.record(main)

@@ -518,6 +518,19 @@ int crimac_labels_test_transform(const void* labels_in, int label_bytes, const f
                                  int mask_pings, int n_range, int seabed_pad, int seabed_rule, int overlap,
                                  short* labels_out, int B, int C, int H, int W, void* stream);
 
+/* fp16 copies of forward tensors for the backward pass of precision 'h3f' (plane-pair forward == CRIMAC_PREC_H3P, backward
+ * on the CRIMAC_PREC_FP16 kernels): all tensors of a step in one launch.  kind 0: src fp32 -> dst fp16 (round to nearest
+ * even); kind 1: src fp16 plane pairs ([8 hi | 8 lo] per 8-channel group, addressed like fp32) -> dst = the hi plane
+ * (which is the fp16 rounding of the values).  Tensors are contiguous, n_elems % 8 == 0, 16-byte aligned; descs is a
+ * HOST array read during the call (at most 96 entries).  The reference has no counterpart (it trains in fp32). */
+typedef struct crimac_shadow_desc {
+  const void* src;
+  void* dst;
+  long n_elems;
+  int kind;
+} crimac_shadow_desc;
+int crimac_shadow_fp16(const crimac_shadow_desc* descs, int n, void* stream);
+
 /* ---- measurement support (bench.py only, not on the product path) --------------------------- */
 
 /* MFMA-only calibration launch: `blocks` workgroups of 4 waves each issue iters x 8 v_mfma_f32_16x16x32_bf16 on
