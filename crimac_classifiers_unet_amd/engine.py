@@ -214,7 +214,7 @@ class UNetEngine:
         dev = self.device
         i16 = torch.int16
         self._ltab = None
-        self.pk = {}      # train-mode operand planes
+        self.pk = self.pk_main = {}      # train-mode operand planes (pk_main: the forward personality's, whatever self.pk is)
         self.pk_eval = {}  # eval-mode (BN folded) forward planes + folded bias
         self.dw_plan = None       # (B, H, W) the partial-sum workspace of the weight gradients is laid out for
         self.dw_off = {}          # layer key -> (first float, slabs, floats per slab) in self.dw_packed
@@ -387,7 +387,7 @@ class UNetEngine:
         for d, l in zip(arr, layers):
             up = isinstance(l, _UpConv)
             key = l.key if up else l.conv_key
-            pk = self.pk[key]
+            pk = self.pk_main[key]                    # (never the fp16 personality's planes of an h3f backward pass)
             cin_pad = l.cin if up else l.cin_pad
             n = (4 if up else 9) * l.cout * cin_pad
             d.w = self.P[key + ".weight"].data_ptr()
@@ -541,7 +541,7 @@ class UNetEngine:
         self._wg_launches += 1
         flops = sum(q["flops"] for q in pend)
         args = (self.prec_bwd, C.byref(arr), len(pend), B, ptr(items_dev), cap, C.byref(counts), ctr)
-        self._on_side(lambda: call("crimac_wgrad_group", *args, flops=flops))
+        self._on_side(lambda: call("crimac_wgrad_group", *args, flops=flops, mfmas=hip.MFMAS_PER_PRODUCT[args[0]]))
 
     def _on_side(self, fn):
         """Run ``fn`` (kernel launches) on the weight-gradient side stream, ordered after everything queued on the
@@ -575,7 +575,7 @@ class UNetEngine:
         else:
             name, args = "crimac_wgrad", (prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, ptr(dwt),
                                           self.wgrad_target_blocks)
-        self._on_side(lambda: call(name, *args, flops=flops))
+        self._on_side(lambda: call(name, *args, flops=flops, mfmas=hip.MFMAS_PER_PRODUCT[prec]))
 
     def _join_wgrad(self):
         if self._side is not None:
@@ -697,16 +697,16 @@ class UNetEngine:
             if cols is not None:                      # a range of the output channels (crimac_conv3x3_cols)
                 call("crimac_conv3x3_cols", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
                      out.p, out.ld, relu, mode, s0, s1, reps, by, by_ld, bvec, self.cmax,
-                     cols[0], cols[1], flops=flops * cols[1] / cout)
+                     cols[0], cols[1], flops=flops * cols[1] / cout, mfmas=hip.MFMAS_PER_PRODUCT[prec])
                 return mode != 0
             call("crimac_conv3x3", prec, x.p, x.ld, B, H, W, cin, cout, w_hi, w_lo, ptr(bias),
                  out.p, out.ld, relu, mode, s0, s1, reps, by, by_ld, bvec, self.cmax,
-                 flops=flops)
+                 flops=flops, mfmas=hip.MFMAS_PER_PRODUCT[prec])
             return mode != 0
         if self.is_hp:
             raise NotImplementedError("precision 'h3p' runs on the halo convolution kernels only (CRIMAC_CONV_IMPL=halo)")
         call("crimac_igemm_conv", prec, x.p, x.ld, B, H, W, H, W, cin, cout, 9, 3, 1, 1, w_hi, w_lo,
-             ptr(bias), cout, out.p, out.ld, relu, 0, 0, flops=flops)
+             ptr(bias), cout, out.p, out.ld, relu, 0, 0, flops=flops, mfmas=hip.MFMAS_PER_PRODUCT[prec])
         if stats:
             call("crimac_colstats", self.prec, out.p, out.ld, B * H * W, cout, ptr(stats[0]), ptr(stats[1]))
             return True
@@ -724,7 +724,8 @@ class UNetEngine:
         pk = self.pk[u.key]
         call("crimac_igemm_conv", self.prec, x.p, x.ld, B, H, W, H, W, u.cin, 4 * u.cout, 1, 1, 0, 1,
              ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), ptr(self.P[u.key + ".bias"]), u.cout, out.p, out.ld,
-             hip.EPI_OUT_PLANES if self.is_hp else 0, 1, u.cout, flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+             hip.EPI_OUT_PLANES if self.is_hp else 0, 1, u.cout, flops=2.0 * 4 * u.cin * u.cout * B * H * W,
+             mfmas=hip.MFMAS_PER_PRODUCT[self.prec])
 
     def _upconv_dgrad(self, dy: Act, u, out: Act, B, H, W, next_bn=None):
         """dy on the fine grid [B,2H,2W,cout] -> dx on the coarse grid [B,H,W,cin].
@@ -738,7 +739,7 @@ class UNetEngine:
             blk, y = next_bn
             call("crimac_upconv2x2_dgrad_bnb_prec", self.prec, dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]),
                  out.p, out.ld,
-                 *self._bnb_args(blk, y), flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+                 *self._bnb_args(blk, y), flops=2.0 * 4 * u.cin * u.cout * B * H * W, mfmas=hip.MFMAS_PER_PRODUCT[self.prec])
             return True
         self._upconv_dgrad_plain(dy, u, out, B, H, W)
         return False
@@ -747,7 +748,7 @@ class UNetEngine:
         pk = self.pk[u.key]
         call("crimac_igemm_conv", self.prec_bwd, dy.p, dy.ld, B, 2 * H, 2 * W, H, W, u.cout, u.cin, 4, 2, 0,
              2, ptr(pk["dg_hi"]), ptr(pk["dg_lo"]), None, 0, out.p, out.ld, 0, 0, 0,
-             flops=2.0 * 4 * u.cin * u.cout * B * H * W)
+             flops=2.0 * 4 * u.cin * u.cout * B * H * W, mfmas=hip.MFMAS_PER_PRODUCT[self.prec_bwd])
 
     # SyncBN (optional, N > 1): BatchNorm statistics over the GLOBAL batch.  Per BN layer one all-reduce of
     # (sum y, sum y^2) [2 x cmax fp64] in the forward pass and one of (sum dz, sum dz*xhat) in the backward
@@ -987,7 +988,7 @@ class UNetEngine:
                     call("crimac_conv3x3_pool", self.prec, a1.p, a1.ld, B, h, w, c, c, ptr(pe2["fwd_hi"]),
                          ptr(pe2["fwd_lo"]), ptr(pe2["bias"]), a2.p, a2.ld,
                          hip.EPI_RELU | (hip.EPI_OUT_PLANES if self.is_hp else 0), pool.p, pool.ld,
-                         flops=2.0 * 9 * c * c * B * h * w)
+                         flops=2.0 * 9 * c * c * B * h * w, mfmas=hip.MFMAS_PER_PRODUCT[self.prec])
                 else:
                     self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True, out_planes=True)
                     if pool is not None:

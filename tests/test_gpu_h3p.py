@@ -640,3 +640,93 @@ def test_reproducible_weight_gradients_in_h3p(shape):
             outs.append(grad.cpu())
         assert torch.equal(outs[-1], outs[-2])
         assert relerr(outs[-1], ref) < 2 * TOL
+
+
+# ---- 'h3f': the plane-pair forward pass with the backward pass on the fp16 kernels ------------------------------------------
+def _model_f(seed=0):
+    m = pkg.UNet_Baseline(3, 4, precision="h3f")
+    m.load_state_dict(synth.synth_state_dict(seed=seed))
+    return m.cuda()
+
+
+def test_h3f_forward_is_h3p_bit_for_bit_and_gradients_meet_the_h3p_bar(golden_dir):
+    """precision 'h3f': (1) eval logits are IDENTICAL to 'h3p' (bit for bit), train-mode logits, loss and BatchNorm running
+    statistics equal to fp32 rounding -- the same kernels on the same operands; (2) every gradient of the golden training step is within the tolerance the
+    all-plane-pair backward pass is held to (max(6 x the reference's own fp32-vs-fp64 noise, 3e-3)), norms included;
+    (3) no step is skipped at the default loss scale."""
+    import re
+    pre_bn_bias = re.compile(r"(down_convs\.\d+\.main\.[03]|up_convs\.\d+\.conv[12])\.bias")
+    fix = np.load(os.path.join(golden_dir, "full64_256.npz"))
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 256, 256, seed=1)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(2, 256, 256, seed=2)).cuda()
+    mf, mp = _model_f().eval(), _model().eval()
+    with torch.no_grad():
+        assert torch.equal(mf(x), mp(x))
+    crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+    out = {}
+    for name, m in (("h3f", mf), ("h3p", mp)):
+        m.train()
+        logits = m(x)
+        loss = crit(logits, lab.long())
+        loss.backward()
+        out[name] = (logits.detach().clone(), float(loss), {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    # (train mode: the BatchNorm statistics are added up by atomics in arrival order, so two runs of the SAME precision
+    # differ in the last bits too -- equal to fp32 rounding, not bit for bit)
+    assert _rel(out["h3f"][0], out["h3p"][0]) < 2e-6 and abs(out["h3f"][1] - out["h3p"][1]) <= 1e-6 * abs(out["h3p"][1])
+    for k, v in out["h3p"][2].items():
+        assert _rel(out["h3f"][2][k], v) < 1e-6, k
+    worst, worst_p = 0.0, 0.0
+    for (k, p), (_, q) in zip(mf.named_parameters(), mp.named_parameters()):
+        if pre_bn_bias.fullmatch(k):
+            continue
+        gn, noise = float(fix["gnorm/" + k]), float(fix["gnoise/" + k])
+        tol = max(6 * noise, 3e-3)
+        g_ = p.grad.detach().cpu()
+        assert abs(float(g_.double().norm()) - gn) <= tol * gn, (k, float(g_.double().norm()), gn)
+        if "grad/" + k in fix.files:
+            r = _l2(g_, fix["grad/" + k])
+            worst = max(worst, r / tol)
+            worst_p = max(worst_p, _l2(q.grad.detach().cpu(), fix["grad/" + k]) / tol)
+            assert r < tol, (k, r, tol)
+    print(f"worst gradient L2-rel / tolerance: h3f {worst:.3f}, h3p {worst_p:.3f}")
+    assert mf.engine.skipped_steps() == 0
+
+
+def test_h3f_training_trajectory_and_other_shapes():
+    """Three fused h3f steps track the reference golden trajectory like h3p's; a ragged, deeper-than-default case and a
+    wide one run against the oracle (loss + four gradients), so every shadow / personality seam sees odd shapes."""
+    from oracle import unet_oracle as orc
+    fix = np.load(os.path.join(os.path.dirname(__file__), "golden", "full64_256.npz"))
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 256, 256, seed=1)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(2, 256, 256, seed=2)).cuda()
+    m = _model_f().train()
+    eng = m.engine
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    losses = [float(eng.train_step(x, lab, cw, lr=0.005, momentum=0.95)) for _ in range(3)]
+    print("h3f losses", losses, "golden", fix["losses"].tolist())
+    assert eng.skipped_steps() == 0
+    for a, b in zip(losses, fix["losses"]):
+        assert abs(a - float(b)) < 2e-3 * abs(float(b))
+    # eval after training steps: the follower planes were re-packed (forward personality), logits finite
+    m.eval()
+    with torch.no_grad():
+        assert bool(torch.isfinite(m(x)).all())
+    for cfg in (dict(depth=3, in_channels=6, batch=3, hw=(48, 80)), dict(depth=4, start_filts=128, batch=1, hw=(32, 32))):
+        depth, cin, sf = cfg.get("depth", 5), cfg.get("in_channels", 4), cfg.get("start_filts", 64)
+        B, (H, W) = cfg["batch"], cfg["hw"]
+        sd = synth.synth_state_dict(in_channels=cin, depth=depth, start_filts=sf, seed=9)
+        xx = torch.from_numpy(synth.synth_echogram_batch(B, cin, H, W, seed=91))
+        ll = torch.from_numpy(synth.synth_labels(B, H, W, seed=92))
+        mm = pkg.UNet_Baseline(3, cin, depth=depth, start_filts=sf, precision="h3f")
+        mm.load_state_dict(sd)
+        mm.cuda().train()
+        ref_loss, ref_logits, ref_grads, _ = orc.loss_and_grads(sd, xx, ll)
+        crit = pkg.WeightedCrossEntropy([10.0, 300.0, 250.0]).cuda()
+        logits = mm(xx.cuda())
+        loss = crit(logits, ll.long().cuda())
+        loss.backward()
+        assert _rel(logits.detach(), ref_logits) < 1e-4 and abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+        g = {k: p.grad for k, p in mm.named_parameters()}
+        for k in ("conv_final.weight", "down_convs.0.main.0.weight", f"down_convs.{depth - 1}.main.3.weight", "up_convs.0.upconv.weight"):
+            assert _l2(g[k], ref_grads[k]) < 5e-2, (cfg, k, _l2(g[k], ref_grads[k]))
+        assert mm.engine.skipped_steps() == 0
