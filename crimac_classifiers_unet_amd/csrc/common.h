@@ -197,6 +197,7 @@ __host__ __device__ inline long il_pos(int c, int K) {
     if ((prec) == CRIMAC_PREC_BF16) { using TF = bf16_t; using TP = bf16_t; __VA_ARGS__; } \
     else if ((prec) == CRIMAC_PREC_FP16) { using TF = half_t; using TP = half_t; __VA_ARGS__; } \
     else if ((prec) == CRIMAC_PREC_H3P) { using TF = float; using TP = hp_t; __VA_ARGS__; } \
+    else if ((prec) == CRIMAC_PREC_H3F_BWD) { using TF = float; using TP = half_t; __VA_ARGS__; } \
     else { using TF = float; using TP = float; __VA_ARGS__; }                             \
   } while (0)
 

@@ -308,6 +308,8 @@ int launch(ConvParams p, hipStream_t st) {
 }  // namespace
 
 // conv3x3_glds.hip: 16-bit-storage direct-to-LDS variants (fp16 != 0: IEEE half, else bf16)
+int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
+                                  const EpiParams& epi, hipStream_t st, int n_first, int n_count);
 int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
                            const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16);
 int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
@@ -337,6 +339,29 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
                        int stat_replicas, const void* bnb_y, long bnb_y_ld, const float* bnb_vec,
                        long bnb_stride, int n_first, int n_count, void* stream, void* pool_out = nullptr,
                        long pool_ld = 0) {
+  if (prec == CRIMAC_PREC_H3F_BWD) {
+    // the backward pass of 'h3f': fp16 operands.  With CRIMAC_EPI_OUT_PLANES the output is an MFMA operand too (the up half
+    // of a decoder block's d(concat)): fp16 in, fp16 out -- the fp16 mode's launch; otherwise fp32 out
+    CRIMAC_REQUIRE(!pool_out && Cin > 0 && Cin % 64 == 0 && N > 0 && N % 64 == 0 && in && w_hi && out && B > 0 && H > 0 && W > 0,
+                   "conv3x3 (H3F_BWD): Cin, N multiples of 64 (got %d, %d)", Cin, N);
+    if (relu & CRIMAC_EPI_OUT_PLANES)
+      return conv3x3_run(CRIMAC_PREC_FP16, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld, relu & CRIMAC_EPI_RELU,
+                         stat_mode, stat_sum, stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, n_first,
+                         n_count, stream);
+    CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0, "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
+    CRIMAC_REQUIRE(stat_mode >= 0 && stat_mode <= 2 && (stat_mode == 0 || (stat_sum && stat_sumsq && stat_replicas >= 1)),
+                   "conv3x3: stat_mode %d needs both accumulators and replicas >= 1", stat_mode);
+    CRIMAC_REQUIRE(stat_mode != 2 || (bnb_y && bnb_vec && bnb_y_ld >= N && bnb_y_ld % 8 == 0 && bnb_stride >= N),
+                   "conv3x3: stat_mode 2 needs y, its pixel stride and the BatchNorm vectors");
+    CRIMAC_REQUIRE(n_first >= 0 && n_count > 0 && n_first + n_count <= N, "conv3x3_cols: bad channel range");
+    EpiParams e{};
+    e.bias = bias; e.out = out; e.out_ld = out_ld; e.relu = relu & CRIMAC_EPI_RELU; e.H = H; e.W = W; e.N = N;
+    e.stat_mode = stat_mode; e.stat_sum = stat_mode ? stat_sum : nullptr; e.stat_sumsq = stat_sumsq;
+    e.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
+    e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
+    e.acc_scale = 1.f;
+    return crimac_conv3x3_glds_16_f32out(in, in_ld, B, H, W, Cin, N, w_hi, e, (hipStream_t)stream, n_first, n_count);
+  }
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0 && pool_ld >= N && pool_ld % 8 == 0 && stat_mode == 0 &&
                                n_first == 0 && n_count == N && !(Cin == 16 && N == 64)),

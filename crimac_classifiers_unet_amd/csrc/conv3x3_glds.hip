@@ -1442,6 +1442,25 @@ int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int 
   return out_planes ? launch_w4<64, half_t, hp_t, true>(p, st) : launch_w4<64, half_t, float, true>(p, st);
 }
 
+// CRIMAC_PREC_H3F_BWD: fp16 input and weights (1 MFMA per product), fp32 output -- the input-gradient convolutions of the
+// 'h3f' mode (their output `da` feeds elementwise kernels that decide ReLU masks and pool positions on fp32 values, and the
+// fused BatchNorm-backward sums read the forward pass's fp32 y).  The same kernel forms as the 16-bit modes; 64-channel
+// ranges take the tall form (the persistent 64 -> 64 kernel has no fp32 output).
+int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
+                                  const EpiParams& epi, hipStream_t st, int n_first, int n_count) {
+  ConvParams p;
+  p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
+  p.w_hi = (const unsigned short*)w_hi;
+  p.epi = epi;
+  p.n_first = n_first; p.n_count = n_count;
+  const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
+  if (n_count % 128 == 0 && n_first % 128 == 0)
+    return small ? launch_wch<half_t, float, false>(p, st) : launch_w4<128, half_t, float, false>(p, st);
+  CRIMAC_REQUIRE(n_first % 64 == 0 && n_count % 64 == 0, "conv3x3 (fp16 operands, fp32 output): channel range [%d, +%d) must be "
+                 "multiples of 64", n_first, n_count);
+  return small ? launch_wch<half_t, float, false, 2>(p, st) : launch_w4<64, half_t, float, false>(p, st);
+}
+
 // 16-bit storage, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
 int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
                            const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16) {

@@ -1179,6 +1179,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 #define ST ((hipStream_t)stream)
 #define PREC_OK(name) \
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, name ": bad precision %d", prec)
+// ... and the entry points that also take CRIMAC_PREC_H3F_BWD (da, y fp32 -> dy fp16)
+#define PREC_OK_BWD16(name) \
+  CRIMAC_REQUIRE((prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX) || prec == CRIMAC_PREC_H3F_BWD, name ": bad precision %d", prec)
 
 extern "C" int crimac_nchw_to_nhwc(int prec, const float* in, void* out, int B, int C, int H, int W,
                                    long ld, void* stream) {
@@ -1429,7 +1432,7 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
                                    const float* invstd, const double* sum_dz,
                                    const double* sum_dz_xhat, long M, long count, int C, void* dy, long dy_ld,
                                    float* dgamma, float* dbeta, float* dbias, void* stream) {
-  PREC_OK("bn_bwd_apply");
+  PREC_OK_BWD16("bn_bwd_apply");
   CRIMAC_REQUIRE(da && y && scale && shift && mean && invstd && sum_dz && sum_dz_xhat && dy && dgamma &&
                      dbeta && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (count == 0 || count >= M),
                  "bn_bwd_apply: bad arguments");
@@ -1458,7 +1461,7 @@ extern "C" int crimac_bn_bwd_apply_replicas(int prec, const void* da, long da_ld
                                             const float* bn_vec, long bn_stride, const double* sum_dz,
                                             const double* sum_dz_xhat, int replicas, long M, long count, int C,
                                             void* dy, long dy_ld, float* dgamma, float* dbeta, void* stream) {
-  PREC_OK("bn_bwd_apply_replicas");
+  PREC_OK_BWD16("bn_bwd_apply_replicas");
   CRIMAC_REQUIRE(da && y && bn_vec && bn_stride >= C && sum_dz && sum_dz_xhat && replicas >= 1 && dy && dgamma &&
                      dbeta && M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (count == 0 || count >= M),
                  "bn_bwd_apply_replicas: bad arguments");

@@ -313,61 +313,3 @@ extern "C" int crimac_unpack_wgrad_layers(const crimac_layer_desc* descs, int n_
   CRIMAC_REQUIRE(descs && n_layers > 0, "unpack_wgrad_layers: bad arguments");
   return run_layers(reinterpret_cast<const HostDesc*>(descs), n_layers, 1, 1, (hipStream_t)stream);
 }
-
-// ---- fp16 copies of saved forward tensors (precision 'h3f': plane-pair forward, fp16 backward) ---------------------------
-// The backward pass of 'h3f' runs on the 16-bit kernels: it reads the forward pass's conv outputs y (fp32) and activations
-// (fp16 plane pairs) as plain fp16 NHWC tensors.  One launch converts all of them: every tensor is contiguous, so both
-// conversions are flat -- fp32: 8 floats -> 8 halves (round to nearest even); plane pairs: the hi plane of an 8-channel
-// group IS the fp16 rounding of its values (common.h hp_split), so 32 bytes [8 hi | 8 lo] -> the 16 bytes of hi.
-namespace {
-constexpr int kMaxShadow = 96;
-struct ShadowTable {
-  const void* src[kMaxShadow];
-  void* dst[kMaxShadow];
-  long n8[kMaxShadow];         // 8-element groups
-  unsigned char kind[kMaxShadow];
-  int n;
-};
-__global__ __launch_bounds__(256) void shadow_fp16_kernel(ShadowTable tb) {
-  const int d = blockIdx.y;
-  const long n8 = tb.n8[d];
-  const int kind = tb.kind[d];
-  u32x4* dst = reinterpret_cast<u32x4*>(tb.dst[d]);
-  const u32x4* src = reinterpret_cast<const u32x4*>(tb.src[d]);
-  for (long g = blockIdx.x * 256L + threadIdx.x; g < n8; g += (long)gridDim.x * 256) {
-    if (kind == 1) {
-      dst[g] = __builtin_nontemporal_load(src + 2 * g);                  // the hi plane of the group
-    } else {
-      const u32x4 a = __builtin_nontemporal_load(src + 2 * g), b = __builtin_nontemporal_load(src + 2 * g + 1);
-      u32x4 o;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        o[j] = (unsigned)E16<half_t>::bits(__uint_as_float(a[2 * j])) | ((unsigned)E16<half_t>::bits(__uint_as_float(a[2 * j + 1])) << 16);
-        o[2 + j] = (unsigned)E16<half_t>::bits(__uint_as_float(b[2 * j])) | ((unsigned)E16<half_t>::bits(__uint_as_float(b[2 * j + 1])) << 16);
-      }
-      dst[g] = o;
-    }
-  }
-}
-}  // namespace
-
-extern "C" int crimac_shadow_fp16(const crimac_shadow_desc* descs, int n, void* stream) {
-  CRIMAC_REQUIRE(descs && n > 0 && n <= kMaxShadow, "shadow_fp16: 1..%d tensors per call (got %d)", kMaxShadow, n);
-  ShadowTable tb;
-  tb.n = n;
-  long biggest = 0;
-  for (int i = 0; i < n; ++i) {
-    CRIMAC_REQUIRE(descs[i].src && descs[i].dst && descs[i].n_elems > 0 && descs[i].n_elems % 8 == 0 &&
-                       (descs[i].kind == 0 || descs[i].kind == 1),
-                   "shadow_fp16: tensor %d: bad descriptor (n_elems=%ld kind=%d)", i, descs[i].n_elems, descs[i].kind);
-    CRIMAC_REQUIRE(((uintptr_t)descs[i].src % 16 == 0) && ((uintptr_t)descs[i].dst % 16 == 0), "shadow_fp16: tensor %d: 16-byte alignment", i);
-    tb.src[i] = descs[i].src; tb.dst[i] = descs[i].dst; tb.n8[i] = descs[i].n_elems / 8; tb.kind[i] = (unsigned char)descs[i].kind;
-    if (tb.n8[i] > biggest) biggest = tb.n8[i];
-  }
-  long bx = (biggest + 256L * 8 - 1) / (256L * 8);      // ~8 groups per thread for the largest tensor
-  if (bx < 1) bx = 1;
-  if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(shadow_fp16_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream, tb);
-  CRIMAC_LAUNCH_CHECK();
-  return CRIMAC_OK;
-}

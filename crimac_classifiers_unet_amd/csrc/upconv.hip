@@ -322,17 +322,17 @@ bool crimac_upconv_wch_ok(int ntaps, long in_bytes, int K, int N, int cout_up, l
 }
 
 // fmt: 0 bf16, 1 fp16, 2 plane pairs in / plane pairs out, 3 plane pairs in / fp32 out (CRIMAC_PREC_H3P; K, in_ld in
-// ELEMENTS of the plane-pair tensor: the kernel sees twice as many halves)
+// ELEMENTS of the plane-pair tensor: the kernel sees twice as many halves), 4 fp16 in / fp32 out (CRIMAC_PREC_H3F_BWD)
 static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W, int K, int N, const void* w,
                       const float* bias, int cout_up, void* out, long out_ld, const EpiParams* bnb, hipStream_t st,
                       int fmt) {
   const int fp16 = fmt == 1;
-  if (fmt >= 2) { K *= 2; in_ld *= 2; }
+  if (fmt == 2 || fmt == 3) { K *= 2; in_ld *= 2; }          // (plane-pair input: twice as many halves)
   UpParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.ntaps = ntaps;
   p.w = (const unsigned short*)w; p.bias = bias; p.cout = cout_up; p.out = out; p.out_ld = out_ld;
   p.epi = EpiParams{};
-  p.epi.acc_scale = fmt >= 2 ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
+  p.epi.acc_scale = (fmt == 2 || fmt == 3) ? 1.f / (float)(1 << CRIMAC_F32H3_WSHIFT) : 1.f;
   p.epi.bias = nullptr; p.epi.out = out; p.epi.out_ld = out_ld; p.epi.relu = 0; p.epi.H = H; p.epi.W = W; p.epi.N = N;
   p.epi.stat_sum = nullptr; p.epi.stat_sumsq = nullptr; p.epi.stat_replicas = 1; p.epi.stat_mode = 0;
   if (bnb) {
@@ -345,6 +345,10 @@ static int upconv_run(int ntaps, const void* in, long in_ld, int B, int H, int W
     return launch<true, half_t, hp_t, true>(p, st);
   }
   if (fmt == 3) return ntaps == 1 ? launch<true, half_t, float, true>(p, st) : launch<false, half_t, float, true>(p, st);
+  if (fmt == 4) {
+    CRIMAC_REQUIRE(ntaps == 4, "upconv (fp16 operands, fp32 output): the input gradient only");
+    return launch<false, half_t, float, false>(p, st);
+  }
   if (fp16) return ntaps == 1 ? launch<true, half_t>(p, st) : launch<false, half_t>(p, st);
   return ntaps == 1 ? launch<true, bf16_t>(p, st) : launch<false, bf16_t>(p, st);
 }
@@ -372,8 +376,8 @@ extern "C" int crimac_upconv2x2_dgrad_bnb_prec(int prec, const void* dy, long dy
                                           const void* w_dg_hi, void* dx, long dx_ld, const void* bnb_y,
                                           long bnb_y_ld, const float* bnb_vec, long bnb_stride, double* stat_sum,
                                           double* stat_sumsq, int stat_replicas, void* stream) {
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16 || prec == CRIMAC_PREC_H3P,
-                 "upconv2x2_dgrad_bnb: 16-bit storage modes and plane pairs only (prec=%d)", prec);
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16 || prec == CRIMAC_PREC_H3P || prec == CRIMAC_PREC_H3F_BWD,
+                 "upconv2x2_dgrad_bnb: 16-bit storage modes, plane pairs and H3F_BWD only (prec=%d)", prec);
   const bool hp = prec == CRIMAC_PREC_H3P;
   CRIMAC_REQUIRE(dy && w_dg_hi && dx && B > 0 && H > 0 && W > 0, "upconv2x2_dgrad_bnb: bad arguments");
   CRIMAC_REQUIRE(dy_ld >= Cout && dy_ld % 8 == 0 && dx_ld >= Cin && dx_ld % 8 == 0,
@@ -390,7 +394,7 @@ extern "C" int crimac_upconv2x2_dgrad_bnb_prec(int prec, const void* dy, long dy
   e.stat_sum = stat_sum; e.stat_sumsq = stat_sumsq; e.stat_replicas = stat_replicas;
   e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
   return upconv_run(4, dy, dy_ld, B, H, W, Cout, Cin, w_dg_hi, nullptr, 0, dx, dx_ld, &e, (hipStream_t)stream,
-                    hp ? 3 : (prec == CRIMAC_PREC_FP16 ? 1 : 0));
+                    hp ? 3 : (prec == CRIMAC_PREC_H3F_BWD ? 4 : (prec == CRIMAC_PREC_FP16 ? 1 : 0)));
 }
 
 // bf16 form (kept for existing callers)

@@ -35,6 +35,10 @@ struct WgradParams {
   int tiles_per_block;
   int nsplits;
   long partial_stride;     // 0: dw += acc by fp32 atomics; > 0: plain stores into dw + split * partial_stride
+  // 16-bit kernels only: bytes per ELEMENT of each operand tensor.  2 = a 16-bit tensor; 4 (CRIMAC_PREC_H3F_BWD, the
+  // activation operand) = an fp16 plane-pair tensor of which the contraction takes the hi plane: the first 16 bytes of
+  // every 32-byte [8 hi | 8 lo] group -- the same lane -> 8-channel-unit map, addressed in 4-byte elements
+  int f_es = 2, s_es = 2;
 };
 
 __device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 1) << 6; }
@@ -799,7 +803,7 @@ void wgrad_kernel(WgradParams p) {
       const int u = c ^ (swz16(row) >> 4);
       int ry, rx;
       f_geo(i, ry, rx);
-      f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * 2) : OOB;
+      f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * p.f_es) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -809,7 +813,7 @@ void wgrad_kernel(WgradParams p) {
       int ry, rx;
       s_geo(i, ry, rx);
       const bool ok = k < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
-      s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * 2) : OOB;
+      s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * p.s_es) : OOB;
     }
     // an operand tile that only ONE channel tile of the other operand multiplies is read exactly once from memory:
     // non-temporal (it would only displace what other kernels keep in the caches); otherwise the default policy --
@@ -824,7 +828,8 @@ void wgrad_kernel(WgradParams p) {
       tile_origin(tile, b, y0, x0);
       unsigned char* base = smem + (team * 2 + buf) * BUF_BYTES;
       const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<TA*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+          const_cast<char*>(reinterpret_cast<const char*>(fp) + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld * p.f_es), 0,
+          0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         int ry, rx;
@@ -840,7 +845,8 @@ void wgrad_kernel(WgradParams p) {
       unsigned char* sbase = base + F_BYTES;
       const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0, sx0 = MODE == 0 ? x0 - 1 : 2 * x0;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<TA*>(sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+          const_cast<char*>(reinterpret_cast<const char*>(sp) + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld * p.s_es), 0,
+          0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
         const int k = wave + 4 * i;
@@ -1169,6 +1175,7 @@ struct GroupParams {
   int cap;
   int count[8];
   unsigned* counter;         // [8], zeroed by the caller before the launch
+  int f_es, s_es;            // bytes per element of the F (dY) / S (X) tensors: 2, or 4 = plane pairs, hi plane (WgradParams)
   int max_items;             // items a workgroup takes before it exits and gives its CU back (<= 0: until the queue is empty)
 };
 
@@ -1278,7 +1285,7 @@ void wgrad_group_kernel(GroupParams gp) {
         const int u = c ^ (swz16(row) >> 4);
         int ry, rx;
         f_geo(i, ry, rx);
-        f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * 2) : OOB;
+        f_rel[i] = (cf0 + u * 8) < p.CF ? (unsigned)(((ry * (long)p.Wf + rx) * p.f_ld + cf0 + u * 8) * gp.f_es) : OOB;
       }
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
@@ -1288,7 +1295,7 @@ void wgrad_group_kernel(GroupParams gp) {
         int ry, rx;
         s_geo(i, ry, rx);
         const bool ok = kk < S_ROWS_PAD / 8 && row < S_ROWS && (cs0 + u * 8) < p.CS;
-        s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * 2) : OOB;
+        s_rel[i] = ok ? (unsigned)(((ry * (long)Ws + rx) * p.s_ld + cs0 + u * 8) * gp.s_es) : OOB;
       }
       auto issue_tile = [&](long tile, int buf) {
         const int txi = (int)(tile % p.tiles_x);
@@ -1298,7 +1305,8 @@ void wgrad_group_kernel(GroupParams gp) {
         const int y0 = tyi * TR, x0 = txi * 16;
         unsigned char* base = smem + (team * 2 + buf) * BUF_BYTES;
         const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<TA*>(fp + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld), 0, 0x7FFFFFFF, 0x00020000);
+            const_cast<char*>(reinterpret_cast<const char*>(fp) + ((b * p.Hf + y0) * (long)p.Wf + x0) * p.f_ld * gp.f_es), 0,
+            0x7FFFFFFF, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
           int ry, rx;
@@ -1310,7 +1318,8 @@ void wgrad_group_kernel(GroupParams gp) {
         unsigned char* sbase = base + F_BYTES;
         const int sy0 = y0 - 1, sx0 = x0 - 1;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<TA*>(sp + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld), 0, 0x7FFFFFFF, 0x00020000);
+            const_cast<char*>(reinterpret_cast<const char*>(sp) + ((b * Hs + sy0) * (long)Ws + sx0) * p.s_ld * gp.s_es), 0,
+            0x7FFFFFFF, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
           const int kk = wave + 4 * i;
@@ -1703,6 +1712,13 @@ int teams_of(int prec, int mode) {
 
 int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* s, long s_ld, int CS, int B, int Hf,
               int Wf, float* dw, long partial_stride, int target_blocks, void* stream) {
+  const bool mix = prec == CRIMAC_PREC_H3F_BWD;
+  if (mix) {
+    // fp16 contraction; the ACTIVATION operand (S for the convolution, F for the transposed convolution) is an fp16
+    // plane-pair tensor read through its hi plane, the GRADIENT operand plain fp16
+    CRIMAC_REQUIRE(partial_stride == 0, "wgrad (H3F_BWD): the slab form is not available");
+    prec = CRIMAC_PREC_FP16;
+  }
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "wgrad: bad precision %d", prec);
   CRIMAC_REQUIRE(prec != CRIMAC_PREC_F32H3, "wgrad: F32H3 is a forward-operand mode (fp16 planes have no range for "
                  "unscaled gradients); call the backward kernels with CRIMAC_PREC_F32X3, or use CRIMAC_PREC_H3P");
@@ -1716,6 +1732,11 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
   WgradParams p;
   p.f = f; p.f_ld = f_ld; p.CF = CF; p.s = s; p.s_ld = s_ld; p.CS = CS;
   p.B = B; p.Hf = Hf; p.Wf = Wf; p.dw = dw; p.partial_stride = partial_stride;
+  if (mix) {
+    if (mode == 0) p.s_es = 4; else p.f_es = 4;
+    const long ldmax = f_ld > s_ld ? f_ld : s_ld;
+    CRIMAC_REQUIRE((20L * Wf + 64) * ldmax * 4 < (1L << 31), "wgrad (H3F_BWD): a tile's DMA offsets exceed 32 bits");
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool two = teams_of(prec, mode) == 2;
   if (prec == CRIMAC_PREC_BF16) {
@@ -1744,16 +1765,17 @@ int wgrad_run(int prec, int mode, const void* f, long f_ld, int CF, const void* 
 
 // ---- grouped launch: plan (host) and launch ------------------------------------------------------------------------------
 static int group_check(int prec, const crimac_wgrad_group_layer* L, int n, int B) {
-  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16 || prec == CRIMAC_PREC_H3P,
-                 "wgrad_group: 16-bit storage precisions and plane pairs only (prec=%d)", prec);
+  CRIMAC_REQUIRE(prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16 || prec == CRIMAC_PREC_H3P || prec == CRIMAC_PREC_H3F_BWD,
+                 "wgrad_group: 16-bit storage precisions, plane pairs and H3F_BWD only (prec=%d)", prec);
   const bool hp = prec == CRIMAC_PREC_H3P;
+  const bool mix = prec == CRIMAC_PREC_H3F_BWD;       // (S = the activation: plane pairs addressed in 4-byte elements)
   CRIMAC_REQUIRE(L && n >= 1 && n <= CRIMAC_WGRAD_GROUP_MAX_LAYERS && B > 0, "wgrad_group: 1..%d layers", CRIMAC_WGRAD_GROUP_MAX_LAYERS);
   for (int i = 0; i < n; ++i) {
     CRIMAC_REQUIRE(L[i].CF > 0 && L[i].CF % 8 == 0 && L[i].CS >= 64 && L[i].CS % 8 == 0, "wgrad_group: layer %d: CF=%d CS=%d "
                    "(CS >= 64: the first layer keeps its own launch)", i, L[i].CF, L[i].CS);
     CRIMAC_REQUIRE(L[i].f_ld >= L[i].CF && L[i].s_ld >= L[i].CS && L[i].f_ld % 8 == 0 && L[i].s_ld % 8 == 0 && L[i].Hf > 0 && L[i].Wf > 0,
                    "wgrad_group: layer %d: bad strides / sizes", i);
-    CRIMAC_REQUIRE((10L * L[i].Wf + 18) * (L[i].f_ld > L[i].s_ld ? L[i].f_ld : L[i].s_ld) * (hp ? 4 : 2) < (1L << 31),
+    CRIMAC_REQUIRE((10L * L[i].Wf + 18) * (L[i].f_ld > L[i].s_ld ? L[i].f_ld : L[i].s_ld) * ((hp || mix) ? 4 : 2) < (1L << 31),
                    "wgrad_group: layer %d: a tile's DMA offsets exceed 32 bits", i);
     CRIMAC_REQUIRE(!hp || (L[i].CF % 64 == 0 && L[i].CS % 64 == 0), "wgrad_group: layer %d: plane pairs need whole 64-channel "
                    "tiles (CF=%d CS=%d)", i, L[i].CF, L[i].CS);
@@ -1841,6 +1863,7 @@ extern "C" int crimac_wgrad_group(int prec, const crimac_wgrad_group_layer* laye
                    "wgrad_group: layer %d was not planned for this geometry (crimac_wgrad_group_plan)", i);
   }
   gp.B = B; gp.items = items; gp.cap = cap; gp.counter = counters;
+  gp.f_es = 2; gp.s_es = prec == CRIMAC_PREC_H3F_BWD ? 4 : 2;
   long total = 0;
   for (int x = 0; x < 8; ++x) {
     CRIMAC_REQUIRE(counts[x] >= 0 && counts[x] <= cap, "wgrad_group: queue %d holds %d items, capacity %d", x, counts[x], cap);
@@ -1878,7 +1901,7 @@ extern "C" int crimac_wgrad_group(int prec, const crimac_wgrad_group_layer* laye
     if (crimac_first_use_on_device(&attr_devs))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(wgrad_group_kernel<bf16_t>, dim3(ncu), dim3(512), lds, st, gp);
-  } else {
+  } else {                                 // fp16, and H3F_BWD (fp16 contraction, S read from plane pairs)
     static unsigned long long attr_devs = 0;
     if (crimac_first_use_on_device(&attr_devs))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

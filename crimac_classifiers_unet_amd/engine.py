@@ -99,12 +99,16 @@ class UNetEngine:
         # (h3p: the output gradients dy are fp16 PLANE PAIRS -- same range, 11 more bits -- and travel scaled likewise)
         self.loss_scale = 2.0 ** 16 if precision in ("fp16", "h3p", "h3f") else 1.0
         self.dynamic_loss_scale = precision in ("fp16", "h3p", "h3f")
-        # h3f: forward = h3p (plane pairs, 3 MFMAs per product: the logits, the loss and the BatchNorm statistics are h3p's,
-        # bit for bit); backward = the fp16 mode's (loss-scaled fp16 storage, 1 MFMA per product) on fp16 COPIES of the
-        # tensors the forward pass saved (crimac_shadow_fp16).  The parity bar of the north star is on the forward pass;
-        # gradients are held to the reference's own fp32-vs-fp64 noise (a few 1e-3), which an 11-bit backward pass on an
-        # exact forward pass meets -- at a third of the MFMAs and half the bytes of the plane-pair backward pass.
+        # h3f: forward = h3p (plane pairs, 3 MFMAs per product: the logits, the loss and the BatchNorm statistics are
+        # h3p's); in the backward pass only the MFMA OPERANDS drop to plain fp16 (1 MFMA per product): the output gradients
+        # dy are stored as fp16, the input-gradient weight planes are fp16, and the weight gradients read the hi plane of
+        # the plane-pair activations.  Everything the backward pass DECIDES on -- ReLU masks, xhat, max-pool positions --
+        # still comes from the forward pass's fp32 y, and activation gradients da stay fp32 (CRIMAC_PREC_H3F_BWD).  A
+        # first form that ran the whole fp16 backward pass on fp16 copies of y was 4e-2 off on the first layer's gradient:
+        # rounding y flips ReLU masks and pool positions (discrete errors), rounding a gradient does not.
         self.bwd16 = precision == "h3f"
+        if self.bwd16:
+            self.prec_bwd = hip.PREC_H3F_BWD
         self._scale_state = None            # int32[2] on the GPU: [overflow this step, steps skipped]
         self._skipped_seen = 0
         self._good_checks = 0
@@ -425,6 +429,10 @@ class UNetEngine:
             if self.bwd16:
                 call("crimac_pack_layers", C.byref(self._ltab16, first * C.sizeof(hip.LayerDesc)), n, hip.PLANES_FP16)
 
+    def _pk_bwd(self, key):
+        """Operand planes the backward pass's contractions read (h3f: the fp16 input-gradient planes)."""
+        return self.pk16[key] if self.bwd16 else self.pk[key]
+
     def _fwd_planes_arg(self):
         """`planes` of the forward personality (inside an h3f backward pass self.planes_arg is the fp16 personality's)."""
         return hip.PREC_PLANES_ARG[hip.PREC_NAMES[self.precision]]
@@ -499,7 +507,7 @@ class UNetEngine:
             return False
         if prec == hip.PREC_H3P:                      # plane pairs: whole 64 x 64 channel tiles
             return self.wgrad_group_h3p and cf % 64 == 0 and cs % 64 == 0
-        return prec in hip.PREC_16BIT
+        return prec in hip.PREC_16BIT or prec == hip.PREC_H3F_BWD
 
     def _group_plan(self, B, shapes):
         """Planned layer array, device copy of the 8 item queues, their lengths -- cached per geometry."""
@@ -732,15 +740,20 @@ class UNetEngine:
 
         next_bn=(block, y): dx is the ``da`` of that BatchNorm block -> take its backward sums in the epilogue
         (bf16 kernel shapes only).  Returns whether they were taken."""
-        pk = self.pk[u.key]
+        pk = self._pk_bwd(u.key)
+        hp_in = self.is_hp and not self.bwd16          # (dy is a plane-pair tensor: 8 bytes per element of halves)
+        prec = self.prec_bwd if self.bwd16 else self.prec
         if (next_bn is not None and self.fuse_bn_bwd and self.fuse_up_bnb and self.lds_dma
-                and u.cout % (32 if self.is_hp else 64) == 0 and u.cin % 128 == 0
-                and (16 if self.is_hp else 8) * B * H * W * dy.ld < (1 << 31)):
+                and u.cout % (32 if hp_in else 64) == 0 and u.cin % 128 == 0
+                and (16 if hp_in else 8) * B * H * W * dy.ld < (1 << 31)):
             blk, y = next_bn
-            call("crimac_upconv2x2_dgrad_bnb_prec", self.prec, dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]),
+            call("crimac_upconv2x2_dgrad_bnb_prec", prec, dy.p, dy.ld, B, H, W, u.cout, u.cin, ptr(pk["dg_hi"]),
                  out.p, out.ld,
-                 *self._bnb_args(blk, y), flops=2.0 * 4 * u.cin * u.cout * B * H * W, mfmas=hip.MFMAS_PER_PRODUCT[self.prec])
+                 *self._bnb_args(blk, y), flops=2.0 * 4 * u.cin * u.cout * B * H * W, mfmas=hip.MFMAS_PER_PRODUCT[prec])
             return True
+        if self.bwd16:
+            raise NotImplementedError("h3f: transposed-convolution shape outside the fused input-gradient kernel "
+                                      f"(Cout={u.cout} % 64, Cin={u.cin} % 128)")
         self._upconv_dgrad_plain(dy, u, out, B, H, W)
         return False
 
@@ -1049,70 +1062,10 @@ class UNetEngine:
                  ptr(self._bnf(head_bn, 2)) if head_bn is not None else None,
                  ptr(self._bnf(head_bn, 3)) if head_bn is not None else None)
         saved["head_in"] = cur if head_bn is None else None
-        if training and self.bwd16:
-            saved = self._shadow_saved(saved)
         self.saved = saved if training else None
         if training:
             self.forward_generation += 1
         return logits
-
-    # ------------------------------------------------------------------------------------------
-    # h3f: fp16 copies of the saved forward tensors, and the fp16 personality of the backward pass
-    # ------------------------------------------------------------------------------------------
-    def _shadow_saved(self, saved):
-        """The ``saved`` dictionary of a plane-pair training forward with every tensor replaced by its fp16 copy (one
-        crimac_shadow_fp16 launch): conv outputs y (fp32) are rounded, activations (plane pairs) give their hi plane."""
-        ys = set()
-        for k, v in saved.items():
-            if isinstance(v, tuple):
-                idx = (1, 3) if k.startswith("e") else (2, 4)
-                for i in idx:
-                    ys.add(id(v[i].t))
-        twins, descs = {}, []
-
-        def twin(a):
-            if a is None:
-                return None
-            t = a.t
-            if id(t) not in twins:
-                if not t.is_contiguous() or t.dtype != torch.float32 or t.numel() % 8:
-                    raise RuntimeError("h3f: a saved forward tensor is not a contiguous 4-byte-addressed buffer")
-                t16 = self._buf(f"s16.{len(twins)}", tuple(t.shape), torch.float16)
-                twins[id(t)] = t16
-                descs.append((t, t16, 0 if id(t) in ys else 1))
-            return Act(twins[id(t)], a.C, a.off, a.ld)
-        out = {}
-        for k, v in saved.items():
-            if isinstance(v, tuple):
-                out[k] = tuple(twin(a) for a in v)
-            elif isinstance(v, Act):
-                out[k] = twin(v)
-            else:
-                out[k] = v
-        arr = (hip.ShadowDesc * len(descs))()
-        for d, (t, t16, kind) in zip(arr, descs):
-            d.src, d.dst, d.n_elems, d.kind = t.data_ptr(), t16.data_ptr(), t.numel(), kind
-        call("crimac_shadow_fp16", C.byref(arr), len(descs))
-        return out
-
-    def _as_fp16_engine(self):
-        """Context manager: inside it this engine has the attributes of an fp16 engine (kernel precision, storage type of
-        new buffers, operand planes) -- the backward pass of 'h3f' is literally the fp16 mode's."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            names = ("prec", "prec_bwd", "act_dtype", "planes", "planes_arg", "is16", "is_hp", "lds_dma", "pk")
-            old = {n: getattr(self, n) for n in names}
-            self.prec = self.prec_bwd = hip.PREC_FP16
-            self.act_dtype, self.planes, self.planes_arg = torch.float16, 1, hip.PLANES_FP16
-            self.is16, self.is_hp, self.lds_dma, self.pk = True, False, True, self.pk16
-            try:
-                yield
-            finally:
-                for n, v in old.items():
-                    setattr(self, n, v)
-        return ctx()
 
     # ------------------------------------------------------------------------------------------
     # backward
@@ -1137,7 +1090,9 @@ class UNetEngine:
             call("crimac_bn_bwd_reduce", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
                  ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), M, b.cout,
                  ptr(self._stat(b, 2)), ptr(self._stat(b, 3)))
-        dy = Act(self._buf(f"{tag}.dy", (M, b.cout)), b.cout)
+        # (h3f: dy is an MFMA operand of the backward pass only -> plain fp16; da and y stay fp32)
+        dy = Act(self._buf(f"{tag}.dy", (M, b.cout), torch.float16 if self.bwd16 else None), b.cout)
+        prec_apply = self.prec_bwd if self.bwd16 else self.prec
         dgamma, dbeta = self.G[b.bn_key + ".weight"], self.G[b.bn_key + ".bias"]
         if world > 1:
             # gamma / beta gradients are this rank's LOCAL sums (the gradient exchange adds the ranks up); the
@@ -1151,11 +1106,11 @@ class UNetEngine:
         # (d(conv bias in front of train-mode BN) = sum dy == 0 exactly: left at the zero fill -- the reference holds
         # ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
         if folded:
-            call("crimac_bn_bwd_apply_replicas", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 0)), self.cmax,
+            call("crimac_bn_bwd_apply_replicas", prec_apply, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 0)), self.cmax,
                  ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), self._nrep(b.cout), M, M, b.cout, dy.p, dy.ld,
                  ptr(dgamma), ptr(dbeta))
         else:
-            call("crimac_bn_bwd_apply", self.prec, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
+            call("crimac_bn_bwd_apply", prec_apply, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 2)),
                  ptr(self._bnf(b, 3)), ptr(self._bnf(b, 0)), ptr(self._bnf(b, 1)), ptr(self._stat(b, 2)),
                  ptr(self._stat(b, 3)), M, M * world, b.cout, dy.p, dy.ld, ptr(dgamma), ptr(dbeta), None)
         self._wgrad(self.prec_bwd, 0, dy.p, dy.ld, b.cout, x_in.p, x_in.ld, b.cin_pad, B, h, w, b.conv_key,
@@ -1176,7 +1131,13 @@ class UNetEngine:
                 # gradients) -> plane pairs; the skip half is read by unpool_add -> fp32: always two launches
                 if stats is None or b.cin != 2 * C_up or C_up % 64 != 0:
                     raise NotImplementedError("h3p: decoder convolution shape outside the plane-pair kernels")
-                self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                dx_up = dx_out
+                if self.bwd16:
+                    # h3f: the up half is an fp16 operand (2-byte elements) -- a buffer of its own, not a slice of the
+                    # 4-byte-addressed d(concat) buffer
+                    dx_up = Act(self._buf(f"{tag}.dup16", (M, C_up), torch.float16), C_up)
+                    self._dup16[bias_from_stats[2]] = dx_up
+                self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_up, B, h, w, b.cout, b.cin, relu=False,
                               dgrad=True, stats=stats, cols=(0, C_up), out_planes=True)
                 if side_ok:
                     ev = self._side_events[self._side_i % len(self._side_events)]
@@ -1184,13 +1145,13 @@ class UNetEngine:
                     ev.record()
                     with torch.cuda.stream(side):
                         side.wait_event(ev)
-                        self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                        self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                       dgrad=True, cols=(C_up, C_up))
                         done = torch.cuda.Event()
                         done.record()
                     self._skip_done[bias_from_stats[2]] = done
                 else:
-                    self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                    self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                   dgrad=True, cols=(C_up, C_up))
                 fused = True
             elif (stats is not None and side_ok
@@ -1199,21 +1160,21 @@ class UNetEngine:
                 # decoder conv1: dx_out = d(concat [up | skip]).  The up half (and its column sums = the transposed
                 # convolution's bias gradient) is needed at once; the skip half only when the encoder level is
                 # reached -> side stream, off the critical path
-                self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                               dgrad=True, stats=stats, cols=(0, C_up))
                 ev = self._side_events[self._side_i % len(self._side_events)]
                 self._side_i += 1
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                    self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                   dgrad=True, cols=(C_up, C_up))
                     done = torch.cuda.Event()
                     done.record()
                 self._skip_done[bias_from_stats[2]] = done
                 fused = True
             else:
-                fused = self._conv3x3(dy, self.pk[b.conv_key], None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                fused = self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                       dgrad=True, stats=stats, bnb=next_bn if stats is None else None)
             if stats is not None:
                 grad, C = bias_from_stats[:2]
@@ -1270,12 +1231,6 @@ class UNetEngine:
 
         on_ready(lo, hi): called when flat_g[lo:hi] is final (see grad_ranges) so that the gradient
         exchange of that range can start while the rest of the backward pass runs."""
-        if self.bwd16 and self.prec != hip.PREC_FP16:
-            with self._as_fp16_engine():
-                return self._backward(dlogits, on_ready, before_join)
-        return self._backward(dlogits, on_ready, before_join)
-
-    def _backward(self, dlogits, on_ready=None, before_join=None):
         ranges = self.grad_ranges() if on_ready is not None else None
         s = self.saved
         if s is None:
@@ -1286,6 +1241,7 @@ class UNetEngine:
         self._skip_done = {}
         self._unpacked = {}
         self._wg_pending, self._wg_launches = [], 0
+        self._dup16 = {}
         self._plan_dw(B, H, W)
         self.flat_g.zero_()
         if not self.use_wgrad_partials:
@@ -1340,7 +1296,7 @@ class UNetEngine:
             # transposed conv bias gradient (unet.py:130) = column sums of dcat[:, :c]: from the dgrad epilogue
             self._block_bwd(f"g.d{j}.1", b1, da1, y1, catA, B, h, w, M, dcat, reduce_done=fused,
                             bias_from_stats=(self.G[u.key + ".bias"], c, j))
-            dup = dcat.slice(0, c)
+            dup = self._dup16.get(j) or dcat.slice(0, c)
             skip_grad[L] = dcat.slice(c, c)
             hp, wp, Mp = geo[L + 1]
             self._wgrad(self.prec_bwd, 1, x_prev.p, x_prev.ld, u.cin, dup.p, dup.ld, u.cout, B, hp, wp, u.key,

@@ -19,11 +19,12 @@ PREC_F32X6 = 2
 PREC_FP16 = 3
 PREC_F32H3 = 4
 PREC_H3P = 5             # pre-split fp16 plane pairs (CRIMAC_PREC_H3P): F32H3's arithmetic on the LDS-DMA kernels
-# 'h3f': the forward pass of 'h3p' (same kernels, same bits) with the BACKWARD pass on the fp16 kernels -- an engine-level
-# mode (engine.py), not a kernel precision: forward launches carry PREC_H3P, backward launches PREC_FP16
+PREC_H3F_BWD = 6         # CRIMAC_PREC_H3F_BWD: the backward pass of 'h3f' (fp16 MFMA operands, everything else as H3P)
+# 'h3f': the forward pass of 'h3p' (same kernels, same bits) with fp16 MFMA operands in the BACKWARD pass -- an engine-level
+# mode (engine.py): forward launches carry PREC_H3P, the backward pass's contractions and BatchNorm-backward PREC_H3F_BWD
 PREC_NAMES = {"bf16": PREC_BF16, "f32x3": PREC_F32X3, "f32x6": PREC_F32X6, "fp16": PREC_FP16, "f32h3": PREC_F32H3,
               "h3p": PREC_H3P, "h3f": PREC_H3P}
-MFMAS_PER_PRODUCT = {PREC_BF16: 1, PREC_FP16: 1, PREC_F32X3: 3, PREC_F32H3: 3, PREC_H3P: 3, PREC_F32X6: 6}
+MFMAS_PER_PRODUCT = {PREC_BF16: 1, PREC_FP16: 1, PREC_F32X3: 3, PREC_F32H3: 3, PREC_H3P: 3, PREC_F32X6: 6, PREC_H3F_BWD: 1}
 PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1, PREC_F32H3: 2, PREC_H3P: 2}   # 16-bit planes per operand
 # `planes` argument of the packing entry points (CRIMAC_PLANES_* of the header): bits 0-3 planes, bit 4 / 5 forward /
 # input-gradient planes in IEEE half, bits 8-15 log2 of the scale on the forward planes
@@ -101,7 +102,6 @@ SIGNATURES = {
     "crimac_refine_labels": [_vp, _i, _vp, _vp, _i, _f, _f, _i, _vp, _i, _i, _i, _i, _vp],
     "crimac_pr_histogram": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_mfma_calibrate": [_i, _i, _vp, _vp],
-    "crimac_shadow_fp16": [_vp, _i, _vp],
     "crimac_labels_test_transform": [_vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i,
                                      _i, _i],
     "crimac_scatter_patches": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i,
@@ -125,10 +125,6 @@ class WgradGroupLayer(C.Structure):
 
 WGRAD_GROUP_MAX_LAYERS = 16      # CRIMAC_WGRAD_GROUP_MAX_LAYERS
 
-
-class ShadowDesc(C.Structure):
-    """crimac_shadow_desc: one tensor of a crimac_shadow_fp16 call."""
-    _fields_ = [("src", _vp), ("dst", _vp), ("n_elems", _l), ("kind", _i)]
 
 _lib = None
 

@@ -72,6 +72,17 @@ extern "C" {
                              * Weight planes: crimac_pack_* with CRIMAC_PLANES_H3P (interleaved [32 hi | 32 lo] per 32-channel
                              * block, both directions fp16 and pre-scaled by 2^CRIMAC_F32H3_WSHIFT; `w_lo` is unused). */
 #define CRIMAC_PREC_MAX 5
+/* Backward-pass precision of the engine's 'h3f' mode (forward pass = CRIMAC_PREC_H3P): the MFMA operands of the backward
+ * pass are plain fp16 (1 MFMA per product) -- output gradients dy [pixels][ld] of 2-byte halves, input-gradient weight
+ * planes packed with CRIMAC_PLANES_FP16 -- while everything else keeps its H3P format: conv outputs y and activation
+ * gradients da fp32 (so ReLU masks, xhat, max-pool positions are decided on exactly the forward pass's values), forward
+ * activations fp16 plane pairs (a 16-bit contraction reads their hi plane: the fp16 rounding of the value, the first 16
+ * bytes of each 32-byte group).  Accepted ONLY by: crimac_conv3x3 / crimac_conv3x3_cols (input fp16, output fp32, or fp16
+ * with CRIMAC_EPI_OUT_PLANES), crimac_upconv2x2_dgrad_bnb_prec (input fp16, output fp32), crimac_wgrad / crimac_wgrad_group
+ * (the GRADIENT operand fp16 -- F for mode 0, S for mode 1 --, the ACTIVATION operand plane pairs addressed in 4-byte
+ * elements), crimac_bn_bwd_apply / crimac_bn_bwd_apply_replicas (da, y fp32 -> dy fp16).  The reference has no
+ * counterpart (fp32 everywhere). */
+#define CRIMAC_PREC_H3F_BWD 6
 #define CRIMAC_F32H3_WSHIFT 8
 /* `planes` argument of the weight-packing entry points: 1..3 bf16 planes (BF16 / F32X3 / F32X6), or
  * CRIMAC_PLANES_FP16 = one IEEE-half plane each way (FP16), or CRIMAC_PLANES_F32H3.  Layout of the argument: bits
@@ -517,19 +528,6 @@ int crimac_labels_test_transform(const void* labels_in, int label_bytes, const f
                                  int seabed_ping0, int seabed_pings, const unsigned char* seabed_mask, int mask_ping0,
                                  int mask_pings, int n_range, int seabed_pad, int seabed_rule, int overlap,
                                  short* labels_out, int B, int C, int H, int W, void* stream);
-
-/* fp16 copies of forward tensors for the backward pass of precision 'h3f' (plane-pair forward == CRIMAC_PREC_H3P, backward
- * on the CRIMAC_PREC_FP16 kernels): all tensors of a step in one launch.  kind 0: src fp32 -> dst fp16 (round to nearest
- * even); kind 1: src fp16 plane pairs ([8 hi | 8 lo] per 8-channel group, addressed like fp32) -> dst = the hi plane
- * (which is the fp16 rounding of the values).  Tensors are contiguous, n_elems % 8 == 0, 16-byte aligned; descs is a
- * HOST array read during the call (at most 96 entries).  The reference has no counterpart (it trains in fp32). */
-typedef struct crimac_shadow_desc {
-  const void* src;
-  void* dst;
-  long n_elems;
-  int kind;
-} crimac_shadow_desc;
-int crimac_shadow_fp16(const crimac_shadow_desc* descs, int n, void* stream);
 
 /* ---- measurement support (bench.py only, not on the product path) --------------------------- */
 

@@ -642,7 +642,7 @@ def test_reproducible_weight_gradients_in_h3p(shape):
         assert relerr(outs[-1], ref) < 2 * TOL
 
 
-# ---- 'h3f': the plane-pair forward pass with the backward pass on the fp16 kernels ------------------------------------------
+# ---- 'h3f': the plane-pair forward pass; fp16 MFMA operands in the backward pass (CRIMAC_PREC_H3F_BWD) ---------------------
 def _model_f(seed=0):
     m = pkg.UNet_Baseline(3, 4, precision="h3f")
     m.load_state_dict(synth.synth_state_dict(seed=seed))
@@ -730,3 +730,82 @@ def test_h3f_training_trajectory_and_other_shapes():
         for k in ("conv_final.weight", "down_convs.0.main.0.weight", f"down_convs.{depth - 1}.main.3.weight", "up_convs.0.upconv.weight"):
             assert _l2(g[k], ref_grads[k]) < 5e-2, (cfg, k, _l2(g[k], ref_grads[k]))
         assert mm.engine.skipped_steps() == 0
+
+
+H3F = hip.PREC_H3F_BWD
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 128, 256), (3, 20, 24, 64, 64), (2, 64, 64, 128, 64), (2, 16, 16, 256, 128)])
+def test_h3f_backward_kernels_against_torch(shape):
+    """The contractions and the BatchNorm-backward of CRIMAC_PREC_H3F_BWD, one by one: (1) the input gradient of a 3x3
+    convolution from an fp16 dy with fp16 weight planes into an fp32 da, with the fused BatchNorm-backward sums read from an
+    fp32 y -- and as an fp16 output (CRIMAC_EPI_OUT_PLANES); (2) the weight gradient with F = fp16 dy and S = the hi plane
+    of a PLANE-PAIR activation (and the transposed convolution's, with the roles swapped); (3) bn_bwd_apply from fp32
+    (da, y) into an fp16 dy."""
+    B, H, W, Ci, Co = shape                       # forward conv Ci -> Co
+    g = torch.Generator().manual_seed(51)
+    M = B * H * W
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    dy = torch.randn(B, Co, H, W, generator=g).half().float()              # exact in fp16
+    x = hp_round(torch.randn(B, Ci, H, W, generator=g))                     # a plane-pair activation
+    i16 = dict(dtype=torch.int16, device="cuda")
+    fh, fl, dh, dl = (torch.empty(9 * Co * Ci, **i16), torch.empty(8, **i16), torch.empty(9 * Ci * Co, **i16), torch.empty(8, **i16))
+    call("crimac_pack_conv3x3", ptr(w.cuda()), Co, Ci, Ci, None, hip.PLANES_FP16, ptr(fh), ptr(fl), ptr(dh), ptr(dl))
+    w16 = w.half().float()
+    dyn = dy.permute(0, 2, 3, 1).reshape(M, Co).half().cuda().contiguous()
+    # (1) input gradient, fp32 out + fused sums on an fp32 y
+    ref_da = torch.nn.grad.conv2d_input((B, Ci, H, W), w16.double(), dy.double(), padding=1).float()
+    y_prev = torch.randn(M, Ci, generator=g) * 1.5 + 0.3
+    vec = torch.stack([torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5,
+                       torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3]).contiguous()
+    R = 5
+    acc = torch.zeros(2, R, Ci, dtype=torch.float64, device="cuda")
+    da = torch.empty(M, Ci, dtype=torch.float32, device="cuda")
+    yd, vd = y_prev.cuda(), vec.cuda()
+    call("crimac_conv3x3", H3F, ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dl), None, ptr(da), Ci, 0, 2, ptr(acc[0]),
+         ptr(acc[1]), R, ptr(yd), Ci, ptr(vd), Ci)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(da, B, H, W), ref_da) < 5e-6
+    dz = torch.where((y_prev * vec[2] + vec[3]) > 0, da.cpu(), torch.zeros(()))
+    xhat = (y_prev - vec[0]) * vec[1]
+    assert relerr(acc[0].sum(0).cpu(), dz.double().sum(0)) < 1e-5 and relerr(acc[1].sum(0).cpu(), (dz * xhat).double().sum(0)) < 1e-5
+    # ... and with an fp16 output (the up half of a decoder block's d(concat))
+    da16 = torch.empty(M, Ci, dtype=torch.float16, device="cuda")
+    call("crimac_conv3x3", H3F, ptr(dyn), Co, B, H, W, Co, Ci, ptr(dh), ptr(dl), None, ptr(da16), Ci, hip.EPI_OUT_PLANES, 0,
+         None, None, 1, None, 0, None, 0)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(da16, B, H, W), ref_da) < 1e-3
+    # (2) weight gradient: F = fp16 dy, S = hi plane of the plane-pair activation
+    xn = to_nhwc_hp(x)
+    x_hi = x.half().float()
+    ref_dw = torch.nn.grad.conv2d_weight(x_hi.double(), (Co, Ci, 3, 3), dy.double(), padding=1).float()
+    dwp = torch.zeros(9 * Co * Ci, dtype=torch.float32, device="cuda")
+    call("crimac_wgrad", H3F, 0, ptr(dyn), Co, Co, ptr(xn), Ci, Ci, B, H, W, ptr(dwp), 0)
+    grad = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_conv3x3", ptr(dwp), Co, Ci, Ci, ptr(grad))
+    torch.cuda.synchronize()
+    assert relerr(grad.cpu(), ref_dw) < 2e-5
+    # transposed convolution Ci -> Co on the coarse grid: F = plane-pair x (coarse), S = fp16 dY (fine)
+    dyf = torch.randn(B, Co, 2 * H, 2 * W, generator=g).half().float()
+    wg = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x_hi.double(), wg, None, stride=2).backward(dyf.double())
+    dyfn = dyf.permute(0, 2, 3, 1).reshape(4 * M, Co).half().cuda().contiguous()
+    dwu = torch.zeros(4 * Ci * Co, dtype=torch.float32, device="cuda")
+    call("crimac_wgrad", H3F, 1, ptr(xn), Ci, Ci, ptr(dyfn), Co, Co, B, H, W, ptr(dwu), 0)
+    gu = torch.empty(Ci, Co, 2, 2, dtype=torch.float32, device="cuda")
+    call("crimac_unpack_wgrad_upconv2x2", ptr(dwu), Ci, Co, ptr(gu))
+    torch.cuda.synchronize()
+    assert relerr(gu.cpu(), wg.grad.float()) < 2e-5
+    # (3) bn_bwd_apply: (da fp32, y fp32) -> dy fp16, against the plane-pair form of the same kernel
+    sums = torch.zeros(2, R, Ci, dtype=torch.float64, device="cuda")
+    sums[0, 0], sums[1, 0] = acc[0].sum(0), acc[1].sum(0)
+    out16 = torch.empty(M, Ci, dtype=torch.float16, device="cuda")
+    outpp = torch.empty(M, Ci, dtype=torch.float32, device="cuda")
+    dgam, dbet = torch.empty(Ci, device="cuda"), torch.empty(Ci, device="cuda")
+    for prec_, o in ((H3F, out16), (P, outpp)):
+        call("crimac_bn_bwd_apply_replicas", prec_, ptr(da), Ci, ptr(yd), Ci, ptr(vd), Ci, ptr(sums[0]), ptr(sums[1]), R, M, M, Ci,
+             ptr(o), Ci, ptr(dgam), ptr(dbet))
+    torch.cuda.synchronize()
+    want = hp_unpack(outpp)
+    assert relerr(out16.float().cpu(), want) < 1e-3
+    assert float((out16.float().cpu() - want).abs().max()) <= 2.0 ** -10 * float(want.abs().max())
