@@ -344,11 +344,12 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     // of a decoder block's d(concat)): fp16 in, fp16 out -- the fp16 mode's launch; otherwise fp32 out
     CRIMAC_REQUIRE(!pool_out && Cin > 0 && Cin % 64 == 0 && N > 0 && N % 64 == 0 && in && w_hi && out && B > 0 && H > 0 && W > 0,
                    "conv3x3 (H3F_BWD): Cin, N multiples of 64 (got %d, %d)", Cin, N);
-    if (relu & CRIMAC_EPI_OUT_PLANES)
-      return conv3x3_run(CRIMAC_PREC_FP16, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld, relu & CRIMAC_EPI_RELU,
+    if (relu & CRIMAC_EPI_OUT_PLANES)      // (column sums taken here are a bias gradient: of the unrounded results)
+      return conv3x3_run(CRIMAC_PREC_FP16, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld,
+                         (relu & CRIMAC_EPI_RELU) | CRIMAC_EPI_STAT_RAW,
                          stat_mode, stat_sum, stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, n_first,
                          n_count, stream);
-    CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0, "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
+    CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= n_first + n_count && out_ld % 8 == 0, "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
     CRIMAC_REQUIRE(stat_mode >= 0 && stat_mode <= 2 && (stat_mode == 0 || (stat_sum && stat_sumsq && stat_replicas >= 1)),
                    "conv3x3: stat_mode %d needs both accumulators and replicas >= 1", stat_mode);
     CRIMAC_REQUIRE(stat_mode != 2 || (bnb_y && bnb_vec && bnb_y_ld >= N && bnb_y_ld % 8 == 0 && bnb_stride >= N),
@@ -369,7 +370,9 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
                  "range, and not the first-layer kernel");
   CRIMAC_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv3x3: Cin=%d must be a positive multiple of 16", Cin);
   CRIMAC_REQUIRE(N > 0 && N % 64 == 0, "conv3x3: N=%d must be a positive multiple of 64", N);
-  CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= N && out_ld % 8 == 0,
+  // (a channel range [n_first, +n_count) only touches the output columns below n_first + n_count: a range that starts at
+  // 0 may go to a buffer of its own with a narrower pixel stride)
+  CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= n_first + n_count && out_ld % 8 == 0,
                  "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
   CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && in && w_hi && out, "conv3x3: bad arguments");
   const bool is16 = prec == CRIMAC_PREC_BF16 || prec == CRIMAC_PREC_FP16;
@@ -386,6 +389,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   EpiParams& e = p.epi;
   const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
   const int cin4 = (relu & CRIMAC_EPI_CIN4) != 0;
+  e.stat_raw = (relu & CRIMAC_EPI_STAT_RAW) != 0;
   relu &= CRIMAC_EPI_RELU;
   CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode != 2),
                  "conv3x3: plane-pair output is an H3P option (never with the fused BatchNorm-backward sums)");

@@ -1080,7 +1080,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
           const T16 q = (T16)v;
           *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
           if (mode == 1) {
-            const float vs = (float)q;        // statistics of the value as STORED (pixels outside the image: 0)
+            const float vs = e.stat_raw ? v : (float)q;        // statistics of the value as STORED (pixels outside the image: 0)
             cs1[j] += okm[r] ? vs : 0.f;
             cs2[j] += okm[r] ? vs * vs : 0.f;
           }
@@ -1389,6 +1389,9 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
     const long nt = (long)B * cdiv(H, TR) * cdiv(W, TC);
     if (n_count == 64 && Cin == 64 && nt >= 512 && H % TR == 0 && W % TC == 0) return launch_p64<T16>(p, st);
     const bool small_t = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
+    // other 64-channel ranges (small images, Cin != 64): the tall form of the channel-split kernel
+    if ((n_first % 128 != 0 || n_count % 128 != 0) && n_first % 64 == 0 && n_count % 64 == 0 && small_t)
+      return launch_wch<T16, T16, false, 2>(p, st);
     CRIMAC_REQUIRE(n_first % 128 == 0 && n_count % 128 == 0 && small_t,
                    "conv3x3_cols: channel range [%d, +%d) of %d not supported (multiples of 128, or 64 of a "
                    "64-input-channel convolution with >= 512 tiles)", n_first, n_count, N);

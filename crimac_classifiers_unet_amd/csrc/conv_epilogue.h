@@ -29,6 +29,8 @@ struct EpiParams {
   float acc_scale;        // the accumulators are multiplied by this before the bias (F32H3: 2^-WSHIFT; else 1)
   void* pool_out;         // != NULL: also the 2x2/2 max-pool of the stored tile, [B][H/2][W/2][pool_ld] (eval path:
   long pool_ld;           //          nn.MaxPool2d behind the block, unet.py:85-86 -- no second pass over the output)
+  int stat_raw;           // stat_mode 1: sum the fp32 results BEFORE the rounding of the store (CRIMAC_EPI_STAT_RAW: the
+                          // sums are a bias gradient, not the statistics of a stored tensor)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0) -- here that means for the
@@ -169,7 +171,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ACC (&acc)[MT][NT], con
         const TS q = (TS)v;
         *reinterpret_cast<TS*>(stage + (row - ps * RPASS) * STAGE_PITCH + col * (int)sizeof(TS)) = q;
         if (mode == 1) {
-          const float vs = HPO ? storage_round<hp_t>(v) : (float)q;       // statistics of the value as STORED
+          const float vs = e.stat_raw ? v : (HPO ? storage_round<hp_t>(v) : (float)q);      // statistics of the value as STORED
           const bool ok = FULL || ((y0 + (row >> 4) < e.H) && (x0 + (row & 15) < e.W));
           cs1[j] += ok ? vs : 0.f;
           cs2[j] += ok ? vs * vs : 0.f;

@@ -108,6 +108,9 @@ extern "C" {
  * unet.py:77 with in_channels <= 4) -- selects the persistent first-layer kernel, which contracts their hi / lo planes as
  * sixteen pseudo-channels.  Without it the generic kernel runs. */
 #define CRIMAC_EPI_CIN4 4
+/* bit 3: with stat_mode 1 the sums are taken of the fp32 results BEFORE the rounding of the store (they are then a bias
+ * gradient -- the transposed convolution's, unet.py:130 -- not the statistics of the stored tensor) */
+#define CRIMAC_EPI_STAT_RAW 8
 
 /* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
  * struct passed by pointer (crimac_layer_desc), the meaning of an argument or the set of precisions changes, and a

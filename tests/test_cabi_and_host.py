@@ -229,7 +229,9 @@ def test_planes_argument_layout_matches_the_header():
     assert "#define CRIMAC_PLANES_FWD_FP16 16" in text and "#define CRIMAC_PLANES_DG_FP16 32" in text
     assert "#define CRIMAC_F32H3_WSHIFT 8" in text
     assert hip.PLANES_FP16 == 1 | 16 | 32 and hip.PLANES_F32H3 == 2 | 16 | (8 << 8)
-    assert hip.PREC_NAMES == {"bf16": 0, "f32x3": 1, "f32x6": 2, "fp16": 3, "f32h3": 4, "h3p": 5}
+    # ('h3f' is an engine mode: forward launches carry H3P, the backward pass's contractions CRIMAC_PREC_H3F_BWD)
+    assert hip.PREC_NAMES == {"bf16": 0, "f32x3": 1, "f32x6": 2, "fp16": 3, "f32h3": 4, "h3p": 5, "h3f": 5}
+    assert "#define CRIMAC_PREC_H3F_BWD 6" in text and hip.PREC_H3F_BWD == 6
     assert hip.PREC_BACKWARD[hip.PREC_F32H3] == hip.PREC_F32X3
     lib = hip.load_library()
     # argument checks of the packers run without a GPU: a plane count of 0 or stray bits are refused

@@ -675,20 +675,23 @@ def test_h3f_forward_is_h3p_bit_for_bit_and_gradients_meet_the_h3p_bar(golden_di
     assert _rel(out["h3f"][0], out["h3p"][0]) < 2e-6 and abs(out["h3f"][1] - out["h3p"][1]) <= 1e-6 * abs(out["h3p"][1])
     for k, v in out["h3p"][2].items():
         assert _rel(out["h3f"][2][k], v) < 1e-6, k
-    worst, worst_p = 0.0, 0.0
+    worst, worst_p, bad = 0.0, 0.0, []
     for (k, p), (_, q) in zip(mf.named_parameters(), mp.named_parameters()):
         if pre_bn_bias.fullmatch(k):
             continue
         gn, noise = float(fix["gnorm/" + k]), float(fix["gnoise/" + k])
         tol = max(6 * noise, 3e-3)
         g_ = p.grad.detach().cpu()
-        assert abs(float(g_.double().norm()) - gn) <= tol * gn, (k, float(g_.double().norm()), gn)
+        if abs(float(g_.double().norm()) - gn) > tol * gn:
+            bad.append((k, "norm", float(g_.double().norm()), gn, tol))
         if "grad/" + k in fix.files:
-            r = _l2(g_, fix["grad/" + k])
-            worst = max(worst, r / tol)
-            worst_p = max(worst_p, _l2(q.grad.detach().cpu(), fix["grad/" + k]) / tol)
-            assert r < tol, (k, r, tol)
+            r, rp = _l2(g_, fix["grad/" + k]), _l2(q.grad.detach().cpu(), fix["grad/" + k])
+            worst, worst_p = max(worst, r / tol), max(worst_p, rp / tol)
+            print(f"  {k:40s} noise {noise:.2e}  h3f {r:.2e} ({r / tol:.2f} tol)  h3p {rp:.2e} ({rp / tol:.2f} tol)")
+            if r >= tol:
+                bad.append((k, "l2", r, rp, tol))
     print(f"worst gradient L2-rel / tolerance: h3f {worst:.3f}, h3p {worst_p:.3f}")
+    assert not bad, bad
     assert mf.engine.skipped_steps() == 0
 
 

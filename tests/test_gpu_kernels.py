@@ -706,7 +706,8 @@ def test_upconv_dgrad_with_fused_bn_backward_sums(shape, prec):
 def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape, prec):
     """crimac_conv3x3_cols on [0, N/2) and [N/2, N) (weights / bias / out / accumulators of the FULL convolution)
     reproduces crimac_conv3x3 bit for bit, statistics included; unsupported ranges fail loudly.  The second shape
-    takes the persistent 64-channel kernel for each half, the first the channel-split kernel."""
+    takes the persistent 64-channel kernel for each half, the first the channel-split kernel, the third (64-channel halves
+    on a small image) the tall form."""
     B, H, W, Ci, Co = shape
     P = hip.PREC_NAMES[prec]
     g = torch.Generator().manual_seed(41)
@@ -721,15 +722,16 @@ def test_conv3x3_cols_two_ranges_equal_the_full_convolution(shape, prec):
     call("crimac_conv3x3", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(full), Co, 1, 1,
          ptr(st_full[0]), ptr(st_full[1]), 4, None, 0, None, 0)
     half = Co // 2
-    supported = half % 128 == 0 or (half == 64 and Ci == 64 and B * ((H + 15) // 16) * ((W + 15) // 16) >= 512)
     parts = torch.zeros(M, Co, dtype=_dt(prec), device="cuda")
     st = torch.zeros(2, 4, Co, dtype=torch.float64, device="cuda")
-    args = lambda n0: ("crimac_conv3x3_cols", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(parts), Co,
-                       1, 1, ptr(st[0]), ptr(st[1]), 4, None, 0, None, 0, n0, half)
-    if not supported:
-        with pytest.raises(hip.HipLibraryError):
-            call(*args(0))
-        return
+    args = lambda n0, n=half: ("crimac_conv3x3_cols", P, ptr(xin), Ci, B, H, W, Ci, Co, ptr(fh), ptr(fl), ptr(bd), ptr(parts), Co,
+                               1, 1, ptr(st[0]), ptr(st[1]), 4, None, 0, None, 0, n0, n)
+    # ranges are multiples of 64 channels (128: channel-split kernel; 64 of a 64-input-channel convolution with >= 512
+    # tiles: persistent kernel; any other 64: the tall form) -- anything else fails loudly
+    with pytest.raises(hip.HipLibraryError):
+        call(*args(0, 32))
+    with pytest.raises(hip.HipLibraryError):
+        call(*args(Co - 64, 128))
     call(*args(0))
     call(*args(half))
     torch.cuda.synchronize()
