@@ -18,7 +18,7 @@ import threading
 import numpy as np
 import torch
 
-RING = 3          # slots: one being filled by the host thread, one uploading, one being consumed by the step
+RING = 4          # slots: one being filled by the host thread, one or two staged / uploading, one being consumed by the step
 
 
 class _Slot:
