@@ -73,7 +73,7 @@ def parse_args(argv=None):
                          "while staging) and a bf16-plane backward; f32x6: 6 MFMAs, fp32-equivalent gradients too")
     ap.add_argument("--roofline-steps", type=int, default=30, help="serialized steps of the per-kernel (roofline) pass")
     ap.add_argument("--roofline-warmup", type=int, default=10, help="serialized warm-up steps in front of that pass")
-    ap.add_argument("--loop-iters", type=int, default=60, help="iterations of the train_loop leg (SegPipe.train_model + DataLoader)")
+    ap.add_argument("--loop-iters", type=int, default=300, help="iterations of the train_loop leg (SegPipe.train_model + DataLoader)")
     ap.add_argument("--loop-workers", type=int, default=4,
                     help="DataLoader workers of the train_loop leg (the yaml's num_workers; 8 measured slower than 4 on the "
                          "16-core share of a GPU box: 2049 vs 2221 patches/s in bf16)")
@@ -491,7 +491,7 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
     import crimac_classifiers_unet_amd as pkg
     from crimac_classifiers_unet_amd import synth
 
-    B, iters = args.batch, max(args.loop_iters, 30)
+    B, iters = args.batch, max(args.loop_iters, 30)     # (a pass pays the DataLoader's start-up once: ~0.2 s, 4 workers)
     n_distinct = 2 * B
     data = synth.synth_echogram_batch(n_distinct, 4, 256, 256, seed=300)
     labels = synth.synth_labels(n_distinct, 256, 256, seed=301)
@@ -524,9 +524,13 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
 
     import contextlib
     lg = LastLoss()
+    phases = {}
+    if pin_batches:
+        pipe.stager_stats = phases                    # seconds per staging phase (staging.BatchStager._note)
     with contextlib.redirect_stdout(sys.stderr):      # (train_model prints "Training complete" like the reference)
         pipe.train_model(dl, None, logger=lg)         # untimed: workers, allocations, first-touch
         torch.cuda.synchronize()
+        phases.clear()
         t0 = time.perf_counter()
         pipe.train_model(dl, None, logger=lg)
         torch.cuda.synchronize()
@@ -543,6 +547,7 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
             "dataloader_workers": nw, "input_staging": "pinned ring + copy stream (staging.BatchStager)" if pin_batches
             else "in-line .to(device) as the reference (pipeline.py:163-164)",
             "vs_resident_batch": pps / resident_patches_per_s, "final_loss": lg.last,
+            "host_phases_ms_per_step": {k[:-2]: round(1e3 * v / iters, 3) for k, v in sorted(phases.items())} or None,
             "timed": "SegPipeUNet.train_model over a DataLoader (default collate, batch dict of the reference): collate + "
                      "hand-over + H2D + step, one full pass of the DataLoader after one untimed pass"}
 

@@ -184,7 +184,8 @@ class SegPipe:
             the upload of step i + 1 runs under step i; ``pin_batches: False`` keeps the in-line copy."""
             if self.pin_batches and self.device.type == "cuda":
                 from .staging import BatchStager
-                for i, x, lab, _ in BatchStager(dataloader_train, self.device):
+                for i, x, lab, _ in BatchStager(dataloader_train, self.device, yield_batch=False,
+                                                stats=getattr(self, "stager_stats", None)):
                     yield i, x, lab
                 return
             for i, batch in enumerate(dataloader_train):

@@ -2,11 +2,20 @@
 
 The reference moves every batch to the device inside the step (``batch['data'].float().to(device)``): the DataLoader
 hands PAGEABLE tensors, so that copy is synchronous -- 37.7 MB (32 x 4 x 256 x 256 fp32) in front of a 12 ms step.
-Here a host thread pulls the DataLoader one batch ahead and copies ``data`` and ``labels`` -- in the dtype they arrive in,
-one plain memcpy each (numpy, GIL released; a torch CPU copy would start an OpenMP team per calling thread, one thread per
-VISIBLE core: 256 on a GPU box whose cgroup grants 16 -- measured 43 ms per batch) -- into a ring of PINNED buffers; the
-upload runs on a copy stream into a ring of device buffers, the reference's ``.float()`` happens on the device, and the
-training stream waits for the upload's event only -- the H2D of step i + 1 runs under step i.
+Here two host threads work ahead of the training thread:
+  stage    pulls the DataLoader (parent-side unpickling and mapping of the worker's shared-memory batch: 1-3 ms), copies
+           ``data`` and ``labels`` -- in the dtype they arrive in, one plain memcpy each (numpy, GIL released; a torch
+           CPU copy would start an OpenMP team per calling thread, one thread per VISIBLE core: 256 on a GPU box whose
+           cgroup grants 16 -- measured 43 ms per batch) -- into a PINNED buffer (2.5-5 ms: first touch of the mapping),
+           uploads it on a copy stream into a ring of device buffers and waits for the upload (0.75 ms);
+  release  gives the batch's pages back (5-9 ms of page-table teardown, see ``release_pages``).
+The reference's ``.float()`` happens on the device; the H2D of step i + 1 runs under step i.  No GPU event is waited for
+or polled ACROSS threads (an event recorded by the training thread and queried from the staging thread read "not ready"
+35-45 ms after a 0.6 ms upload had been issued, tools/diag_loop_graph.py round 4): the staging thread synchronises the
+copy stream it issued on, and the training thread hands a device slot back after synchronising, itself, on the event it
+recorded behind the step two iterations back -- which also keeps the host at most two steps ahead of the GPU.
+Measured (round 4, 1 MI355X, 4 workers, 300 iterations): SegPipe.train_model 12.15 ms per bf16 step (resident batch 11.6)
+and 19.3 ms per h3f step (18.2); steady state is GPU-bound (11.8 ms cycle), the rest is the DataLoader's start-up.
 The same structure feeds the tiled-inference path (tiled_inference.predict_survey: reader thread -> pinned staging ->
 copy stream -> two resident chunk buffers).
 """
@@ -18,42 +27,72 @@ import threading
 import numpy as np
 import torch
 
-RING = 4          # slots: one being filled by the host thread, one or two staged / uploading, one being consumed by the step
+MADV_REMOVE = 9   # <linux/mman.h>: free the backing pages of a shared (tmpfs) mapping
+_PAGE = 4096
+
+
+def _libc_madvise():
+    import ctypes
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    libc.madvise.restype = ctypes.c_int
+    return libc.madvise
+
+
+def collated_in_worker(dataloader):
+    """True when every tensor the DataLoader yields is a FRESH shared-memory segment nobody else maps: worker processes
+    + automatic batching + ``default_collate`` (which stacks the samples into storage it allocates in shared memory,
+    torch/utils/data/_utils/collate.py) -- what the reference's four DataLoaders are (train.py:73,101, evaluate.py:69,107)."""
+    from torch.utils.data import default_collate
+    return (getattr(dataloader, "num_workers", 0) > 0 and getattr(dataloader, "batch_size", None) is not None
+            and getattr(dataloader, "collate_fn", None) is default_collate)
+
+
+RING = 6          # device / pinned slots: one being filled, up to three staged, two in steps the GPU may still be running
+AHEAD = 2         # steps the training thread may be ahead of the GPU before it waits (frees the slot of step i - AHEAD)
 
 
 class _Slot:
-    __slots__ = ("data_pin", "lab_pin", "data_dev", "lab_dev", "uploaded", "consumed", "used")
+    __slots__ = ("data_pin", "lab_pin", "data_dev", "lab_dev", "done")
 
     def __init__(self):
         self.data_pin = self.lab_pin = self.data_dev = self.lab_dev = None
-        self.uploaded = torch.cuda.Event()
-        self.consumed = torch.cuda.Event()
-        self.used = False
+        self.done = torch.cuda.Event()       # recorded on the training stream behind the step that read the slot
 
 
 class BatchStager:
     """Iterate ``dataloader`` yielding ``(index, data_dev [B,C,H,W] float32, labels_dev [B,H,W], batch)`` with the
-    tensors already (asynchronously) on ``device``; the caller's CURRENT stream is made to wait for the upload.
+    tensors already on ``device`` (uploaded, and the upload complete, before they are yielded).
 
-    The yielded device tensors belong to the ring: they stay valid until RING - 1 further batches have been yielded
-    (the ring records an event on the caller's stream when the next batch is asked for, i.e. after the step that used
-    them was enqueued)."""
+    The yielded device tensors belong to the ring: they stay valid until AHEAD further batches have been yielded (an event
+    is recorded on the caller's CURRENT stream when the next batch is asked for, i.e. after the step that used them was
+    enqueued; the slot is refilled only after that event has completed)."""
 
-    def __init__(self, dataloader, device, keys=("data", "labels"), stats=None):
+    def __init__(self, dataloader, device, keys=("data", "labels"), stats=None, yield_batch=True):
+        self.yield_batch = yield_batch       # False: `batch` is yielded as None (the loop needs the two tensors only)
+        # Dropping a 37 MB batch a worker collated costs ~5-6 ms of page-table teardown + page freeing, and tensor
+        # deallocation runs UNDER THE GIL: the training thread stalled that long every step (tools/diag_loop_graph.py:
+        # 6.2-6.7 ms "release" per batch; a pure-Python ticker thread saw one > 1 ms gap per batch).  The release thread
+        # frees the pages with madvise(MADV_REMOVE) through ctypes (no GIL) before the last reference goes; the
+        # deallocation that follows finds nothing to tear down (0.6 ms).  Only for batches nobody else can see.
+        import os
+        self.release_pages = ((not yield_batch) and collated_in_worker(dataloader)
+                              and os.environ.get("CRIMAC_STAGER_RELEASE_PAGES", "1") != "0")
+        self._madvise = _libc_madvise() if self.release_pages else None
+        self._dead = queue.Queue()
         self.stats = stats                   # dict: seconds spent per phase (diagnostics: tools/diag_train_loop.py)
         self.dataloader = dataloader
         self.device = torch.device(device)
         self.keys = keys
         self.slots = [_Slot() for _ in range(RING)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self._q = queue.Queue(maxsize=RING - 2)      # filled pinned slots waiting for their upload
-        self._free = queue.Queue()
+        self._q = queue.Queue(maxsize=RING - AHEAD - 1)      # uploaded slots waiting for their step
+        self._free = queue.Queue()                   # slots no GPU work refers to
         for k in range(RING):
             self._free.put(k)
         self._stop = False
         self._err = None
 
-    # -- host thread: DataLoader -> pinned ------------------------------------------------------------------------
     def _ensure(self, slot, data, labels):
         # The device buffers are allocated ON THE COPY STREAM: the caching allocator hands a block that was freed on a
         # stream back to allocations on that stream at once (later work of the stream is ordered behind its last use).
@@ -73,58 +112,97 @@ class BatchStager:
     def _note(self, key, t0):
         if self.stats is not None:
             import time
-            self.stats[key] = self.stats.get(key, 0.0) + time.perf_counter() - t0
+            now = time.perf_counter()
+            self.stats[key] = self.stats.get(key, 0.0) + now - t0
+            tr = self.stats.get("trace")
+            if tr is not None:
+                tr.append((threading.current_thread().name[-5:], key[:-2], t0, now))
 
-    def _producer(self):
+    # -- thread 1: DataLoader -> pinned memcpy -> upload ---------------------------------------------------------------------------
+    def _stager(self):
         import time
         try:
-            it = iter(self.dataloader)
             i = -1
+            it = iter(self.dataloader)
             while True:
                 t0 = time.perf_counter()
-                try:
-                    batch = next(it)
-                except StopIteration:
+                batch = next(it, None)
+                self._note("fetch_next_s", t0)
+                if batch is None or self._stop:
                     break
                 i += 1
-                self._note("producer_next_s", t0)
                 t0 = time.perf_counter()
                 k = self._free.get()
-                self._note("producer_wait_slot_s", t0)
+                self._note("stage_wait_slot_s", t0)
                 if self._stop:
                     return
                 slot = self.slots[k]
+                t0 = time.perf_counter()
                 data = batch[self.keys[0]]
                 labels = batch.get(self.keys[1]) if len(self.keys) > 1 else None
                 if not torch.is_tensor(data):
                     data = torch.as_tensor(data)
                 if labels is not None and not torch.is_tensor(labels):
                     labels = torch.as_tensor(labels)
-                if slot.used:
-                    slot.uploaded.synchronize()          # the previous upload out of this pinned slot has finished
+                self._note("stage_prep_s", t0)
+                t0 = time.perf_counter()
                 self._ensure(slot, data, labels)
+                self._note("stage_ensure_s", t0)
                 t0 = time.perf_counter()
                 np.copyto(slot.data_pin.numpy(), data.contiguous().numpy())      # memcpy, GIL released
                 if labels is not None:
                     np.copyto(slot.lab_pin.numpy(), labels.contiguous().numpy())
-                self._note("producer_copy_s", t0)
+                self._note("stage_memcpy_s", t0)
                 t0 = time.perf_counter()
-                self._q.put((i, k, batch, labels is not None))
-                self._note("producer_wait_queue_s", t0)
-                if self._stop:
-                    return
-        except BaseException as e:                        # surfaced in the consumer
+                with torch.cuda.stream(self.copy_stream):
+                    slot.data_dev.copy_(slot.data_pin, non_blocking=True)
+                    if labels is not None:
+                        slot.lab_dev.copy_(slot.lab_pin, non_blocking=True)
+                self.copy_stream.synchronize()            # (GIL released) the batch is on the device from here on
+                self._note("stage_upload_s", t0)
+                has_lab = labels is not None
+                t0 = time.perf_counter()
+                del data, labels
+                if not self.yield_batch:                  # the 37 MB mapping is released here, not by the training thread
+                    self._dead.put(batch)
+                    batch = None
+                self._note("stage_handoff_s", t0)
+                t0 = time.perf_counter()
+                self._q.put((i, k, batch, has_lab))
+                batch = None
+                self._note("stage_wait_step_s", t0)
+        except BaseException as e:
             self._err = e
         finally:
             self._q.put(None)
 
-    # -- consumer -------------------------------------------------------------------------------------------------
+    # -- thread 2: page release -------------------------------------------------------------------------------------
+    def _release(self, batch):
+        import time
+        t0 = time.perf_counter()
+        if self.release_pages:
+            for v in (batch.values() if isinstance(batch, dict) else ()):
+                if torch.is_tensor(v) and v.device.type == "cpu" and v.is_shared() and v.is_contiguous():
+                    p, nb = v.data_ptr(), v.numel() * v.element_size()
+                    lo, hi = (p + _PAGE - 1) & ~(_PAGE - 1), (p + nb) & ~(_PAGE - 1)
+                    if hi - lo >= (1 << 20):
+                        self._madvise(lo, hi - lo, MADV_REMOVE)      # (a failure only means the slow path below)
+        batch = v = None
+        self._note("release_s", t0)
+
+    def _releaser(self):
+        while True:
+            batch = self._dead.get()
+            if batch is None:
+                return
+            self._release(batch)
+            batch = None
+
+    # -- consumer: the training thread ------------------------------------------------------------------------------
     # CPython hands the GIL from a running thread to a waiting one only every `sys.getswitchinterval()` = 5 ms unless the
     # running thread blocks.  The training thread spends a step's worth of host time in short Python stretches between
-    # GIL-releasing launches; the staging thread, woken by the DataLoader's queue, needs the GIL a dozen times per batch
-    # (unpickling the batch, wrapping tensors) and waited up to 5 ms each time: 14.2 ms per step for an 11.8 ms GPU step
-    # (tools/diag_train_loop.py: staging thread 5.6 ms in next() + 3.7 ms memcpy + ~5 ms unaccounted per batch).  While
-    # a stager runs the interval is 0.2 ms.
+    # GIL-releasing launches; the staging threads, woken by the DataLoader's queue, need the GIL a dozen times per batch
+    # (unpickling the batch, wrapping tensors) and waited up to 5 ms each time.  While a stager runs the interval is 0.2 ms.
     SWITCH_INTERVAL_S = 2e-4
 
     def __iter__(self):
@@ -137,36 +215,41 @@ class BatchStager:
             sys.setswitchinterval(old_interval)
 
     def _iterate(self):
-        th = threading.Thread(target=self._producer, daemon=True, name="crimac-batch-stager")
-        th.start()
+        import collections
+        import time
+        threads = [threading.Thread(target=self._stager, daemon=True, name="crimac-batch-stage")]
+        rel = threading.Thread(target=self._releaser, daemon=True, name="crimac-batch-release")
+        for th in threads + [rel]:
+            th.start()
         main = torch.cuda.current_stream(self.device)
+        in_flight = collections.deque()                   # slots whose step has been enqueued, oldest first
         prev = None
         try:
-            import time
             while True:
-                t0 = time.perf_counter()
-                item = self._q.get()
-                self._note("consumer_wait_batch_s", t0)
                 if prev is not None:
                     # the step that used the previous slot has been enqueued on the caller's stream by now
-                    self.slots[prev].consumed.record(main)
-                    self._free.put(prev)
+                    self.slots[prev].done.record(main)
+                    in_flight.append(prev)
                     prev = None
+                # slots go back to the staging thread BEFORE this thread waits for its next batch (the other order had
+                # the two threads waiting for each other: 5-6 ms "wait slot" beside 2-4 ms "wait batch" per step)
+                t0 = time.perf_counter()
+                while len(in_flight) > AHEAD:             # recorded by THIS thread: completes when that step has
+                    k_old = in_flight.popleft()
+                    self.slots[k_old].done.synchronize()
+                    self._free.put(k_old)
+                while in_flight and self.slots[in_flight[0]].done.query():
+                    self._free.put(in_flight.popleft())
+                self._note("step_wait_gpu_s", t0)
+                t0 = time.perf_counter()
+                item = self._q.get()
+                self._note("step_wait_batch_s", t0)
                 if item is None:
                     if self._err is not None:
                         raise self._err
                     return
                 i, k, batch, has_lab = item
                 slot = self.slots[k]
-                with torch.cuda.stream(self.copy_stream):
-                    if slot.used:
-                        self.copy_stream.wait_event(slot.consumed)     # device slot free again
-                    slot.data_dev.copy_(slot.data_pin, non_blocking=True)
-                    if has_lab:
-                        slot.lab_dev.copy_(slot.lab_pin, non_blocking=True)
-                    slot.uploaded.record(self.copy_stream)
-                slot.used = True
-                main.wait_event(slot.uploaded)
                 prev = k
                 x = slot.data_dev
                 if x.dtype != torch.float32:              # the reference's `.float()` (pipeline.py:163), on the device
@@ -174,13 +257,15 @@ class BatchStager:
                 yield i, x, (slot.lab_dev if has_lab else None), batch
         finally:
             self._stop = True
-            try:                                          # unblock a producer waiting for a free slot
+            try:                                          # unblock a stager waiting for a free slot
                 self._free.put_nowait(0)
             except queue.Full:                            # pragma: no cover
                 pass
-            while th.is_alive():
+            while any(th.is_alive() for th in threads):   # drain the queue until the staging thread has left
                 try:
-                    self._q.get(timeout=0.05)
+                    self._q.get(timeout=0.02)
                 except queue.Empty:
                     pass
+            self._dead.put(None)
+            rel.join()
             torch.cuda.current_stream(self.device).synchronize()     # nothing still reads the ring
