@@ -691,6 +691,8 @@ def run_rank(args):
                 for r_, pat in ((roof, "conv3x3"), (roof_w, "wgrad")):
                     sel = [v for k, v in pm["kernels"].items() if k.startswith(pat)]
                     nl = sum(v["launches"] for v in sel)
+                    # (the mean over all launches of the class, like `achieved`; for the weight gradients that mixes
+                    # the grouped launches -- 1.5 GB each in bf16 -- with the single-layer ones, 0.3 GB)
                     r_["traffic"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / nl if nl else None
                     r_["traffic_source"] = ("REPLAYED from the committed profile " + pm["_file"] + " (rocprofv3 --pmc FETCH_SIZE / "
                                             "WRITE_SIZE passes of this command on the serialized step; FETCH_SIZE doubled per the "
@@ -698,13 +700,13 @@ def run_rank(args):
             ut = load_profile_json(f"r04_{prec}_mfma_util.json") or load_profile_json(f"r03_{prec}_mfma_util.json")
             if ut:
                 for r_, key in ((roof, "conv3x3"), (roof_w, "wgrad")):
-                    r_["mfma_busy_frac"] = ut.get(key, {}).get("mfma_busy_frac")
+                    r_["mfma_busy_frac"] = (ut.get(key + "_group") or ut.get(key, {})).get("mfma_busy_frac")
                     r_["util_source"] = "REPLAYED from the committed profile " + ut["_file"] + " (not observed in this run): " + str(ut.get("note"))
             # (no replayed clocks: the shader clock under a dense MFMA stream is OBSERVED in this run, before and after
             # the serialized pass -- roofline.mfma_calibration)
-        if sf == 64 and args.precision in ("bf16", "h3p"):
+        if sf == 64 and args.precision in ("bf16", "h3p", "h3f"):
             replay(rl, main["roofline_wgrad"], args.precision)
-        if parity is not None and args.parity_precision in ("bf16", "h3p"):
+        if parity is not None and args.parity_precision in ("bf16", "h3p", "h3f"):
             replay(parity["roofline"], parity["roofline_wgrad"], args.parity_precision)
         workload = ("BASELINE configs[1]: U-Net (depth 5, 64 filters) train step, batch 32 x 4x256x256 per GPU"
                     if sf == 64 else

@@ -18,7 +18,7 @@ import sys
 
 GROUPS = {"conv3x3": r"conv3x3_(wch|p64|glds_w4|c16)_kernel|conv3x3_kernel", "conv3x3_wch": r"conv3x3_wch_kernel",
           "conv3x3_p64": r"conv3x3_p64_kernel", "conv3x3_w4": r"conv3x3_glds_w4_kernel",
-          "wgrad": r"wgrad(_up_pp|_pp)?_kernel", "wgrad_pp": r"wgrad_pp_kernel", "upconv": r"upconv_wch_kernel"}
+          "wgrad": r"wgrad(_up_pp|_pp)?_kernel", "wgrad_group": r"wgrad(_pp)?_group_kernel", "wgrad_pp": r"wgrad_pp_kernel", "upconv": r"upconv_wch_kernel"}
 
 
 def main():

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT/gpurun_out/r4_profiles
 mkdir -p $R
 export TMPDIR=/tmp
-for P in bf16 h3p; do
+for P in ${PRECS:-bf16 h3f}; do
   BARGS="--precision $P --steps 4 --warmup 2 --no-cpu-baseline --no-tiled --no-parity-mode --no-infer --no-wide --no-train-loop --roofline-steps 3 --roofline-warmup 1"
   cd /tmp
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/${P}_prof -- python3 $GRAFT_REPO_ROOT/bench.py $BARGS > $R/${P}_prof.log 2>&1 || { echo prof failed; tail -20 $R/${P}_prof.log; exit 1; }
