@@ -119,6 +119,11 @@ class UNet_Baseline(nn.Module):
                  'h3p'   -- the fast parity mode: f32h3's forward arithmetic with the operands stored as fp16 PLANE PAIRS
                             (hi + lo) split once by the kernel that produces them, so every contraction runs on the LDS-DMA
                             kernels; the backward pass runs on loss-scaled fp16 plane pairs as well (overflow skip as 'fp16')
+                 'h3f'   -- parity TRAINING at speed: the 'h3p' forward (bit-identical logits) with a 1-MFMA fp16 backward --
+                            output gradients, the up-half of d(concat) and the input-gradient weight planes in plain
+                            fp16, conv outputs and activation gradients in fp32 (ReLU / max-pool decisions as in 'h3p'),
+                            weight gradients on the hi plane of the saved activations; every gradient tensor inside the
+                            tolerance 'h3p' is held to (worst 0.76 of it); 1.39x the training rate of 'h3p'
                  'fp16'  -- fp16 activations / MFMA, fp32 accumulate, loss-scaled gradients with overflow skip
                             (BASELINE configs[4]); same kernels and rate as 'bf16'
       infer_precision: precision of EVAL-mode forwards (``model.eval()``; ``predict_softmax``; tiled inference).
