@@ -135,7 +135,8 @@ def test_conv3x3_dgrad(prec, shape):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shape", [(2, 8, 8, 128, 64), (1, 4, 8, 256, 128), (2, 24, 40, 128, 64), (1, 16, 16, 64, 32),
-                                   (2, 64, 64, 256, 128)])      # the last: many workgroups in flight (timing hazards)
+                                   (2, 64, 64, 256, 128),       # many workgroups in flight (timing hazards)
+                                   (1, 5, 20, 128, 128), (2, 7, 33, 256, 64)])   # odd rows / ragged columns, 128- and 64-wide S
 def test_upconv2x2_forward_dgrad_wgrad(prec, shape):
     B, H, W, Ci, Co = shape
     g = torch.Generator().manual_seed(4)
@@ -201,6 +202,7 @@ def test_conv3x3_wgrad(prec, shape, target_blocks):
 
 @pytest.mark.parametrize("mode,shape", [(0, (2, 128, 128, 128, 64)), (0, (1, 256, 256, 64, 64)),
                                         (0, (2, 100, 120, 64, 128)), (1, (2, 64, 64, 128, 64)),
+                                        (1, (2, 64, 64, 256, 128)), (1, (4, 128, 128, 128, 64)),
                                         (0, (2, 128, 128, 16, 64))])      # (the last: first-layer narrow-S kernel)
 @pytest.mark.parametrize("prec", LOWP)
 def test_wgrad_many_workgroups_auto_split(mode, shape, prec):
