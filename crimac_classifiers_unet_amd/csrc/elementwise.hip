@@ -595,12 +595,23 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
           o[j] = (ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f);
           if constexpr (BNB) o[j] = storage_round<T>(o[j]);          // the sums see da as it is stored
         }
-        store8(da + pix[d] * da_ld + c0, o);
+        if (da) store8(da + pix[d] * da_ld + c0, o);      // (da == nullptr: sums only -- unpool_bn_bwd_apply rebuilds da)
         if constexpr (BNB) bnb_accum_v(k, yv[d], o, d1, d2);
       }
     }
   }
   if constexpr (BNB) bnb_flush(bnb, lds, C, c0, d1, d2, 256);
+}
+
+// dy of one element from (y, d(activation)) and the per-channel constants.  ONE spelling with explicit fused multiply-adds
+// and contraction off, shared by every apply kernel: left to the compiler, the stand-alone and the unpool-fused kernel
+// contracted the same source differently and 15 % of their fp32 results differed in the last bit.
+__device__ __forceinline__ float bn_bwd_dy(float yv, float g, float sc, float sh, float mu, float is, float k1, float k2) {
+#pragma clang fp contract(off)
+  const float act = __builtin_fmaf(yv, sc, sh);
+  const float dz = act > 0.f ? g : 0.f;
+  const float xh = (yv - mu) * is;
+  return sc * __builtin_fmaf(-xh, k2, dz - k1);
 }
 
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------------------
@@ -664,10 +675,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
                            load8(y + m * y_ld + c0, yv);
 #pragma unroll
                            for (int j = 0; j < 8; ++j) {
-                             const float act = yv[j] * sc[j] + sh[j];
-                             const float dz = act > 0.f ? g[j] : 0.f;
-                             const float xh = (yv[j] - mu[j]) * is[j];
-                             o[j] = sc[j] * (dz - k1[j] - xh * k2[j]);
+                             o[j] = bn_bwd_dy(yv[j], g[j], sc[j], sh[j], mu[j], is[j], k1[j], k2[j]);
                              q0[j] = o[j];
                            }
                            store8(dy + m * dy_ld + c0, o);
@@ -742,13 +750,86 @@ void bn_bwd_apply_stream_kernel(
       if (m + u * stride >= M) continue;
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float act = yv[u][j] * sc[j] + sh[j];
-        const float dz = act > 0.f ? g[u][j] : 0.f;
-        const float xh = (yv[u][j] - mu[j]) * is[j];
-        o[j] = sc[j] * (dz - k1[j] - xh * k2[j]);
-      }
+      for (int j = 0; j < 8; ++j) o[j] = bn_bwd_dy(yv[u][j], g[u][j], sc[j], sh[j], mu[j], is[j], k1[j], k2[j]);
       store8(dy + (m + u * stride) * dy_ld + c0, o);
+    }
+  }
+}
+
+// ---- max-pool / skip backward + BatchNorm + ReLU backward in one pass (round 4) ----------------------------------------
+// The block output of an encoder level feeds the max-pool and the skip connection: its gradient da = ds + unpool(dp) used
+// to be WRITTEN by unpool_add (which takes the BatchNorm-backward sums on the way) and READ again by bn_bwd_apply.  Here
+// unpool_add runs sums-only (da == nullptr) and this kernel rebuilds da from (dp, ds, y) -- the same arithmetic, the same
+// rounding to the storage type of da -- while it forms dy: 11 instead of 12.5 bytes per element in bf16 (20 instead of 23
+// in h3f), one tensor less in HBM.  T: storage of dp, ds, y (and of the da that is no longer stored); TA: of the forward
+// activation (decides the rounding the pool argmax saw); TD: of dy.
+template <typename T, typename TD, typename TA>
+__global__ __launch_bounds__(256) void unpool_bn_bwd_apply_kernel(
+    const T* __restrict__ dp, long dp_ld, const T* __restrict__ ds, long ds_ld, const T* __restrict__ y, long y_ld,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, int nrep,
+    long count, TD* __restrict__ dy, long dy_ld, int B, int H, int W, int C, float* dgamma, float* dbeta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bn_smem[];
+  float* k12 = reinterpret_cast<float*>(bn_smem + 512 * sizeof(double));      // [2][C]
+  const double invM = 1.0 / (double)count;
+  {
+    const bool writer = blockIdx.x == 0;
+    replica_sums_block(sum_dz, sum_dzx, nrep, C, reinterpret_cast<double*>(bn_smem), [&](int c, double s1, double s2) {
+      k12[c] = (float)(s1 * invM);
+      k12[C + c] = (float)(s2 * invM);
+      if (writer) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+    });
+    __syncthreads();
+  }
+  const int cpr = C / 8;
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  if (rl >= rpi) return;
+  const int c0 = chunk * 8;
+  float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
+    k1[j] = k12[c0 + j];
+    k2[j] = k12[C + c0 + j];
+  }
+  const int Hp = H / 2, Wp = W / 2;
+  const long npool = (long)B * Hp * Wp;
+  for (long r = (long)blockIdx.x * rpi + rl; r < npool; r += (long)gridDim.x * rpi) {
+    const int xp = (int)(r % Wp);
+    const long t = r / Wp;
+    const int yp = (int)(t % Hp);
+    const long b = t / Hp;
+    float g[8], av[4][8], yv[4][8];
+    load8s(dp + r * dp_ld + c0, g);
+    long pix[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      pix[d] = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
+      load8s(y + pix[d] * y_ld + c0, yv[d]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[d][j] = storage_round<TA>(fmaxf(yv[d][j] * sc[j] + sh[j], 0.f));   // (as unpool_add)
+    }
+    int arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int best = 0;
+      float bv = av[0][j];
+#pragma unroll
+      for (int d = 1; d < 4; ++d)
+        if (av[d][j] > bv) { bv = av[d][j]; best = d; }   // first maximum wins (aten max_pool2d)
+      arg[j] = best;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float o[8];
+      if (ds) load8s(ds + pix[d] * ds_ld + c0, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dav = storage_round<T>((ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f));     // da as it was stored
+        o[j] = bn_bwd_dy(yv[d][j], dav, sc[j], sh[j], mu[j], is[j], k1[j], k2[j]);
+      }
+      store8(dy + pix[d] * dy_ld + c0, o);
     }
   }
 }
@@ -1387,11 +1468,11 @@ extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const voi
                                  int C, const void* bnb_y, long bnb_y_ld, const float* bnb_vec, long bnb_stride,
                                  double* stat_sum, double* stat_sumsq, int stat_replicas, void* stream) {
   PREC_OK("unpool_add");
-  CRIMAC_REQUIRE(dp && a && da && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 &&
+  CRIMAC_REQUIRE(dp && a && (da || stat_sum) && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 &&
                      C % 8 == 0 && C <= 2048,
-                 "unpool_add: bad arguments");
-  CRIMAC_REQUIRE(dp_ld >= C && a_ld >= C && da_ld >= C && (!ds || ds_ld >= C) && dp_ld % 8 == 0 &&
-                     a_ld % 8 == 0 && da_ld % 8 == 0 && (!ds || ds_ld % 8 == 0),
+                 "unpool_add: bad arguments (da may be NULL only with the fused BatchNorm-backward sums)");
+  CRIMAC_REQUIRE(dp_ld >= C && a_ld >= C && (!da || da_ld >= C) && (!ds || ds_ld >= C) && dp_ld % 8 == 0 &&
+                     a_ld % 8 == 0 && (!da || da_ld % 8 == 0) && (!ds || ds_ld % 8 == 0),
                  "unpool_add: bad pixel strides");
   CRIMAC_REQUIRE(bnb_args_ok(bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas, C),
                  "unpool_add: bad arguments of the fused BatchNorm-backward sums");
@@ -1474,6 +1555,38 @@ extern "C" int crimac_bn_bwd_apply_replicas(int prec, const void* da, long da_ld
                                                  ST, (const T*)da, da_ld, (const T*)y, y_ld, bn_vec + 2 * bn_stride,
                                                  bn_vec + 3 * bn_stride, bn_vec, bn_vec + bn_stride, sum_dz, sum_dz_xhat,
                                                  M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, replicas));
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
+
+// crimac_unpool_add (sums only: da == NULL) + crimac_bn_bwd_apply_replicas without the round trip of da through HBM.
+// prec as for crimac_bn_bwd_apply_replicas (CRIMAC_PREC_H3F_BWD: dp, ds, y fp32 -> dy fp16; the pool argmax is taken on the
+// plane-pair rounding of the activation, as the forward pass stored it).
+extern "C" int crimac_unpool_bn_bwd_apply_replicas(int prec, const void* dp, long dp_ld, const void* ds, long ds_ld,
+                                                   const void* y, long y_ld, const float* bn_vec, long bn_stride,
+                                                   const double* sum_dz, const double* sum_dz_xhat, int replicas,
+                                                   long count, void* dy, long dy_ld, int B, int H, int W, int C,
+                                                   float* dgamma, float* dbeta, void* stream) {
+  PREC_OK_BWD16("unpool_bn_bwd_apply_replicas");
+  CRIMAC_REQUIRE(dp && y && bn_vec && bn_stride >= C && sum_dz && sum_dz_xhat && replicas >= 1 && dy && dgamma && dbeta &&
+                     B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0 && C <= 2048,
+                 "unpool_bn_bwd_apply_replicas: bad arguments");
+  const long M = (long)B * H * W;
+  CRIMAC_REQUIRE(count == 0 || count >= M, "unpool_bn_bwd_apply_replicas: count smaller than the pixels of this call");
+  if (count == 0) count = M;
+  CRIMAC_REQUIRE(dp_ld >= C && y_ld >= C && dy_ld >= C && (!ds || ds_ld >= C) && dp_ld % 8 == 0 && y_ld % 8 == 0 &&
+                     dy_ld % 8 == 0 && (!ds || ds_ld % 8 == 0),
+                 "unpool_bn_bwd_apply_replicas: bad pixel strides");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  const int grid = grid_for(total, 256);
+  const size_t lds = 512 * sizeof(double) + 2 * (size_t)C * sizeof(float);
+#define UBA(T, TD, TA)                                                                                                  \
+  hipLaunchKernelGGL((unpool_bn_bwd_apply_kernel<T, TD, TA>), dim3(grid), dim3(256), lds, ST, (const T*)dp, dp_ld,      \
+                     (const T*)ds, ds_ld, (const T*)y, y_ld, bn_vec + 2 * bn_stride, bn_vec + 3 * bn_stride, bn_vec,    \
+                     bn_vec + bn_stride, sum_dz, sum_dz_xhat, replicas, count, (TD*)dy, dy_ld, B, H, W, C, dgamma, dbeta)
+  if (prec == CRIMAC_PREC_H3F_BWD) UBA(float, half_t, hp_t);
+  else CRIMAC_FOR_STORAGE2(prec, T, TP, UBA(T, TP, TP));
+#undef UBA
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
 }

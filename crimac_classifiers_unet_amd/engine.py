@@ -674,6 +674,9 @@ class UNetEngine:
     # ------------------------------------------------------------------------------------------
     conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
     fuse_bn_bwd = os.environ.get("CRIMAC_FUSE_BNB", "1") != "0"   # BN-backward sums inside the dgrad conv
+    # encoder levels: d(block output) = d(skip) + unpool(d(pooled)) is rebuilt by the BatchNorm-backward apply pass instead
+    # of being stored by crimac_unpool_add and read back (crimac_unpool_bn_bwd_apply_replicas)
+    fuse_unpool_apply = os.environ.get("CRIMAC_FUSE_UNPOOL_APPLY", "1") != "0"
     fuse_eval_pool = os.environ.get("CRIMAC_FUSE_EVAL_POOL", "1") != "0"   # eval: max-pool in the conv epilogue
     fuse_up_bnb = os.environ.get("CRIMAC_FUSE_UPBNB", "1") != "0"  # ... and inside the transposed-conv dgrad
     # BatchNorm+ReLU of the last decoder block applied inside the 1x1 head (needs fuse_bn_bwd: the head's backward
@@ -1071,14 +1074,16 @@ class UNetEngine:
     # backward
     # ------------------------------------------------------------------------------------------
     def _block_bwd(self, tag, b, da: Act, y: Act, x_in: Act, B, h, w, M, dx_out: Act, reduce_done=False,
-                   next_bn=None, bias_from_stats=None):
+                   next_bn=None, bias_from_stats=None, unpool_src=None):
         """Backward of conv3x3+BN+ReLU given da (grad of the block output).
 
         reduce_done: the producer of ``da`` already accumulated this block's BatchNorm-backward sums
         into its replica accumulators (conv3x3 stat_mode 2).  next_bn=(block, y): ``dx_out`` is the
         ``da`` of that block -> fuse ITS sums into the dgrad convolution.  bias_from_stats=(grad, C, level):
         also take the per-channel sums of the first C channels of ``dx_out`` (a transposed-conv bias
-        gradient) from the dgrad epilogue.  Returns whether next_bn's sums were fused."""
+        gradient) from the dgrad epilogue.  unpool_src=(dp, ds): ``da`` was NOT stored -- it is ds + unpool(dp), whose
+        BatchNorm-backward sums crimac_unpool_add took (sums-only call); the apply kernel rebuilds it.
+        Returns whether next_bn's sums were fused."""
         world = self._sync_world()
         folded = reduce_done and self.fold_bn_finalize and world == 1     # the replicas are added up by the apply kernel
         if folded:
@@ -1105,7 +1110,14 @@ class UNetEngine:
             dgamma, dbeta = scr[0], scr[1]
         # (d(conv bias in front of train-mode BN) = sum dy == 0 exactly: left at the zero fill -- the reference holds
         # ~1e-8 rounding noise there; 2048 x C same-address atomics saved)
-        if folded:
+        if unpool_src is not None:
+            if not folded:
+                raise RuntimeError("unpool_src needs the folded BatchNorm-backward path")
+            dp_, ds_ = unpool_src
+            call("crimac_unpool_bn_bwd_apply_replicas", prec_apply, dp_.p, dp_.ld, ds_.p if ds_ is not None else None,
+                 ds_.ld if ds_ is not None else 0, y.p, y.ld, ptr(self._bnf(b, 0)), self.cmax, ptr(self._stat(b, 0)),
+                 ptr(self._stat(b, 1)), self._nrep(b.cout), M, dy.p, dy.ld, B, h, w, b.cout, ptr(dgamma), ptr(dbeta))
+        elif folded:
             call("crimac_bn_bwd_apply_replicas", prec_apply, da.p, da.ld, y.p, y.ld, ptr(self._bnf(b, 0)), self.cmax,
                  ptr(self._stat(b, 0)), ptr(self._stat(b, 1)), self._nrep(b.cout), M, M, b.cout, dy.p, dy.ld,
                  ptr(dgamma), ptr(dbeta))
@@ -1313,19 +1325,29 @@ class UNetEngine:
             c = self.sf * 2 ** i
             b1, b2 = self.enc[i]
             x_in, y1, a1, y2, a2 = s[f"e{i}"]
+            unpool_src = None
             if i == D - 1:
                 da2 = d_cur
             else:
-                da2 = Act(self._buf(f"g.e{i}.a2", (M, c)), c)
                 ds = skip_grad[i]
                 ev = self._skip_done.pop(D - 2 - i, None)
                 if ev is not None:                      # skip half of d(concat) was produced on the side stream
                     torch.cuda.current_stream().wait_event(ev)
+                # da2 = ds + unpool(d_pool) is consumed by this block's BatchNorm backward only: with the fused sums it
+                # is never stored -- the first pass takes the sums, the apply pass rebuilds it (-1.5 of 12.5 bytes per
+                # element of the two passes in bf16)
+                if (self.fuse_unpool_apply and self.fuse_bn_bwd and self.fold_bn_finalize
+                        and self._sync_world() == 1):
+                    da2, unpool_src = None, (d_pool, ds)
+                else:
+                    da2 = Act(self._buf(f"g.e{i}.a2", (M, c)), c)
                 call("crimac_unpool_add", self.prec, d_pool.p, d_pool.ld, a2.p, a2.ld, ds.p, ds.ld,
-                     da2.p, da2.ld, B, h, w, c, *self._bnb_args(b2, y2 if self.fuse_bn_bwd else None))
+                     da2.p if da2 is not None else None, da2.ld if da2 is not None else 0, B, h, w, c,
+                     *self._bnb_args(b2, y2 if self.fuse_bn_bwd else None))
             da1 = Act(self._buf(f"g.e{i}.a1", (M, c)), c)
             fused = self._block_bwd(f"g.e{i}.2", b2, da2, y2, a1, B, h, w, M, da1, next_bn=(b1, y1),
-                                    reduce_done=(self.fuse_bn_bwd and i != D - 1) or (i == D - 1 and cur_done))
+                                    reduce_done=(self.fuse_bn_bwd and i != D - 1) or (i == D - 1 and cur_done),
+                                    unpool_src=unpool_src)
             if i > 0:
                 d_pool = Act(self._buf(f"g.e{i}.xin", (M, b1.cin)), b1.cin)
                 self._block_bwd(f"g.e{i}.1", b1, da1, y1, x_in, B, h, w, M, d_pool, reduce_done=fused)

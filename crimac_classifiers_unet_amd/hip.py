@@ -40,7 +40,7 @@ EPI_RELU, EPI_OUT_PLANES, EPI_CIN4 = 1, 2, 4      # `relu` argument of the convo
 PREC_BACKWARD = {PREC_F32H3: PREC_F32X3}
 PREC_16BIT = (PREC_BF16, PREC_FP16)
 
-ABI_VERSION = 4          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
+ABI_VERSION = 5          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -79,6 +79,8 @@ SIGNATURES = {
     "crimac_bn_bwd_apply": [_i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _vp, _l, _vp,
                             _vp, _vp, _vp],
     "crimac_bn_bwd_apply_replicas": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _l, _l, _i, _vp, _l, _vp, _vp, _vp],
+    "crimac_unpool_bn_bwd_apply_replicas": [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _l, _vp, _l, _i, _i, _i, _i,
+                                            _vp, _vp, _vp],
     "crimac_head_fwd": [_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_head_bwd": [_i, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp,
                         _i, _vp],

@@ -117,7 +117,7 @@ extern "C" {
  * binding must refuse a library whose version differs from the header it was written against (an older build that
  * happens to export every symbol would walk a descriptor array with the wrong stride).  crimac_layer_desc_size() is
  * sizeof(crimac_layer_desc) as the library was compiled. */
-#define CRIMAC_ABI_VERSION 4
+#define CRIMAC_ABI_VERSION 5
 int crimac_version(void);
 int crimac_layer_desc_size(void);
 const char* crimac_last_error(void);
@@ -352,6 +352,15 @@ int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const void* y, lon
 int crimac_bn_bwd_apply_replicas(int prec, const void* da, long da_ld, const void* y, long y_ld, const float* bn_vec,
                                  long bn_stride, const double* sum_dz, const double* sum_dz_xhat, int replicas, long M,
                                  long count, int C, void* dy, long dy_ld, float* dgamma, float* dbeta, void* stream);
+
+/* Round 4: crimac_unpool_add (called with da == NULL: it then only takes the BatchNorm-backward sums) followed by
+ * crimac_bn_bwd_apply_replicas, without the round trip of da = ds + unpool(dp) through HBM: da is rebuilt from (dp, ds, y)
+ * with the arithmetic and the storage rounding of crimac_unpool_add while dy is formed.  Backward of
+ * MaxPool2d(2,2) + skip + BatchNorm2d + ReLU of one encoder level (reference unet.py:85-92, :78-82).  ds may be NULL. */
+int crimac_unpool_bn_bwd_apply_replicas(int prec, const void* dp, long dp_ld, const void* ds, long ds_ld, const void* y,
+                                        long y_ld, const float* bn_vec, long bn_stride, const double* sum_dz,
+                                        const double* sum_dz_xhat, int replicas, long count, void* dy, long dy_ld, int B,
+                                        int H, int W, int C, float* dgamma, float* dbeta, void* stream);
 
 /* ---- 1x1 head, loss, optimiser --------------------------------------------------------------- */
 

@@ -1034,3 +1034,79 @@ def test_backward_with_grouped_weight_gradients_equals_the_ungrouped_backward(pr
     for k in ("range", "three"):
         a, b = res[k][o:o + n].double(), base[o:o + n].double()
         assert float((a - b).norm() / b.norm()) < 3e-4, k
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "f32x6", "h3p", "h3f"])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64), (1, 8, 8, 512), (3, 32, 32, 128), (2, 64, 64, 64)])
+def test_unpool_bn_bwd_apply_rebuilds_the_gradient_bit_for_bit(prec, shape):
+    """crimac_unpool_bn_bwd_apply_replicas (round 4) against the two kernels it replaces on the same inputs and the SAME
+    replica accumulators: crimac_unpool_add stores da = ds + unpool(dp) and takes the BatchNorm-backward sums,
+    crimac_bn_bwd_apply_replicas turns (da, y) into dy; the fused kernel rebuilds da from (dp, ds, y).  dy, dgamma, dbeta:
+    identical bits, in every storage family (h3p: dy as fp16 plane pairs; h3f: fp32 in, fp16 dy)."""
+    B, H, W, C = shape
+    M, Mp = B * H * W, B * (H // 2) * (W // 2)
+    g = torch.Generator().manual_seed(91)
+    fwd = {"h3p": hip.PREC_H3P, "h3f": hip.PREC_H3P}.get(prec, hip.PREC_NAMES.get(prec))       # precision of unpool_add
+    app = {"h3p": hip.PREC_H3P, "h3f": hip.PREC_H3F_BWD}.get(prec, hip.PREC_NAMES.get(prec))   # ... of the apply pass
+    dt = _DT.get(prec, torch.float32)                        # storage of dp, ds, y, da
+    dy_dt = {"h3p": torch.float32, "h3f": torch.float16}.get(prec, dt)      # (plane pairs: 4 bytes per element)
+    y = (torch.randn(M, C, generator=g) * 2).to(dt).cuda()
+    # ties in the pooled activation (equal maxima, and whole windows at zero after the ReLU) are the interesting case
+    y[: M // 3] = (y[: M // 3].float().round()).to(dt)
+    dp = torch.randn(Mp, C, generator=g).to(dt).cuda()
+    ds = torch.randn(M, C, generator=g).to(dt).cuda()
+    stride = C + 8
+    vec = torch.zeros(4, stride)
+    vec[0, :C] = torch.randn(C, generator=g) * 0.3                       # mean
+    vec[1, :C] = torch.rand(C, generator=g) + 0.5                        # invstd
+    vec[2, :C] = (torch.rand(C, generator=g) + 0.5) * vec[1, :C]         # scale = gamma * invstd
+    vec[3, :C] = torch.randn(C, generator=g) * 0.5 - vec[0, :C] * vec[2, :C]
+    vec = vec.cuda()
+    nrep = 16
+    s0 = torch.zeros(nrep, C, dtype=torch.float64, device="cuda")
+    s1 = torch.zeros(nrep, C, dtype=torch.float64, device="cuda")
+    da = torch.empty(M, C, dtype=dt, device="cuda")
+    a_dummy = torch.zeros(8, dtype=torch.float32, device="cuda")         # (not read when the sums are fused)
+    call("crimac_unpool_add", fwd, ptr(dp), C, ptr(a_dummy), C, ptr(ds), C, ptr(da), C, B, H, W, C,
+         ptr(y), C, ptr(vec), stride, ptr(s0), ptr(s1), nrep)
+    # the sums-only form accumulates the same sums (fp64 atomics: compare after the replicas are added up)
+    t0, t1 = torch.zeros_like(s0), torch.zeros_like(s1)
+    call("crimac_unpool_add", fwd, ptr(dp), C, ptr(a_dummy), C, ptr(ds), C, None, 0, B, H, W, C,
+         ptr(y), C, ptr(vec), stride, ptr(t0), ptr(t1), nrep)
+    torch.cuda.synchronize()
+    assert relerr(t0.sum(0), s0.sum(0)) < 1e-5 and relerr(t1.sum(0), s1.sum(0)) < 1e-5      # (fp32 partial sums per workgroup)
+    out = {}
+    for fused in (False, True):
+        dy = torch.full((M, C), float("nan"), dtype=dy_dt, device="cuda")
+        dg = torch.empty(C, dtype=torch.float32, device="cuda")
+        db = torch.empty(C, dtype=torch.float32, device="cuda")
+        if fused:
+            call("crimac_unpool_bn_bwd_apply_replicas", app, ptr(dp), C, ptr(ds), C, ptr(y), C, ptr(vec), stride, ptr(s0),
+                 ptr(s1), nrep, M, ptr(dy), C, B, H, W, C, ptr(dg), ptr(db))
+        else:
+            call("crimac_bn_bwd_apply_replicas", app, ptr(da), C, ptr(y), C, ptr(vec), stride, ptr(s0), ptr(s1), nrep, M, M, C,
+                 ptr(dy), C, ptr(dg), ptr(db))
+        torch.cuda.synchronize()
+        out[fused] = (dy, dg, db)
+    raw = (lambda t: t.view(torch.int32) if t.dtype == torch.float32 else t.view(torch.int16))
+    if not torch.equal(raw(out[True][0]), raw(out[False][0])):
+        a_, b_ = out[True][0].float(), out[False][0].float()
+        bad = (a_ != b_).nonzero()
+        i0 = bad[0]
+        raise AssertionError(f"dy differs at {len(bad)} of {a_.numel()} elements, first {i0.tolist()}: {a_[tuple(i0)].item()!r} vs "
+                             f"{b_[tuple(i0)].item()!r}; max abs diff {float((a_ - b_).abs().max())}")
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+    assert bool(torch.isfinite(out[True][0].float()).all()) or prec == "h3p"
+    # ... and without a skip gradient (ds = NULL)
+    dy2 = torch.empty(M, C, dtype=dy_dt, device="cuda")
+    call("crimac_unpool_bn_bwd_apply_replicas", app, ptr(dp), C, None, 0, ptr(y), C, ptr(vec), stride, ptr(s0), ptr(s1), nrep,
+         M, ptr(dy2), C, B, H, W, C, ptr(out[True][1]), ptr(out[True][2]))
+    da0 = torch.empty(M, C, dtype=dt, device="cuda")
+    u0, u1 = torch.zeros_like(s0), torch.zeros_like(s1)
+    call("crimac_unpool_add", fwd, ptr(dp), C, ptr(a_dummy), C, None, 0, ptr(da0), C, B, H, W, C, ptr(y), C, ptr(vec), stride,
+         ptr(u0), ptr(u1), nrep)
+    dy3 = torch.empty(M, C, dtype=dy_dt, device="cuda")
+    call("crimac_bn_bwd_apply_replicas", app, ptr(da0), C, ptr(y), C, ptr(vec), stride, ptr(s0), ptr(s1), nrep, M, M, C,
+         ptr(dy3), C, ptr(out[False][1]), ptr(out[False][2]))
+    torch.cuda.synchronize()
+    assert torch.equal(raw(dy2), raw(dy3))
