@@ -14,7 +14,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(conv3x3_wch_kernel|conv3x3_glds_w4_kernel|conv3x3_c16_kernel|conv3x3_p64_kernel|conv3x3_kernel|upconv_wch_kernel|wgrad_pp_group_kernel|wgrad_group_kernel|wgrad_up_pp_kernel|wgrad_pp_kernel|wgrad_kernel|igemm_kernel|bn_\w+_kernel|colstats_kernel|"
+        m = re.search(r"(conv3x3_wch_kernel|conv3x3_glds_w4_kernel|conv3x3_c16_kernel|conv3x3_p64_kernel|conv3x3_kernel|upconv_wch_kernel|wgrad_pp_group_kernel|wgrad_group_kernel|wgrad_up_pp_kernel|wgrad_pp_kernel|wgrad_kernel|igemm_kernel|unpool_bn_bwd_apply_kernel|bn_\w+_kernel|colstats_kernel|"
                       r"unpool_add_kernel|head_\w+_kernel|sgd_kernel|pack_\w+_kernel|unpack_\w+_kernel)", r["Kernel_Name"])
         if not m:
             continue
