@@ -1477,7 +1477,9 @@ extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const voi
   CRIMAC_REQUIRE(bnb_args_ok(bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas, C),
                  "unpool_add: bad arguments of the fused BatchNorm-backward sums");
   const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-  const int grid = grid_for(total, 256);
+  // with the fused sums every workgroup ends with 2 C LDS-atomic columns and 2 C fp64 atomics: four pooled pixels per
+  // thread instead of one (512 ch @ 32^2: 61 -> see tools/bench_unpool.py)
+  const int grid = grid_for(total, stat_sum ? 256 * 4 : 256);
   BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
 #define UA(T, TA, BNB, LDS)                                                                               \
   hipLaunchKernelGGL((unpool_add_kernel<T, BNB, TA>), dim3(grid), dim3(256), LDS, ST, (const T*)dp, dp_ld, \
@@ -1578,7 +1580,9 @@ extern "C" int crimac_unpool_bn_bwd_apply_replicas(int prec, const void* dp, lon
                      dy_ld % 8 == 0 && (!ds || ds_ld % 8 == 0),
                  "unpool_bn_bwd_apply_replicas: bad pixel strides");
   const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-  const int grid = grid_for(total, 256);
+  // every workgroup adds up the replica accumulators first (replicas x C x 2 doubles): four pooled pixels = 16 rows per
+  // thread, the share of bn_bwd_apply_stream_kernel's threads (one per thread: 80 us for 512 ch @ 32^2, the plain apply 36)
+  const int grid = grid_for(total, 256 * 4);
   const size_t lds = 512 * sizeof(double) + 2 * (size_t)C * sizeof(float);
 #define UBA(T, TD, TA)                                                                                                  \
   hipLaunchKernelGGL((unpool_bn_bwd_apply_kernel<T, TD, TA>), dim3(grid), dim3(256), lds, ST, (const T*)dp, dp_ld,      \

@@ -107,6 +107,8 @@ class UNetEngine:
         # first form that ran the whole fp16 backward pass on fp16 copies of y was 4e-2 off on the first layer's gradient:
         # rounding y flips ReLU masks and pool positions (discrete errors), rounding a gradient does not.
         self.bwd16 = precision == "h3f"
+        env = os.environ.get("CRIMAC_FUSE_UNPOOL_APPLY")
+        self.fuse_unpool_apply = (env != "0") if env is not None else precision not in ("bf16", "fp16")
         if self.bwd16:
             self.prec_bwd = hip.PREC_H3F_BWD
         self._scale_state = None            # int32[2] on the GPU: [overflow this step, steps skipped]
@@ -675,8 +677,11 @@ class UNetEngine:
     conv_impl = os.environ.get("CRIMAC_CONV_IMPL", "halo")     # 'halo' (conv3x3.hip) | 'gather' (igemm.hip)
     fuse_bn_bwd = os.environ.get("CRIMAC_FUSE_BNB", "1") != "0"   # BN-backward sums inside the dgrad conv
     # encoder levels: d(block output) = d(skip) + unpool(d(pooled)) is rebuilt by the BatchNorm-backward apply pass instead
-    # of being stored by crimac_unpool_add and read back (crimac_unpool_bn_bwd_apply_replicas)
-    fuse_unpool_apply = os.environ.get("CRIMAC_FUSE_UNPOOL_APPLY", "1") != "0"
+    # of being stored by crimac_unpool_add and read back (crimac_unpool_bn_bwd_apply_replicas).  Default (set in __init__):
+    # on where the gradient is stored in 4 bytes (h3p / h3f / fp32 modes: -0.10 to -0.17 ms of an 18 ms h3f step); off for
+    # 16-bit storage, where the sums-only pass is bound by its arithmetic, not by the bytes it no longer writes (bf16:
+    # 11.39-11.44 -> 11.42-11.46 ms, same box).  CRIMAC_FUSE_UNPOOL_APPLY=0/1 forces it.
+    fuse_unpool_apply = None
     fuse_eval_pool = os.environ.get("CRIMAC_FUSE_EVAL_POOL", "1") != "0"   # eval: max-pool in the conv epilogue
     fuse_up_bnb = os.environ.get("CRIMAC_FUSE_UPBNB", "1") != "0"  # ... and inside the transposed-conv dgrad
     # BatchNorm+ReLU of the last decoder block applied inside the 1x1 head (needs fuse_bn_bwd: the head's backward
