@@ -48,6 +48,22 @@ def collated_in_worker(dataloader):
             and getattr(dataloader, "collate_fn", None) is default_collate)
 
 
+def release_shared_pages(batch, madvise=None, min_bytes=1 << 20):
+    """Give the pages behind the shared-memory tensors of ``batch`` (a dict as default_collate builds it in a worker) back
+    to the kernel with madvise(MADV_REMOVE) -- through ctypes, i.e. WITHOUT the GIL -- so that dropping the batch
+    afterwards is cheap.  The tensors read as zeros from then on: only for batches nobody else refers to
+    (``collated_in_worker``).  Returns the number of bytes released; a failing madvise only means the slow path."""
+    madvise = madvise or _libc_madvise()
+    done = 0
+    for v in (batch.values() if isinstance(batch, dict) else ()):
+        if torch.is_tensor(v) and v.device.type == "cpu" and v.is_shared() and v.is_contiguous():
+            p, nb = v.data_ptr(), v.numel() * v.element_size()
+            lo, hi = (p + _PAGE - 1) & ~(_PAGE - 1), (p + nb) & ~(_PAGE - 1)
+            if hi - lo >= min_bytes and madvise(lo, hi - lo, MADV_REMOVE) == 0:
+                done += hi - lo
+    return done
+
+
 RING = 6          # device / pinned slots: one being filled, up to three staged, two in steps the GPU may still be running
 AHEAD = 2         # steps the training thread may be ahead of the GPU before it waits (frees the slot of step i - AHEAD)
 
@@ -181,13 +197,8 @@ class BatchStager:
         import time
         t0 = time.perf_counter()
         if self.release_pages:
-            for v in (batch.values() if isinstance(batch, dict) else ()):
-                if torch.is_tensor(v) and v.device.type == "cpu" and v.is_shared() and v.is_contiguous():
-                    p, nb = v.data_ptr(), v.numel() * v.element_size()
-                    lo, hi = (p + _PAGE - 1) & ~(_PAGE - 1), (p + nb) & ~(_PAGE - 1)
-                    if hi - lo >= (1 << 20):
-                        self._madvise(lo, hi - lo, MADV_REMOVE)      # (a failure only means the slow path below)
-        batch = v = None
+            release_shared_pages(batch, self._madvise)
+        batch = None
         self._note("release_s", t0)
 
     def _releaser(self):
