@@ -108,6 +108,7 @@ class BatchStager:
             self._free.put(k)
         self._stop = False
         self._err = None
+        self._it = None
 
     def _ensure(self, slot, data, labels):
         # The device buffers are allocated ON THE COPY STREAM: the caching allocator hands a block that was freed on a
@@ -139,7 +140,7 @@ class BatchStager:
         import time
         try:
             i = -1
-            it = iter(self.dataloader)
+            it = self._it
             while True:
                 t0 = time.perf_counter()
                 batch = next(it, None)
@@ -228,6 +229,18 @@ class BatchStager:
     def _iterate(self):
         import collections
         import time
+        # The DataLoader's iterator is created HERE, by the training thread, before any helper thread exists: creating it
+        # forks the worker processes, and a fork out of a helper thread of a process that has live threads of its own
+        # (the HIP runtime's, a previous stager's) left workers that died with a segmentation fault now and then
+        # (tests/test_gpu_unet.py::test_batch_stager_..., one run in three).  The staging thread only calls next().
+        # ... and with no cyclic garbage pending: a forked worker starts with a garbage collection (multiprocessing's
+        # after-fork hooks), and collecting an unreachable stager / engine of the PARENT there runs the destructors of its
+        # events and pinned tensors -- HIP calls in a forked child: "Fatal Python error: Segmentation fault ...
+        # Garbage-collecting ... _run_after_forkers" (seen with the stager of a loop that had ended in an exception).
+        if getattr(self.dataloader, "num_workers", 0) > 0:
+            import gc
+            gc.collect()
+        self._it = iter(self.dataloader)
         threads = [threading.Thread(target=self._stager, daemon=True, name="crimac-batch-stage")]
         rel = threading.Thread(target=self._releaser, daemon=True, name="crimac-batch-release")
         for th in threads + [rel]:
@@ -257,7 +270,8 @@ class BatchStager:
                 self._note("step_wait_batch_s", t0)
                 if item is None:
                     if self._err is not None:
-                        raise self._err
+                        err, self._err = self._err, None
+                        raise err
                     return
                 i, k, batch, has_lab = item
                 slot = self.slots[k]
@@ -279,4 +293,12 @@ class BatchStager:
                     pass
             self._dead.put(None)
             rel.join()
+            self._it = None                                # (the workers are shut down by this thread, too)
             torch.cuda.current_stream(self.device).synchronize()     # nothing still reads the ring
+            # the ring's events, pinned and device buffers go NOW, by reference count, in this process -- not whenever a
+            # garbage collection finds the stager (the exception kept in _err refers to the staging thread's frame, which
+            # refers to the stager: a cycle)
+            err, self._err = self._err, None
+            self.slots = []
+            self.copy_stream = None
+            del err

@@ -510,6 +510,56 @@ def test_train_model_pinned_input_ring_equals_the_inline_copy(workers):
     assert l2rel(params[True], params[False]) < 1e-4
 
 
+class _FailingCrops(torch.utils.data.Dataset):
+    """Small batch-dict Dataset whose item `bad` raises (a corrupt survey file in the reference's readers)."""
+
+    def __init__(self, n, bad=None):
+        self.n, self.bad = n, bad
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if i == self.bad:
+            raise OSError(f"crop {i} is unreadable")
+        g = np.random.default_rng(i)
+        return {"data": g.standard_normal((4, 32, 32)).astype(np.float32), "labels": np.full((32, 32), i % 3, np.int16),
+                "center_coordinates": np.array([i, i], dtype=np.int64)}
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_batch_stager_delivers_in_order_surfaces_loader_errors_and_survives_an_early_exit(workers):
+    """staging.BatchStager around a DataLoader: every batch arrives once, in order, on the device and equal to what the
+    DataLoader yields; an exception inside the Dataset (here: in a worker process, too) comes out of the training thread's
+    loop instead of hanging it; leaving the loop early (an exception in the step, `break`) stops the helper threads."""
+    import threading
+    from crimac_classifiers_unet_amd.staging import BatchStager
+    dl = torch.utils.data.DataLoader(_FailingCrops(24), batch_size=4, shuffle=False, num_workers=workers)
+    ref = [b for b in torch.utils.data.DataLoader(_FailingCrops(24), batch_size=4, shuffle=False, num_workers=0)]
+    seen = []
+    for i, x, lab, batch in BatchStager(dl, "cuda:0", yield_batch=False):
+        assert batch is None and x.is_cuda and x.dtype == torch.float32 and lab.dtype == torch.int16
+        seen.append((i, x.clone(), lab.clone()))          # (the ring reuses the buffers)
+    assert [i for i, _, _ in seen] == list(range(6))
+    for (i, x, lab), r in zip(seen, ref):
+        assert torch.equal(x.cpu(), r["data"]) and torch.equal(lab.cpu(), r["labels"])
+    # yield_batch=True hands the DataLoader's own dict on (center_coordinates for the callers that want them)
+    for i, x, lab, batch in BatchStager(dl, "cuda:0"):
+        assert torch.equal(batch["center_coordinates"], ref[i]["center_coordinates"]) and torch.equal(x.cpu(), batch["data"])
+    # a failing item: the error reaches the consumer after the good batches in front of it
+    bad = torch.utils.data.DataLoader(_FailingCrops(24, bad=13), batch_size=4, shuffle=False, num_workers=workers)
+    got = []
+    with pytest.raises(Exception, match="crop 13 is unreadable"):
+        for i, x, lab, _ in BatchStager(bad, "cuda:0", yield_batch=False):
+            got.append(i)
+    assert got == [0, 1, 2]
+    # early exit: the generator's cleanup runs, no helper thread stays behind
+    it = iter(BatchStager(dl, "cuda:0", yield_batch=False))
+    next(it), next(it)
+    it.close()
+    assert not [t.name for t in threading.enumerate() if t.name.startswith("crimac-batch")]
+
+
 def test_validation_f1_matches_cpu_reference_path():
     """The 'F1 vs CPU ref' half of the metric (pipeline.py:242-341): get_predictions_dataloader +
     compute_evaluation_metrics through the GPU pipeline vs the same steps on the CPU oracle."""
