@@ -76,6 +76,31 @@ class _Slot:
         self.done = torch.cuda.Event()       # recorded on the training stream behind the step that read the slot
 
 
+# The ring survives its stager: a pass over the DataLoader (one call of train_model) used to start with six pinned
+# allocations of 37 MB (hipHostMalloc: 20-70 ms each on a loaded host -- 0.4-1.3 ms per step averaged over 300 iterations,
+# a third of the loop's distance to the resident-batch step).  One idle ring per device is kept here; it is reachable, so a
+# forked DataLoader worker never finalises it (see _iterate).
+_RING_LOCK = threading.Lock()
+_IDLE_RINGS = {}
+
+
+def _take_ring(device):
+    with _RING_LOCK:
+        ring = _IDLE_RINGS.pop(str(device), None)
+    return ring if ring is not None else [_Slot() for _ in range(RING)]
+
+
+def _give_ring(device, slots):
+    with _RING_LOCK:
+        _IDLE_RINGS.setdefault(str(device), slots)
+
+
+def release_ring_cache():
+    """Free the cached pinned / device buffers (they are reused by the next pass otherwise)."""
+    with _RING_LOCK:
+        _IDLE_RINGS.clear()
+
+
 class BatchStager:
     """Iterate ``dataloader`` yielding ``(index, data_dev [B,C,H,W] float32, labels_dev [B,H,W], batch)`` with the
     tensors already on ``device`` (uploaded, and the upload complete, before they are yielded).
@@ -100,7 +125,7 @@ class BatchStager:
         self.dataloader = dataloader
         self.device = torch.device(device)
         self.keys = keys
-        self.slots = [_Slot() for _ in range(RING)]
+        self.slots = _take_ring(self.device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._q = queue.Queue(maxsize=RING - AHEAD - 1)      # uploaded slots waiting for their step
         self._free = queue.Queue()                   # slots no GPU work refers to
@@ -119,11 +144,11 @@ class BatchStager:
         # tests/test_gpu_unet.py::test_train_model_pinned_input_ring_equals_the_inline_copy with DataLoader workers).
         with torch.cuda.stream(self.copy_stream):
             if (slot.data_pin is None or slot.data_pin.shape != data.shape or slot.data_pin.dtype != data.dtype):
-                slot.data_pin = torch.empty(data.shape, dtype=data.dtype).pin_memory()
+                slot.data_pin = torch.empty(data.shape, dtype=data.dtype, pin_memory=True)
                 slot.data_dev = torch.empty(data.shape, dtype=data.dtype, device=self.device)
             if labels is not None and (slot.lab_pin is None or slot.lab_pin.shape != labels.shape
                                        or slot.lab_pin.dtype != labels.dtype):
-                slot.lab_pin = torch.empty(labels.shape, dtype=labels.dtype).pin_memory()
+                slot.lab_pin = torch.empty(labels.shape, dtype=labels.dtype, pin_memory=True)
                 slot.lab_dev = torch.empty(labels.shape, dtype=labels.dtype, device=self.device)
 
     def _note(self, key, t0):
@@ -237,8 +262,8 @@ class BatchStager:
         # after-fork hooks), and collecting an unreachable stager / engine of the PARENT there runs the destructors of its
         # events and pinned tensors -- HIP calls in a forked child: "Fatal Python error: Segmentation fault ...
         # Garbage-collecting ... _run_after_forkers" (seen with the stager of a loop that had ended in an exception).
-        if getattr(self.dataloader, "num_workers", 0) > 0:
-            import gc
+        if getattr(self.dataloader, "num_workers", 0) > 0 and getattr(self.dataloader, "_iterator", None) is None:
+            import gc                                      # (persistent workers that are already running: no fork)
             gc.collect()
         self._it = iter(self.dataloader)
         threads = [threading.Thread(target=self._stager, daemon=True, name="crimac-batch-stage")]
@@ -295,10 +320,11 @@ class BatchStager:
             rel.join()
             self._it = None                                # (the workers are shut down by this thread, too)
             torch.cuda.current_stream(self.device).synchronize()     # nothing still reads the ring
-            # the ring's events, pinned and device buffers go NOW, by reference count, in this process -- not whenever a
-            # garbage collection finds the stager (the exception kept in _err refers to the staging thread's frame, which
-            # refers to the stager: a cycle)
+            # the ring's events, pinned and device buffers leave the stager NOW (back to the module's cache, where they stay
+            # reachable) -- not whenever a garbage collection finds the stager: the exception kept in _err refers to the
+            # staging thread's frame, which refers to the stager (a cycle), and the collection might be a forked worker's
             err, self._err = self._err, None
-            self.slots = []
+            slots, self.slots = self.slots, []
+            _give_ring(self.device, slots)
             self.copy_stream = None
-            del err
+            del err, slots

@@ -55,8 +55,6 @@ for nw in (workers if os.environ.get('ALONE') else []):
     del dl
 
 stats = {}
-orig = staging.BatchStager.__init__
-staging.BatchStager.__init__ = lambda self, dl, dev, keys=("data", "labels"), stats_=None, yield_batch=True: orig(self, dl, dev, keys, stats, yield_batch)
 for nw in workers:
     dl = loader(nw)
     pipe = pkg.SegPipeUNet(checkpoint_dir=None, data_mode="zarr", frequencies=[18, 38, 120, 200], patch_size=[256, 256],
@@ -65,6 +63,7 @@ for nw in workers:
                            late_meta_inject=False, eval_mode="all", experiment_name="diag", precision=prec, infer_precision=prec,
                            loss_flush=10 ** 9)
     pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+    pipe.stager_stats = stats
     with contextlib.redirect_stdout(sys.stderr):
         pipe.train_model(dl, None, None)
         torch.cuda.synchronize()
