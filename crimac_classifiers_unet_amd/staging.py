@@ -14,8 +14,8 @@ or polled ACROSS threads (an event recorded by the training thread and queried f
 35-45 ms after a 0.6 ms upload had been issued, tools/diag_loop_graph.py round 4): the staging thread synchronises the
 copy stream it issued on, and the training thread hands a device slot back after synchronising, itself, on the event it
 recorded behind the step two iterations back -- which also keeps the host at most two steps ahead of the GPU.
-Measured (round 4, 1 MI355X, 4 workers, 300 iterations): SegPipe.train_model 12.15 ms per bf16 step (resident batch 11.6)
-and 19.3 ms per h3f step (18.2); steady state is GPU-bound (11.8 ms cycle), the rest is the DataLoader's start-up.
+Measured (round 4, 1 MI355X, 4 workers, 300 iterations): SegPipe.train_model 11.4 ms per bf16 step (resident batch 11.4)
+and 17.8 ms per h3f step (17.9) -- the loop runs at the resident-batch rate.
 The same structure feeds the tiled-inference path (tiled_inference.predict_survey: reader thread -> pinned staging ->
 copy stream -> two resident chunk buffers).
 """
