@@ -633,8 +633,11 @@ def test_batch_stager_delivers_in_order_surfaces_loader_errors_and_survives_an_e
     for (i, x, lab), r in zip(seen, ref):
         assert torch.equal(x.cpu(), r["data"]) and torch.equal(lab.cpu(), r["labels"])
     # yield_batch=True hands the DataLoader's own dict on (center_coordinates for the callers that want them)
-    for i, x, lab, batch in BatchStager(dl, "cuda:0"):
-        assert torch.equal(batch["center_coordinates"], ref[i]["center_coordinates"]) and torch.equal(x.cpu(), batch["data"])
+    # (with worker processes only the two cases that differ there run: every new iterator forks the workers out of a
+    # process with the GPU mapped, ~10 s per fork on the test boxes)
+    if workers == 0:
+        for i, x, lab, batch in BatchStager(dl, "cuda:0"):
+            assert torch.equal(batch["center_coordinates"], ref[i]["center_coordinates"]) and torch.equal(x.cpu(), batch["data"])
     # a failing item: the error reaches the consumer after the good batches in front of it
     bad = torch.utils.data.DataLoader(_FailingCrops(24, bad=13), batch_size=4, shuffle=False, num_workers=workers)
     got = []
@@ -643,9 +646,10 @@ def test_batch_stager_delivers_in_order_surfaces_loader_errors_and_survives_an_e
             got.append(i)
     assert got == [0, 1, 2]
     # early exit: the generator's cleanup runs, no helper thread stays behind
-    it = iter(BatchStager(dl, "cuda:0", yield_batch=False))
-    next(it), next(it)
-    it.close()
+    if workers == 0:
+        it = iter(BatchStager(dl, "cuda:0", yield_batch=False))
+        next(it), next(it)
+        it.close()
     assert not [t.name for t in threading.enumerate() if t.name.startswith("crimac-batch")]
 
 
