@@ -625,6 +625,14 @@ def test_batch_stager_delivers_in_order_surfaces_loader_errors_and_survives_an_e
     from crimac_classifiers_unet_amd.staging import BatchStager
     dl = torch.utils.data.DataLoader(_FailingCrops(24), batch_size=4, shuffle=False, num_workers=workers)
     ref = [b for b in torch.utils.data.DataLoader(_FailingCrops(24), batch_size=4, shuffle=False, num_workers=0)]
+    # a failing item FIRST: the error reaches the consumer after the good batches in front of it -- and the next
+    # DataLoader's workers are then forked while the dead loop's stager is still around (the round-4 worker crash)
+    bad = torch.utils.data.DataLoader(_FailingCrops(24, bad=13), batch_size=4, shuffle=False, num_workers=workers)
+    got = []
+    with pytest.raises(Exception, match="crop 13 is unreadable"):
+        for i, x, lab, _ in BatchStager(bad, "cuda:0", yield_batch=False):
+            got.append(i)
+    assert got == [0, 1, 2]
     seen = []
     for i, x, lab, batch in BatchStager(dl, "cuda:0", yield_batch=False):
         assert batch is None and x.is_cuda and x.dtype == torch.float32 and lab.dtype == torch.int16
@@ -638,13 +646,6 @@ def test_batch_stager_delivers_in_order_surfaces_loader_errors_and_survives_an_e
     if workers == 0:
         for i, x, lab, batch in BatchStager(dl, "cuda:0"):
             assert torch.equal(batch["center_coordinates"], ref[i]["center_coordinates"]) and torch.equal(x.cpu(), batch["data"])
-    # a failing item: the error reaches the consumer after the good batches in front of it
-    bad = torch.utils.data.DataLoader(_FailingCrops(24, bad=13), batch_size=4, shuffle=False, num_workers=workers)
-    got = []
-    with pytest.raises(Exception, match="crop 13 is unreadable"):
-        for i, x, lab, _ in BatchStager(bad, "cuda:0", yield_batch=False):
-            got.append(i)
-    assert got == [0, 1, 2]
     # early exit: the generator's cleanup runs, no helper thread stays behind
     if workers == 0:
         it = iter(BatchStager(dl, "cuda:0", yield_batch=False))
