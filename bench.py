@@ -479,19 +479,18 @@ def measure_tiled(model, args, log, world=1):
             "written_frac_sampled": written / (n_range * ((n_pings + 63) // 64))}
 
 
-def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_batches=True):
-    """The loop the reference actually runs (pipeline.py:161-181): ``SegPipeUNet.train_model`` fed by a
-    ``torch.utils.data.DataLoader`` (default collate, worker processes) over an in-memory synthetic Dataset that yields
-    the reference's batch dict -- ``data`` float32 [4, 256, 256], ``labels`` int16 [256, 256], ``center_coordinates``
-    int64 [2] per sample (SURVEY.md A10) -- so the timed region contains the collate, the worker -> parent hand-over,
-    the H2D copy (pinned ring + copy stream, staging.py) and the step.  One untimed pass over the DataLoader first
-    (worker start-up, pinned / device allocations), then one timed pass; workers persist between the two."""
+_LOOP_DL = {}
+
+
+def train_loop_dataloader(args):
+    """ONE DataLoader (persistent workers) for all train_loop legs: forking a worker out of this process -- tens of GB of
+    GPU mappings by now -- takes seconds, and three legs would fork twelve."""
     import numpy as np
     import torch
-    import crimac_classifiers_unet_amd as pkg
     from crimac_classifiers_unet_amd import synth
-
-    B, iters = args.batch, max(args.loop_iters, 30)     # (a pass pays the DataLoader's start-up once: ~0.2 s, 4 workers)
+    if "dl" in _LOOP_DL:
+        return _LOOP_DL["dl"]
+    B, iters = args.batch, max(args.loop_iters, 30)
     n_distinct = 2 * B
     data = synth.synth_echogram_batch(n_distinct, 4, 256, 256, seed=300)
     labels = synth.synth_labels(n_distinct, 256, 256, seed=301)
@@ -505,8 +504,26 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
             return {"data": data[k], "labels": labels[k], "center_coordinates": np.array([128, 128 + i], dtype=np.int64)}
 
     nw = max(int(args.loop_workers), 0)
-    dl = torch.utils.data.DataLoader(SyntheticCrops(), batch_size=B, shuffle=False, num_workers=nw, drop_last=True,
-                                     persistent_workers=nw > 0)
+    _LOOP_DL["dl"] = torch.utils.data.DataLoader(SyntheticCrops(), batch_size=B, shuffle=False, num_workers=nw, drop_last=True,
+                                                 persistent_workers=nw > 0)
+    return _LOOP_DL["dl"]
+
+
+def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_batches=True):
+    """The loop the reference actually runs (pipeline.py:161-181): ``SegPipeUNet.train_model`` fed by a
+    ``torch.utils.data.DataLoader`` (default collate, worker processes) over an in-memory synthetic Dataset that yields
+    the reference's batch dict -- ``data`` float32 [4, 256, 256], ``labels`` int16 [256, 256], ``center_coordinates``
+    int64 [2] per sample (SURVEY.md A10) -- so the timed region contains the collate, the worker -> parent hand-over,
+    the H2D copy (pinned ring + copy stream, staging.py) and the step.  One untimed pass over the DataLoader first
+    (worker start-up, pinned / device allocations), then one timed pass; workers persist between the two."""
+    import numpy as np
+    import torch
+    import crimac_classifiers_unet_amd as pkg
+    from crimac_classifiers_unet_amd import synth
+
+    B, iters = args.batch, max(args.loop_iters, 30)     # (a pass pays the DataLoader's start-up once)
+    nw = max(int(args.loop_workers), 0)
+    dl = train_loop_dataloader(args)
     pipe = pkg.SegPipeUNet(checkpoint_dir=None, data_mode="zarr", frequencies=[18, 38, 120, 200], patch_size=[256, 256],
                            loss_type="CE", lr=0.005, lr_reduction=0.5, lr_step=1000, momentum=0.95, batch_size=B,
                            num_workers=nw, iterations=iters, test_iter=10, log_step=10 ** 9, save_model_params=False,
@@ -535,7 +552,7 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
         pipe.train_model(dl, None, logger=lg)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    del dl, pipe                                      # (worker processes and the model go before anything else is timed)
+    del dl, pipe                                      # (the model goes before anything else is timed; the workers stay for the next leg)
     import gc
     gc.collect()
     torch.cuda.empty_cache()
@@ -680,6 +697,9 @@ def run_rank(args):
                                                                pin_batches=False)
         if parity is not None:
             parity["train_loop"] = measure_train_loop(args, args.parity_precision, dev, log, parity["train_patches_per_s"])
+        _LOOP_DL.clear()                                   # (the worker processes end here, before the CPU baseline is timed)
+        import gc
+        gc.collect()
     if rank == 0:
         sf = args.start_filts
         rl = main["roofline"]
