@@ -761,7 +761,7 @@ class UNetEngine:
             return True
         if self.bwd16:
             raise NotImplementedError("h3f: transposed-convolution shape outside the fused input-gradient kernel "
-                                      f"(Cout={u.cout} % 64, Cin={u.cin} % 128)")
+                                      f"(Cout={u.cout} % 64, Cin={u.cin} % 128); precision 'h3p' covers it")
         self._upconv_dgrad_plain(dy, u, out, B, H, W)
         return False
 
