@@ -480,56 +480,106 @@ def measure_tiled(model, args, log, world=1):
 
 
 _LOOP_DL = {}
+LOOP_MODES = {"transformed": 0, "raw_f32": 1, "raw_f64": 2, "host_chain": 3}
+
+
+class _HostChain:
+    """The reference's worker-side transform chain (batch/dataset.py:89-103) on one raw crop -- the CPU-baseline leg of
+    ``train_loop_raw``: oracle/augment_oracle.worker_train_chain (pinned bit for bit against the imported reference,
+    tests/test_worker_chain.py), with a RandomState per sample."""
+
+    def __call__(self, data, labels, index):
+        import numpy as np
+        from oracle import augment_oracle           # (CPU baseline leg only)
+        return augment_oracle.worker_train_chain(data, labels, np.random.RandomState(0x5EED + index))
+
+
+class _LegSampler:
+    """The index range of the leg being measured; lives in the parent, so one set of worker processes serves all legs."""
+    lo = hi = 0
+
+    def __iter__(self):
+        return iter(range(self.lo, self.hi))
+
+    def __len__(self):
+        return self.hi - self.lo
 
 
 def train_loop_dataloader(args):
     """ONE DataLoader (persistent workers) for all train_loop legs: forking a worker out of this process -- tens of GB of
-    GPU mappings by now -- takes seconds, and three legs would fork twelve."""
+    GPU mappings by now -- takes seconds, and six legs would fork twenty-four.  The leg is encoded in the sample index
+    (index >> 32, LOOP_MODES); the sampler (parent side) hands out the index range of the current leg."""
     import numpy as np
     import torch
     from crimac_classifiers_unet_amd import synth
     if "dl" in _LOOP_DL:
-        return _LOOP_DL["dl"]
-    B, iters = args.batch, max(args.loop_iters, 30)
+        return _LOOP_DL["dl"], _LOOP_DL["sampler"]
+    B = args.batch
     n_distinct = 2 * B
     data = synth.synth_echogram_batch(n_distinct, 4, 256, 256, seed=300)
     labels = synth.synth_labels(n_distinct, 256, 256, seed=301)
+    # raw legs: an in-memory survey with annotated schools (the label refinement has its real work to do), NaN / Inf samples
+    survey = synth.SyntheticSurveyReader(n_pings=16384, n_range=1024, block=4096, schools=60, bad_frac=1e-4, seed=5)
+    raw = {1: synth.RawCropDataset(survey, (256, 256), 1 << 31, seed=21, dtype=np.float32),
+           2: synth.RawCropDataset(survey, (256, 256), 1 << 31, seed=21, dtype=np.float64),
+           3: synth.RawCropDataset(survey, (256, 256), 1 << 31, seed=21, dtype=np.float32, transform=_HostChain())}
 
-    class SyntheticCrops(torch.utils.data.Dataset):
+    class LoopCrops(torch.utils.data.Dataset):
         def __len__(self):
-            return iters * B
+            return 1 << 34
 
-        def __getitem__(self, i):
-            k = i % n_distinct
-            return {"data": data[k], "labels": labels[k], "center_coordinates": np.array([128, 128 + i], dtype=np.int64)}
+        def __getitem__(self, index):
+            mode, i = index >> 32, index & 0xFFFFFFFF
+            if mode == 0:        # pre-transformed crops at zero host cost: the hand-over / collate / H2D machinery alone
+                k = i % n_distinct
+                return {"data": data[k], "labels": labels[k], "center_coordinates": np.array([128, 128 + i], dtype=np.int64)}
+            return raw[mode][i]
 
     nw = max(int(args.loop_workers), 0)
-    _LOOP_DL["dl"] = torch.utils.data.DataLoader(SyntheticCrops(), batch_size=B, shuffle=False, num_workers=nw, drop_last=True,
+    sampler = _LegSampler()
+    _LOOP_DL["sampler"] = sampler
+    _LOOP_DL["dl"] = torch.utils.data.DataLoader(LoopCrops(), batch_size=B, sampler=sampler, num_workers=nw, drop_last=True,
                                                  persistent_workers=nw > 0)
-    return _LOOP_DL["dl"]
+    return _LOOP_DL["dl"], sampler
 
 
-def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_batches=True):
+def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_batches=True, mode="transformed", iters=None):
     """The loop the reference actually runs (pipeline.py:161-181): ``SegPipeUNet.train_model`` fed by a
     ``torch.utils.data.DataLoader`` (default collate, worker processes) over an in-memory synthetic Dataset that yields
-    the reference's batch dict -- ``data`` float32 [4, 256, 256], ``labels`` int16 [256, 256], ``center_coordinates``
+    the reference's batch dict -- ``data`` [4, 256, 256], ``labels`` int16 [256, 256], ``center_coordinates``
     int64 [2] per sample -- so the timed region contains the collate, the worker -> parent hand-over,
     the H2D copy (pinned ring + copy stream, staging.py) and the step.  One untimed pass over the DataLoader first
-    (worker start-up, pinned / device allocations), then one timed pass; workers persist between the two."""
+    (worker start-up, pinned / device allocations), then one timed pass; workers persist between the two.
+
+    ``mode`` (LOOP_MODES):
+      transformed  the Dataset returns ready-made dB crops and final labels at zero host cost (round 4's ``train_loop``):
+                   the staging machinery alone;
+      raw_f32 /    ``train_loop_raw``: every ``__getitem__`` draws a random centre and GATHERS a raw crop from an in-memory
+      raw_f64      survey (linear sv + raw annotation ids: the reference's Dataset built with its three transform hooks set
+                   to None, batch/dataset.py:76-110; float32 = the memmap flavour's crop dtype, float64 = the zarr
+                   flavour's), and ``SegPipeUNet(gpu_augment=True, gpu_label_transform=True)`` runs add_noise / flip /
+                   refine_label_boundary / convert_label_indexing / remove_nan_inf / db_with_limits on the GPU in front of
+                   the step -- all inside the timed region;
+      host_chain   the CPU baseline of that leg: the same crops with the reference's transform chain run IN THE WORKERS
+                   (oracle/augment_oracle.worker_train_chain == the imported reference bit for bit), default pipeline."""
     import numpy as np
     import torch
     import crimac_classifiers_unet_amd as pkg
     from crimac_classifiers_unet_amd import synth
 
-    B, iters = args.batch, max(args.loop_iters, 30)     # (a pass pays the DataLoader's start-up once)
+    B = args.batch
+    iters = int(iters) if iters else max(args.loop_iters, 30)     # (a pass pays the DataLoader's start-up once)
     nw = max(int(args.loop_workers), 0)
-    dl = train_loop_dataloader(args)
+    dl, sampler = train_loop_dataloader(args)
+    sampler.lo = LOOP_MODES[mode] << 32
+    sampler.hi = sampler.lo + iters * B
+    on_gpu = mode in ("raw_f32", "raw_f64")
     pipe = pkg.SegPipeUNet(checkpoint_dir=None, data_mode="zarr", frequencies=[18, 38, 120, 200], patch_size=[256, 256],
                            loss_type="CE", lr=0.005, lr_reduction=0.5, lr_step=1000, momentum=0.95, batch_size=B,
                            num_workers=nw, iterations=iters, test_iter=10, log_step=10 ** 9, save_model_params=False,
                            meta_channels=[], late_meta_inject=False, eval_mode="all", experiment_name="bench",
                            precision=precision, infer_precision=precision, pin_batches=pin_batches,
-                           loss_flush=10 ** 9)
+                           loss_flush=10 ** 9, gpu_augment=on_gpu, gpu_label_transform=on_gpu)
     pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
 
     class LastLoss:
@@ -558,15 +608,21 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
     torch.cuda.empty_cache()
     pps = iters * B / dt
     assert lg.last is not None and lg.last == lg.last, "train_loop: NaN loss"
-    log(f"{precision}: train_loop ({'pinned ring' if pin_batches else 'in-line copy'}, {nw} workers): {pps:.0f} patches/s "
+    log(f"{precision}: train_loop[{mode}] ({'pinned ring' if pin_batches else 'in-line copy'}, {nw} workers): {pps:.0f} patches/s "
         f"= {pps / resident_patches_per_s:.3f} of the resident-batch figure")
     return {"patches_per_s": pps, "ms_per_step": 1e3 * dt / iters, "iterations": iters, "batch": B,
-            "dataloader_workers": nw, "input_staging": "pinned ring + copy stream (staging.BatchStager)" if pin_batches
+            "dataset": mode, "dataloader_workers": nw, "input_staging": "pinned ring + copy stream (staging.BatchStager)" if pin_batches
             else "in-line .to(device) as the reference (pipeline.py:163-164)",
             "vs_resident_batch": pps / resident_patches_per_s, "final_loss": lg.last,
             "host_phases_ms_per_step": {k[:-2]: round(1e3 * v / iters, 3) for k, v in sorted(phases.items())} or None,
-            "timed": "SegPipeUNet.train_model over a DataLoader (default collate, batch dict of the reference): collate + "
-                     "hand-over + H2D + step, one full pass of the DataLoader after one untimed pass"}
+            "timed": {"transformed": "SegPipeUNet.train_model over a DataLoader (default collate, batch dict of the reference): "
+                                     "collate + hand-over + H2D + step, one full pass of the DataLoader after one untimed pass",
+                      "raw_f32": "random centre + crop gather from the in-memory survey in the workers (float32 crops), collate, "
+                                 "hand-over, H2D, add_noise / flip / label refinement + indexing / remove_nan_inf / dB ON THE GPU, step",
+                      "raw_f64": "as raw_f32 with float64 crops (what the reference's zarr crop returns): twice the bytes through "
+                                 "collate, hand-over and H2D; the `.float()` runs on the device",
+                      "host_chain": "random centre + crop gather + the reference's transform chain (add_noise, flip, label "
+                                    "refinement + indexing, remove_nan_inf, dB) IN THE WORKERS, collate, hand-over, H2D, step"}[mode]}
 
 
 def load_profile_json(name):
@@ -697,6 +753,23 @@ def run_rank(args):
                                                                pin_batches=False)
         if parity is not None:
             parity["train_loop"] = measure_train_loop(args, args.parity_precision, dev, log, parity["train_patches_per_s"])
+        # train_loop_raw: the loop a drop-in user runs -- real crop gathers in the workers, raw crops up,
+        # the whole transform chain on the GPU -- next to its CPU baseline (the same chain in the workers)
+        raw = measure_train_loop(args, args.precision, dev, log, main["train_patches_per_s"], mode="raw_f32")
+        raw["float64_crops"] = measure_train_loop(args, args.precision, dev, log, main["train_patches_per_s"], mode="raw_f64")
+        hc = measure_train_loop(args, args.precision, dev, log, main["train_patches_per_s"], mode="host_chain",
+                                iters=max(12, args.loop_iters // 8))
+        nw_ = max(int(args.loop_workers), 1)
+        hc["host_ms_per_patch_per_worker"] = 1e3 * nw_ / hc["patches_per_s"]
+        hc["what"] = ("CPU baseline of train_loop_raw, kind 'port': the reference's per-sample transform chain in the DataLoader "
+                      "workers (reference measured in the build container: 12.4 ms per float32 patch and core -- add_noise 8.3, "
+                      "label transform 3.0, dB 0.9; profiles/r05_reference_host_chain.txt)")
+        raw["host_chain_baseline"] = hc
+        raw["speedup_vs_host_chain"] = raw["patches_per_s"] / hc["patches_per_s"]
+        main["train_loop_raw"] = raw
+        if parity is not None:
+            parity["train_loop_raw"] = measure_train_loop(args, args.parity_precision, dev, log, parity["train_patches_per_s"],
+                                                          mode="raw_f32")
         _LOOP_DL.clear()                                   # (the worker processes end here, before the CPU baseline is timed)
         import gc
         gc.collect()
@@ -756,6 +829,8 @@ def run_rank(args):
         }
         if main.get("train_loop") is not None:
             out["train_loop"] = main["train_loop"]
+        if main.get("train_loop_raw") is not None:
+            out["train_loop_raw"] = main["train_loop_raw"]
         if main.get("exchange") is not None:
             out["exchange"] = main["exchange"]
         if parity is not None:

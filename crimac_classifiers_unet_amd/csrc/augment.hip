@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void augment_db_kernel(
     const float* __restrict__ data, const void* __restrict__ labels_in, int label_bytes,
     T* __restrict__ out, short* __restrict__ labels_out, unsigned char* __restrict__ aux, int thr_channel,
     float thr_lo, float thr_hi, int B, int C, int H, int W, int ld,
-    unsigned seed_lo, unsigned seed_hi, int do_noise, int do_flip, float p_apply, float p_change) {
+    unsigned seed_lo, unsigned seed_hi, int do_noise, int do_flip, int db_scaled, float p_apply, float p_change) {
   const long HW = (long)H * W, npix = (long)B * HW;
   for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < npix;
        pix += (long)gridDim.x * blockDim.x) {
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void augment_db_kernel(
       if (c == thr_channel) thr_hit = d > thr_lo && d < thr_hi;      // on the augmented linear value; NaN -> false
       if (!isfinite(d)) { if (c == 0) nonfinite0 = true; d = 0.f; }
       d = 10.f * log10f(d + 1e-10f);
-      v[c] = fminf(fmaxf(d, -75.f), 0.f);
+      d = fminf(fmaxf(d, -75.f), 0.f);
+      // db_with_limits_scaled (db_with_limits.py:27-33), the data transform of the metadata configurations
+      // (batch/transforms.py:50-51): 1 + dB / |limit_low| in [0, 1]
+      v[c] = db_scaled ? 1.f + d / 75.f : d;
     }
     for (int c = C; c < ld; ++c) v[c] = 0.f;
     T* dst = out + (((long)b * H + y) * W + xo) * ld;
@@ -87,12 +90,40 @@ __global__ __launch_bounds__(256) void augment_db_kernel(
   }
 }
 
+// flip_x_axis_metadata (flip_x_axis.py:27-32) for the planes that do not go through augment_db_kernel -- the metadata
+// planes of UNet_LateMetInject: the ping axis of sample b is flipped under the SAME per-sample decision (same Philox
+// draw) as its data and labels.
+__global__ __launch_bounds__(256) void flip_planes_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                          int C, int H, int W, unsigned seed_lo, unsigned seed_hi,
+                                                          int do_flip, float p_apply) {
+  const long CHW = (long)C * H * W, n = (long)B * CHW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / CHW);
+    const u4 s = philox4x32_10(u4{0u, 0u, 0u, 0xA5A5A5A5u}, seed_lo ^ (unsigned)b, seed_hi);
+    const bool flip = do_flip && u01(s.y) < p_apply;
+    const int x = (int)(i % W);
+    out[flip ? i - x + (W - 1 - x) : i] = in[i];
+  }
+}
+
 }  // namespace
+
+extern "C" int crimac_augment_flip_planes(const float* in, float* out, int B, int C, int H, int W,
+                                          unsigned long long seed, int do_flip, void* stream) {
+  CRIMAC_REQUIRE(in && out && in != out && B > 0 && C > 0 && H > 0 && W > 0, "augment_flip_planes: bad arguments");
+  const long n = (long)B * C * H * W;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(flip_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, B, C, H, W,
+                     (unsigned)seed, (unsigned)(seed >> 32), do_flip, 0.5f);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
 
 extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* labels_in, int label_bytes,
                                       void* out, short* labels_out, unsigned char* aux_mask, int thr_channel,
                                       float thr_lo, float thr_hi, int B, int C, int H, int W, long ld,
-                                      unsigned long long seed, int do_noise, int do_flip, void* stream) {
+                                      unsigned long long seed, int do_noise, int do_flip, int db_scaled, void* stream) {
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "augment_db_nhwc: bad precision %d", prec);
   CRIMAC_REQUIRE(data && out && B > 0 && C > 0 && C <= 16 && H > 0 && W > 0 && ld >= C && ld <= 16 && ld % 8 == 0,
                  "augment_db_nhwc: bad arguments (C=%d ld=%ld)", C, ld);
@@ -108,7 +139,7 @@ extern "C" int crimac_augment_db_nhwc(int prec, const float* data, const void* l
   hipStream_t st = (hipStream_t)stream;
   CRIMAC_FOR_STORAGE2(prec, TF_, T, hipLaunchKernelGGL(augment_db_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, data,
                                                  labels_in, label_bytes, (T*)out, labels_out, aux_mask, thr_channel,
-                                                 thr_lo, thr_hi, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, 0.5f,
+                                                 thr_lo, thr_hi, B, C, H, W, (int)ld, lo, hi, do_noise, do_flip, db_scaled, 0.5f,
                                                  0.05f));
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;

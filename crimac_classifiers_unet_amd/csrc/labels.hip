@@ -144,7 +144,10 @@ __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
             const int xs = xd - tc.seabed_ping0;
             below = xs >= 0 && xs < tc.seabed_pings && (yd - tc.seabed_pad) >= tc.seabed[xs];
           } else if (tc.seabed_mask) {
-            const int xm = xd - tc.mask_ping0;
+            // mask_ping0 == CRIMAC_MASK_PER_PATCH: the mask is laid out per patch, [B][W][n_range] (columns the patch
+            // has outside the survey are zero rows) -- a batch whose patches lie anywhere in a long survey
+            const bool per_patch = tc.mask_ping0 == CRIMAC_MASK_PER_PATCH;
+            const int xm = per_patch ? b * W + x : xd - tc.mask_ping0;
             below = xm >= 0 && xm < tc.mask_pings && tc.seabed_mask[(long)xm * tc.n_range + (yd - tc.seabed_pad)];
           }
           if (below) l = -50;
@@ -166,7 +169,77 @@ __global__ __launch_bounds__(kThreads) void refine_labels_kernel(
   }
 }
 
+// get_extended_label_mask_for_crop (batch/label_transforms/extend_label_masks.py:35-98), the last link of
+// define_label_transform_test when eval_mode is 'region' / 'trace' (batch/transforms.py:87-90): a pixel keeps its label
+// only inside a (host-extended) school bounding box, everything else becomes `ignore_val`; remove_nan_inf's label rule
+// (which the reference applies AFTER the label chain) is re-applied on top.  One workgroup per patch; the boxes are
+// filtered against the patch 1024 at a time into an LDS list, every thread carries the keep flags of its 64-pixel column
+// share in registers.
+constexpr int kBoxRound = 1024;
+
+__global__ __launch_bounds__(kThreads) void extend_mask_kernel(short* __restrict__ labels, const float* __restrict__ data,
+                                                               int C, const long long* __restrict__ centres,
+                                                               const int* __restrict__ boxes, int n_boxes, int ignore_val,
+                                                               int H, int W) {
+  __shared__ int list[kBoxRound][4];
+  __shared__ int n_list;
+  const int b = blockIdx.x, tid = threadIdx.x, HW = H * W;
+  // the reference places the crop at centre - shape // 2 (extend_label_masks.py:64), one pixel off the crop's real
+  // origin (utils/np.py:378-380) -- restated as is
+  const int yul = (int)centres[2 * b] - H / 2, xul = (int)centres[2 * b + 1] - W / 2;
+  const int per_thread = (HW + kThreads - 1) / kThreads;
+  unsigned long long keep = 0;                             // one bit per pixel of this thread (H * W <= 64 * 1024)
+  for (int r0 = 0; r0 < n_boxes; r0 += kBoxRound) {
+    if (tid == 0) n_list = 0;
+    __syncthreads();
+    const int k = r0 + tid;
+    if (tid < kBoxRound && k < n_boxes) {
+      // rows / columns of the patch the box covers: [max(b0 - yul, 0), min(b1 - yul, H)) x [max(b2 - xul, 0), min(b3 - xul, W))
+      const int ya = max(boxes[4 * k] - yul, 0), yb = min(boxes[4 * k + 1] - yul, H);
+      const int xa = max(boxes[4 * k + 2] - xul, 0), xb = min(boxes[4 * k + 3] - xul, W);
+      if (yb > ya && xb > xa) {
+        const int at = atomicAdd(&n_list, 1);
+        list[at][0] = ya; list[at][1] = yb; list[at][2] = xa; list[at][3] = xb;
+      }
+    }
+    __syncthreads();
+    const int nl = n_list;
+    if (nl > 0) {
+      for (int j = 0; j < per_thread; ++j) {
+        const int i = tid + j * kThreads;
+        if (i >= HW) break;
+        const int y = i / W, x = i - y * W;
+        bool in = false;
+        for (int q = 0; q < nl && !in; ++q) in = y >= list[q][0] && y < list[q][1] && x >= list[q][2] && x < list[q][3];
+        if (in) keep |= 1ull << j;
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j < per_thread; ++j) {
+    const int i = tid + j * kThreads;
+    if (i >= HW) break;
+    const long gi = (long)b * HW + i;
+    if (!isfinite(data[(long)b * C * HW + i])) labels[gi] = -100;
+    else if (!((keep >> j) & 1)) labels[gi] = (short)ignore_val;
+  }
+}
+
 }  // namespace
+
+extern "C" int crimac_labels_extend_mask(short* labels, const float* data, int C, const long long* centres,
+                                         const int* boxes, int n_boxes, int ignore_val, int B, int H, int W,
+                                         void* stream) {
+  CRIMAC_REQUIRE(labels && data && centres && (boxes || n_boxes == 0) && n_boxes >= 0 && C > 0,
+                 "labels_extend_mask: bad arguments (n_boxes=%d)", n_boxes);
+  CRIMAC_REQUIRE(B > 0 && H > 0 && W > 0 && (long)H * W <= 64L * kThreads,
+                 "labels_extend_mask: patch of %d x %d (at most 65536 pixels)", H, W);
+  CRIMAC_REQUIRE(ignore_val >= -32768 && ignore_val <= 32767, "labels_extend_mask: ignore_val %d", ignore_val);
+  hipLaunchKernelGGL(extend_mask_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, labels, data, C, centres, boxes,
+                     n_boxes, ignore_val, H, W);
+  CRIMAC_LAUNCH_CHECK();
+  return CRIMAC_OK;
+}
 
 extern "C" int crimac_refine_labels(const void* labels_in, int label_bytes, const unsigned char* aux_mask,
                                     const float* data, int thr_channel, float thr_lo, float thr_hi, int mode,

@@ -1570,8 +1570,10 @@ class UNetEngine:
     # on-GPU augmentation (BASELINE configs[4]; reference: batch/data_augmentation/*)
     # ------------------------------------------------------------------------------------------
     @_on_device
-    def augment_batch(self, data_linear, labels, seed, do_noise=True, do_flip=True, refine_labels=None):
+    def augment_batch(self, data_linear, labels, seed, do_noise=True, do_flip=True, refine_labels=None, db_scaled=False):
         """add_noise + flip_x_axis + remove_nan_inf + db_with_limits + NCHW->NHWC in one kernel.
+        ``db_scaled``: db_with_limits_scaled instead (1 + dB / 75), the data transform of the metadata configurations
+        (batch/transforms.py:50-51).
 
         data_linear [B,C,H,W] fp32 LINEAR sv on the GPU, labels [B,H,W] int16/32/64 (or None).
         refine_labels=(thr_channel, thr_lo, thr_hi): ``labels`` are RAW annotation ids and the reference's
@@ -1597,7 +1599,7 @@ class UNetEngine:
         call("crimac_augment_db_nhwc", self.prec, ptr(data_linear), ptr(lab_in),
              lab_in.element_size() if lab_in is not None else 0, ptr(x), ptr(lab_out), ptr(aux), int(thr_c),
              float(lo), float(hi), B, C, H, W, CIN_PAD, int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if do_noise else 0,
-             1 if do_flip else 0)
+             1 if do_flip else 0, 1 if db_scaled else 0)
         if aux is not None:
             refined = self._buf("aug.labels_refined", (B, H, W), torch.int16)
             call("crimac_refine_labels", ptr(lab_out), 2, ptr(aux), None, int(thr_c), float(lo), float(hi), 1,
@@ -1606,11 +1608,28 @@ class UNetEngine:
         return x, lab_out
 
     @_on_device
+    def flip_planes(self, planes, seed, do_flip=True):
+        """The metadata planes [B,Cm,H,W] of a batch flipped along the ping axis under the same per-sample draws as
+        ``augment_batch(..., seed)`` flips data and labels (flip_x_axis_metadata, flip_x_axis.py:27-32)."""
+        planes = planes.contiguous().float()
+        B, Cm, H, W = planes.shape
+        out = self._buf("aug.meta", (B, Cm, H, W), torch.float32)
+        call("crimac_augment_flip_planes", ptr(planes), ptr(out), B, Cm, H, W, int(seed) & 0xFFFFFFFFFFFFFFFF,
+             1 if do_flip else 0)
+        return out
+
+    @_on_device
     def train_step_augmented(self, data_linear, labels, class_w, lr, momentum, seed, grad_sync=None,
-                             do_noise=True, do_flip=True, ignore_index=-100, refine_labels=None):
+                             do_noise=True, do_flip=True, ignore_index=-100, refine_labels=None, meta=None):
         """Training step on RAW linear-sv crops: augmentation and dB transform (and, with ``refine_labels``,
-        the label transform on raw annotation ids) run on the GPU."""
+        the label transform on raw annotation ids) run on the GPU.  ``meta`` [B,Cm,H,W] (UNet_LateMetInject): the
+        reference's *_metadata augmentations (batch/transforms.py:41-42) -- noise on the data planes only, the flip on
+        data, metadata and labels alike -- and the scaled dB transform of the metadata configurations (:50-51)."""
         B, _, H, W = data_linear.shape
-        x, lab = self.augment_batch(data_linear, labels, seed, do_noise, do_flip, refine_labels)
-        logits = self.forward_nhwc(x, B, H, W, training=True)
+        if self.lmi:
+            meta = self.flip_planes(self._meta(meta, data_linear), seed, do_flip)
+        elif meta is not None:
+            raise ValueError("this model takes no metadata tensor (late_meta_inject=False)")
+        x, lab = self.augment_batch(data_linear, labels, seed, do_noise, do_flip, refine_labels, db_scaled=self.lmi)
+        logits = self.forward_nhwc(x, B, H, W, training=True, meta=meta)
         return self._loss_backward_update(logits, lab, class_w, lr, momentum, grad_sync, ignore_index)

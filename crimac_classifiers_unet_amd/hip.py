@@ -40,7 +40,7 @@ EPI_RELU, EPI_OUT_PLANES, EPI_CIN4 = 1, 2, 4      # `relu` argument of the convo
 PREC_BACKWARD = {PREC_F32H3: PREC_F32X3}
 PREC_16BIT = (PREC_BF16, PREC_FP16)
 
-ABI_VERSION = 5          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
+ABI_VERSION = 6          # CRIMAC_ABI_VERSION of include/crimac_unet_hip.h this binding was written against
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -100,12 +100,14 @@ SIGNATURES = {
     "crimac_scatter_patches_ex": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i,
                                   _i, _i, _vp, _i, _vp],
     "crimac_augment_db_nhwc": [_i, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _i, _l, C.c_ulonglong,
-                               _i, _i, _vp],
+                               _i, _i, _i, _vp],
+    "crimac_augment_flip_planes": [_vp, _vp, _i, _i, _i, _i, C.c_ulonglong, _i, _vp],
     "crimac_refine_labels": [_vp, _i, _vp, _vp, _i, _f, _f, _i, _vp, _i, _i, _i, _i, _vp],
     "crimac_pr_histogram": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "crimac_mfma_calibrate": [_i, _i, _vp, _vp],
     "crimac_labels_test_transform": [_vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i,
                                      _i, _i],
+    "crimac_labels_extend_mask": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "crimac_scatter_patches": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i,
                                _i, _vp, _vp],
 }
@@ -126,6 +128,7 @@ class WgradGroupLayer(C.Structure):
 
 
 WGRAD_GROUP_MAX_LAYERS = 16      # CRIMAC_WGRAD_GROUP_MAX_LAYERS
+MASK_PER_PATCH = -2147483648      # CRIMAC_MASK_PER_PATCH
 
 
 _lib = None

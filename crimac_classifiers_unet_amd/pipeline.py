@@ -51,7 +51,8 @@ class SegPipe:
                  lr_step, momentum, batch_size, num_workers, iterations, test_iter, log_step,
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
                  precision="bf16", infer_precision="h3p", loss_flush=50, gpu_augment=False, random_seed=0,
-                 gpu_metrics=False, gpu_label_transform=False, sync_bn=False, pin_batches=True, **kwargs):
+                 gpu_metrics=False, gpu_label_transform=False, sync_bn=False, pin_batches=True,
+                 release_batch_pages=True, **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -90,6 +91,11 @@ class SegPipe:
         # pin_batches: train_model stages the DataLoader's batches through a pinned ring on a copy stream (H2D of step
         # i + 1 under step i); False = the reference's in-line `.to(device)` (pipeline.py:163-164)
         self.pin_batches = bool(pin_batches)
+        # release_batch_pages (with pin_batches): once a worker-collated batch has been copied to pinned memory its shared-
+        # memory pages are handed back with madvise(MADV_REMOVE) off the training thread (staging.release_shared_pages) --
+        # the batch's tensors read as zeros afterwards.  train_model never hands those batches out; set False if a
+        # DataLoader wrapper of yours keeps references to the batches it yields
+        self.release_batch_pages = bool(release_batch_pages)
         self.loss_flush = max(int(loss_flush), 1)
         # gpu_augment: the train Dataset hands RAW linear-sv crops (augmentation_function=None,
         # data_transform_function=None) and add_noise / flip_x_axis / remove_nan_inf / db_with_limits
@@ -104,6 +110,10 @@ class SegPipe:
         self.gpu_label_transform = bool(gpu_label_transform)
         if self.gpu_label_transform and not self.gpu_augment:
             raise ValueError("gpu_label_transform needs gpu_augment (the transform runs on the augmented crop)")
+        if self.gpu_augment and self.use_metadata and not self.late_meta_inject:
+            raise NotImplementedError("gpu_augment with metadata planes as extra INPUT channels (late_meta_inject=False): the "
+                                      "on-GPU data transform would take them for sv; use late_meta_inject=True or the host "
+                                      "transforms")
         self.random_seed = int(random_seed)
         # gpu_metrics: in-training validation builds the PR curve / F1 from GPU histograms instead of
         # shipping every pixel's probability to sklearn (same numbers; the logger gets no pr_curve)
@@ -185,7 +195,8 @@ class SegPipe:
             if self.pin_batches and self.device.type == "cuda":
                 from .staging import BatchStager
                 for i, x, lab, _ in BatchStager(dataloader_train, self.device, yield_batch=False,
-                                                stats=getattr(self, "stager_stats", None)):
+                                                stats=getattr(self, "stager_stats", None),
+                                                release_pages=self.release_batch_pages):
                     yield i, x, lab
                 return
             for i, batch in enumerate(dataloader_train):
@@ -205,14 +216,20 @@ class SegPipe:
                 nf = len(self.frequencies)
                 inputs_train, meta_train = inputs_train[:, :nf], inputs_train[:, nf:]
             if self.gpu_augment:
-                if self.late_meta_inject:
-                    raise NotImplementedError("gpu_augment with late metadata injection: the metadata planes follow the "
-                                              "flip of the reference's *_metadata augmentations, which run on the host")
+                if i == 0 and bool((inputs_train < 0).any()):
+                    # (one device -> host sync, first batch only) linear sv is non-negative; dB data is not
+                    raise ValueError("gpu_augment=True, but the training Dataset yields negative values: it still applies "
+                                     "its own data transform (db_with_limits).  Build it with augmentation_function=None, "
+                                     "data_transform_function=None (and label_transform_function=None with "
+                                     "gpu_label_transform) so that it hands RAW linear-sv crops, or switch gpu_augment off")
                 rank = parallel.env_world()[1]
+                # (late metadata injection: add_noise_metadata / flip_x_axis_metadata, batch/transforms.py:41-42 -- the
+                # metadata planes take the flip, and the data transform is db_with_limits_scaled, :50-51)
                 loss = engine.train_step_augmented(
                     inputs_train, labels_train, criterion.weight, optimizer.param_groups[0]["lr"],
                     self.momentum, seed=(self.random_seed << 40) ^ (rank << 32) ^ i, grad_sync=grad_sync,
-                    refine_labels=(len(self.frequencies) - 1, 1e-7, 1e-4) if self.gpu_label_transform else None)
+                    refine_labels=(len(self.frequencies) - 1, 1e-7, 1e-4) if self.gpu_label_transform else None,
+                    meta=meta_train)
             else:
                 loss = engine.train_step(inputs_train, labels_train, criterion.weight,
                                          optimizer.param_groups[0]["lr"], self.momentum,
@@ -257,58 +274,124 @@ class SegPipe:
 
     # -- test-time transforms on the GPU (the validation / evaluate flows) ---------------------
     _test_source = None
+    TEST_SEABED_BLOCK = 4096         # pings per block of the reader's seabed mask that is read and checked at a time
 
-    def use_gpu_test_transform(self, reader, patch_overlap=0, seabed_pad=10):
+    def use_gpu_test_transform(self, reader, patch_overlap=0, seabed_pad=10, extend_size=20):
         """From here on the validation / test DataLoaders hand RAW crops: the reference ``Dataset`` built with
         ``label_transform_function=None`` and ``data_transform_function=None`` (batch/dataset.py:89-103 then applies
         nothing), i.e. ``data`` = linear sv, ``labels`` = raw annotation ids (-100 outside the data),
         ``center_coordinates`` = (range idx, ping idx).  ``define_label_transform_test`` (batch/transforms.py:81-99) and
-        ``define_data_transform`` (:49-55) run on the GPU instead: ``crimac_labels_test_transform`` +
-        ``crimac_augment_db_nhwc`` (remove_nan_inf + db_with_limits, straight into the first convolution's layout).
-        ``reader``: the survey's zarr reader (``shape``, ``get_seabed``, ``get_seabed_mask``) the crops come from -- its
-        seabed is uploaded once.  ``None`` switches back to host-transformed batches."""
+        ``define_data_transform`` (:49-55) run on the GPU instead: ``crimac_labels_test_transform`` (+
+        ``crimac_labels_extend_mask`` when ``eval_mode`` is 'region' / 'trace', :87-90, ``extend_size`` as
+        define_label_transform_test's default) + ``crimac_augment_db_nhwc`` (remove_nan_inf + db_with_limits -- the scaled
+        form with metadata channels, :50-51 -- straight into the first convolution's layout).
+        ``reader``: the survey's zarr reader (``shape``, ``get_seabed``, ``get_seabed_mask``) the crops come from.  Its
+        per-ping seabed vector is read once (4 bytes per ping); the 2-D seabed mask -- which the vector must reproduce
+        exactly, ``tiled_inference.seabed_vector_or_mask`` -- is read and checked lazily, ``TEST_SEABED_BLOCK`` pings at
+        a time, for the blocks the batches actually touch; a batch touching a block the vector cannot express takes the
+        reader's mask per patch, as the reference does (mask_label_seabed.py:40-52).  ``None`` switches back to
+        host-transformed batches."""
         if reader is None:
             self._test_source = None
             return
         if getattr(reader, "data_format", "zarr") != "zarr":
             raise NotImplementedError("use_gpu_test_transform: zarr readers only (the memmap flow's set_data_border_value "
                                       "lives in the tiled path, tiled_inference.predict_echogram_memm)")
+        if self.use_metadata and not self.late_meta_inject:
+            raise NotImplementedError("use_gpu_test_transform with metadata planes as extra input channels "
+                                      "(late_meta_inject=False)")
+        n_pings, n_range = (int(v) for v in reader.shape)
+        boxes = None
+        if self.eval_mode in ("region", "trace"):
+            # get_extended_label_mask_for_crop (extend_label_masks.py:57-80); the reference asks the reader for
+            # get_object_bounding_boxes(), which only its memmap Echogram defines (data_reader.py:404) -- a zarr reader
+            # without it fails there with an AttributeError
+            if not hasattr(reader, "get_object_bounding_boxes"):
+                raise NotImplementedError(
+                    f"eval_mode={self.eval_mode!r}: the reader has no get_object_bounding_boxes() (the reference's "
+                    "get_extended_label_mask_for_crop needs it, extend_label_masks.py:67); use eval_mode='all'")
+            bb = np.array(reader.get_object_bounding_boxes(), dtype=np.int64).reshape(-1, 4)
+            if self.eval_mode == "region":
+                bb[:, 0] -= int(extend_size)
+                bb[:, 1] += int(extend_size)
+            else:
+                bb[:, 0] = 0
+                bb[:, 1] = int(reader.shape[0])          # (the reference's `echogram.shape[0]`, :78)
+            bb[:, 2] -= int(extend_size)
+            bb[:, 3] += int(extend_size)
+            boxes = torch.from_numpy(np.ascontiguousarray(bb.astype(np.int32))).to(self.device)
+        elif self.eval_mode != "all":
+            raise ValueError(f"eval_mode={self.eval_mode!r}: 'all', 'region' or 'trace' (batch/transforms.py:87)")
+        sb = np.ascontiguousarray(np.asarray(reader.get_seabed(0, n_pings, return_numpy=True)).astype(np.int32))
+        self._test_source = {"reader": reader, "seabed_host": sb, "seabed_dev": None, "blocks": {},
+                             "boxes": boxes, "n_pings": n_pings, "n_range": n_range,
+                             "overlap": int(patch_overlap), "pad": int(seabed_pad)}
+
+    def _test_seabed(self, centres, B, W):
+        """(seabed vector on the device, None) when the seabed vector reproduces the reader's mask on every block of pings
+        the batch touches, else (None, per-patch mask [B * W, n_range] uint8 on the device)."""
         from .tiled_inference import seabed_vector_or_mask
-        n_pings, n_range = reader.shape
-        sb = np.asarray(reader.get_seabed(0, n_pings, return_numpy=True)).astype(np.int32)
-        sb, mask = seabed_vector_or_mask(reader, 0, n_pings, n_range, sb, 0)
-        dev = self.device
-        self._test_source = {
-            "seabed": None if mask is not None else torch.from_numpy(np.ascontiguousarray(sb)).to(dev),
-            "mask": None if mask is None else torch.from_numpy(mask).to(dev),
-            "n_pings": int(n_pings), "n_range": int(n_range), "overlap": int(patch_overlap), "pad": int(seabed_pad)}
+        src = self._test_source
+        n_pings, n_range, blk = src["n_pings"], src["n_range"], self.TEST_SEABED_BLOCK
+        spans = []
+        for cx in centres[:, 1].tolist():
+            x0 = int(cx) - W // 2 + 1
+            spans.append((max(x0, 0), min(x0 + W, n_pings), x0))
+        ok = True
+        for xs, xe, _ in spans:
+            for k in range(xs // blk, (xe - 1) // blk + 1) if xe > xs else ():
+                if k not in src["blocks"]:
+                    s_, e_ = k * blk, min((k + 1) * blk, n_pings)
+                    sb2, mask = seabed_vector_or_mask(src["reader"], s_, e_, n_range, src["seabed_host"], 0)
+                    if sb2 is not src["seabed_host"]:            # pings without a detected bottom were patched in
+                        src["seabed_host"], src["seabed_dev"] = np.ascontiguousarray(sb2), None
+                    src["blocks"][k] = mask is None
+                ok = ok and src["blocks"][k]
+        if ok:
+            if src["seabed_dev"] is None:
+                src["seabed_dev"] = torch.from_numpy(src["seabed_host"]).to(self.device)
+            return src["seabed_dev"], None
+        m = np.zeros((B, W, n_range), dtype=np.uint8)
+        for b, (xs, xe, x0) in enumerate(spans):
+            if xe > xs:
+                got = src["reader"].get_seabed_mask(xs, xe - xs, 0, n_range, return_numpy=True)
+                m[b, xs - x0:xe - x0] = np.asarray(getattr(got, "values", got)) != 0
+        return None, torch.from_numpy(m.reshape(B * W, n_range)).to(self.device)
 
     def _predict_raw_batch(self, batch):
         """(logits, transformed int16 labels on the device) of one batch of RAW crops (``use_gpu_test_transform``)."""
-        from .hip import call, ptr
+        from .hip import MASK_PER_PATCH, call, ptr
         src, dev = self._test_source, self.device
-        if self.late_meta_inject:
-            raise NotImplementedError("use_gpu_test_transform with late metadata injection")
         self.model.eval()
         data = batch["data"].to(dev)
         if data.dtype != torch.float32:
             data = data.float()
+        meta = None
+        if self.late_meta_inject:                # pipeline.py:210-216: data planes | metadata planes
+            nf = len(self.frequencies)
+            data, meta = data[:, :nf], data[:, nf:].contiguous()
         data = data.contiguous()
         labels = batch["labels"].to(dev)
         if labels.dtype not in (torch.int16, torch.int32, torch.int64):
             labels = labels.long()
         labels = labels.contiguous()
-        cen = torch.as_tensor(batch["center_coordinates"]).to(dev).long().contiguous()
+        cen_host = torch.as_tensor(batch["center_coordinates"]).long().reshape(-1, 2)
+        cen = cen_host.to(dev).contiguous()
         B, C, H, W = data.shape
+        seabed, mask = self._test_seabed(cen_host.numpy(), B, W)
         out = torch.empty((B, H, W), dtype=torch.int16, device=dev)
         eng = self.model.infer_engine
         with torch.no_grad(), torch.cuda.device(dev):
             call("crimac_labels_test_transform", ptr(labels), labels.element_size(), ptr(data), len(self.frequencies) - 1,
-                 1e-7, 1e-4, ptr(cen), ptr(src["seabed"]), 0, src["n_pings"] if src["seabed"] is not None else 0,
-                 ptr(src["mask"]), 0, src["n_pings"] if src["mask"] is not None else 0, src["n_range"], src["pad"], 0,
-                 src["overlap"], ptr(out), B, C, H, W)
-            x, _ = eng.augment_batch(data, None, 0, do_noise=False, do_flip=False)     # remove_nan_inf + db_with_limits
-            logits = eng.forward_nhwc(x, B, H, W, training=False)
+                 1e-7, 1e-4, ptr(cen), ptr(seabed), 0, src["n_pings"] if seabed is not None else 0,
+                 ptr(mask), MASK_PER_PATCH if mask is not None else 0, B * W if mask is not None else 0, src["n_range"],
+                 src["pad"], 0, src["overlap"], ptr(out), B, C, H, W)
+            if src["boxes"] is not None:         # eval_mode 'region' / 'trace'
+                call("crimac_labels_extend_mask", ptr(out), ptr(data), C, ptr(cen), ptr(src["boxes"]),
+                     int(src["boxes"].shape[0]), -1, B, H, W)
+            # remove_nan_inf + db_with_limits (db_with_limits_scaled with metadata channels)
+            x, _ = eng.augment_batch(data, None, 0, do_noise=False, do_flip=False, db_scaled=self.use_metadata)
+            logits = eng.forward_nhwc(x, B, H, W, training=False, meta=meta)
         return logits, out
 
     def set_label_ignore_val(self, labels):

@@ -109,7 +109,7 @@ class BatchStager:
     is recorded on the caller's CURRENT stream when the next batch is asked for, i.e. after the step that used them was
     enqueued; the slot is refilled only after that event has completed)."""
 
-    def __init__(self, dataloader, device, keys=("data", "labels"), stats=None, yield_batch=True):
+    def __init__(self, dataloader, device, keys=("data", "labels"), stats=None, yield_batch=True, release_pages=True):
         self.yield_batch = yield_batch       # False: `batch` is yielded as None (the loop needs the two tensors only)
         # Dropping a 37 MB batch a worker collated costs ~5-6 ms of page-table teardown + page freeing, and tensor
         # deallocation runs UNDER THE GIL: the training thread stalled that long every step (tools/diag_loop_graph.py:
@@ -117,7 +117,8 @@ class BatchStager:
         # frees the pages with madvise(MADV_REMOVE) through ctypes (no GIL) before the last reference goes; the
         # deallocation that follows finds nothing to tear down (0.6 ms).  Only for batches nobody else can see.
         import os
-        self.release_pages = ((not yield_batch) and collated_in_worker(dataloader)
+        # (release_pages=False -- yaml `release_batch_pages` -- or CRIMAC_STAGER_RELEASE_PAGES=0 keep the batches intact)
+        self.release_pages = (bool(release_pages) and (not yield_batch) and collated_in_worker(dataloader)
                               and os.environ.get("CRIMAC_STAGER_RELEASE_PAGES", "1") != "0")
         self._madvise = _libc_madvise() if self.release_pages else None
         self._dead = queue.Queue()

@@ -168,12 +168,33 @@ class SyntheticSurveyReader:
         def max(self):
             return SyntheticSurveyReader._Val(np.max(self.values))
 
-    def __init__(self, n_pings=65536, n_range=1024, channels=4, seabed_index=900, block=4096, seed=1):
+    def __init__(self, n_pings=65536, n_range=1024, channels=4, seabed_index=900, block=4096, seed=1, schools=0,
+                 bad_frac=0.0):
+        """``schools`` > 0: that many annotated schools per ``block`` pings -- elliptic regions of species id 27 (sandeel),
+        1 (other), 12 and 5000 (species the model does not use) whose pixels in the LAST frequency channel lie mostly
+        between the refine thresholds [1e-7, 1e-4] (refine_label_boundary.py:27), with weak holes and rims, so the label
+        refinement has its real work to do; ``bad_frac``: that share of NaN (channel 0) and Inf (last channel) samples."""
         rng = np.random.Generator(np.random.PCG64(seed))
-        blk = np.power(10.0, rng.uniform(-7.5, 0.0, size=(channels, min(block, n_pings), n_range))).astype(np.float32)
+        nb = min(block, n_pings)
+        blk = np.power(10.0, rng.uniform(-7.5, 0.0, size=(channels, nb, n_range))).astype(np.float32)
+        lab_blk = np.zeros((nb, n_range), dtype=np.int16)
+        if schools > 0:
+            blk[-1] = np.power(10.0, rng.uniform(-9.0, -2.0, size=(nb, n_range))).astype(np.float32)
+            for k in range(schools):
+                cx, cy = int(rng.integers(0, nb)), int(rng.integers(0, max(min(seabed_index, n_range), 1)))
+                rx, ry = int(rng.integers(6, 70)), int(rng.integers(4, 40))
+                x0, x1, y0, y1 = max(cx - rx, 0), min(cx + rx + 1, nb), max(cy - ry, 0), min(cy + ry + 1, n_range)
+                xx, yy = np.mgrid[x0:x1, y0:y1]
+                blob = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+                lab_blk[x0:x1, y0:y1][blob] = (27, 1, 27, 12, 1, 27, 5000)[k % 7]
+                strong = blob & (rng.random(blob.shape) < 0.8)
+                blk[-1, x0:x1, y0:y1][strong] = np.power(10.0, rng.uniform(-6.9, -4.1, size=int(strong.sum()))).astype(np.float32)
+        if bad_frac > 0:
+            blk[0][rng.random((nb, n_range)) < bad_frac] = np.nan
+            blk[-1][rng.random((nb, n_range)) < bad_frac] = np.inf
         reps = -(-n_pings // blk.shape[1])
         self.sv = np.ascontiguousarray(np.tile(blk, (1, reps, 1))[:, :n_pings])
-        self.labels = np.zeros((n_pings, n_range), dtype=np.int16)
+        self.labels = np.ascontiguousarray(np.tile(lab_blk, (reps, 1))[:n_pings])
         self.seabed = np.full(n_pings, seabed_index, dtype=np.int64)
         self._mask = None
         self.shape = (n_pings, n_range)
@@ -230,3 +251,64 @@ def synth_metadata(batch, channels=7, height=256, width=256, seed=3):
         else:
             out[:, c] = rng.uniform(0.6, 1.0, size=(batch, 1, width)) - r
     return out
+
+
+def raw_crop(reader, centre, window_size, dtype=np.float32):
+    """One RAW crop around ``centre`` = (range idx, ping idx) as the reference's ``get_crop`` hands it to the transform
+    chain (batch/dataset.py:358-407 for zarr readers, :254-287 for memmap ones): ``data`` [C, H, W] LINEAR sv (H = range,
+    W = pings; patch pixel p <-> data coordinate centre - n // 2 + 1 + p, utils/np.py:378-380), 0 outside the survey and
+    where the reader holds NaN; ``labels`` [H, W] raw annotation ids, -100 (LABEL_BOUNDARY_VAL) outside the survey.
+    ``dtype``: float32 is what the memmap flavour returns (the dtype of the .dat files), float64 what the zarr flavour
+    returns (its output array is ``np.ones(...) * 0``, dataset.py:361)."""
+    H, W = int(window_size[0]), int(window_size[1])
+    n_pings, n_range = reader.shape
+    y0, x0 = int(centre[0]) - H // 2 + 1, int(centre[1]) - W // 2 + 1
+    ys, ye = max(y0, 0), min(y0 + H, n_range)
+    xs, xe = max(x0, 0), min(x0 + W, n_pings)
+    n_ch = reader.sv.shape[0] if hasattr(reader, "sv") else 4
+    data = np.zeros((n_ch, H, W), dtype=dtype)
+    labels = np.full((H, W), LABEL_IGNORE_VAL, dtype=np.int16)
+    if ye > ys and xe > xs:
+        sv = reader.get_data_slice(idx_ping=xs, n_pings=xe - xs, idx_range=ys, n_range=ye - ys, return_numpy=True)
+        sv = np.asarray(sv)[:, :, ys:ye] if np.asarray(sv).shape[2] != ye - ys else np.asarray(sv)
+        lab = np.asarray(reader.get_label_slice(idx_ping=xs, n_pings=xe - xs, idx_range=ys, n_range=ye - ys,
+                                                return_numpy=True))
+        lab = lab[:, ys:ye] if lab.shape[1] != ye - ys else lab
+        blockd = data[:, ys - y0:ye - y0, xs - x0:xe - x0]
+        blockd[...] = sv.swapaxes(1, 2)
+        nan = np.isnan(blockd)                                   # (dataset.py:402: NaN -> 0)
+        if nan.any():
+            blockd[nan] = 0
+        labels[ys - y0:ye - y0, xs - x0:xe - x0] = lab.T
+    return data, labels
+
+
+class RawCropDataset:
+    """Map-style dataset of RAW training crops over an in-memory survey: what the reference's ``Dataset`` yields when it
+    is built for the on-GPU transform chain -- ``augmentation_function=None, label_transform_function=None,
+    data_transform_function=None`` (batch/dataset.py:76-110 then applies nothing): a random patch centre, the crop
+    gather, and the batch dict ``{'data': linear sv [C, H, W], 'labels': raw annotation ids int16 [H, W],
+    'center_coordinates': int64 [2]}``.  ``transform(data, labels, index) -> (data, labels)`` runs in the worker on the
+    raw crop (bench.py's host-chain baseline plugs the reference's transform chain in there).
+
+    The centre of sample ``i`` is a function of (seed, i) alone -- the same crops whatever the number of workers -- drawn
+    uniformly over the survey (crops at its rim carry -100 labels, like the reference's)."""
+
+    def __init__(self, reader, window_size, n_samples, seed=0, dtype=np.float32, transform=None):
+        self.reader, self.window_size, self.n_samples = reader, tuple(window_size), int(n_samples)
+        self.seed, self.dtype, self.transform = int(seed), dtype, transform
+
+    def __len__(self):
+        return self.n_samples
+
+    def centre(self, index):
+        rng = np.random.Generator(np.random.PCG64([self.seed, int(index)]))
+        n_pings, n_range = self.reader.shape
+        return np.array([int(rng.integers(0, n_range)), int(rng.integers(0, n_pings))], dtype=np.int64)
+
+    def __getitem__(self, index):
+        c = self.centre(index)
+        data, labels = raw_crop(self.reader, c, self.window_size, self.dtype)
+        if self.transform is not None:
+            data, labels = self.transform(data, labels, int(index))
+        return {"data": data, "labels": np.asarray(labels).astype(np.int16), "center_coordinates": c}

@@ -117,7 +117,7 @@ extern "C" {
  * binding must refuse a library whose version differs from the header it was written against (an older build that
  * happens to export every symbol would walk a descriptor array with the wrong stride).  crimac_layer_desc_size() is
  * sizeof(crimac_layer_desc) as the library was compiled. */
-#define CRIMAC_ABI_VERSION 5
+#define CRIMAC_ABI_VERSION 6
 int crimac_version(void);
 int crimac_layer_desc_size(void);
 const char* crimac_last_error(void);
@@ -502,11 +502,20 @@ int crimac_meta_bwd(const float* dlogits, const float* meta, int Cm, int B, int 
  * data[thr_channel] < thr_hi, bit 1 = channel 0 non-finite -- the inputs of crimac_refine_labels, which
  * then runs the reference's label transform in its place (batch/dataset.py:89-103).  Per sample with p=.5:
  * 5 % of the values x U(1,10) or x U(0,1) (half each); per sample with p=.5: ping axis flipped.
- * Randomness: Philox4x32-10 keyed on (seed, sample index), counter = element index. */
+ * Randomness: Philox4x32-10 keyed on (seed, sample index), counter = element index.
+ * db_scaled != 0: db_with_limits_scaled (db_with_limits.py:27-33: 1 + dB / 75 in [0, 1]), the data transform of the
+ * metadata configurations (define_data_transform(use_metadata=True), batch/transforms.py:50-51). */
 int crimac_augment_db_nhwc(int prec, const float* data, const void* labels_in, int label_bytes, void* out,
                            short* labels_out, unsigned char* aux_mask, int thr_channel, float thr_lo,
                            float thr_hi, int B, int C, int H, int W, long ld, unsigned long long seed,
-                           int do_noise, int do_flip, void* stream);
+                           int do_noise, int do_flip, int db_scaled, void* stream);
+
+/* flip_x_axis_metadata (flip_x_axis.py:27-32) for planes that do not pass through crimac_augment_db_nhwc -- the
+ * metadata planes of UNet_LateMetInject (add_noise_metadata, add_noise.py:42-63, leaves them untouched): in [B][C][H][W]
+ * fp32 -> out (another buffer), the ping axis of sample b flipped under the same per-sample draw (same seed) as its
+ * data and labels. */
+int crimac_augment_flip_planes(const float* in, float* out, int B, int C, int H, int W, unsigned long long seed,
+                               int do_flip, void* stream);
 
 /* ---- training label transform ------------------------------------------------ */
 
@@ -540,6 +549,23 @@ int crimac_labels_test_transform(const void* labels_in, int label_bytes, const f
                                  int seabed_ping0, int seabed_pings, const unsigned char* seabed_mask, int mask_ping0,
                                  int mask_pings, int n_range, int seabed_pad, int seabed_rule, int overlap,
                                  short* labels_out, int B, int C, int H, int W, void* stream);
+
+/* mask_ping0 value of crimac_labels_test_transform: the seabed mask is laid out PER PATCH, [B][W][n_range] (column x of
+ * patch b at row b * W + x; columns outside the survey all zero), mask_pings = B * W -- for batches whose patches lie
+ * anywhere in a long survey (the reference reads the mask per patch, mask_label_seabed.py:40-52). */
+#define CRIMAC_MASK_PER_PATCH (-2147483647 - 1)
+
+/* get_extended_label_mask_for_crop (batch/label_transforms/extend_label_masks.py:35-98): the extra link of
+ * define_label_transform_test for eval_mode 'region' / 'trace' (batch/transforms.py:87-90; evaluate.py:50, :92).  In place
+ * on the int16 labels crimac_labels_test_transform produced: a pixel keeps its label only inside one of the school
+ * bounding boxes, everything else becomes ignore_val (the reference's default: -1); then remove_nan_inf's label rule
+ * (remove_nan_inf.py:30-32, applied by the reference after the whole label chain): -100 where data channel 0 is not
+ * finite.  boxes [n_boxes][4] int32 = (y0, y1, x0, x1) in echogram coordinates, ALREADY extended by the caller as
+ * extend_label_masks.py:70-80 does ('region': all four sides by extend_size; 'trace': y0 = 0, y1 = echogram.shape[0],
+ * x by extend_size); the patch is placed at centre - size / 2 as the reference places it (:64).  centres [B][2] int64,
+ * data [B][C][H][W] fp32 linear sv; H * W <= 65536. */
+int crimac_labels_extend_mask(short* labels, const float* data, int C, const long long* centres, const int* boxes,
+                              int n_boxes, int ignore_val, int B, int H, int W, void* stream);
 
 /* ---- measurement support (bench.py only, not on the product path) --------------------------- */
 

@@ -52,7 +52,7 @@ def binary_closing_disk7(mask):
     return ero
 
 
-def refine_label_boundary(thr_channel, labels, threshold_val=(1e-7, 1e-4), ignore_zero_inside_bbox=True):
+def refine_label_boundary(thr_channel, labels, threshold_val=(1e-7, 1e-4), ignore_zero_inside_bbox=True, closing=None):
     """refine_label_boundary.py:35-104 for one patch.  thr_channel: data[freq_idx] [H,W] (linear sv, as the
     reference compares it: in the array's own dtype), labels [H,W] raw annotation ids."""
     below = LABEL_REFINE_BOUNDARY_VAL if ignore_zero_inside_bbox else 0
@@ -66,7 +66,7 @@ def refine_label_boundary(thr_channel, labels, threshold_val=(1e-7, 1e-4), ignor
     hi = np.asarray(threshold_val[1]).astype(thr_channel.dtype)
     with np.errstate(invalid="ignore"):
         mask_threshold = (labels > 0) & (thr_channel > lo) & (thr_channel < hi)     # :92-93
-    closed = binary_closing_disk7(mask_threshold[y0:y1, x0:x1])                  # :95
+    closed = (closing or binary_closing_disk7)(mask_threshold[y0:y1, x0:x1])     # :95 (`closing`: scipy's, for timing legs)
     mask = np.zeros(labels.shape, dtype=bool)
     mask[y0:y1, x0:x1] = (~closed) & (new_labels[y0:y1, x0:x1] > 0)             # :97-98
     new_labels[mask] = below                                                     # :100
@@ -109,8 +109,39 @@ def convert_label_indexing_unused_species(labels):
     return out
 
 
+def extend_boxes(boxes, mask_type, extend_size, shape0):
+    """extend_label_masks.py:69-80: the school bounding boxes (y0, y1, x0, x1) as the mask uses them -- 'region': grown by
+    ``extend_size`` on all four sides; 'trace': the whole first axis of the reader (``echogram.shape[0]``: the range axis
+    of a memmap Echogram, the PING axis of the zarr reader -- restated as the reference has it), pings grown."""
+    bb = np.array(boxes, dtype=np.int64).reshape(-1, 4).copy()
+    if mask_type == "region":
+        bb[:, 0] -= extend_size
+        bb[:, 1] += extend_size
+    else:
+        bb[:, 0] = 0
+        bb[:, 1] = shape0
+    bb[:, 2] -= extend_size
+    bb[:, 3] += extend_size
+    return bb
+
+
+def extend_label_mask(labels, centre, boxes_extended, ignore_val=-1):
+    """get_extended_label_mask_for_crop.__call__ (extend_label_masks.py:57-98) for one patch: everything outside the
+    (extended) boxes -> ``ignore_val`` (the reference's constructor default, -1: define_label_transform_test does not
+    pass one, batch/transforms.py:88-89).  The patch is placed at centre - shape // 2 (:64)."""
+    H, W = labels.shape
+    yul, xul = int(centre[0]) - H // 2, int(centre[1]) - W // 2
+    out = np.full(labels.shape, ignore_val, dtype=labels.dtype)
+    for b0, b1, b2, b3 in np.asarray(boxes_extended).reshape(-1, 4):
+        if min(b1, yul + H) - max(b0, yul) >= 0 and min(b3, xul + W) - max(b2, xul) >= 0:      # overlap(), :21-29
+            ya, yb = max(b0 - yul, 0), min(b1 - yul, H)
+            xa, xb = max(b2 - xul, 0), min(b3 - xul, W)
+            out[ya:yb, xa:xb] = labels[ya:yb, xa:xb]
+    return out
+
+
 def test_label_transform(data, labels, centre, thr_channel_idx, seabed, n_range, patch_overlap=0, seabed_rule="zarr",
-                         seabed_mask=None, threshold_val=(1e-7, 1e-4), nan_rule=True):
+                         seabed_mask=None, threshold_val=(1e-7, 1e-4), nan_rule=True, boxes_extended=None):
     """define_label_transform_test (batch/transforms.py:81-99, label_masks='all') followed by remove_nan_inf's label rule
     (remove_nan_inf.py:30-32), for ONE patch: convert_label_indexing_unused_species -> refine_label_boundary (on the
     converted labels and the RAW linear-sv crop: the label transform runs before the data transform, batch/dataset.py:
@@ -120,7 +151,8 @@ def test_label_transform(data, labels, centre, thr_channel_idx, seabed, n_range,
     idx) of the patch, ``seabed`` per-ping seabed index vector indexed by global ping (``seabed_mask`` [n_pings, n_range],
     zarr rule only: the reader's own 2-D mask instead).  seabed_rule: 'zarr' -- the reader shifts the mask down by the pad
     INSIDE the slice it is asked for (data_reader.py:837-841) -- or 'memm' -- ``Echogram.get_seabed_mask``: absolute rows
-    >= seabed + pad (data_reader.py:407-431).  H and W even (the reference's own coordinate helpers disagree by one pixel
+    >= seabed + pad (data_reader.py:407-431).  ``boxes_extended`` (``extend_boxes``): eval_mode 'region' / 'trace', the
+    chain's optional last link.  H and W even (the reference's own coordinate helpers disagree by one pixel
     for odd sizes).  Returns int16 labels in {-100, -70, -50, -30, -10, 0, 1, 2}."""
     H, W = labels.shape
     assert H % 2 == 0 and W % 2 == 0
@@ -150,6 +182,8 @@ def test_label_transform(data, labels, centre, thr_channel_idx, seabed, n_range,
         out[o:-o, o:-o] = lab[o:-o, o:-o]
         out[lab == LABEL_BOUNDARY_VAL] = LABEL_BOUNDARY_VAL
         lab = out
+    if boxes_extended is not None:          # eval_mode 'region' / 'trace' (batch/transforms.py:87-90)
+        lab = extend_label_mask(lab, centre, boxes_extended)
     if nan_rule:
         lab[~np.isfinite(np.asarray(data)[0])] = LABEL_IGNORE_VAL
     return lab.astype(np.int16)

@@ -117,3 +117,66 @@ def test_pipeline_predict_batch_splits_data_and_metadata(case):
     batch = {"data": torch.cat((x, meta), dim=1).double(), "labels": lab}       # as the reference Dataset collates it
     out = pipe.predict_batch(batch)
     assert rel(out, fix["logits_eval"]) < 2e-5
+
+
+@pytest.mark.gpu
+def test_gpu_augment_with_late_injection_follows_the_metadata_augmentations(case):
+    """gpu_augment + late metadata injection (VERDICT r4 missing #4): add_noise_metadata / flip_x_axis_metadata
+    (batch/transforms.py:41-42: noise on the data planes only, the flip on data, metadata and labels alike) and
+    db_with_limits_scaled (:50-51) on the GPU.  The fused step on raw crops equals the oracle's step on the crops the
+    augmentation oracle produces (same Philox stream) with the metadata planes flipped by the same per-sample draws."""
+    from oracle import augment_oracle as aorc
+    fix, sd, x, meta, lab = case
+    x_lin = torch.pow(10.0, x / 10.0)
+    for seed in range(40, 60):            # a seed under which one sample is flipped and the other is not
+        _, _, noisy, flipped = aorc.augment_db(x_lin.numpy(), lab.numpy(), seed)
+        if flipped[0] != flipped[1] and noisy.any():
+            break
+    xa, la, noisy, flipped = aorc.augment_db(x_lin.numpy(), lab.numpy(), seed, scaled=True)
+    assert xa.min() >= 0.0 and xa.max() <= 1.0
+    meta_a = meta.clone()
+    for b in range(2):
+        if flipped[b]:
+            meta_a[b] = meta[b].flip(-1)
+    ref_loss, _, ref_grads, _ = orc.loss_and_grads(sd, torch.from_numpy(xa), torch.from_numpy(la), meta=meta_a)
+    m = pkg.UNet_LateMetInject(3, 4, CM, precision="f32x6")
+    m.load_state_dict(sd)
+    m.cuda().train()
+    eng = m.engine
+    got_meta = eng.flip_planes(meta.cuda(), seed)
+    assert torch.equal(got_meta.cpu(), meta_a)
+    xg, lg = eng.augment_batch(x_lin.cuda(), lab.cuda(), seed, db_scaled=True)
+    xg = xg.float().reshape(2, HW, HW, -1)[..., :4].permute(0, 3, 1, 2).cpu()
+    assert float((xg - torch.from_numpy(xa)).abs().max()) < 1e-5 and torch.equal(lg.cpu(), torch.from_numpy(la))
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    loss = eng.train_step_augmented(x_lin.cuda(), lab.cuda(), cw, lr=0.0, momentum=0.0, seed=seed, meta=meta.cuda())
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    for k in ("conv_final.weight", "post_processing_weights.main.0.weight", "down_convs.0.main.0.weight"):
+        e = float((eng.G[k].double().cpu() - ref_grads[k].double()).norm() / ref_grads[k].double().norm())
+        assert e < 2e-2, (k, e)
+    with pytest.raises(ValueError, match="needs the metadata tensor"):
+        eng.train_step_augmented(x_lin.cuda(), lab.cuda(), cw, lr=0.0, momentum=0.0, seed=seed)
+    # through the pipeline: the batch dict carries data | metadata planes (pipeline.py:170-174)
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(pkg.__file__), "configs", "pipeline_config.yaml")))
+    cfg.update(save_model_params=False, late_meta_inject=True, precision="f32x6", gpu_augment=True, lr=0.0,
+               log_step=10 ** 9, lr_step=10 ** 9, random_seed=0,
+               meta_channels={"portion_year": True, "portion_day": True, "depth_rel": True, "depth_abs_surface": True,
+                              "depth_abs_seabed": True, "time_diff": True})
+    pipe = pkg.SegPipeUNet(experiment_name="t", **{k: v for k, v in cfg.items() if k != "experiment_name"})
+    pipe.model.load_state_dict(sd)
+    batch = {"data": torch.cat((x_lin, meta), dim=1), "labels": lab}
+    pipe.train_model([batch], [], None)
+    xa0, la0, _, fl0 = aorc.augment_db(x_lin.numpy(), lab.numpy(), 0, scaled=True)       # seed of step 0, rank 0
+    m0 = torch.stack([meta[b].flip(-1) if fl0[b] else meta[b] for b in range(2)])
+    l0, _, _, _ = orc.loss_and_grads(sd, torch.from_numpy(xa0), torch.from_numpy(la0), meta=m0)
+    s = pipe.model.engine.last_loss_sums.cpu()
+    assert abs(float(s[0] / s[1]) - float(l0)) < 1e-4 * abs(float(l0))
+    # host-transformed (dB) data handed to a gpu_augment pipeline is refused on the first batch
+    pipe2 = pkg.SegPipeUNet(experiment_name="t", **{k: v for k, v in cfg.items() if k != "experiment_name"})
+    pipe2.model.load_state_dict(sd)
+    with pytest.raises(ValueError, match="negative values"):
+        pipe2.train_model([{"data": torch.cat((x, meta), dim=1), "labels": lab}], [], None)
+    with pytest.raises(NotImplementedError, match="extra INPUT channels"):
+        pkg.SegPipeUNet(experiment_name="t", **{**{k: v for k, v in cfg.items() if k != "experiment_name"},
+                                                "late_meta_inject": False})

@@ -18,7 +18,12 @@ class _Val:
 class FakeZarrReader:
     data_format = "zarr"
 
-    def __init__(self, sv, labels, seabed, name="fake_survey", mask=None):
+    def __init__(self, sv, labels, seabed, name="fake_survey", mask=None, boxes=None):
+        # boxes [n, 4] = (y0, y1, x0, x1) school bounding boxes: the real zarr reader has no get_object_bounding_boxes
+        # (only the memmap Echogram does, data_reader.py:404); a reader that offers it can serve eval_mode 'region' / 'trace'
+        if boxes is not None:
+            self._boxes = np.asarray(boxes).astype(int)
+            self.get_object_bounding_boxes = lambda: self._boxes.copy()
         self.sv = sv                    # [C, pings, range] linear sv, float32
         self.labels = labels            # [pings, range] raw species labels
         self.seabed = seabed            # [pings] seabed range index
@@ -110,7 +115,8 @@ class FakeEchogram:
     in ABSOLUTE range coordinates -- unlike the zarr reader, whose pad shifts the mask inside the requested slice)."""
     data_format = "memmap"
 
-    def __init__(self, sv_hw, labels_hw, seabed, frequencies=(18, 38, 120, 200), name="fake_echogram"):
+    def __init__(self, sv_hw, labels_hw, seabed, frequencies=(18, 38, 120, 200), name="fake_echogram", boxes=None):
+        self.object_bounding_boxes = np.zeros((0, 4), int) if boxes is None else np.asarray(boxes).astype(int)
         self.sv = sv_hw                 # [C, range, pings] linear sv
         self.labels = labels_hw         # [range, pings] raw species labels
         self._seabed = np.asarray(seabed).astype(np.int64)
@@ -128,6 +134,9 @@ class FakeEchogram:
 
     def label_memmap(self, heave=True):
         return self.labels
+
+    def get_object_bounding_boxes(self):            # data_reader.py:404-405
+        return self.object_bounding_boxes.copy()
 
     def get_seabed(self, idx_ping=None, n_pings=1, save_to_file=True, ignore_saved=False):
         return self._seabed[idx_ping:idx_ping + n_pings].copy()
