@@ -49,8 +49,10 @@ DTYPE_LABEL = {"bf16": "bf16", "fp16": "fp16", "f32x3": "fp32 storage, 3x bf16 M
                       "(~2^-21), fp32 accumulate; conv outputs / activation gradients fp32; loss-scaled backward",
                "f32x6": "fp32 storage, 6x bf16 MFMA per product (fp32-equivalent)",
                "h3f": "forward: fp16 plane pairs, 3x fp16 MFMA per product (bit-identical to h3p: logits, loss, BatchNorm "
-                      "statistics); backward: loss-scaled fp16 storage, 1 MFMA per product, on fp16 copies of the saved "
-                      "forward tensors; fp32 accumulate, fp32 weights / optimiser"}
+                      "statistics); backward: 1 MFMA per product -- output gradients dy and the up half of d(concat) stored as "
+                      "loss-scaled fp16, input-gradient weight planes fp16, weight gradients on the hi plane of the saved "
+                      "plane-pair activations; conv outputs y and activation gradients da stay fp32 (ReLU masks and pool "
+                      "positions decide as in h3p); fp32 accumulate, fp32 weights / optimiser"}
 CONV_KERNELS = ("crimac_conv3x3: conv3x3_wch_kernel + conv3x3_p64_kernel + conv3x3_glds_w4_kernel + "
                 "conv3x3_c16_kernel (halo-staged implicit-GEMM 3x3 conv, fwd + dgrad, all layers)")
 
@@ -464,6 +466,32 @@ def measure_tiled(model, args, log, world=1):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         n_patches, written, n_mine, dt = int(agg[0]), int(agg[1]), int(agg[2]), float(tmax)
         assert n_mine == n_pings, (n_mine, n_pings)          # the ranks covered the survey exactly once
+    handoff = None
+    if world > 1:
+        # the opt-in ordered hand-off (predict_survey(ordered_to_rank0=True)): rank 0 must receive EVERY chunk of the survey
+        # in ping order (what the reference's sequential append_to_zarr writer needs), the other ranks yield nothing
+        dist.barrier()
+        t1 = time.perf_counter()
+        got = [(s, e, int((out[0, :, ::64] != 0).sum())) for s, e, out in
+               ti.predict_survey(reader, pipe, (256, 256), 20, args.batch, preload, out_dtype=np.float16, ordered_to_rank0=True)]
+        torch.cuda.synchronize()
+        dt_o = time.perf_counter() - t1
+        dev = next(model.parameters()).device
+        cnt = torch.tensor([len(got)], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt)
+        tmax_o = torch.tensor([dt_o], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax_o, op=dist.ReduceOp.MAX)
+        if dist.get_rank() == 0:
+            plan = ti.plan_chunks(0, n_pings, preload)
+            assert [g[:2] for g in got] == plan, "ordered hand-off: rank 0 did not get every chunk in ping order"
+            assert int(cnt) == len(plan), "ordered hand-off: a rank other than 0 yielded chunks"
+            handoff = {"chunks_on_rank0": len(got), "chunks_of_survey": len(plan), "in_ping_order": True,
+                       "written_sampled": sum(g[2] for g in got), "seconds": float(tmax_o),
+                       "patches_per_s": n_patches / float(tmax_o),
+                       "what": "predict_survey(ordered_to_rank0=True): chunk-sharded compute, every finished float16 chunk handed "
+                               "to rank 0 point-to-point (isend / irecv), rank 0 yields the survey in ping order"}
+        else:
+            assert got == [], "ordered hand-off: a rank other than 0 yielded chunks"
     ti.release_staging()          # (0.5 GB of pinned host memory + two device chunk buffers kept between surveys: freed before
     #                                the next leg is timed -- the parity leg ran 6 % slower behind a tiled leg that kept them)
     return {"workload": f"BASELINE configs[3]: synthetic survey sv [4, {n_pings}, {n_range}] fp32, flat seabed 900, "
@@ -476,6 +504,7 @@ def measure_tiled(model, args, log, world=1):
             "patches_per_s": n_patches / dt, "pings_per_s": n_pings / dt, "n_patches": n_patches, "seconds": dt,
             "precision": model.precision,
             "timed": "host reader + H2D + crop/dB gather + U-Net + softmax + scatter + D2H of [2, range, pings] float16",
+            "ordered_handoff": handoff,
             "written_frac_sampled": written / (n_range * ((n_pings + 63) // 64))}
 
 

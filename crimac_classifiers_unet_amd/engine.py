@@ -148,6 +148,19 @@ class UNetEngine:
             raise ValueError(f"late metadata injection supports 1..8 metadata channels, got {self.meta_channels}")
         if self.lmi and self.bwd16:
             raise NotImplementedError("precision 'h3f' with late metadata injection (use 'h3p')")
+        if self.bwd16:
+            # h3f's fp16 backward pass exists on the fused kernels only: checked HERE, not in the first backward pass
+            # (ADVICE r4): every transposed convolution inside crimac_upconv2x2_dgrad_bnb_prec's shapes, the fused
+            # BatchNorm-backward paths switched on
+            bad = [u.key for u in self.ups if u.cout % 64 != 0 or u.cin % 128 != 0]
+            if bad:
+                raise NotImplementedError(f"precision 'h3f': transposed convolutions {bad} lie outside the fused input-gradient "
+                                          "kernel (Cout % 64, Cin % 128); precision 'h3p' covers them")
+            off = [n for n, v in (("CRIMAC_FUSE_BNB", self.fuse_bn_bwd), ("CRIMAC_FUSE_UPBNB", self.fuse_up_bnb)) if not v]
+            if off or not self.lds_dma:
+                raise NotImplementedError("precision 'h3f' needs the fused BatchNorm-backward kernels"
+                                          + (f" ({', '.join(off)} = 0 switches them off)" if off else "")
+                                          + "; precision 'h3p' runs without them")
         self.blocks = [b for pair in self.enc for b in pair] + [b for pair in self.dec for b in pair]
         for k, b in enumerate(self.blocks):
             b.idx = k

@@ -64,6 +64,32 @@ def release_shared_pages(batch, madvise=None, min_bytes=1 << 20):
     return done
 
 
+COPY_THREADS = 4              # host threads of one pageable -> pinned batch copy
+COPY_SPLIT_BYTES = 8 << 20    # arrays smaller than this are copied by the calling thread alone
+_COPY_POOL = None
+
+
+def parallel_copyto(dst, src):
+    """``np.copyto(dst, src)`` for two C-contiguous arrays of one dtype, split along the first axis over COPY_THREADS
+    threads (numpy releases the GIL inside the copy).  One thread moves a worker-collated batch at 9-10 GB/s (first touch of
+    the shared-memory mapping): 3.6 ms for a float32 batch of 32 crops, 7.2 ms for the float64 crops of the reference's
+    zarr flavour (batch/dataset.py:361) -- with the fetch and the upload in front and behind it the staging thread then
+    needs longer than a 11.4 ms step (bench.py train_loop_raw, float64 leg: 0.89 of the resident-batch rate)."""
+    global _COPY_POOL
+    n = dst.shape[0] if dst.ndim else 0
+    if dst.nbytes < COPY_SPLIT_BYTES or n < 2 or COPY_THREADS < 2:
+        np.copyto(dst, src)
+        return
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=COPY_THREADS, thread_name_prefix="crimac-batch-copy")
+    parts = min(COPY_THREADS, n)
+    cuts = [n * k // parts for k in range(parts + 1)]
+    futs = [_COPY_POOL.submit(np.copyto, dst[a:b], src[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    for f in futs:
+        f.result()
+
+
 RING = 6          # device / pinned slots: one being filled, up to three staged, two in steps the GPU may still be running
 AHEAD = 2         # steps the training thread may be ahead of the GPU before it waits (frees the slot of step i - AHEAD)
 
@@ -192,7 +218,7 @@ class BatchStager:
                 self._ensure(slot, data, labels)
                 self._note("stage_ensure_s", t0)
                 t0 = time.perf_counter()
-                np.copyto(slot.data_pin.numpy(), data.contiguous().numpy())      # memcpy, GIL released
+                parallel_copyto(slot.data_pin.numpy(), data.contiguous().numpy())      # memcpy, GIL released
                 if labels is not None:
                     np.copyto(slot.lab_pin.numpy(), labels.contiguous().numpy())
                 self._note("stage_memcpy_s", t0)

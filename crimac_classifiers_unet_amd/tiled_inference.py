@@ -293,7 +293,7 @@ class _OrderedHandoff:
             yield next(own)
             for s, e, buf, req in reqs:
                 req.wait()
-                yield s, e, buf.cpu().numpy().copy() if self.device_tensors else buf.numpy().copy()
+                yield s, e, buf.cpu().numpy() if self.device_tensors else buf.numpy().copy()      # (.cpu() is a fresh array; the host buffer is reused)
 
 
 _STAGING = {}          # (device, sizes) -> pinned / device staging buffers of predict_survey
@@ -307,7 +307,7 @@ def release_staging():
 
 def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, preload_n_pings,
                    start_ping=0, labels_available=True, out_dtype=np.float32, stats=None, predict_fn=None,
-                   shard="chunk", ordered_to_rank0=None, **kwargs):
+                   shard="chunk", ordered_to_rank0=False, **kwargs):
     """Generator over chunks: yields ``(start_ping, end_ping, out[2, n_range, end-start] numpy)``.
 
     Multi-GPU (torch.distributed initialised, one process per GPU).  EVERY rank must iterate the
@@ -315,14 +315,17 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
       ``shard="chunk"`` (default) -- rank r owns chunks r, r + N, r + 2N, ...: every rank reads, uploads and predicts
           only ITS ping ranges; the reader I/O and the PCIe traffic scale with the ranks too.  What the generators yield
           is set by ``ordered_to_rank0``:
-            True (the default under torch.distributed) -- the finished float16 / float32 chunks are handed to rank 0
+            True (opt-in) -- the finished float16 / float32 chunks are handed to rank 0
               point-to-point (one send per chunk, 16.8 MB as float16; RCCL: device to device over xGMI, off the compute
               stream; gloo: host tensors) and RANK 0 YIELDS EVERY CHUNK OF THE SURVEY IN PING ORDER, the other ranks
               yield nothing: the reference's strictly sequential writer (``append_to_zarr`` with
               ``append_dim='ping_time'`` and resume by ``sizes['ping_time']``, save_predict.py:107-134) runs unchanged on
-              rank 0, and a caller that writes on rank 0 only loses nothing;
-            False -- no communication at all: each rank yields its OWN chunks only (disjoint ping ranges); for callers
-              that write regions themselves.
+              rank 0, and a caller that writes on rank 0 only loses nothing.  Rank 0 MUST then consume every chunk: the
+              other ranks block in their sends (gloo) or queue them on RCCL's stream until rank 0 has posted the matching
+              receive -- a consumer that stops early on rank 0 (exception, ``break``, resume logic) strands them until the
+              process group's timeout, which is why this form has to be asked for;
+            False (default) -- no communication at all: each rank yields its OWN chunks only (disjoint ping ranges); for
+              callers that write regions themselves.
       ``shard="patch"`` -- every rank walks every chunk, takes patches p = rank (mod N) of it and the per-rank float16
           outputs are summed (one all-reduce of the chunk per chunk): every rank yields every chunk.
 
@@ -350,7 +353,7 @@ def predict_survey(reader, segpipe, patch_size, patch_overlap, batch_size, prelo
     if ordered_to_rank0 and share_patches:
         raise ValueError("predict_survey: ordered_to_rank0 belongs to shard='chunk' (with shard='patch' every rank already "
                          "yields every chunk)")
-    ordered = multi and not share_patches and (ordered_to_rank0 is None or bool(ordered_to_rank0))
+    ordered = multi and not share_patches and bool(ordered_to_rank0)
     all_chunks = chunks
     rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
     if multi and not share_patches:

@@ -394,11 +394,11 @@ def _tiled_rank_worker(rank, world, port, out):
     if rank == 0:
         out["chunks"] = [(s, e, o.copy()) for s, e, o in chunks]
     # chunk sharding: rank r owns chunks r, r + N, ...; no collective; together the ranks cover the survey once
-    mine = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16, ordered_to_rank0=False))
+    mine = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 350, out_dtype=np.float16))      # (default: own chunks)
     out[f"own{rank}"] = [(s, e, o.copy()) for s, e, o in mine]
-    # the default under torch.distributed: chunk-sharded compute, ordered hand-off -- rank 0 yields the WHOLE survey in
+    # opt-in (ordered_to_rank0=True): chunk-sharded compute, ordered hand-off -- rank 0 yields the WHOLE survey in
     # ping order (what a sequential append_to_zarr writer on rank 0 needs), the other ranks yield nothing
-    ordered = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 175, out_dtype=np.float16))
+    ordered = list(ti.predict_survey(reader, pipe, (256, 256), 20, 2, 175, out_dtype=np.float16, ordered_to_rank0=True))
     out[f"ordered{rank}"] = [(s, e, o.copy()) for s, e, o in ordered]
     dist.barrier()
     dist.destroy_process_group()
