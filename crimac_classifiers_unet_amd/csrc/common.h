@@ -172,6 +172,15 @@ __host__ inline bool planes_arg_ok(int planes_arg) {
   if ((planes_arg & 0x40) && npl != 2) return false;           // interleaved rows are plane PAIRS
   return npl >= 1 && npl <= 3 && (planes_arg >> 16) == 0 && sh <= 16;
 }
+// Fragment-major weight plane (CRIMAC_EPI_WFRAG, CRIMAC_LAYER_*_FRAG): position (in halves) of the 8 columns c .. c + 7
+// (c % 8 == 0) of row r at tap t in a plane of R rows x K columns.  A (tap, 32-row block, 64-column chunk) is 4 KB: four
+// fragments [k-step ks2][row half nb] of 1 KB each, lane (c % 32) / 8 * 16 + r % 16 of a fragment at 16 bytes per lane -- what
+// conv3x3_wch_kernel's lane (fr = lane & 15, fq = lane >> 4) loads into f.b[ks2 * 2 + nb].
+__host__ __device__ inline long wfrag_index(int t, int r, int c, int R, int K) {
+  const long blk = ((long)t * (R >> 5) + (r >> 5)) * (K >> 6) + (c >> 6);
+  return ((blk * 4 + (((c & 63) >> 5) << 1) + ((r & 31) >> 4)) * 64 + (((c & 31) >> 3) << 4) + (r & 15)) * 8 + (c & 7);
+}
+
 // Interleaved plane-pair rows (CRIMAC_PLANES_INTERLEAVED): a row of K channels is 2K halves, block size CB = min(K, 32);
 // channel c of plane k sits at (c / CB) * 2CB + k * CB + c % CB.
 __host__ __device__ constexpr int il_cb(int K) { return K < 32 ? K : 32; }

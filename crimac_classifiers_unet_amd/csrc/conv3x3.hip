@@ -311,7 +311,7 @@ int launch(ConvParams p, hipStream_t st) {
 int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
                                   const EpiParams& epi, hipStream_t st, int n_first, int n_count);
 int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
-                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16);
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16, int wfrag);
 int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
                           const EpiParams& epi, hipStream_t st, int fp16);
 // conv3x3_glds.hip: plane-pair input (CRIMAC_PREC_H3P), Cin % 32 == 0; out_planes: plane-pair output, else fp32
@@ -390,6 +390,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
   const int cin4 = (relu & CRIMAC_EPI_CIN4) != 0;
   e.stat_raw = (relu & CRIMAC_EPI_STAT_RAW) != 0;
+  const int wfrag = (relu & CRIMAC_EPI_WFRAG) != 0;
   relu &= CRIMAC_EPI_RELU;
   CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode != 2),
                  "conv3x3: plane-pair output is an H3P option (never with the fused BatchNorm-backward sums)");
@@ -435,8 +436,10 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     if (out_planes) return n128 ? launch<hp_t, 2, 128, 16, 8, half_t, hp_t>(p, st) : launch<hp_t, 2, 64, 16, 8, half_t, hp_t>(p, st);
     return n128 ? launch<hp_t, 2, 128, 16, 8, half_t, float>(p, st) : launch<hp_t, 2, 64, 16, 8, half_t, float>(p, st);
   }
+  CRIMAC_REQUIRE(!wfrag || (is16 && Cin % 64 == 0 && use_glds && !pool_out),
+                 "conv3x3: fragment-major weights (CRIMAC_EPI_WFRAG) are read by the 16-bit channel-split kernel only");
   if (is16 && Cin % 64 == 0 && use_glds)
-    return crimac_conv3x3_glds_16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, fp16);
+    return crimac_conv3x3_glds_16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, fp16, wfrag);
   // first layer (4 input channels padded to 16): persistent one-barrier kernel
   if (is16 && Cin == 16 && N == 64 && use_glds)
     return crimac_conv3x3_c16_16(in, in_ld, B, H, W, N, w_hi, e, st, fp16);

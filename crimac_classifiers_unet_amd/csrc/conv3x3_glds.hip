@@ -50,6 +50,7 @@ struct ConvParams {
   EpiParams epi;
   int tiles_y, tiles_x;
   int n_first, n_count;      // output-channel range of this launch (crimac_conv3x3_cols); default the whole N
+  int wfrag = 0;             // the weight plane is FRAGMENT-MAJOR (CRIMAC_EPI_WFRAG, common.h wfrag_index): channel-split kernel only
 };
 
 // Epilogue staging of an output storage type: 16-bit types stage the whole 256-row tile; fp32 and plane pairs (staged
@@ -393,20 +394,41 @@ __device__ __forceinline__ void wch_issue(const unsigned (&av)[3][2], WchFrags& 
   f.a[H & 1][2] = lds_read128_asm<base + 2 * (HP * RB)>(av[t % 3][ks2]);
   f.a[H & 1][3] = lds_read128_asm<base + 3 * (HP * RB)>(av[t % 3][ks2]);
 }
+// WF (fragment-major weight plane, common.h wfrag_index): the four fragments of a (tap, 32-channel block, 64-deep chunk) are
+// four CONSECUTIVE kilobytes, lane l at byte 16 l of each -- every load instruction reads whole 128-byte lines (the row-major
+// plane [tap][N][Cin] gives a wave instruction 16 rows x 64 bytes: sixteen half lines).  One address register, four
+// immediates.  Measured as an ablation first (round 5, r5_08: -2.5 % over the conv launches of a step, -12 % on the
+// 1024-channel bottleneck layers, whose workgroups stream 2.4 MB of weights each).
+template <bool WF = false>
 __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsigned short* s1, bf16x8 (&bf)[4]) {
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off\n\t"
-      "global_load_dwordx4 %1, %5, off\n\t"
-      "global_load_dwordx4 %2, %4, off offset:64\n\t"
-      "global_load_dwordx4 %3, %5, off offset:64"
-      : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
-      : "v"(s0), "v"(s1)
-      : "memory");
+#ifdef CRIMAC_EXP_WCH_NOW        // (ablation build: no weight stream -- the MFMAs run on whatever the registers hold)
+  asm volatile("" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) : "v"(s0), "v"(s1));
+  return;
+#endif
+  if constexpr (WF) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %4, off offset:1024\n\t"
+        "global_load_dwordx4 %2, %4, off offset:2048\n\t"
+        "global_load_dwordx4 %3, %4, off offset:3072"
+        : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
+        : "v"(s0)
+        : "memory");
+  } else {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %5, off\n\t"
+        "global_load_dwordx4 %2, %4, off offset:64\n\t"
+        "global_load_dwordx4 %3, %5, off offset:64"
+        : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2]), "=&v"(bf[3])
+        : "v"(s0), "v"(s1)
+        : "memory");
+  }
 }
 // PP (plane pairs): k-step 0 of a chunk is the hi plane of 32 channels, k-step 1 their lo plane, in both operands: the
 // hi fragments of A meet both weight planes (hi*lo, then hi*hi), the lo fragments the hi weights only -- 3 MFMAs per
 // fragment pair, 16 + 8 per pair of groups, on the same reads and weight loads as the 16-bit kernel's 8 + 8.
-template <typename T16, bool PP, int H, int NQ = 4, bool ILV = false, typename ACC>
+template <typename T16, bool PP, int H, int NQ = 4, bool ILV = false, bool WF = false, typename ACC>
 __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsigned short* wtap, long w_tap, long w_nb,
                                            const unsigned short* wnext_chunk, WchFrags& f, ACC& acc) {
   constexpr int t = H / (2 * NQ), ks2 = (H / NQ) % 2, q = H % NQ, NH = 18 * NQ;
@@ -419,10 +441,10 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
     }
     if constexpr (t < 8) {
       const unsigned short* s = wtap + (t + 1) * w_tap;
-      wch_load_b(s, s + w_nb, f.b[(t + 1) & 1]);
+      wch_load_b<WF>(s, s + w_nb, f.b[(t + 1) & 1]);
     } else {
       const unsigned short* s = wnext_chunk ? wnext_chunk : wtap;
-      wch_load_b(s, s + w_nb, f.b[1]);
+      wch_load_b<WF>(s, s + w_nb, f.b[1]);
     }
   }
   if constexpr (H + 1 < NH) {
@@ -444,7 +466,7 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
     for (int nb = 0; nb < 2; ++nb)
       acc[4 * q + j][nb] = E16<T16>::mfma16(f.a[H & 1][j], f.b[t & 1][(PP ? 0 : ks2 * 2) + nb],
                                                                     acc[4 * q + j][nb]);
-  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1, NQ, ILV>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
+  if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1, NQ, ILV, WF>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
 // FORM 1 ("S22"): the 2 x 2 form for 64-channel tiles: waves = 2 pixel halves (8 image rows each) x 2 channel halves (32
@@ -456,7 +478,7 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
 // Why: in FORM 1 a wave's tap is 48 MFMAs (plane pairs) between two weight-fragment waits and a workgroup's prologue,
 // halo waits and epilogue (28 k cycles) stand against 13.8 k cycles of MFMA work per SIMD: MFMA busy 0.45 (PMC) where the
 // 128-channel form reaches 0.77.
-template <typename T16, int MODE, typename TO = T16, bool PP = false, int FORM = 0>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums)
+template <typename T16, int MODE, typename TO = T16, bool PP = false, int FORM = 0, bool WF = false>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums); WF: fragment-major weight plane
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? 3 : 2, FORM == 1 ? 3 : 2))) void conv3x3_wch_kernel(ConvParams p) {
   constexpr bool S22 = FORM != 0;                  // waves = pixel halves x channel halves
   constexpr int BN = S22 ? 64 : 128, NW = 4;
@@ -529,8 +551,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   const int fr = lane & 15, fq = lane >> 4;
   const int wc = S22 ? (wave & 1) : wave, wp = S22 ? (wave >> 1) : 0;
   // weight fragments of this lane: rows n0 + 32*wc + nb*16 + fr of tap t, k = kc*64 + ks2*32 + fq*8 .. +8
-  const unsigned short* wrow = p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
+  // (WF: block (n0 / 32 + wc) of the tap's N / 32 blocks, Cin / 64 chunks of 2048 halves each, lane l at 8 l)
+  const unsigned short* wrow = WF ? p.w_hi + ((long)((n0 >> 5) + wc) * (p.Cin >> 6)) * 2048 + lane * 8
+                                  : p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
   const long w_tap = (long)p.N * p.Cin, w_nb = 16L * p.Cin;
+  constexpr int W_CHUNK = WF ? 2048 : BK;             // halves between two 64-channel chunks of a tap
   // A fragment: M tile i = image row i of the tile, lane's pixel column fr -> halo row (i + ky) * HP + fr + kx
   unsigned av[3][2];
   {
@@ -559,7 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   for (int nb = 0; nb < 2; ++nb) bias_pre[nb] = p.epi.bias ? p.epi.bias[n0 + wc * 32 + nb * 16 + (lane & 15)] : 0.f;
 #endif
   issue_halo(0);                         // (in flight together with the first weight fragments: one latency, not two)
-  wch_load_b(wrow, wrow + w_nb, f.b[1]);
+  wch_load_b<WF>(wrow, wrow + w_nb, f.b[1]);
   wch_land_b(f.b[1]);                    // vmcnt(0): the fragments and the first halo chunk
   CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
   CRIMAC_CPH(0)
@@ -571,10 +596,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(1)
-    const unsigned short* wtap = wrow + kc * BK;
-    const unsigned short* wnext = kc + 1 < kchunks ? wtap + BK : nullptr;
+    const unsigned short* wtap = wrow + (long)kc * W_CHUNK;
+    const unsigned short* wnext = kc + 1 < kchunks ? wtap + W_CHUNK : nullptr;
     wch_issue<0, NQ, ILV>(av, f);
-    wch_step<T16, PP, 0, NQ, ILV>(av, wtap, w_tap, w_nb, wnext, f, acc);
+    wch_step<T16, PP, 0, NQ, ILV, WF>(av, wtap, w_tap, w_nb, wnext, f, acc);
     wch_land_b(f.b[1]);
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(2)
@@ -600,7 +625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
 #endif
 }
 
-template <typename T16, typename TO = T16, bool PP = false, int S22 = 0>      // S22: the kernel's FORM
+template <typename T16, typename TO = T16, bool PP = false, int S22 = 0, bool WF = false>      // S22: the kernel's FORM
 int launch_wch(ConvParams p, hipStream_t st) {
   constexpr int BN = S22 ? 64 : 128;
   constexpr int TRK = S22 == 2 ? 32 : TR;
@@ -614,24 +639,24 @@ int launch_wch(ConvParams p, hipStream_t st) {
   static_assert(stage <= 80 * 1024 && HALO_BYTES <= 80 * 1024, "two workgroups per CU");
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP, S22>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 0, TO, PP, S22, WF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP, S22>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 1, TO, PP, S22, WF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (!__is_same(TO, hp_t))
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2, TO, PP, S22>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wch_kernel<T16, 2, TO, PP, S22, WF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const dim3 grid((unsigned)ntiles, p.n_count / BN);
   const int mode = p.epi.stat_sum ? p.epi.stat_mode : 0;
   if constexpr (__is_same(TO, hp_t)) {
     CRIMAC_REQUIRE(mode != 2, "conv3x3: plane-pair output with fused BatchNorm-backward sums");
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP, S22>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP, S22>), grid, dim3(256), lds, st, p);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP, S22, WF>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP, S22, WF>), grid, dim3(256), lds, st, p);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP, S22>), grid, dim3(256), lds, st, p);
-    else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP, S22>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2, TO, PP, S22>), grid, dim3(256), lds, st, p);
+    if (mode == 0) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 0, TO, PP, S22, WF>), grid, dim3(256), lds, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 1, TO, PP, S22, WF>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_wch_kernel<T16, 2, TO, PP, S22, WF>), grid, dim3(256), lds, st, p);
   }
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1383,6 +1408,16 @@ template <typename T16>
 int glds_dispatch(ConvParams p, hipStream_t st) {
   const int B = p.B, H = p.H, W = p.W, Cin = p.Cin, N = p.N, n_first = p.n_first, n_count = p.n_count;
   const long in_ld = p.in_ld;
+  if (p.wfrag) {
+    // a fragment-major weight plane: only the channel-split kernel (128-channel form) reads it
+    const bool small_f = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
+    CRIMAC_REQUIRE(N % 128 == 0 && n_first % 128 == 0 && n_count % 128 == 0 && Cin % 64 == 0,
+                   "conv3x3: fragment-major weights (CRIMAC_EPI_WFRAG) need N and the channel range in multiples of 128 and "
+                   "Cin %% 64 == 0 (N=%d range [%d, +%d) Cin=%d)", N, n_first, n_count, Cin);
+    CRIMAC_REQUIRE(small_f, "conv3x3: fragment-major weights (CRIMAC_EPI_WFRAG): the input tensor exceeds the 2 GB the "
+                   "channel-split kernel addresses (B=%d H=%d W=%d ld=%ld): pack row-major planes (CRIMAC_WFRAG=0)", B, H, W, in_ld);
+    return launch_wch<T16, T16, false, 0, true>(p, st);
+  }
   if (n_first != 0 || n_count != N) {
     // a range of output channels (crimac_conv3x3_cols): 64 of them with the persistent 64-channel kernel,
     // multiples of 128 with the channel-split kernel
@@ -1466,8 +1501,9 @@ int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int 
 
 // 16-bit storage, Cin % 64 == 0, N % 64 == 0; argument checks are done by crimac_conv3x3 (conv3x3.hip).
 int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
-                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16) {
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16, int wfrag) {
   ConvParams p;
+  p.wfrag = wfrag;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;

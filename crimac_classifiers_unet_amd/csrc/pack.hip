@@ -22,9 +22,10 @@ struct LayerDesc {             // mirrors crimac_layer_desc (include/crimac_unet
   unsigned short* fwd_lo;
   unsigned short* dg_hi;
   unsigned short* dg_lo;
-  int kind, Co, Ci, Ci_pad;
+  int kind, Co, Ci, Ci_pad;  // (kind: bit 0 only here; the fragment-major flags travel in `frag`)
   int dw_splits;             // partial slabs of dw to add up (crimac_wgrad_partials); <= 1: dw is the gradient
   long dw_stride;            // floats between slabs
+  int frag;                  // bit 0: fwd_hi fragment-major, bit 1: dg_hi fragment-major (common.h wfrag_index)
 };
 
 struct Table {
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol][(il + q) * T + t] * a_sc;
       if (pf.interleaved) put_planes8_il(v, a_hi, (long)t * g.outer + o0 + ol, i0 + il, g.inner_pad, a_fp16);
+      else if (d.frag & 1) put_planes8(v, npl, a_hi, a_lo, wfrag_index(t, o0 + ol, i0 + il, g.outer, g.inner_pad), n, a_fp16);
       else put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, a_fp16);
     }
   } else if (a_hi) {
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol + q][il * T + t] * b_sc;
       if (pf.interleaved) put_planes8_il(v, b_hi, (long)tt * g.inner + i0 + il, o0 + ol, g.outer, b_fp16);
+      else if (d.frag & 2) put_planes8(v, npl, b_hi, b_lo, wfrag_index(tt, i0 + il, o0 + ol, g.inner, g.outer), n, b_fp16);
       else put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, b_fp16);
     }
   }
@@ -244,8 +247,19 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream
     tb.n = n - base < kMaxLayers ? n - base : kMaxLayers;
     int total = 0;
     for (int i = 0; i < tb.n; ++i) {
-      const HostDesc& h = descs[base + i];
-      CRIMAC_REQUIRE((h.kind == 0 || h.kind == 1) && h.Co > 0 && h.Ci > 0, "layer %d: bad kind/shape", base + i);
+      HostDesc h = descs[base + i];
+      const int frag = ((h.kind & CRIMAC_LAYER_FWD_FRAG) ? 1 : 0) | ((h.kind & CRIMAC_LAYER_DG_FRAG) ? 2 : 0);
+      CRIMAC_REQUIRE((h.kind & ~(1 | CRIMAC_LAYER_FWD_FRAG | CRIMAC_LAYER_DG_FRAG)) == 0 && h.Co > 0 && h.Ci > 0,
+                     "layer %d: bad kind/shape", base + i);
+      h.kind &= 1;
+      if (frag && mode == 0) {
+        CRIMAC_REQUIRE(h.kind == 0 && planes == 1 && !(planes_arg & CRIMAC_PLANES_INTERLEAVED),
+                       "layer %d: fragment-major planes are a single-plane 16-bit Conv2d layout", base + i);
+        CRIMAC_REQUIRE(!(frag & 1) || (h.Co % 32 == 0 && h.Ci_pad % 64 == 0), "layer %d: fragment-major forward plane needs "
+                       "Co %% 32 == 0 and Ci_pad %% 64 == 0 (Co=%d Ci_pad=%d)", base + i, h.Co, h.Ci_pad);
+        CRIMAC_REQUIRE(!(frag & 2) || (h.dg_hi && h.Ci % 32 == 0 && h.Co % 64 == 0 && h.Ci_pad == h.Ci),
+                       "layer %d: fragment-major input-gradient plane needs Ci %% 32 == 0 and Co %% 64 == 0", base + i);
+      }
       CRIMAC_REQUIRE(h.Co % TILE == 0 && (h.kind == 0 || h.Ci % TILE == 0),
                      "layer %d: Co (and the transposed convolution's Ci) must be multiples of %d", base + i, TILE);
       CRIMAC_REQUIRE(h.kind == 1 || (h.Ci_pad >= h.Ci && h.Ci_pad % 2 == 0), "layer %d: bad Ci_pad", base + i);
@@ -265,6 +279,7 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream
       d.dg_hi = (unsigned short*)h.dg_hi; d.dg_lo = (unsigned short*)h.dg_lo;
       d.kind = h.kind; d.Co = h.Co; d.Ci = h.Ci; d.Ci_pad = h.kind == 0 ? h.Ci_pad : h.Ci;
       d.dw_splits = h.dw_splits; d.dw_stride = h.dw_stride;
+      d.frag = mode == 0 ? frag : 0;
       if (mode == 1)
         CRIMAC_REQUIRE(h.dw_splits <= 1 || h.dw_stride >= (long)(h.kind == 0 ? 9L * h.Co * h.Ci_pad : 4L * h.Co * h.Ci),
                        "layer %d: dw_stride smaller than one packed gradient", base + i);

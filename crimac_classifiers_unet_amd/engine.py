@@ -251,6 +251,14 @@ class UNetEngine:
                 "dg_hi": torch.empty(m_hi * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
                 "dg_lo": torch.empty(8 if il else n_lo * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
             }
+            # fragment-major planes (round 5, CRIMAC_EPI_WFRAG): the 16-bit modes pack the planes the channel-split kernel
+            # reads as WHOLE 128-channel ranges so that its weight loads are whole cache lines.  Forward plane: N = cout in
+            # multiples of 128 and 64-deep chunks; input-gradient plane: N = cin likewise -- except a decoder block's conv1
+            # whose two d(concat) halves (cin / 2 channels each) are launched separately and are not multiples of 128
+            wf = self.wfrag and self.is16 and self.conv_impl == "halo"
+            self.pk[b.conv_key]["fwd_frag"] = bool(wf and b.cout % 128 == 0 and b.cin_pad % 64 == 0)
+            self.pk[b.conv_key]["dg_frag"] = bool(wf and has_dg and b.cin % 128 == 0 and b.cout % 64 == 0
+                                                   and not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0))
             self.pk_eval[b.conv_key] = {
                 "fwd_hi": torch.empty(m_hi * n_f, dtype=i16, device=dev),
                 "fwd_lo": torch.empty(8 if il else n_lo * n_f, dtype=i16, device=dev),
@@ -420,6 +428,8 @@ class UNetEngine:
             d.dg_hi = pk["dg_hi"].data_ptr() if pk["dg_hi"] is not None else None
             d.dg_lo = pk["dg_lo"].data_ptr() if pk["dg_lo"] is not None else None
             d.kind, d.Co, d.Ci, d.Ci_pad = (1 if up else 0), l.cout, l.cin, cin_pad
+            if not up:
+                d.kind |= (hip.LAYER_FWD_FRAG if pk.get("fwd_frag") else 0) | (hip.LAYER_DG_FRAG if pk.get("dg_frag") else 0)
         bounds, pos = [], 0
         for g in groups:
             bounds.append((pos, len(g)))
@@ -700,6 +710,7 @@ class UNetEngine:
     # BatchNorm+ReLU of the last decoder block applied inside the 1x1 head (needs fuse_bn_bwd: the head's backward
     # rebuilds its input from the y it reads for the fused sums)
     fuse_head_bn = fuse_bn_bwd and os.environ.get("CRIMAC_FUSE_HEADBN", "1") != "0"
+    wfrag = os.environ.get("CRIMAC_WFRAG", "1") != "0"      # fragment-major weight planes for the channel-split kernel (16-bit modes)
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
                  stats=None, bnb=None, cols=None, out_planes=False, stat_reps=None):
@@ -713,6 +724,8 @@ class UNetEngine:
         if self.is_hp and cin_real is not None and cin_real <= 4 and cin == CIN_PAD and not dgrad:
             relu |= hip.EPI_CIN4          # (the network input: channels 4 .. 15 of the padded pixel are zero)
         w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
+        if pk.get("dg_frag" if dgrad else "fwd_frag"):
+            relu |= hip.EPI_WFRAG         # (the plane was packed fragment-major: _alloc_static)
         prec = self.prec_bwd if dgrad else self.prec
         if self.conv_impl == "halo":
             mode, s0, s1, by, by_ld, bvec = 0, None, None, None, 0, None

@@ -111,6 +111,13 @@ extern "C" {
 /* bit 3: with stat_mode 1 the sums are taken of the fp32 results BEFORE the rounding of the store (they are then a bias
  * gradient -- the transposed convolution's, unet.py:130 -- not the statistics of the stored tensor) */
 #define CRIMAC_EPI_STAT_RAW 8
+/* bit 4: the weight plane w_hi is FRAGMENT-MAJOR (packed by crimac_pack_layers for a layer whose `kind` carries
+ * CRIMAC_LAYER_FWD_FRAG / CRIMAC_LAYER_DG_FRAG): element (tap t, row r of R = N, column c of K = Cin) at
+ *   ((((t * R/32 + r/32) * K/64 + c/64) * 4 + ((c % 64) / 32) * 2 + (r % 32) / 16) * 64 + ((c % 32) / 8) * 16 + r % 16) * 8 + c % 8
+ * -- the four MFMA weight fragments of a (tap, 32-row block, 64-column chunk) are four consecutive kilobytes with lane l's
+ * 16 bytes at 16 l, so that every weight load of the channel-split kernel reads whole cache lines.  16-bit precisions
+ * (BF16 / FP16), N and the channel range multiples of 128, Cin % 64 == 0. */
+#define CRIMAC_EPI_WFRAG 16
 
 /* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
  * struct passed by pointer (crimac_layer_desc), the meaning of an argument or the set of precisions changes, and a
@@ -270,13 +277,17 @@ typedef struct crimac_layer_desc {
   void* fwd_lo;
   void* dg_hi;         /* may be NULL (no input gradient needed: first layer) */
   void* dg_lo;
-  int kind;            /* 0: Conv2d 3x3, 1: ConvTranspose2d 2x2 stride 2 */
+  int kind;            /* bit 0 -- 0: Conv2d 3x3, 1: ConvTranspose2d 2x2 stride 2; kind 0, 16-bit single-plane packs only:
+                        * | CRIMAC_LAYER_FWD_FRAG: fwd_hi is written FRAGMENT-MAJOR (CRIMAC_EPI_WFRAG; Co % 32 == 0, Ci_pad % 64 == 0),
+                        * | CRIMAC_LAYER_DG_FRAG: dg_hi likewise (rows = Ci, columns = Co: Ci % 32 == 0, Co % 64 == 0) */
   int Co, Ci, Ci_pad;  /* Ci_pad: kind 0 only */
   int dw_splits;       /* crimac_unpack_wgrad_layers: `dw` holds this many partial slabs (crimac_wgrad_partials),
                         * added up in a fixed order (bit-reproducible; more than 16 slabs are first folded IN PLACE
                         * into the first 16, so dw is scratch afterwards); 0 or 1: dw is the finished sum (crimac_wgrad) */
   long dw_stride;      /* floats between two slabs */
 } crimac_layer_desc;
+#define CRIMAC_LAYER_FWD_FRAG 16
+#define CRIMAC_LAYER_DG_FRAG 32
 int crimac_pack_layers(const crimac_layer_desc* descs, int n_layers, int planes, void* stream);
 int crimac_unpack_wgrad_layers(const crimac_layer_desc* descs, int n_layers, void* stream);
 

@@ -793,6 +793,84 @@ def test_whole_network_pack_and_unpack_equal_the_per_layer_kernels(planes):
     assert torch.equal(keep[2][4], keep[2][5]) and float(keep[1][4].abs().max()) == 0
 
 
+def _wfrag_index(t, r, c, R, K):
+    """common.h wfrag_index, vectorised (c % 8 == 0: position of the 8 columns c .. c + 7 of row r at tap t)."""
+    blk = (t * (R // 32) + r // 32) * (K // 64) + c // 64
+    return ((blk * 4 + ((c % 64) // 32) * 2 + (r % 32) // 16) * 64 + ((c % 32) // 8) * 16 + r % 16) * 8
+
+
+@pytest.mark.parametrize("prec", LOWP)
+@pytest.mark.parametrize("shape", [(2, 32, 48, 128, 128), (1, 24, 40, 128, 256), (3, 16, 16, 256, 128)])
+def test_fragment_major_weight_planes_pack_and_convolve_bit_for_bit(prec, shape):
+    """CRIMAC_LAYER_FWD_FRAG / CRIMAC_LAYER_DG_FRAG + CRIMAC_EPI_WFRAG (round 5): crimac_pack_layers writes the planes the
+    channel-split kernel reads in fragment-major order -- a permutation of the row-major plane in 16-byte units -- and the
+    convolution on them (forward with statistics, input gradient with the fused BatchNorm-backward sums, a 128-channel range of
+    the input gradient) is BIT-identical to the convolution on the row-major plane."""
+    import ctypes
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(31)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).cuda()
+    planes = hip.PREC_PLANES_ARG[hip.PREC_NAMES[prec]]
+    n = 9 * Co * Ci
+    i16 = torch.int16
+    bufs = {}
+    for tag, kind in (("row", 0), ("frag", hip.LAYER_FWD_FRAG | hip.LAYER_DG_FRAG)):
+        d = (hip.LayerDesc * 1)()
+        bufs[tag] = {k: torch.full((n,), -1, dtype=i16, device="cuda") for k in ("fwd_hi", "dg_hi")}
+        lo = torch.zeros(8, dtype=i16, device="cuda")
+        d[0].w = w.data_ptr()
+        d[0].fwd_hi, d[0].fwd_lo = bufs[tag]["fwd_hi"].data_ptr(), lo.data_ptr()
+        d[0].dg_hi, d[0].dg_lo = bufs[tag]["dg_hi"].data_ptr(), lo.data_ptr()
+        d[0].kind, d[0].Co, d[0].Ci, d[0].Ci_pad = kind, Co, Ci, Ci
+        call("crimac_pack_layers", ctypes.byref(d), 1, planes)
+    torch.cuda.synchronize()
+    # the fragment-major plane is the row-major plane with its 16-byte units moved to wfrag_index
+    for key, R, K in (("fwd_hi", Co, Ci), ("dg_hi", Ci, Co)):
+        t, r, c = np.meshgrid(np.arange(9), np.arange(R), np.arange(0, K, 8), indexing="ij")
+        src = ((t * R + r) * K + c).reshape(-1)
+        dst = _wfrag_index(t, r, c, R, K).reshape(-1)
+        assert len(set(dst.tolist())) == len(dst) and dst.max() == 9 * R * K - 8
+        row = bufs["row"][key].cpu().numpy().reshape(-1, 8)
+        frag = bufs["frag"][key].cpu().numpy().reshape(-1, 8)
+        assert np.array_equal(frag[dst // 8], row[src // 8]), key
+    x = to_nhwc(_round(torch.randn(B, Ci, H, W, generator=g), prec), prec)
+    dy = to_nhwc(_round(torch.randn(B, Co, H, W, generator=g), prec), prec)
+    bias = torch.randn(Co, generator=g).cuda()
+    yprev = to_nhwc(_round(torch.randn(B, Ci, H, W, generator=g) * 1.5 + 0.3, prec), prec)
+    vec = torch.stack([torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5,
+                       torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3]).contiguous().cuda()
+    M, P = B * H * W, hip.PREC_NAMES[prec]
+    res = {}
+    for tag, flag in (("row", 0), ("frag", hip.EPI_WFRAG)):
+        out = torch.empty(M, Co, dtype=_dt(prec), device="cuda")
+        st = torch.zeros(2, 3, Co, dtype=torch.float64, device="cuda")
+        call("crimac_conv3x3", P, ptr(x), Ci, B, H, W, Ci, Co, ptr(bufs[tag]["fwd_hi"]), None, ptr(bias), ptr(out), Co,
+             hip.EPI_RELU | flag, 1, ptr(st[0]), ptr(st[1]), 3, None, 0, None, 0)
+        da = torch.empty(M, Ci, dtype=_dt(prec), device="cuda")
+        acc = torch.zeros(2, 3, Ci, dtype=torch.float64, device="cuda")
+        call("crimac_conv3x3", P, ptr(dy), Co, B, H, W, Co, Ci, ptr(bufs[tag]["dg_hi"]), None, None, ptr(da), Ci, flag, 2,
+             ptr(acc[0]), ptr(acc[1]), 3, ptr(yprev), Ci, ptr(vec), Ci)
+        half = None
+        if Ci % 256 == 0:                      # the second 128-channel range of the input gradient alone (decoder conv1)
+            half = torch.zeros(M, Ci, dtype=_dt(prec), device="cuda")
+            call("crimac_conv3x3_cols", P, ptr(dy), Co, B, H, W, Co, Ci, ptr(bufs[tag]["dg_hi"]), None, None, ptr(half), Ci,
+                 flag, 0, None, None, 1, None, 0, None, 0, Ci // 2, Ci // 2)
+        torch.cuda.synchronize()
+        res[tag] = (out, st.sum(1), da, half)
+    assert torch.equal(res["row"][0], res["frag"][0]) and torch.equal(res["row"][2], res["frag"][2])
+    assert relerr(res["frag"][1].cpu(), res["row"][1].cpu()) < 1e-9
+    if res["row"][3] is not None:
+        assert torch.equal(res["row"][3], res["frag"][3]) and float(res["frag"][3][:, Ci // 2:].float().abs().max()) > 0
+        assert torch.equal(res["frag"][3][:, Ci // 2:], res["frag"][2][:, Ci // 2:])
+    # and what the planes cannot serve fails loudly: a 64-channel range, a split precision
+    with pytest.raises(hip.HipLibraryError, match="fragment-major"):
+        call("crimac_conv3x3_cols", P, ptr(dy), Co, B, H, W, Co, Ci, ptr(bufs["frag"]["dg_hi"]), None, None, ptr(res["frag"][2]),
+             Ci, hip.EPI_WFRAG, 0, None, None, 1, None, 0, None, 0, 0, 64)
+    with pytest.raises(hip.HipLibraryError, match="fragment-major"):
+        call("crimac_conv3x3", hip.PREC_F32X6, ptr(x), Ci, B, H, W, Ci, Co, ptr(bufs["frag"]["fwd_hi"]), ptr(bufs["frag"]["fwd_hi"]),
+             None, ptr(res["frag"][0]), Co, hip.EPI_WFRAG, 0, None, None, 1, None, 0, None, 0)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "f32x3"])
 @pytest.mark.parametrize("mode,shape", [(0, (2, 64, 64, 64, 128)), (1, (2, 32, 32, 128, 64)), (0, (1, 40, 24, 16, 64))])
 def test_wgrad_partial_slabs_sum_to_the_atomic_result_and_are_reproducible(prec, mode, shape):
