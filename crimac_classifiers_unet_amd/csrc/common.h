@@ -170,7 +170,7 @@ __host__ __device__ inline PlaneFmt plane_fmt(int planes_arg) {
 __host__ inline bool planes_arg_ok(int planes_arg) {
   const int npl = planes_arg & 15, sh = (planes_arg >> 8) & 255;
   if ((planes_arg & 0x40) && npl != 2) return false;           // interleaved rows are plane PAIRS
-  return npl >= 1 && npl <= 3 && (planes_arg >> 16) == 0 && sh <= 16;
+  return npl >= 1 && npl <= 3 && (planes_arg >> 17) == 0 && sh <= 16;      // (bit 16: CRIMAC_PLANES_FWD_FRAG)
 }
 // Fragment-major weight plane (CRIMAC_EPI_WFRAG, CRIMAC_LAYER_*_FRAG): position (in halves) of the 8 columns c .. c + 7
 // (c % 8 == 0) of row r at tap t in a plane of R rows x K columns.  A (tap, 32-row block, 64-column chunk) is 4 KB: four

@@ -309,7 +309,7 @@ int launch(ConvParams p, hipStream_t st) {
 
 // conv3x3_glds.hip: 16-bit-storage direct-to-LDS variants (fp16 != 0: IEEE half, else bf16)
 int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
-                                  const EpiParams& epi, hipStream_t st, int n_first, int n_count);
+                                  const EpiParams& epi, hipStream_t st, int n_first, int n_count, int wfrag);
 int crimac_conv3x3_glds_16(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
                            const EpiParams& epi, hipStream_t st, int n_first, int n_count, int fp16, int wfrag);
 int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N, const void* w_hi,
@@ -318,7 +318,7 @@ int crimac_conv3x3_c16_16(const void* in, long in_ld, int B, int H, int W, int N
 int crimac_conv3x3_c16_hp(const void* in, long in_ld, int B, int H, int W, int N, const void* w, const EpiParams& epi,
                           hipStream_t st, int out_planes);
 int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w,
-                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes);
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes, int wfrag);
 
 // register-staged kernel for one 16-bit storage type (odd channel counts, A/B runs)
 template <typename T16>
@@ -346,7 +346,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
                    "conv3x3 (H3F_BWD): Cin, N multiples of 64 (got %d, %d)", Cin, N);
     if (relu & CRIMAC_EPI_OUT_PLANES)      // (column sums taken here are a bias gradient: of the unrounded results)
       return conv3x3_run(CRIMAC_PREC_FP16, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld,
-                         (relu & CRIMAC_EPI_RELU) | CRIMAC_EPI_STAT_RAW,
+                         (relu & (CRIMAC_EPI_RELU | CRIMAC_EPI_WFRAG)) | CRIMAC_EPI_STAT_RAW,
                          stat_mode, stat_sum, stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, n_first,
                          n_count, stream);
     CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= n_first + n_count && out_ld % 8 == 0, "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
@@ -361,7 +361,8 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     e.stat_replicas = stat_replicas > 0 ? stat_replicas : 1;
     e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
     e.acc_scale = 1.f;
-    return crimac_conv3x3_glds_16_f32out(in, in_ld, B, H, W, Cin, N, w_hi, e, (hipStream_t)stream, n_first, n_count);
+    return crimac_conv3x3_glds_16_f32out(in, in_ld, B, H, W, Cin, N, w_hi, e, (hipStream_t)stream, n_first, n_count,
+                                         (relu & CRIMAC_EPI_WFRAG) != 0);
   }
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0 && pool_ld >= N && pool_ld % 8 == 0 && stat_mode == 0 &&
@@ -422,8 +423,10 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     // plane-pair input: the 16-bit LDS-DMA kernels on a tensor of 2 Cin halves per pixel (3 MFMAs per product);
     // the first layer (4 input channels padded to 16) runs on the register-staged kernel, whose staging copies the
     // pre-split halves
+    CRIMAC_REQUIRE(!wfrag || (Cin % 32 == 0 && use_glds),
+                   "conv3x3 (plane pairs): fragment-major weights (CRIMAC_EPI_WFRAG) are read by the channel-split kernel only");
     if (Cin % 32 == 0 && use_glds)
-      return crimac_conv3x3_glds_hp(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, out_planes);
+      return crimac_conv3x3_glds_hp(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, out_planes, wfrag);
     CRIMAC_REQUIRE(!pool_out, "conv3x3_pool (plane pairs): Cin %% 32 == 0 only");
     // first layer (4 input channels padded to 16): the persistent 16-channel kernel on hi / lo pseudo-channels
     static const int c16hp = getenv("CRIMAC_CONV_C16HP") ? atoi(getenv("CRIMAC_CONV_C16HP")) : 1;
@@ -436,8 +439,8 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     if (out_planes) return n128 ? launch<hp_t, 2, 128, 16, 8, half_t, hp_t>(p, st) : launch<hp_t, 2, 64, 16, 8, half_t, hp_t>(p, st);
     return n128 ? launch<hp_t, 2, 128, 16, 8, half_t, float>(p, st) : launch<hp_t, 2, 64, 16, 8, half_t, float>(p, st);
   }
-  CRIMAC_REQUIRE(!wfrag || (is16 && Cin % 64 == 0 && use_glds && !pool_out),
-                 "conv3x3: fragment-major weights (CRIMAC_EPI_WFRAG) are read by the 16-bit channel-split kernel only");
+  CRIMAC_REQUIRE(!wfrag || (is16 && Cin % 64 == 0 && use_glds),
+                 "conv3x3: fragment-major weights (CRIMAC_EPI_WFRAG) are read by the 16-bit / plane-pair channel-split kernel only");
   if (is16 && Cin % 64 == 0 && use_glds)
     return crimac_conv3x3_glds_16(in, in_ld, B, H, W, Cin, N, w_hi, e, st, n_first, n_count, fp16, wfrag);
   // first layer (4 input channels padded to 16): persistent one-barrier kernel

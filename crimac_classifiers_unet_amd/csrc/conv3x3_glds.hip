@@ -1456,7 +1456,7 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
 // pixel (3 MFMAs per product); output fp32 (out_planes == 0) or plane pairs.  The persistent 64 -> 64 kernel has no
 // plane-pair form (144 KB of weights do not fit beside the halos): those layers take the pixel-split kernel.
 int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w,
-                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes) {
+                           const EpiParams& epi, hipStream_t st, int n_first, int n_count, int out_planes, int wfrag) {
   ConvParams p;
   p.in = in; p.in_ld = 2 * in_ld; p.B = B; p.H = H; p.W = W; p.Cin = 2 * Cin; p.N = N;
   p.w_hi = (const unsigned short*)w;
@@ -1464,6 +1464,12 @@ int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int 
   p.n_first = n_first; p.n_count = n_count;
   const bool small = (((long)B * H * W - 1) * p.in_ld + p.Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
+  if (wfrag) {      // fragment-major plane (rows of 2 Cin halves): the 128-channel form of the channel-split kernel only
+    CRIMAC_REQUIRE(N % 128 == 0 && n_count % 128 == 0 && n_first % 128 == 0 && small,
+                   "conv3x3 (plane pairs): fragment-major weights (CRIMAC_EPI_WFRAG) need N and the channel range in multiples of "
+                   "128 and an input tensor below 2 GB (N=%d range [%d, +%d))", N, n_first, n_count);
+    return out_planes ? launch_wch<half_t, hp_t, true, 0, true>(p, st) : launch_wch<half_t, float, true, 0, true>(p, st);
+  }
   if (n_count % 128 == 0 && n_first % 128 == 0 && small && w4 != 1)
     return out_planes ? launch_wch<half_t, hp_t, true>(p, st) : launch_wch<half_t, float, true>(p, st);
   CRIMAC_REQUIRE(n_first % 64 == 0 && n_count % 64 == 0, "conv3x3 (plane pairs): channel range [%d, +%d) must be "
@@ -1485,13 +1491,19 @@ int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int 
 // fused BatchNorm-backward sums read the forward pass's fp32 y).  The same kernel forms as the 16-bit modes; 64-channel
 // ranges take the tall form (the persistent 64 -> 64 kernel has no fp32 output).
 int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int W, int Cin, int N, const void* w_hi,
-                                  const EpiParams& epi, hipStream_t st, int n_first, int n_count) {
+                                  const EpiParams& epi, hipStream_t st, int n_first, int n_count, int wfrag) {
   ConvParams p;
   p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.N = N;
   p.w_hi = (const unsigned short*)w_hi;
   p.epi = epi;
   p.n_first = n_first; p.n_count = n_count;
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
+  if (wfrag) {
+    CRIMAC_REQUIRE(N % 128 == 0 && n_count % 128 == 0 && n_first % 128 == 0 && small,
+                   "conv3x3 (fp16 operands, fp32 output): fragment-major weights (CRIMAC_EPI_WFRAG) need N and the channel range in "
+                   "multiples of 128 and an input tensor below 2 GB (N=%d range [%d, +%d))", N, n_first, n_count);
+    return launch_wch<half_t, float, false, 0, true>(p, st);
+  }
   if (n_count % 128 == 0 && n_first % 128 == 0)
     return small ? launch_wch<half_t, float, false>(p, st) : launch_w4<128, half_t, float, false>(p, st);
   CRIMAC_REQUIRE(n_first % 64 == 0 && n_count % 64 == 0, "conv3x3 (fp16 operands, fp32 output): channel range [%d, +%d) must be "

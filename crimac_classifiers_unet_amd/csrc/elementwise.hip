@@ -100,7 +100,14 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci,
       v = w[((long)co * Ci + ci) * 9 + t];
       if (scale) v *= scale[co];
     }
-    if (pf.interleaved) put_planes_il(v * pf.fwd_scale, pf.fwd_fp16, fwd_hi, r, ci, Ci_pad);
+    if ((npl & CRIMAC_PLANES_FWD_FRAG) && pf.interleaved) {      // fragment-major (CRIMAC_EPI_WFRAG) on the row of 2 Ci_pad halves
+      const int c = (int)il_pos(ci, Ci_pad);
+      const unsigned short b = f2bits16(v * pf.fwd_scale, pf.fwd_fp16);
+      fwd_hi[wfrag_index(t, co, c, Co, 2 * Ci_pad)] = b;
+      fwd_hi[wfrag_index(t, co, c + il_cb(Ci_pad), Co, 2 * Ci_pad)] = f2bits16(v * pf.fwd_scale - bits162f(b, pf.fwd_fp16), pf.fwd_fp16);
+    } else if (npl & CRIMAC_PLANES_FWD_FRAG) {
+      put_planes(v * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, wfrag_index(t, co, ci, Co, Ci_pad), n_fwd);
+    } else if (pf.interleaved) put_planes_il(v * pf.fwd_scale, pf.fwd_fp16, fwd_hi, r, ci, Ci_pad);
     else put_planes(v * pf.fwd_scale, pf.npl, pf.fwd_fp16, fwd_hi, fwd_lo, i, n_fwd);
   }
   if (dg_hi) {
@@ -1285,6 +1292,11 @@ extern "C" int crimac_pack_conv3x3(const float* w, int Co, int Ci, int Ci_pad, c
                      ((planes & 15) == 1 || (planes & CRIMAC_PLANES_INTERLEAVED) || !dg_hi || dg_lo),
                  "pack_conv3x3: planes=%d needs the lo plane buffers", planes);
   CRIMAC_REQUIRE(!dg_hi || Ci_pad == Ci, "pack_conv3x3: dgrad planes need Ci_pad == Ci");
+  CRIMAC_REQUIRE(!(planes & CRIMAC_PLANES_FWD_FRAG) ||
+                     (Co % 32 == 0 && (((planes & CRIMAC_PLANES_INTERLEAVED) && Ci_pad % 32 == 0) ||
+                                       ((planes & 15) == 1 && Ci_pad % 64 == 0))),
+                 "pack_conv3x3: a fragment-major forward plane needs Co %% 32 == 0 and Ci_pad %% 64 == 0 (single 16-bit plane) or "
+                 "Ci_pad %% 32 == 0 (interleaved pairs) (Co=%d Ci_pad=%d planes=%d)", Co, Ci_pad, planes);
   const int grid = grid_for(9L * Co * Ci_pad, 256);
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid), dim3(256), 0, ST, w, Co, Ci, Ci_pad, scale, planes,
                      (unsigned short*)fwd_hi, (unsigned short*)fwd_lo, (unsigned short*)dg_hi,

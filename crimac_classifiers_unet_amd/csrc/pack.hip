@@ -91,6 +91,16 @@ __device__ __forceinline__ void put_planes8_il(float (&v)[8], unsigned short* bu
   put_planes8(v, 2, dst, dst + il_cb(rowlen), 0, 0, fp16);
 }
 
+// ... fragment-major (common.h wfrag_index on the row of 2 * rowlen halves): the hi group at the halves-column il_pos(col),
+// the lo group one block (32 halves) further
+__device__ __forceinline__ void put_planes8_il_frag(float (&v)[8], unsigned short* buf, int t, int r, int R, int col, int rowlen,
+                                                    int fp16) {
+  const int c = (int)il_pos(col, rowlen);
+  unsigned short* hi = buf + wfrag_index(t, r, c, R, 2 * rowlen);
+  unsigned short* lo = buf + wfrag_index(t, r, c + il_cb(rowlen), R, 2 * rowlen);
+  put_planes8(v, 2, hi, lo, 0, 0, fp16);
+}
+
 __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_arg) {
   __shared__ float tile[TILE][TILE * 9 + 1];
   const PlaneFmt pf = plane_fmt(planes_arg);
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol][(il + q) * T + t] * a_sc;
-      if (pf.interleaved) put_planes8_il(v, a_hi, (long)t * g.outer + o0 + ol, i0 + il, g.inner_pad, a_fp16);
+      if (pf.interleaved && (d.frag & 1)) put_planes8_il_frag(v, a_hi, t, o0 + ol, g.outer, i0 + il, g.inner_pad, a_fp16);
+      else if (pf.interleaved) put_planes8_il(v, a_hi, (long)t * g.outer + o0 + ol, i0 + il, g.inner_pad, a_fp16);
       else if (d.frag & 1) put_planes8(v, npl, a_hi, a_lo, wfrag_index(t, o0 + ol, i0 + il, g.outer, g.inner_pad), n, a_fp16);
       else put_planes8(v, npl, a_hi, a_lo, ((long)t * g.outer + o0 + ol) * g.inner_pad + i0 + il, n, a_fp16);
     }
@@ -150,7 +161,8 @@ __global__ __launch_bounds__(256) void pack_layers_kernel(Table tb, int planes_a
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = tile[ol + q][il * T + t] * b_sc;
-      if (pf.interleaved) put_planes8_il(v, b_hi, (long)tt * g.inner + i0 + il, o0 + ol, g.outer, b_fp16);
+      if (pf.interleaved && (d.frag & 2)) put_planes8_il_frag(v, b_hi, tt, i0 + il, g.inner, o0 + ol, g.outer, b_fp16);
+      else if (pf.interleaved) put_planes8_il(v, b_hi, (long)tt * g.inner + i0 + il, o0 + ol, g.outer, b_fp16);
       else if (d.frag & 2) put_planes8(v, npl, b_hi, b_lo, wfrag_index(tt, i0 + il, o0 + ol, g.inner, g.outer), n, b_fp16);
       else put_planes8(v, npl, b_hi, b_lo, ((long)tt * g.inner + i0 + il) * g.outer + o0 + ol, n, b_fp16);
     }
@@ -253,12 +265,14 @@ int run_layers(const HostDesc* descs, int n, int mode, int planes_arg, hipStream
                      "layer %d: bad kind/shape", base + i);
       h.kind &= 1;
       if (frag && mode == 0) {
-        CRIMAC_REQUIRE(h.kind == 0 && planes == 1 && !(planes_arg & CRIMAC_PLANES_INTERLEAVED),
-                       "layer %d: fragment-major planes are a single-plane 16-bit Conv2d layout", base + i);
-        CRIMAC_REQUIRE(!(frag & 1) || (h.Co % 32 == 0 && h.Ci_pad % 64 == 0), "layer %d: fragment-major forward plane needs "
-                       "Co %% 32 == 0 and Ci_pad %% 64 == 0 (Co=%d Ci_pad=%d)", base + i, h.Co, h.Ci_pad);
-        CRIMAC_REQUIRE(!(frag & 2) || (h.dg_hi && h.Ci % 32 == 0 && h.Co % 64 == 0 && h.Ci_pad == h.Ci),
-                       "layer %d: fragment-major input-gradient plane needs Ci %% 32 == 0 and Co %% 64 == 0", base + i);
+        const bool ilv = (planes_arg & CRIMAC_PLANES_INTERLEAVED) != 0;
+        const int kq = ilv ? 32 : 64;        // (a 64-deep chunk of the row of halves is 32 channels of a plane pair)
+        CRIMAC_REQUIRE(h.kind == 0 && (planes == 1 || ilv),
+                       "layer %d: fragment-major planes are a single-plane 16-bit or interleaved-pair Conv2d layout", base + i);
+        CRIMAC_REQUIRE(!(frag & 1) || (h.Co % 32 == 0 && h.Ci_pad % kq == 0), "layer %d: fragment-major forward plane needs "
+                       "Co %% 32 == 0 and Ci_pad %% %d == 0 (Co=%d Ci_pad=%d)", base + i, kq, h.Co, h.Ci_pad);
+        CRIMAC_REQUIRE(!(frag & 2) || (h.dg_hi && h.Ci % 32 == 0 && h.Co % kq == 0 && h.Ci_pad == h.Ci),
+                       "layer %d: fragment-major input-gradient plane needs Ci %% 32 == 0 and Co %% %d == 0", base + i, kq);
       }
       CRIMAC_REQUIRE(h.Co % TILE == 0 && (h.kind == 0 || h.Ci % TILE == 0),
                      "layer %d: Co (and the transposed convolution's Ci) must be multiples of %d", base + i, TILE);

@@ -251,18 +251,21 @@ class UNetEngine:
                 "dg_hi": torch.empty(m_hi * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
                 "dg_lo": torch.empty(8 if il else n_lo * 9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
             }
-            # fragment-major planes (round 5, CRIMAC_EPI_WFRAG): the 16-bit modes pack the planes the channel-split kernel
-            # reads as WHOLE 128-channel ranges so that its weight loads are whole cache lines.  Forward plane: N = cout in
-            # multiples of 128 and 64-deep chunks; input-gradient plane: N = cin likewise -- except a decoder block's conv1
-            # whose two d(concat) halves (cin / 2 channels each) are launched separately and are not multiples of 128
-            wf = self.wfrag and self.is16 and self.conv_impl == "halo"
-            self.pk[b.conv_key]["fwd_frag"] = bool(wf and b.cout % 128 == 0 and b.cin_pad % 64 == 0)
-            self.pk[b.conv_key]["dg_frag"] = bool(wf and has_dg and b.cin % 128 == 0 and b.cout % 64 == 0
-                                                   and not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0))
+            # fragment-major planes (round 5, CRIMAC_EPI_WFRAG): the 16-bit and plane-pair modes pack the planes the
+            # channel-split kernel reads as WHOLE 128-channel ranges so that its weight loads are whole cache lines.  Forward
+            # plane: N = cout in multiples of 128 and whole 64-deep chunks (of halves: 32 channels of a plane pair);
+            # input-gradient plane: N = cin likewise -- except a decoder block's conv1 whose two d(concat) halves (cin / 2
+            # channels each) are launched separately and are not multiples of 128
+            wf = self.wfrag and (self.is16 or self.is_hp) and self.conv_impl == "halo"
+            kq = 32 if self.is_hp else 64
+            split_ok = not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0)
+            self.pk[b.conv_key]["fwd_frag"] = bool(wf and b.cout % 128 == 0 and b.cin_pad % kq == 0)
+            self.pk[b.conv_key]["dg_frag"] = bool(wf and has_dg and b.cin % 128 == 0 and b.cout % kq == 0 and split_ok)
             self.pk_eval[b.conv_key] = {
                 "fwd_hi": torch.empty(m_hi * n_f, dtype=i16, device=dev),
                 "fwd_lo": torch.empty(8 if il else n_lo * n_f, dtype=i16, device=dev),
                 "bias": torch.empty(b.cout, dtype=torch.float32, device=dev),
+                "fwd_frag": self.pk[b.conv_key]["fwd_frag"],
             }
         for u in self.ups:
             n = 4 * u.cin * u.cout
@@ -280,7 +283,11 @@ class UNetEngine:
                 self.pk16[b.conv_key] = {
                     "fwd_hi": torch.empty(n_f, dtype=i16, device=dev), "fwd_lo": torch.empty(8, dtype=i16, device=dev),
                     "dg_hi": torch.empty(9 * b.cin * b.cout, dtype=i16, device=dev) if has_dg else None,
-                    "dg_lo": torch.empty(8, dtype=i16, device=dev) if has_dg else None}
+                    "dg_lo": torch.empty(8, dtype=i16, device=dev) if has_dg else None,
+                    # (the fp16 personality's input-gradient planes: the 16-bit rule)
+                    "fwd_frag": False,
+                    "dg_frag": bool(self.wfrag and self.conv_impl == "halo" and has_dg and b.cin % 128 == 0 and b.cout % 64 == 0
+                                    and not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0))}
             for u in self.ups:
                 n = 4 * u.cin * u.cout
                 self.pk16[u.key] = {"fwd_hi": torch.empty(n, dtype=i16, device=dev), "fwd_lo": torch.empty(8, dtype=i16, device=dev),
@@ -443,6 +450,7 @@ class UNetEngine:
                 d16.fwd_hi, d16.fwd_lo = pk["fwd_hi"].data_ptr(), pk["fwd_lo"].data_ptr()
                 d16.dg_hi = pk["dg_hi"].data_ptr() if pk["dg_hi"] is not None else None
                 d16.dg_lo = pk["dg_lo"].data_ptr() if pk["dg_lo"] is not None else None
+                d16.kind = (d.kind & 1) | (hip.LAYER_DG_FRAG if pk.get("dg_frag") else 0)
             self._ltab16 = arr16
         return self._ltab
 
@@ -666,8 +674,8 @@ class UNetEngine:
                 pk = self.pk_eval[b.conv_key]
                 pk["bias"].copy_((self.P[b.conv_key + ".bias"] - rm) * s + be)
                 call("crimac_pack_conv3x3", ptr(self.P[b.conv_key + ".weight"]), b.cout, b.cin,
-                     b.cin_pad, ptr(s.contiguous()), self.planes_arg, ptr(pk["fwd_hi"]),
-                     ptr(pk["fwd_lo"]), None, None)
+                     b.cin_pad, ptr(s.contiguous()), self.planes_arg | (hip.PLANES_FWD_FRAG if pk.get("fwd_frag") else 0),
+                     ptr(pk["fwd_hi"]), ptr(pk["fwd_lo"]), None, None)
                 # s must stay alive until the kernel ran: same stream, freed memory is stream-ordered
         # up-conv planes are shared with the train pack (no BN behind them)
         if self._train_pack_dirty:
@@ -1034,7 +1042,8 @@ class UNetEngine:
                     # the max-pool comes out of the conv epilogue (the tile is still in LDS)
                     call("crimac_conv3x3_pool", self.prec, a1.p, a1.ld, B, h, w, c, c, ptr(pe2["fwd_hi"]),
                          ptr(pe2["fwd_lo"]), ptr(pe2["bias"]), a2.p, a2.ld,
-                         hip.EPI_RELU | (hip.EPI_OUT_PLANES if self.is_hp else 0), pool.p, pool.ld,
+                         hip.EPI_RELU | (hip.EPI_OUT_PLANES if self.is_hp else 0)
+                         | (hip.EPI_WFRAG if pe2.get("fwd_frag") else 0), pool.p, pool.ld,
                          flops=2.0 * 9 * c * c * B * h * w, mfmas=hip.MFMAS_PER_PRODUCT[self.prec])
                 else:
                     self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True, out_planes=True)

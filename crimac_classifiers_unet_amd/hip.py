@@ -30,6 +30,7 @@ PREC_PLANES = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: 1, PREC_F3
 # input-gradient planes in IEEE half, bits 8-15 log2 of the scale on the forward planes
 PLANES_FP16 = 1 | 16 | 32
 PLANES_F32H3 = 2 | 16 | (8 << 8)
+PLANES_FWD_FRAG = 65536       # crimac_pack_conv3x3: the forward plane fragment-major (CRIMAC_PLANES_FWD_FRAG)
 PLANES_INTERLEAVED = 64      # both planes in the `hi` buffer, [32 hi | 32 lo] per 32-channel block of a row
 PLANES_H3P = 2 | 16 | 32 | PLANES_INTERLEAVED | 128 | (8 << 8)        # CRIMAC_PLANES_H3P
 PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: PLANES_FP16, PREC_F32H3: PLANES_F32H3,

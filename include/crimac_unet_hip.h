@@ -95,6 +95,8 @@ extern "C" {
 #define CRIMAC_PLANES_F32H3 (2 | CRIMAC_PLANES_FWD_FP16 | (CRIMAC_F32H3_WSHIFT << 8))
 #define CRIMAC_PLANES_INTERLEAVED 64 /* both planes in ONE buffer (`*_hi`; `*_lo` unused), per row of K input channels:
                                       * [CB hi | CB lo] per block of CB = 32 channels (CB = K when K < 32) */
+#define CRIMAC_PLANES_FWD_FRAG 65536 /* crimac_pack_conv3x3 only: the FORWARD plane is written fragment-major (CRIMAC_EPI_WFRAG);
+                                     * single 16-bit plane: Co % 32 == 0, Ci_pad % 64 == 0; interleaved pairs: Ci_pad % 32 == 0 */
 #define CRIMAC_PLANES_DG_SCALED 128  /* the scale of bits 8-15 is applied to the input-gradient planes as well */
 /* H3P: interleaved fp16 plane pairs, forward and input-gradient planes, both pre-scaled by 2^CRIMAC_F32H3_WSHIFT */
 #define CRIMAC_PLANES_H3P (2 | CRIMAC_PLANES_FWD_FP16 | CRIMAC_PLANES_DG_FP16 | CRIMAC_PLANES_INTERLEAVED | \
@@ -116,7 +118,9 @@ extern "C" {
  *   ((((t * R/32 + r/32) * K/64 + c/64) * 4 + ((c % 64) / 32) * 2 + (r % 32) / 16) * 64 + ((c % 32) / 8) * 16 + r % 16) * 8 + c % 8
  * -- the four MFMA weight fragments of a (tap, 32-row block, 64-column chunk) are four consecutive kilobytes with lane l's
  * 16 bytes at 16 l, so that every weight load of the channel-split kernel reads whole cache lines.  16-bit precisions
- * (BF16 / FP16), N and the channel range multiples of 128, Cin % 64 == 0. */
+ * (BF16 / FP16), N and the channel range multiples of 128, Cin % 64 == 0.  Plane pairs (H3P; interleaved rows of 2 Cin halves
+ * [32 hi | 32 lo] per 32-channel block): the same formula on the row of halves, K = 2 Cin, c = the half's position in the row
+ * (Cin % 32 == 0).  H3F_BWD: its fp16 input-gradient planes, as FP16. */
 #define CRIMAC_EPI_WFRAG 16
 
 /* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
@@ -277,7 +281,7 @@ typedef struct crimac_layer_desc {
   void* fwd_lo;
   void* dg_hi;         /* may be NULL (no input gradient needed: first layer) */
   void* dg_lo;
-  int kind;            /* bit 0 -- 0: Conv2d 3x3, 1: ConvTranspose2d 2x2 stride 2; kind 0, 16-bit single-plane packs only:
+  int kind;            /* bit 0 -- 0: Conv2d 3x3, 1: ConvTranspose2d 2x2 stride 2; kind 0, 16-bit single-plane or interleaved-pair packs:
                         * | CRIMAC_LAYER_FWD_FRAG: fwd_hi is written FRAGMENT-MAJOR (CRIMAC_EPI_WFRAG; Co % 32 == 0, Ci_pad % 64 == 0),
                         * | CRIMAC_LAYER_DG_FRAG: dg_hi likewise (rows = Ci, columns = Co: Ci % 32 == 0, Co % 64 == 0) */
   int Co, Ci, Ci_pad;  /* Ci_pad: kind 0 only */

@@ -134,6 +134,80 @@ CONV_SHAPES = [(2, 16, 16, 64, 128), (1, 16, 32, 128, 128), (3, 8, 8, 256, 64), 
                (5, 250, 200, 32, 128), (3, 120, 136, 64, 256)]       # (channel-split kernel, more than two resident rounds, ragged)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 48, 128, 128), (1, 24, 40, 32, 256), (3, 16, 16, 256, 128)])
+def test_fragment_major_plane_pair_weights_convolve_bit_for_bit(shape):
+    """CRIMAC_EPI_WFRAG on plane pairs (round 5): the interleaved rows of 2 Cin halves packed fragment-major -- by the per-layer
+    entry point (CRIMAC_PLANES_FWD_FRAG, the eval packs) and by crimac_pack_layers (CRIMAC_LAYER_*_FRAG, the training packs) --
+    give BIT-identical convolutions: forward with statistics to fp32, forward to plane pairs with the fused pool, input
+    gradient with the fused BatchNorm-backward sums, and the h3f backward's fp16 input gradient."""
+    import ctypes
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(41)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    wd = w.cuda().contiguous()
+    i16 = dict(dtype=torch.int16, device="cuda")
+    n = 2 * 9 * Co * Ci
+    lo = torch.zeros(8, **i16)
+    planes = {}
+    for tag, kind in (("row", 0), ("frag", hip.LAYER_FWD_FRAG | (hip.LAYER_DG_FRAG if Ci % 128 == 0 else 0))):
+        d = (hip.LayerDesc * 1)()
+        planes[tag] = {"fwd": torch.full((n,), -1, **i16), "dg": torch.full((n,), -1, **i16)}
+        d[0].w = wd.data_ptr()
+        d[0].fwd_hi, d[0].fwd_lo = planes[tag]["fwd"].data_ptr(), lo.data_ptr()
+        d[0].dg_hi, d[0].dg_lo = planes[tag]["dg"].data_ptr(), lo.data_ptr()
+        d[0].kind, d[0].Co, d[0].Ci, d[0].Ci_pad = kind, Co, Ci, Ci
+        call("crimac_pack_layers", ctypes.byref(d), 1, hip.PLANES_H3P)
+    one = torch.full((n,), -1, **i16)           # the per-layer entry point writes the same fragment-major forward plane
+    call("crimac_pack_conv3x3", ptr(wd), Co, Ci, Ci, None, hip.PLANES_H3P | hip.PLANES_FWD_FRAG, ptr(one), ptr(lo), None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(one, planes["frag"]["fwd"]) and not torch.equal(one, planes["row"]["fwd"])
+    assert torch.equal(torch.sort(one).values, torch.sort(planes["row"]["fwd"]).values)          # a permutation of the halves
+    x = to_nhwc_hp(torch.randn(B, Ci, H, W, generator=g))
+    dy = to_nhwc_hp(torch.randn(B, Co, H, W, generator=g))
+    bias = torch.randn(Co, generator=g).cuda()
+    yprev = (torch.randn(B * H * W, Ci, generator=g) * 1.5 + 0.3).cuda()
+    vec = torch.stack([torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5,
+                       torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3]).contiguous().cuda()
+    res = {}
+    for tag, flag in (("row", 0), ("frag", hip.EPI_WFRAG)):
+        st = torch.zeros(2, 4, Co, dtype=torch.float64, device="cuda")
+        o32 = torch.full((B * H * W, Co), 7.0, dtype=torch.float32, device="cuda")
+        call("crimac_conv3x3", P, ptr(x), Ci, B, H, W, Ci, Co, ptr(planes[tag]["fwd"]), ptr(lo), ptr(bias), ptr(o32), Co,
+             hip.EPI_RELU | flag, 1, ptr(st[0]), ptr(st[1]), 4, None, 0, None, 0)
+        opp = torch.full((B * H * W, Co), 7.0, dtype=torch.float32, device="cuda")
+        pool = torch.full((B * (H // 2) * (W // 2), Co), 7.0, dtype=torch.float32, device="cuda")
+        call("crimac_conv3x3_pool", P, ptr(x), Ci, B, H, W, Ci, Co, ptr(planes[tag]["fwd"]), ptr(lo), ptr(bias), ptr(opp), Co,
+             hip.EPI_RELU | hip.EPI_OUT_PLANES | flag, ptr(pool), Co)
+        da = None
+        if Ci % 128 == 0:
+            da = torch.full((B * H * W, Ci), 7.0, dtype=torch.float32, device="cuda")
+            acc = torch.zeros(2, 4, Ci, dtype=torch.float64, device="cuda")
+            call("crimac_conv3x3", P, ptr(dy), Co, B, H, W, Co, Ci, ptr(planes[tag]["dg"]), ptr(lo), None, ptr(da), Ci, flag, 2,
+                 ptr(acc[0]), ptr(acc[1]), 4, ptr(yprev), Ci, ptr(vec), Ci)
+        torch.cuda.synchronize()
+        res[tag] = (o32, opp, pool, da)
+    for a, b in zip(res["row"], res["frag"]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert float(res["frag"][0].abs().max()) > 0
+    # the h3f backward's fp16 personality (CRIMAC_PREC_H3F_BWD: fp16 dy and planes, fp32 da)
+    if Ci % 128 == 0:
+        dy16 = torch.randn(B * H * W, Co, generator=g).half().cuda()
+        out = {}
+        for tag, kind, flag in (("row", 0, 0), ("frag", hip.LAYER_DG_FRAG, hip.EPI_WFRAG)):
+            d = (hip.LayerDesc * 1)()
+            f16, g16 = torch.full((n // 2,), -1, **i16), torch.full((n // 2,), -1, **i16)
+            d[0].w = wd.data_ptr()
+            d[0].fwd_hi, d[0].fwd_lo, d[0].dg_hi, d[0].dg_lo = f16.data_ptr(), lo.data_ptr(), g16.data_ptr(), lo.data_ptr()
+            d[0].kind, d[0].Co, d[0].Ci, d[0].Ci_pad = kind, Co, Ci, Ci
+            call("crimac_pack_layers", ctypes.byref(d), 1, hip.PLANES_FP16)
+            da = torch.full((B * H * W, Ci), 7.0, dtype=torch.float32, device="cuda")
+            call("crimac_conv3x3", hip.PREC_H3F_BWD, ptr(dy16), Co, B, H, W, Co, Ci, ptr(g16), None, None, ptr(da), Ci, flag, 0,
+                 None, None, 1, None, 0, None, 0)
+            torch.cuda.synchronize()
+            out[tag] = da
+        assert torch.equal(out["row"], out["frag"]) and float(out["frag"].abs().max()) > 0
+
+
 @pytest.mark.parametrize("shape", CONV_SHAPES)
 def test_conv3x3_forward_fp32_and_plane_pair_outputs(shape):
     B, H, W, Ci, Co = shape
