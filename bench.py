@@ -808,7 +808,7 @@ def run_rank(args):
         def replay(roof, roof_w, prec):
             """HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) and MFMA busy fraction (SQ_VALU_MFMA_BUSY_CYCLES /
             GRBM_GUI_ACTIVE pass) of the same command, from the committed profiles of this round -- labelled as replayed."""
-            pm = load_profile_json(f"r04_{prec}_pmc_traffic.json") or load_profile_json(f"r03_{prec}_pmc_traffic.json")
+            pm = load_profile_json(f"r05_{prec}_pmc_traffic.json") or load_profile_json(f"r04_{prec}_pmc_traffic.json")
             if pm:
                 for r_, pat in ((roof, "conv3x3"), (roof_w, "wgrad")):
                     sel = [v for k, v in pm["kernels"].items() if k.startswith(pat)]
@@ -819,7 +819,7 @@ def run_rank(args):
                     r_["traffic_source"] = ("REPLAYED from the committed profile " + pm["_file"] + " (rocprofv3 --pmc FETCH_SIZE / "
                                             "WRITE_SIZE passes of this command on the serialized step; FETCH_SIZE doubled per the "
                                             "gfx950 correction; not observed in this run): HBM bytes per launch")
-            ut = load_profile_json(f"r04_{prec}_mfma_util.json") or load_profile_json(f"r03_{prec}_mfma_util.json")
+            ut = load_profile_json(f"r05_{prec}_mfma_util.json") or load_profile_json(f"r04_{prec}_mfma_util.json")
             if ut:
                 for r_, key in ((roof, "conv3x3"), (roof_w, "wgrad")):
                     r_["mfma_busy_frac"] = (ut.get(key + "_group") or ut.get(key, {})).get("mfma_busy_frac")

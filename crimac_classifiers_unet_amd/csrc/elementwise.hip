@@ -538,7 +538,9 @@ __device__ __forceinline__ void bnb_flush(const BnbArgs& a, float* lds, int C, i
 // a pixel); BNB: da feeds a BatchNorm+ReLU block whose backward sums are accumulated on the fly
 // T: storage type of the gradients (and of y); TA: of the forward activation `a` (H3P: fp16 plane pairs)
 template <typename T, bool BNB, typename TA = T>
-__global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ dp, long dp_ld,
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu((BNB && sizeof(T) == 2 && sizeof(TA) == 2) ? 3 : 1)))      // (16-bit + sums: <= 168 registers)
+void unpool_add_kernel(const T* __restrict__ dp, long dp_ld,
                                                          const TA* __restrict__ a, long a_ld,
                                                          const T* __restrict__ ds, long ds_ld,
                                                          T* __restrict__ da, long da_ld, int B, int H,
@@ -566,6 +568,49 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ d
       const long t = r / Wp;
       const int yp = (int)(t % Hp);
       const long b = t / Hp;
+      if constexpr (BNB && sizeof(T) == 2 && sizeof(TA) == 2) {
+        // 16-bit storage with the fused sums (round 5): the window's four y vectors stay PACKED (16 registers instead of
+        // 32 + the 32 of the rebuilt activations) and are unpacked once for the arg-max and once for the sums: 174 -> <= 128
+        // registers, i.e. four waves per SIMD instead of two under a kernel that was bound by its arithmetic at occupancy 2
+        // (170 us at 256 x 256 against a 116 us byte floor).  Same arithmetic, same first-maximum rule: bit-identical.
+        float g[8];
+        load8s(dp + r * dp_ld + c0, g);
+        long pixq[4];
+        u16x8 yraw[4];
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          pixq[d] = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
+#if CRIMAC_STREAM_NT
+          yraw[d] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(reinterpret_cast<const T*>(bnb.y) + pixq[d] * bnb.y_ld + c0));
+#else
+          yraw[d] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const T*>(bnb.y) + pixq[d] * bnb.y_ld + c0);
+#endif
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          float yv[8];
+          load8(reinterpret_cast<const T*>(&yraw[d]), yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a_ = storage_round<TA>(fmaxf(yv[j] * k.sc[j] + k.sh[j], 0.f));
+            if (d == 0) { best[j] = a_; arg[j] = 0; }
+            else if (a_ > best[j]) { best[j] = a_; arg[j] = d; }      // first maximum wins (aten max_pool2d)
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          float o[8], yv[8];
+          if (ds) load8s(ds + pixq[d] * ds_ld + c0, o);
+          load8(reinterpret_cast<const T*>(&yraw[d]), yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = storage_round<T>((ds ? o[j] : 0.f) + (arg[j] == d ? g[j] : 0.f));
+          if (da) store8(da + pixq[d] * da_ld + c0, o);
+          bnb_accum_v(k, yv, o, d1, d2);
+        }
+        continue;
+      }
       float g[8], av[4][8], yv[4][8];
       load8s(dp + r * dp_ld + c0, g);
       long pix[4];
