@@ -602,8 +602,15 @@ class UNetEngine:
             side.wait_event(ev)
             fn()
 
+    # (ablation runs only, tools/runs/r5_14.sh: 'single' skips the launches that are not part of a grouped launch -- first
+    # layer and transposed convolutions --, 'all' skips every weight gradient; gradients are then WRONG, the step time shows
+    # what those launches cost the step beyond what the side stream hides)
+    _skip_wgrad = os.environ.get("CRIMAC_EXP_SKIP_WGRAD", "")
+
     def _wgrad(self, prec, mode, f, f_ld, cf, s_, s_ld, cs, B, h, w, key, flops=None):
         dwt, sp, stride = self._dw(key)
+        if self._skip_wgrad == "all" or (self._skip_wgrad == "single" and not self._groupable(prec, mode, cf, cs)):
+            return
         if self._groupable(prec, mode, cf, cs):
             self._wg_pending.append(dict(f=f, f_ld=f_ld, cf=cf, s=s_, s_ld=s_ld, cs=cs, B=B, h=h, w=w, dw=dwt,
                                          flops=flops or 0.0))
