@@ -85,6 +85,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-tiled", action="store_true")
+    ap.add_argument("--tiled-ordered", action="store_true",
+                    help="N > 1: after the timed tiled pass, one more pass with predict_survey(ordered_to_rank0=True) -- every chunk "
+                         "handed to rank 0 point-to-point, asserted complete and in ping order (off by default: the timed legs of "
+                         "the scaling run use collectives only; tools/runs/r5_03.sh rehearses it)")
     ap.add_argument("--no-wide", action="store_true", help="skip the configs[4] (wide net, fp16, GPU augmentation) leg")
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="only start the ranks, all-reduce their ids and print the census (tests/test_bench_spawn.py)")
@@ -467,7 +471,7 @@ def measure_tiled(model, args, log, world=1):
         n_patches, written, n_mine, dt = int(agg[0]), int(agg[1]), int(agg[2]), float(tmax)
         assert n_mine == n_pings, (n_mine, n_pings)          # the ranks covered the survey exactly once
     handoff = None
-    if world > 1:
+    if world > 1 and args.tiled_ordered:
         # the opt-in ordered hand-off (predict_survey(ordered_to_rank0=True)): rank 0 must receive EVERY chunk of the survey
         # in ping order (what the reference's sequential append_to_zarr writer needs), the other ranks yield nothing
         dist.barrier()

@@ -4,7 +4,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT/gpurun_out/r5_03; mkdir -p $R
-CRIMAC_DIST_BACKEND=gloo timeout -k 10 900 python bench.py --gpus 6 --batch 8 --steps 4 --warmup 2 --roofline-steps 3 --roofline-warmup 1 \
+CRIMAC_DIST_BACKEND=gloo timeout -k 10 900 python bench.py --gpus 6 --batch 8 --steps 4 --warmup 2 --roofline-steps 3 --roofline-warmup 1 --tiled-ordered \
   > $R/bench_6rank_gloo.json 2> $R/bench_6rank_gloo.err || { echo bench failed; tail -40 $R/bench_6rank_gloo.err; exit 1; }
 tail -5 $R/bench_6rank_gloo.err
 python - <<'PY'
