@@ -405,6 +405,17 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
   asm volatile("" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) : "v"(s0), "v"(s1));
   return;
 #endif
+#ifdef CRIMAC_EXP_WCH_HALFW       // (ablation build, results garbage: HALF the weight stream -- two of the four fragments per tap)
+  if constexpr (WF) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %4, off offset:1024"
+        : "=&v"(bf[0]), "=&v"(bf[1]), "+v"(bf[2]), "+v"(bf[3])
+        : "v"(s0)
+        : "memory");
+    return;
+  }
+#endif
   if constexpr (WF) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off\n\t"
