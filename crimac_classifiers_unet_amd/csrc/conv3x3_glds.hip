@@ -563,8 +563,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   const int wc = S22 ? (wave & 1) : wave, wp = S22 ? (wave >> 1) : 0;
   // weight fragments of this lane: rows n0 + 32*wc + nb*16 + fr of tap t, k = kc*64 + ks2*32 + fq*8 .. +8
   // (WF: block (n0 / 32 + wc) of the tap's N / 32 blocks, Cin / 64 chunks of 2048 halves each, lane l at 8 l)
+#ifdef CRIMAC_EXP_WCH_SAMEW       // (ablation build, results garbage: EVERY wave streams channel block 0 -- the same bytes per wave,
+  //                                  but all of them L1 / L2 hits: separates the cost of the L2 -> L1 traffic from the L1 -> register path)
+  const unsigned short* wrow = p.w_hi + lane * 8;
+#else
   const unsigned short* wrow = WF ? p.w_hi + ((long)((n0 >> 5) + wc) * (p.Cin >> 6)) * 2048 + lane * 8
                                   : p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
+#endif
   const long w_tap = (long)p.N * p.Cin, w_nb = 16L * p.Cin;
   constexpr int W_CHUNK = WF ? 2048 : BK;             // halves between two 64-channel chunks of a tap
   // A fragment: M tile i = image row i of the tile, lane's pixel column fr -> halo row (i + ky) * HP + fr + kx
