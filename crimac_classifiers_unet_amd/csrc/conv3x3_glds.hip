@@ -416,6 +416,17 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
     return;
   }
 #endif
+#ifdef CRIMAC_EXP_WCH_HALFW       // (ablation build, results garbage: HALF the weight stream -- two of the four fragments per tap)
+  if constexpr (WF) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %4, off offset:1024"
+        : "=&v"(bf[0]), "=&v"(bf[1]), "+v"(bf[2]), "+v"(bf[3])
+        : "v"(s0)
+        : "memory");
+    return;
+  }
+#endif
   if constexpr (WF) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off\n\t"
@@ -567,8 +578,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   //                                  but all of them L1 / L2 hits: separates the cost of the L2 -> L1 traffic from the L1 -> register path)
   const unsigned short* wrow = p.w_hi + lane * 8;
 #else
+#ifdef CRIMAC_EXP_WCH_SAMEW       // (ablation build, results garbage: EVERY wave streams channel block 0 -- the same bytes per wave,
+  //                                  all of them L1 / L2 hits: separates the L2 -> L1 traffic from the delivery into the CU)
+  const unsigned short* wrow = p.w_hi + lane * 8;
+#else
   const unsigned short* wrow = WF ? p.w_hi + ((long)((n0 >> 5) + wc) * (p.Cin >> 6)) * 2048 + lane * 8
                                   : p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
+#endif
 #endif
   const long w_tap = (long)p.N * p.Cin, w_nb = 16L * p.Cin;
   constexpr int W_CHUNK = WF ? 2048 : BK;             // halves between two 64-channel chunks of a tap
