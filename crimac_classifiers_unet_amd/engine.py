@@ -1213,24 +1213,31 @@ class UNetEngine:
                     self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                   dgrad=True, cols=(C_up, C_up))
                 fused = True
-            elif (stats is not None and side_ok
-                    and b.cin == 2 * C_up and b.cout % 64 == 0 and self.is16
-                    and (C_up % 128 == 0 or (C_up == 64 and b.cout == 64 and B * ((h + 15) // 16) * ((w + 15) // 16) >= 512))):
+            elif (stats is not None and b.cin == 2 * C_up and b.cout % 64 == 0 and self.is16
+                    and ((side_ok and C_up % 128 == 0)
+                         or (C_up == 64 and b.cout == 64 and B * ((h + 15) // 16) * ((w + 15) // 16) >= 512))):
                 # decoder conv1: dx_out = d(concat [up | skip]).  The up half (and its column sums = the transposed
                 # convolution's bias gradient) is needed at once; the skip half only when the encoder level is
-                # reached -> side stream, off the critical path
+                # reached -> side stream, off the critical path.  (The last decoder level -- two 64-channel halves of a
+                # 64-channel dy at 256 x 256 -- takes the two launches of the persistent 64 -> 64 kernel with or without a
+                # side stream: 2 x ~150 us against 330-344 us for the one-chunk launch of the channel-split kernel, and the
+                # serialized roofline pass then times the kernels the overlapped step runs.)
                 self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                               dgrad=True, stats=stats, cols=(0, C_up))
-                ev = self._side_events[self._side_i % len(self._side_events)]
-                self._side_i += 1
-                ev.record()
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
+                if side_ok:
+                    ev = self._side_events[self._side_i % len(self._side_events)]
+                    self._side_i += 1
+                    ev.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
+                                      dgrad=True, cols=(C_up, C_up))
+                        done = torch.cuda.Event()
+                        done.record()
+                    self._skip_done[bias_from_stats[2]] = done
+                else:
                     self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
                                   dgrad=True, cols=(C_up, C_up))
-                    done = torch.cuda.Event()
-                    done.record()
-                self._skip_done[bias_from_stats[2]] = done
                 fused = True
             else:
                 fused = self._conv3x3(dy, self._pk_bwd(b.conv_key), None, dx_out, B, h, w, b.cout, b.cin, relu=False,
