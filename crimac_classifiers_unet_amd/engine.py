@@ -261,6 +261,7 @@ class UNetEngine:
             split_ok = not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0)
             self.pk[b.conv_key]["fwd_frag"] = bool(wf and b.cout % 128 == 0 and b.cin_pad % kq == 0)
             self.pk[b.conv_key]["dg_frag"] = bool(wf and has_dg and b.cin % 128 == 0 and b.cout % kq == 0 and split_ok)
+            self.pk[b.conv_key]["frag_ok"] = (self.pk[b.conv_key]["fwd_frag"], self.pk[b.conv_key]["dg_frag"])
             self.pk_eval[b.conv_key] = {
                 "fwd_hi": torch.empty(m_hi * n_f, dtype=i16, device=dev),
                 "fwd_lo": torch.empty(8 if il else n_lo * n_f, dtype=i16, device=dev),
@@ -288,6 +289,7 @@ class UNetEngine:
                     "fwd_frag": False,
                     "dg_frag": bool(self.wfrag and self.conv_impl == "halo" and has_dg and b.cin % 128 == 0 and b.cout % 64 == 0
                                     and not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0))}
+                self.pk16[b.conv_key]["frag_ok"] = (False, self.pk16[b.conv_key]["dg_frag"])
             for u in self.ups:
                 n = 4 * u.cin * u.cout
                 self.pk16[u.key] = {"fwd_hi": torch.empty(n, dtype=i16, device=dev), "fwd_lo": torch.empty(8, dtype=i16, device=dev),
@@ -703,7 +705,31 @@ class UNetEngine:
             self._bufs[key] = t
         return t
 
+    def _wfrag_geometry(self, B, H, W):
+        """Fragment-major planes are read by the channel-split kernel only, which addresses its input with 32-bit byte
+        offsets: a batch whose largest operand tensor (the level-0 concat buffer, 2 * start_filts channels per pixel) reaches
+        2 GB falls back to the 8-wave kernel, which reads row-major planes.  Flip every plane's layout flag for such a
+        geometry (and back), and have the planes re-packed."""
+        es = 4 if self.is_hp else 2
+        small = (B * H * W - 1) * (2 * self.sf) * es + 2 * self.sf * es < (1 << 31)
+        if small == getattr(self, "_wfrag_on", True):
+            return
+        self._wfrag_on = small
+        for pks in (self.pk_main, self.pk_eval, self.pk16):
+            for key, pk in pks.items():
+                ok = pk.get("frag_ok") or (self.pk_main.get(key, {}).get("frag_ok", (False, False)) if pks is self.pk_eval else None)
+                if ok is None:
+                    continue
+                if "fwd_frag" in pk:
+                    pk["fwd_frag"] = bool(small and ok[0])
+                if "dg_frag" in pk:
+                    pk["dg_frag"] = bool(small and ok[1])
+        self._ltab = self._ltab16 = None
+        self._packed_groups = set()
+        self._train_pack_dirty = self._eval_pack_dirty = True
+
     def _geom(self, B, H, W):
+        self._wfrag_geometry(B, H, W)
         D = self.depth
         if H % (2 ** (D - 1)) or W % (2 ** (D - 1)):
             raise ValueError(f"H, W must be divisible by {2 ** (D - 1)} (got {H}x{W})")

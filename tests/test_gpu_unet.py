@@ -1354,3 +1354,58 @@ def test_other_architectures_and_ragged_shapes_match_oracle(cfg):
     for k, v in ref_stats.items():
         if "running" in k:
             assert rel(sdm[k].float(), v.float()) < 1e-3, k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "h3f"])
+def test_row_major_fallback_of_the_weight_planes_is_bit_identical(precision):
+    """Fragment-major weight planes (round 5) are a permutation the channel-split kernel understands; a geometry whose
+    operand tensors reach 2 GB (32-bit offsets in that kernel) makes the engine fall back to row-major planes for the
+    8-wave kernel (`_wfrag_geometry`).  The switch re-packs the planes, and a training step + an eval forward on row-major
+    planes are BIT-identical to the same on fragment-major ones."""
+    sd = synth.synth_state_dict(seed=0)
+    x = torch.from_numpy(synth.synth_echogram_batch(2, 4, 64, 64, seed=5)).cuda()
+    lab = torch.from_numpy(synth.synth_labels(2, 64, 64, seed=6)).cuda()
+    cw = torch.tensor([10.0, 300.0, 250.0], device="cuda")
+    out = {}
+    for tag in ("frag", "row"):
+        m = pkg.UNet_Baseline(3, 4, precision=precision, infer_precision=precision)
+        m.load_state_dict(sd)
+        m.cuda().train()
+        eng = m.engine
+        eng.bind()
+        m.infer_engine.bind()
+        n_frag = sum(bool(pk.get("fwd_frag")) + bool(pk.get("dg_frag")) for pk in eng.pk_main.values())
+        assert n_frag >= 20
+        if tag == "row":
+            eng._wfrag_geometry(4096, 256, 256)          # a geometry past 2 GB: every plane back to row-major
+            assert not any(pk.get("fwd_frag") or pk.get("dg_frag") for pks in (eng.pk_main, eng.pk_eval, eng.pk16)
+                           for pk in pks.values())
+            assert eng._train_pack_dirty and eng._eval_pack_dirty
+            eng._wfrag_geometry = lambda *a: None        # (stay there for the small step below)
+            if m.infer_engine is not eng:
+                m.infer_engine._wfrag_geometry(4096, 256, 256)
+                m.infer_engine._wfrag_geometry = lambda *a: None
+        m.eval()
+        with torch.no_grad():
+            logits = m(x).clone()                        # (eval packs, same weights in both runs: bit for bit)
+            if tag == "row":
+                assert not any(pk.get("fwd_frag") for pk in m.infer_engine.pk_eval.values())
+        m.train()
+        loss = eng.train_step(x, lab, cw, lr=0.005, momentum=0.95)
+        loss2 = eng.train_step(x, lab, cw, lr=0.005, momentum=0.95)
+        out[tag] = (float(loss), float(loss2), eng.flat_p.clone(), logits)
+    assert out["frag"][0] == out["row"][0]               # the first step's forward: same weights, same planes' VALUES
+    assert torch.equal(out["frag"][3], out["row"][3])
+    # (weight gradients are summed by atomics in arrival order: what follows an update agrees to round-off only)
+    assert abs(out["frag"][1] - out["row"][1]) <= 2e-3 * abs(out["frag"][1])
+    rel = float((out["frag"][2] - out["row"][2]).abs().max() / out["frag"][2].abs().max())
+    assert rel < 1e-4, rel
+    # and the switch goes back: a small geometry after a big one re-enables the fragment-major planes
+    m = pkg.UNet_Baseline(3, 4, precision=precision)
+    m.load_state_dict(sd)
+    m.cuda().train()
+    eng = m.engine
+    eng.bind()
+    eng._wfrag_geometry(4096, 256, 256)
+    l3 = float(eng.train_step(x, lab, cw, lr=0.005, momentum=0.95))
+    assert any(pk.get("fwd_frag") for pk in eng.pk_main.values()) and l3 == out["frag"][0]
