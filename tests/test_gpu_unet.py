@@ -1411,3 +1411,45 @@ def test_row_major_fallback_of_the_weight_planes_is_bit_identical(precision):
     eng._wfrag_geometry(4096, 256, 256)
     l3 = float(eng.train_step(x, lab, cw, lr=0.005, momentum=0.95))
     assert any(pk.get("fwd_frag") for pk in eng.pk_main.values()) and abs(l3 - out["frag"][0]) <= 2e-6 * abs(l3)
+
+
+@pytest.mark.parametrize("workers,dtype", [(2, np.float32), (0, np.float64)])
+def test_train_model_on_raw_crops_runs_the_whole_chain_on_the_gpu(workers, dtype):
+    """The loop bench.py's ``train_loop_raw`` times: ``SegPipeUNet(gpu_augment=True, gpu_label_transform=True)``
+    fed by a DataLoader over ``synth.RawCropDataset`` (random centres, real crop gathers of LINEAR sv and RAW annotation ids
+    from a survey with annotated schools and NaN / Inf samples).  Through the pinned ring and through the reference's
+    in-line copy the steps see the same crops: same logged losses; and the first step's loss equals the oracle's on the
+    crops the augmentation + label oracles produce for that batch (same Philox stream)."""
+    from oracle import augment_oracle as aorc, labels_oracle as lorc
+    reader = synth.SyntheticSurveyReader(n_pings=2048, n_range=512, block=2048, schools=40, bad_frac=1e-3, seed=5, seabed_index=400)
+    ds = synth.RawCropDataset(reader, (64, 64), 12, seed=4, dtype=dtype)
+    assert sum(int((ds[i]["labels"] > 0).sum()) for i in range(4)) > 1000      # step 0 sees annotated schools
+    logs = {}
+    for pin in (True, False):
+        pipe = pkg.SegPipeUNet(experiment_name="t", **_pipe_cfg(precision="f32x6", pin_batches=pin, loss_flush=2, num_workers=workers,
+                                                                 gpu_augment=True, gpu_label_transform=True, lr=0.0, random_seed=0,
+                                                                 log_step=10 ** 9, lr_step=10 ** 9))
+        pipe.model.load_state_dict(synth.synth_state_dict(seed=0))
+        dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=workers)
+
+        class Logger:
+            def __init__(self):
+                self.v = []
+
+            def add_scalar(self, tag, scalar_value, global_step):
+                if tag == "train/loss":
+                    self.v.append(float(scalar_value))
+        lg = Logger()
+        pipe.train_model(dl, None, lg)
+        torch.cuda.synchronize()
+        logs[pin] = lg.v
+    assert len(logs[True]) == len(logs[False]) == 3 and all(np.isfinite(logs[True]))
+    for a, b in zip(logs[True], logs[False]):
+        assert abs(a - b) <= 1e-5 * abs(b), logs            # (lr = 0: every step runs on the initial weights)
+    # step 0 against the oracles: augmentation (seed of step 0, rank 0) -> label refinement + indexing + NaN rule -> network
+    raw = np.stack([ds[i]["data"] for i in range(4)]).astype(np.float32)
+    ids = np.stack([ds[i]["labels"] for i in range(4)])
+    xa, la_raw, _, _, lin = aorc.augment_db(raw, ids, 0, return_linear=True)
+    lab = lorc.train_label_transform(lin, la_raw.astype(np.int64), 3)
+    ref_loss, _, _, _ = orc.loss_and_grads(synth.synth_state_dict(seed=0), torch.from_numpy(xa), torch.from_numpy(lab))
+    assert abs(logs[True][0] - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)), (logs[True][0], float(ref_loss))
