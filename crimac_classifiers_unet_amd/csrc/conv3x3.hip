@@ -346,7 +346,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
                    "conv3x3 (H3F_BWD): Cin, N multiples of 64 (got %d, %d)", Cin, N);
     if (relu & CRIMAC_EPI_OUT_PLANES)      // (column sums taken here are a bias gradient: of the unrounded results)
       return conv3x3_run(CRIMAC_PREC_FP16, in, in_ld, B, H, W, Cin, N, w_hi, w_lo, bias, out, out_ld,
-                         (relu & (CRIMAC_EPI_RELU | CRIMAC_EPI_WFRAG)) | CRIMAC_EPI_STAT_RAW,
+                         (relu & (CRIMAC_EPI_RELU | CRIMAC_EPI_WFRAG | CRIMAC_EPI_WROWS)) | CRIMAC_EPI_STAT_RAW,
                          stat_mode, stat_sum, stat_sumsq, stat_replicas, bnb_y, bnb_y_ld, bnb_vec, bnb_stride, n_first,
                          n_count, stream);
     CRIMAC_REQUIRE(in_ld >= Cin && in_ld % 8 == 0 && out_ld >= n_first + n_count && out_ld % 8 == 0, "conv3x3: bad pixel strides (in_ld=%ld out_ld=%ld)", in_ld, out_ld);
@@ -362,7 +362,7 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
     e.bnb_y = bnb_y; e.bnb_y_ld = bnb_y_ld; e.bnb_vec = bnb_vec; e.bnb_stride = bnb_stride;
     e.acc_scale = 1.f;
     return crimac_conv3x3_glds_16_f32out(in, in_ld, B, H, W, Cin, N, w_hi, e, (hipStream_t)stream, n_first, n_count,
-                                         (relu & CRIMAC_EPI_WFRAG) != 0);
+                                         (relu & CRIMAC_EPI_WROWS) ? 2 : (relu & CRIMAC_EPI_WFRAG) != 0);
   }
   CRIMAC_REQUIRE(prec >= CRIMAC_PREC_BF16 && prec <= CRIMAC_PREC_MAX, "conv3x3: bad precision %d", prec);
   CRIMAC_REQUIRE(!pool_out || (H % 2 == 0 && W % 2 == 0 && pool_ld >= N && pool_ld % 8 == 0 && stat_mode == 0 &&
@@ -391,7 +391,8 @@ static int conv3x3_run(int prec, const void* in, long in_ld, int B, int H, int W
   const int out_planes = (relu & CRIMAC_EPI_OUT_PLANES) != 0;
   const int cin4 = (relu & CRIMAC_EPI_CIN4) != 0;
   e.stat_raw = (relu & CRIMAC_EPI_STAT_RAW) != 0;
-  const int wfrag = (relu & CRIMAC_EPI_WFRAG) != 0;
+  CRIMAC_REQUIRE(!(relu & CRIMAC_EPI_WROWS) || (relu & CRIMAC_EPI_WFRAG), "conv3x3: CRIMAC_EPI_WROWS reads a fragment-major plane (CRIMAC_EPI_WFRAG)");
+  const int wfrag = (relu & CRIMAC_EPI_WROWS) ? 2 : (relu & CRIMAC_EPI_WFRAG) != 0;
   relu &= CRIMAC_EPI_RELU;
   CRIMAC_REQUIRE(!out_planes || (prec == CRIMAC_PREC_H3P && stat_mode != 2),
                  "conv3x3: plane-pair output is an H3P option (never with the fused BatchNorm-backward sums)");

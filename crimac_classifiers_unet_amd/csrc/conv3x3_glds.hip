@@ -416,17 +416,6 @@ __device__ __forceinline__ void wch_load_b(const unsigned short* s0, const unsig
     return;
   }
 #endif
-#ifdef CRIMAC_EXP_WCH_HALFW       // (ablation build, results garbage: HALF the weight stream -- two of the four fragments per tap)
-  if constexpr (WF) {
-    asm volatile(
-        "global_load_dwordx4 %0, %4, off\n\t"
-        "global_load_dwordx4 %1, %4, off offset:1024"
-        : "=&v"(bf[0]), "=&v"(bf[1]), "+v"(bf[2]), "+v"(bf[3])
-        : "v"(s0)
-        : "memory");
-    return;
-  }
-#endif
   if constexpr (WF) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off\n\t"
@@ -469,12 +458,22 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
       wch_load_b<WF>(s, s + w_nb, f.b[1]);
     }
   }
+#ifdef CRIMAC_EXP_WCH_FEWA        // (ablation build, results garbage: 3 of 8 groups of LDS fragment reads -- what a form that uses
+  //                                  every halo-row fragment for the three taps of its column would read)
+  if constexpr (H + 1 < NH && (H + 1) % 8 < 3) {
+    wch_issue<H + 1, NQ, ILV>(av, f);
+    wch_release<false>(f, H & 1);
+  } else {
+    wch_release<true>(f, H & 1);
+  }
+#else
   if constexpr (H + 1 < NH) {
     wch_issue<H + 1, NQ, ILV>(av, f);
     wch_release<false>(f, H & 1);
   } else {
     wch_release<true>(f, H & 1);
   }
+#endif
   if constexpr (PP && ks2 == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -491,6 +490,71 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
   if constexpr (H + 1 < NH) wch_step<T16, PP, H + 1, NQ, ILV, WF>(av, wtap, w_tap, w_nb, wnext_chunk, f, acc);
 }
 
+// FORM 3 ("rows"): 64 output channels of a 32 x 16-pixel tile, waves = 4 channel QUARTERS (16 channels each) of all 32
+// image rows.  Same accumulators per wave as the other forms (32 M tiles x 1 channel tile), HALF the weight stream per
+// MFMA -- a (tap, k-step) fragment of 16 channels feeds the 32 MFMAs of the wave's 512 pixels, not 16 -- which is what
+// round 5's ablations priced at 13-15 % of the channel-split launches (profiles/r05_wch_weight_stream_half_same.txt); the
+// halo fragments a 16-channel wave needs per MFMA would double, so the loop runs over HALO rows instead of taps: a
+// (column tap kx, k-step) PHASE walks the 34 halo rows once, and the fragment of halo row r meets the weights of the three
+// row taps ky at output rows r - ky: 34 ds_read_b128 per 96 MFMAs (the tap loop: 48), which the LDS carries easily
+// (profiles/r05_wch_lds_reads_ablation.txt: 3/8 of the reads buy 2.5 %, the reads are not what the kernel waits for).
+// Weights: fragment-major planes only; phase (kx, ks) loads three fragments (ky = 0..2) one phase (96 MFMAs) ahead.
+struct RowFrags {
+  bf16x8 a[4];           // halo-row fragments, read RD_AHEAD rows ahead
+  bf16x8 b[2][3];        // [phase parity][ky]
+};
+constexpr int kRowSteps = 6 * 34, kRowAhead = 3;
+template <int S>
+__device__ __forceinline__ void wrow_issue(const unsigned (&av)[3][2], const unsigned (&avh)[3][2], RowFrags& f) {
+  constexpr int ph = S / 34, r = S % 34, kx = ph >> 1, ks = ph & 1;
+  if constexpr (r < 17) f.a[S & 3] = lds_read128_asm<r * (HP * RB)>(av[kx][ks]);
+  else f.a[S & 3] = lds_read128_asm<(r - 17) * (HP * RB)>(avh[kx][ks]);
+}
+template <int N>
+__device__ __forceinline__ void wrow_release(bf16x8& a) {
+  static_assert(N >= 0 && N <= 3, "reads in flight behind the one awaited");
+  if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) :: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a) :: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a) :: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a) :: "memory");
+}
+__device__ __forceinline__ void wrow_load_b(const unsigned short* s0, const unsigned short* s1, const unsigned short* s2,
+                                            bf16x8 (&bf)[3]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %3, off\n\t"
+      "global_load_dwordx4 %1, %4, off\n\t"
+      "global_load_dwordx4 %2, %5, off"
+      : "=&v"(bf[0]), "=&v"(bf[1]), "=&v"(bf[2])
+      : "v"(s0), "v"(s1), "v"(s2)
+      : "memory");
+}
+__device__ __forceinline__ void wrow_land_b(bf16x8 (&bf)[3]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]) :: "memory");
+}
+// wch: this wave's fragment (lane's 16 bytes) of tap 0, k-step 0 of the current 64-channel chunk; w_tap: halves per tap
+template <typename T16, int S, typename ACC>
+__device__ __forceinline__ void wrow_step(const unsigned (&av)[3][2], const unsigned (&avh)[3][2], const unsigned short* wch,
+                                          long w_tap, const unsigned short* wnext_chunk, RowFrags& f, ACC& acc) {
+  constexpr int ph = S / 34, r = S % 34;
+  if constexpr (r == 0) {
+    wrow_land_b(f.b[ph & 1]);
+    if constexpr (ph < 5) {
+      constexpr int kx = (ph + 1) >> 1, ks = (ph + 1) & 1;
+      const unsigned short* s = wch + kx * w_tap + ks * 1024;
+      wrow_load_b(s, s + 3 * w_tap, s + 6 * w_tap, f.b[(ph + 1) & 1]);
+    } else {
+      const unsigned short* s = wnext_chunk ? wnext_chunk : wch;
+      wrow_load_b(s, s + 3 * w_tap, s + 6 * w_tap, f.b[0]);
+    }
+  }
+  if constexpr (S + kRowAhead < kRowSteps) wrow_issue<S + kRowAhead>(av, avh, f);
+  wrow_release<(kRowSteps - 1 - S < kRowAhead ? kRowSteps - 1 - S : kRowAhead)>(f.a[S & 3]);
+  if constexpr (r < 32) acc[r < 32 ? r : 0][0] = E16<T16>::mfma16(f.a[S & 3], f.b[ph & 1][0], acc[r < 32 ? r : 0][0]);
+  if constexpr (r >= 1 && r < 33) acc[r >= 1 && r < 33 ? r - 1 : 0][0] = E16<T16>::mfma16(f.a[S & 3], f.b[ph & 1][1], acc[r >= 1 && r < 33 ? r - 1 : 0][0]);
+  if constexpr (r >= 2) acc[r >= 2 ? r - 2 : 0][0] = E16<T16>::mfma16(f.a[S & 3], f.b[ph & 1][2], acc[r >= 2 ? r - 2 : 0][0]);
+  if constexpr (S + 1 < kRowSteps) wrow_step<T16, S + 1>(av, avh, wch, w_tap, wnext_chunk, f, acc);
+}
+
 // FORM 1 ("S22"): the 2 x 2 form for 64-channel tiles: waves = 2 pixel halves (8 image rows each) x 2 channel halves (32
 // channels each); the wave's weight fragments still come straight from global memory (each half is fetched by two waves).
 // FORM 2 ("tall"): 64 output channels of a 32 x 16-pixel tile: waves = 2 pixel halves of SIXTEEN image rows x 2 channel
@@ -502,18 +566,21 @@ __device__ __forceinline__ void wch_step(const unsigned (&av)[3][2], const unsig
 // 128-channel form reaches 0.77.
 template <typename T16, int MODE, typename TO = T16, bool PP = false, int FORM = 0, bool WF = false>      // MODE: the epilogue's fused reduction (0 none, 1 BatchNorm statistics, 2 BatchNorm-backward sums); WF: fragment-major weight plane
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ? 3 : 2, FORM == 1 ? 3 : 2))) void conv3x3_wch_kernel(ConvParams p) {
-  constexpr bool S22 = FORM != 0;                  // waves = pixel halves x channel halves
+  constexpr bool S22 = FORM != 0;                  // 64-channel tiles (forms 1, 2: waves = pixel halves x channel halves; 3: channel quarters)
+  constexpr bool ROWS = FORM == 3;
+  static_assert(!ROWS || (WF && !PP), "the rows form reads fragment-major 16-bit planes");
   constexpr int BN = S22 ? 64 : 128, NW = 4;
-  constexpr int NQ = FORM == 1 ? 2 : 4, WR = 4 * NQ;       // image rows (16-pixel M tiles) per wave
-  constexpr int TRK = FORM == 2 ? 32 : TR;                 // image rows of the workgroup's tile
+  constexpr int NQ = FORM == 1 ? 2 : 4, WR = ROWS ? 32 : 4 * NQ;       // image rows (16-pixel M tiles) per wave
+  constexpr int WN = ROWS ? 1 : 2;                         // 16-channel tiles per wave
+  constexpr int TRK = FORM >= 2 ? 32 : TR;                 // image rows of the workgroup's tile
   constexpr bool ILV = FORM == 2;                          // the wave's rows: two blocks of WR / 2 (wch_issue)
   constexpr int HALO_ROWS_K = (TRK + 2) * HP;              // 324 (612)
   constexpr int HALO_INSTR_K = (HALO_ROWS_K + 7) / 8;      // 41 (77) wave-instructions of 8 rows
   constexpr int NH = (HALO_INSTR_K + NW - 1) / NW;         // 11 (20)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef CRIMAC_DIAG_PHASES
-  unsigned long long wph[4] = {0, 0, 0, 0}, wph_t;
-  { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wph_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+  unsigned long long wph[4] = {0, 0, 0, 0}, wph_t, wrt0;
+  { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wph_t), "=s"(wrt0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define CRIMAC_CPH(k) { unsigned long long tn; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     wph[k] += tn - wph_t; wph_t = tn; }
@@ -544,7 +611,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   auto halo_off = [&](int i) -> unsigned {
     const int k = wave + NW * i;
     int row = 8 * k + sub;
-    if constexpr (FORM == 2) asm volatile("" : "+v"(row));          // (recomputed where it is used, not hoisted back into a table)
+    if constexpr (FORM >= 2) asm volatile("" : "+v"(row));          // (recomputed where it is used, not hoisted back into a table)
     const int hy = (row * 3641) >> 16, hx = row - hy * HP;          // row / 18 (exact for row < 4096)
     const unsigned y = (unsigned)(y0 + hy - 1), x = (unsigned)(x0 + hx - 1);
     const bool ok = k < HALO_INSTR_K && row < HALO_ROWS_K && y < (unsigned)p.H && x < (unsigned)p.W;
@@ -552,7 +619,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
     return ok ? (unsigned)((((b * p.H + (int)y) * p.W + (int)x) * (int)p.in_ld + src_unit<PP>(c8 ^ halo_swz(hx)) * 8) * 2)
               : 0x80000000u;
   };
-  constexpr bool HTAB = FORM != 2;
+  constexpr bool HTAB = FORM < 2;
   unsigned h_off[HTAB ? NH : 1];
   if constexpr (HTAB) {
 #pragma unroll
@@ -571,20 +638,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   };
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int wc = S22 ? (wave & 1) : wave, wp = S22 ? (wave >> 1) : 0;
+  const int wc = S22 && !ROWS ? (wave & 1) : wave, wp = S22 && !ROWS ? (wave >> 1) : 0;
   // weight fragments of this lane: rows n0 + 32*wc + nb*16 + fr of tap t, k = kc*64 + ks2*32 + fq*8 .. +8
   // (WF: block (n0 / 32 + wc) of the tap's N / 32 blocks, Cin / 64 chunks of 2048 halves each, lane l at 8 l)
-#ifdef CRIMAC_EXP_WCH_SAMEW       // (ablation build, results garbage: EVERY wave streams channel block 0 -- the same bytes per wave,
-  //                                  but all of them L1 / L2 hits: separates the cost of the L2 -> L1 traffic from the L1 -> register path)
-  const unsigned short* wrow = p.w_hi + lane * 8;
-#else
 #ifdef CRIMAC_EXP_WCH_SAMEW       // (ablation build, results garbage: EVERY wave streams channel block 0 -- the same bytes per wave,
   //                                  all of them L1 / L2 hits: separates the L2 -> L1 traffic from the delivery into the CU)
   const unsigned short* wrow = p.w_hi + lane * 8;
 #else
-  const unsigned short* wrow = WF ? p.w_hi + ((long)((n0 >> 5) + wc) * (p.Cin >> 6)) * 2048 + lane * 8
-                                  : p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
-#endif
+  const unsigned short* wrow = ROWS ? p.w_hi + ((long)((n0 >> 5) + (wave >> 1)) * (p.Cin >> 6)) * 2048 + (wave & 1) * 512 + lane * 8
+                               : WF ? p.w_hi + ((long)((n0 >> 5) + wc) * (p.Cin >> 6)) * 2048 + lane * 8
+                                    : p.w_hi + (long)(n0 + 32 * wc + fr) * p.Cin + fq * 8;
 #endif
   const long w_tap = (long)p.N * p.Cin, w_nb = 16L * p.Cin;
   constexpr int W_CHUNK = WF ? 2048 : BK;             // halves between two 64-channel chunks of a tap
@@ -599,25 +662,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
         av[kx][ks2] = a_lds + (wp * (ILV ? WR / 2 : WR) * HP + fr + kx) * RB + (((4 * ks2 + fq) ^ halo_swz(fr + kx)) << 4);
   }
 
-  f32x4 acc[WR][2];
+  f32x4 acc[WR][WN];
 #pragma unroll
   for (int i = 0; i < WR; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   const int kchunks = p.Cin / BK;
-  WchFrags f;
 #ifndef CRIMAC_WCH_NO_BIAS_PRE
-  // this lane's two bias values, requested here and used by the epilogue (conv_epilogue.h: bias_pre)
-  float bias_pre[2];
+  // this lane's bias values, requested here and used by the epilogue (conv_epilogue.h: bias_pre)
+  float bias_pre[WN];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) bias_pre[nb] = p.epi.bias ? p.epi.bias[n0 + wc * 32 + nb * 16 + (lane & 15)] : 0.f;
+  for (int nb = 0; nb < WN; ++nb) bias_pre[nb] = p.epi.bias ? p.epi.bias[n0 + wc * (16 * WN) + nb * 16 + (lane & 15)] : 0.f;
 #endif
+  unsigned avh[3][2];                    // (rows form) halo rows 17 ..: a ds_read's immediate offset ends at 64 KB
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) avh[kx][ks2] = av[kx][ks2] + 17 * (HP * RB);
+  WchFrags f;
+  RowFrags rf;
   issue_halo(0);                         // (in flight together with the first weight fragments: one latency, not two)
-  wch_load_b<WF>(wrow, wrow + w_nb, f.b[1]);
-  wch_land_b(f.b[1]);                    // vmcnt(0): the fragments and the first halo chunk
+  if constexpr (ROWS) {
+    wrow_load_b(wrow, wrow + 3 * w_tap, wrow + 6 * w_tap, rf.b[0]);
+    wrow_land_b(rf.b[0]);
+  } else {
+    wch_load_b<WF>(wrow, wrow + w_nb, f.b[1]);
+    wch_land_b(f.b[1]);                  // vmcnt(0): the fragments and the first halo chunk
+  }
   CRIMAC_DIAG_STAMP(dg_t0, dg_r0)
   CRIMAC_CPH(0)
   for (int kc = 0; kc < kchunks; ++kc) {
@@ -630,9 +704,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
     CRIMAC_CPH(1)
     const unsigned short* wtap = wrow + (long)kc * W_CHUNK;
     const unsigned short* wnext = kc + 1 < kchunks ? wtap + W_CHUNK : nullptr;
-    wch_issue<0, NQ, ILV>(av, f);
-    wch_step<T16, PP, 0, NQ, ILV, WF>(av, wtap, w_tap, w_nb, wnext, f, acc);
-    wch_land_b(f.b[1]);
+    if constexpr (ROWS) {
+      wrow_issue<0>(av, avh, rf);
+      wrow_issue<1>(av, avh, rf);
+      wrow_issue<2>(av, avh, rf);
+      wrow_step<T16, 0>(av, avh, wtap, w_tap, wnext, rf, acc);
+      wrow_land_b(rf.b[0]);
+    } else {
+      wch_issue<0, NQ, ILV>(av, f);
+      wch_step<T16, PP, 0, NQ, ILV, WF>(av, wtap, w_tap, w_nb, wnext, f, acc);
+      wch_land_b(f.b[1]);
+    }
     __builtin_amdgcn_s_barrier();
     CRIMAC_CPH(2)
   }
@@ -642,11 +724,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
 #endif
   // (tall form, 16-bit output: two slices of 256 rows like the other forms' whole tile -- 16 fully unrolled store rounds
   // spill ~60 registers in the statistics mode)
-  constexpr int EPASS = EpiPasses<TO>::value * (FORM == 2 && sizeof(TO) == 2 ? 2 : 1);
+  constexpr int EPASS = EpiPasses<TO>::value * (FORM >= 2 && sizeof(TO) == 2 ? 2 : 1);
 #ifndef CRIMAC_WCH_NO_BIAS_PRE
-  conv_epilogue<TO, BN, TRK * TC, 256, WR, 2, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc, bias_pre);
+  conv_epilogue<TO, BN, TRK * TC, 256, WR, WN, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc, bias_pre);
 #else
-  conv_epilogue<TO, BN, TRK * TC, 256, WR, 2, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc);
+  conv_epilogue<TO, BN, TRK * TC, 256, WR, WN, f32x4, MODE, EPASS, ILV>(acc, p.epi, smem, b, y0, x0, n0, TRK, wp, wc);
 #endif
 #ifdef CRIMAC_DIAG_PHASES
   // cycles of wave 0: prologue | waiting for the halo chunks | MFMA steps | epilogue (stores issued)
@@ -654,18 +736,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FORM == 1 ?
   const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) % 1024;
   if (tid == 0)
     for (int k = 0; k < 4; ++k) crimac_diag_clock_conv_buf[slot * 4 + k] = wph[k];
+  // wall clock (100 MHz) at the workgroup's entry and exit, and where it ran: [4096 + 2 slot] = entry, [+ 1] = exit << 16 | XCC_ID << 8 | CU
+  {
+    unsigned long long wrt1;
+    unsigned hwid, xcc;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(wrt1), "=s"(hwid), "=s"(xcc) :: "memory");
+    if (tid == 0) {
+      crimac_diag_clock_conv_buf[4096 + 2 * slot] = wrt0;
+      crimac_diag_clock_conv_buf[4096 + 2 * slot + 1] = (wrt1 << 16) | ((unsigned long long)(xcc & 15) << 8) | ((hwid >> 8) & 15) | (((hwid >> 13) & 7) << 4);
+    }
+  }
 #endif
 }
 
 template <typename T16, typename TO = T16, bool PP = false, int S22 = 0, bool WF = false>      // S22: the kernel's FORM
 int launch_wch(ConvParams p, hipStream_t st) {
   constexpr int BN = S22 ? 64 : 128;
-  constexpr int TRK = S22 == 2 ? 32 : TR;
+  constexpr int TRK = S22 >= 2 ? 32 : TR;
   constexpr int HALO_BYTES = ((TRK + 2) * HP + 7) / 8 * 1024;      // one halo buffer, padded to whole DMA instructions
   p.tiles_y = cdiv(p.H, TRK);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr int EPASS = EpiPasses<TO>::value * (S22 == 2 && sizeof(TO) == 2 ? 2 : 1);      // (as in the kernel)
+  constexpr int EPASS = EpiPasses<TO>::value * (S22 >= 2 && sizeof(TO) == 2 ? 2 : 1);      // (as in the kernel)
   constexpr size_t stage = (size_t)(TRK * TC / EPASS) * (BN * EpiPasses<TO>::kStageBytes + 16) + 2 * BN * 4;
   const size_t lds = stage > (size_t)HALO_BYTES ? stage : (size_t)HALO_BYTES;
   static_assert(stage <= 80 * 1024 && HALO_BYTES <= 80 * 1024, "two workgroups per CU");
@@ -1441,8 +1535,14 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
   const int B = p.B, H = p.H, W = p.W, Cin = p.Cin, N = p.N, n_first = p.n_first, n_count = p.n_count;
   const long in_ld = p.in_ld;
   if (p.wfrag) {
-    // a fragment-major weight plane: only the channel-split kernel (128-channel form) reads it
+    // a fragment-major weight plane: only the channel-split kernel reads it (128-channel form; CRIMAC_EPI_WROWS: rows form)
     const bool small_f = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
+    if (p.wfrag == 2) {
+      CRIMAC_REQUIRE(N % 64 == 0 && n_first % 64 == 0 && n_count % 64 == 0 && Cin % 64 == 0 && small_f,
+                     "conv3x3: the rows form (CRIMAC_EPI_WROWS) needs N and the channel range in multiples of 64, Cin %% 64 == 0 "
+                     "and an input tensor below 2 GB (N=%d range [%d, +%d) Cin=%d)", N, n_first, n_count, Cin);
+      return launch_wch<T16, T16, false, 3, true>(p, st);
+    }
     CRIMAC_REQUIRE(N % 128 == 0 && n_first % 128 == 0 && n_count % 128 == 0 && Cin % 64 == 0,
                    "conv3x3: fragment-major weights (CRIMAC_EPI_WFRAG) need N and the channel range in multiples of 128 and "
                    "Cin %% 64 == 0 (N=%d range [%d, +%d) Cin=%d)", N, n_first, n_count, Cin);
@@ -1496,6 +1596,7 @@ int crimac_conv3x3_glds_hp(const void* in, long in_ld, int B, int H, int W, int 
   p.n_first = n_first; p.n_count = n_count;
   const bool small = (((long)B * H * W - 1) * p.in_ld + p.Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
   static const int w4 = getenv("CRIMAC_CONV_W4") ? atoi(getenv("CRIMAC_CONV_W4")) : 0;
+  CRIMAC_REQUIRE(wfrag != 2, "conv3x3 (plane pairs): no rows form (CRIMAC_EPI_WROWS)");
   if (wfrag) {      // fragment-major plane (rows of 2 Cin halves): the 128-channel form of the channel-split kernel only
     CRIMAC_REQUIRE(N % 128 == 0 && n_count % 128 == 0 && n_first % 128 == 0 && small,
                    "conv3x3 (plane pairs): fragment-major weights (CRIMAC_EPI_WFRAG) need N and the channel range in multiples of "
@@ -1530,6 +1631,12 @@ int crimac_conv3x3_glds_16_f32out(const void* in, long in_ld, int B, int H, int 
   p.epi = epi;
   p.n_first = n_first; p.n_count = n_count;
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
+  if (wfrag == 2) {
+    CRIMAC_REQUIRE(N % 64 == 0 && n_count % 64 == 0 && n_first % 64 == 0 && small,
+                   "conv3x3 (fp16 operands, fp32 output): the rows form (CRIMAC_EPI_WROWS) needs N and the channel range in "
+                   "multiples of 64 and an input tensor below 2 GB (N=%d range [%d, +%d))", N, n_first, n_count);
+    return launch_wch<half_t, float, false, 3, true>(p, st);
+  }
   if (wfrag) {
     CRIMAC_REQUIRE(N % 128 == 0 && n_count % 128 == 0 && n_first % 128 == 0 && small,
                    "conv3x3 (fp16 operands, fp32 output): fragment-major weights (CRIMAC_EPI_WFRAG) need N and the channel range in "

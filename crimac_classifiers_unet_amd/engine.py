@@ -261,12 +261,17 @@ class UNetEngine:
             split_ok = not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0)
             self.pk[b.conv_key]["fwd_frag"] = bool(wf and b.cout % 128 == 0 and b.cin_pad % kq == 0)
             self.pk[b.conv_key]["dg_frag"] = bool(wf and has_dg and b.cin % 128 == 0 and b.cout % kq == 0 and split_ok)
+            # rows form of the channel-split kernel (CRIMAC_EPI_WROWS, 16-bit storage): 64-channel tiles, fragment-major planes
+            fr, dr = self._rows_choice(b, has_dg) if (wf and self.is16) else (False, False)
+            self.pk[b.conv_key]["fwd_rows"], self.pk[b.conv_key]["dg_rows"] = fr, dr
+            self.pk[b.conv_key]["fwd_frag"] |= fr
+            self.pk[b.conv_key]["dg_frag"] |= dr
             self.pk[b.conv_key]["frag_ok"] = (self.pk[b.conv_key]["fwd_frag"], self.pk[b.conv_key]["dg_frag"])
             self.pk_eval[b.conv_key] = {
                 "fwd_hi": torch.empty(m_hi * n_f, dtype=i16, device=dev),
                 "fwd_lo": torch.empty(8 if il else n_lo * n_f, dtype=i16, device=dev),
                 "bias": torch.empty(b.cout, dtype=torch.float32, device=dev),
-                "fwd_frag": self.pk[b.conv_key]["fwd_frag"],
+                "fwd_frag": self.pk[b.conv_key]["fwd_frag"], "fwd_rows": fr,
             }
         for u in self.ups:
             n = 4 * u.cin * u.cout
@@ -289,6 +294,9 @@ class UNetEngine:
                     "fwd_frag": False,
                     "dg_frag": bool(self.wfrag and self.conv_impl == "halo" and has_dg and b.cin % 128 == 0 and b.cout % 64 == 0
                                     and not (b.cin == 2 * b.cout and (b.cin // 2) % 128 != 0))}
+                dr = self._rows_choice(b, has_dg)[1] if (self.wfrag and self.conv_impl == "halo") else False
+                self.pk16[b.conv_key]["dg_rows"] = dr
+                self.pk16[b.conv_key]["dg_frag"] |= dr
                 self.pk16[b.conv_key]["frag_ok"] = (False, self.pk16[b.conv_key]["dg_frag"])
             for u in self.ups:
                 n = 4 * u.cin * u.cout
@@ -752,6 +760,20 @@ class UNetEngine:
     # rebuilds its input from the y it reads for the fused sums)
     fuse_head_bn = fuse_bn_bwd and os.environ.get("CRIMAC_FUSE_HEADBN", "1") != "0"
     wfrag = os.environ.get("CRIMAC_WFRAG", "1") != "0"      # fragment-major weight planes for the channel-split kernel (16-bit modes)
+    # rows form of the channel-split kernel (CRIMAC_EPI_WROWS): "0" off, "64" the 64-output-channel launches that the tall form
+    # runs otherwise, "all" every legal layer (A/B runs: slower than the 128-channel form wherever that one applies)
+    conv_rows = os.environ.get("CRIMAC_CONV_ROWS", "0")
+
+    def _rows_choice(self, b, has_dg):
+        """(forward, input gradient) of block b on the rows form.  Not where the persistent 64 -> 64 kernel runs (it reads
+        row-major planes): the 64 -> 64 layers and the two 64-channel d(concat) halves of the last decoder block."""
+        if self.conv_rows not in ("64", "all") or self.conv_impl != "halo" or (b.cin == 64 and b.cout == 64):
+            return False, False
+        fwd = b.cout % 64 == 0 and b.cin_pad % 64 == 0
+        dg = has_dg and b.cin % 64 == 0 and b.cout % 64 == 0 and not (b.cin == 2 * b.cout and b.cin // 2 == 64)
+        if self.conv_rows == "64":
+            fwd, dg = fwd and b.cout == 64, dg and b.cin == 64
+        return bool(fwd), bool(dg)
 
     def _conv3x3(self, x: Act, pk, bias, out: Act, B, H, W, cin, cout, relu, dgrad=False, cin_real=None,
                  stats=None, bnb=None, cols=None, out_planes=False, stat_reps=None):
@@ -767,6 +789,8 @@ class UNetEngine:
         w_hi, w_lo = ptr(pk["dg_hi" if dgrad else "fwd_hi"]), ptr(pk["dg_lo" if dgrad else "fwd_lo"])
         if pk.get("dg_frag" if dgrad else "fwd_frag"):
             relu |= hip.EPI_WFRAG         # (the plane was packed fragment-major: _alloc_static)
+            if pk.get("dg_rows" if dgrad else "fwd_rows"):
+                relu |= hip.EPI_WROWS
         prec = self.prec_bwd if dgrad else self.prec
         if self.conv_impl == "halo":
             mode, s0, s1, by, by_ld, bvec = 0, None, None, None, 0, None
@@ -1076,7 +1100,8 @@ class UNetEngine:
                     call("crimac_conv3x3_pool", self.prec, a1.p, a1.ld, B, h, w, c, c, ptr(pe2["fwd_hi"]),
                          ptr(pe2["fwd_lo"]), ptr(pe2["bias"]), a2.p, a2.ld,
                          hip.EPI_RELU | (hip.EPI_OUT_PLANES if self.is_hp else 0)
-                         | (hip.EPI_WFRAG if pe2.get("fwd_frag") else 0), pool.p, pool.ld,
+                         | (hip.EPI_WFRAG if pe2.get("fwd_frag") else 0)
+                         | (hip.EPI_WROWS if (pe2.get("fwd_frag") and pe2.get("fwd_rows")) else 0), pool.p, pool.ld,
                          flops=2.0 * 9 * c * c * B * h * w, mfmas=hip.MFMAS_PER_PRODUCT[self.prec])
                 else:
                     self._conv3x3(a1, pe2, pe2["bias"], a2, B, h, w, c, c, relu=True, out_planes=True)

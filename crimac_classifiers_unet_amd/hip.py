@@ -37,6 +37,7 @@ PREC_PLANES_ARG = {PREC_BF16: 1, PREC_F32X3: 2, PREC_F32X6: 3, PREC_FP16: PLANES
                    PREC_H3P: PLANES_H3P}
 EPI_RELU, EPI_OUT_PLANES, EPI_CIN4 = 1, 2, 4      # `relu` argument of the convolution entry points (CRIMAC_EPI_*)
 EPI_WFRAG = 16                # ... the weight plane is fragment-major (CRIMAC_EPI_WFRAG)
+EPI_WROWS = 32                # ... and the channel-split kernel's rows form reads it (CRIMAC_EPI_WROWS)
 LAYER_FWD_FRAG, LAYER_DG_FRAG = 16, 32      # crimac_layer_desc.kind flags (CRIMAC_LAYER_*_FRAG)
 # precision the BACKWARD kernels (input gradients, weight gradients) are called with: F32H3 is a forward-operand
 # mode (fp16 planes have no range for gradients), its backward pass runs on the 2-plane bf16 split

@@ -122,6 +122,10 @@ extern "C" {
  * [32 hi | 32 lo] per 32-channel block): the same formula on the row of halves, K = 2 Cin, c = the half's position in the row
  * (Cin % 32 == 0).  H3F_BWD: its fp16 input-gradient planes, as FP16. */
 #define CRIMAC_EPI_WFRAG 16
+/* ... and (with CRIMAC_EPI_WFRAG) the convolution runs the ROWS form of the channel-split kernel: 64-channel x (32 x 16)-pixel
+ * tiles, a wave = 16 channels x 512 pixels, half the weight bytes per MFMA.  16-bit precisions and H3F_BWD; N and the channel
+ * range multiples of 64, Cin % 64 == 0.  Same results up to the order of the fp32 accumulation. */
+#define CRIMAC_EPI_WROWS 32
 
 /* Library identity / error text.  crimac_version() returns CRIMAC_ABI_VERSION of the build: it is bumped whenever a
  * struct passed by pointer (crimac_layer_desc), the meaning of an argument or the set of precisions changes, and a

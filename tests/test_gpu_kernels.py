@@ -800,6 +800,76 @@ def _wfrag_index(t, r, c, R, K):
 
 
 @pytest.mark.parametrize("prec", LOWP)
+@pytest.mark.parametrize("shape", [(2, 32, 48, 128, 128), (1, 24, 40, 128, 256), (3, 16, 16, 256, 128), (2, 64, 32, 128, 64),
+                                   (1, 40, 24, 64, 192)])
+def test_rows_form_of_the_channel_split_convolution(prec, shape):
+    """CRIMAC_EPI_WROWS (round 5): 64-channel x (32 x 16)-pixel tiles, a wave = 16 channels x all 32 image rows, the loop over
+    halo rows (every fragment meets the three row taps).  Same products as the tap loop in another order: against the
+    row-major launch to the storage type's last bit (statistics / BatchNorm-backward sums to fp32 round-off), against a
+    float64 convolution of the same rounded operands to the storage rounding; images that are not multiples of the tile
+    (24 x 40, 16 x 16), 64-channel outputs and ranges, forward with statistics and input gradient with the fused sums."""
+    import ctypes
+    B, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(37)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).cuda()
+    planes = hip.PREC_PLANES_ARG[hip.PREC_NAMES[prec]]
+    n = 9 * Co * Ci
+    i16 = torch.int16
+    bufs = {}
+    for tag, kind in (("row", 0), ("frag", hip.LAYER_FWD_FRAG | hip.LAYER_DG_FRAG)):
+        d = (hip.LayerDesc * 1)()
+        bufs[tag] = {k: torch.full((n,), -1, dtype=i16, device="cuda") for k in ("fwd_hi", "dg_hi")}
+        lo = torch.zeros(8, dtype=i16, device="cuda")
+        d[0].w = w.data_ptr()
+        d[0].fwd_hi, d[0].fwd_lo = bufs[tag]["fwd_hi"].data_ptr(), lo.data_ptr()
+        d[0].dg_hi, d[0].dg_lo = bufs[tag]["dg_hi"].data_ptr(), lo.data_ptr()
+        d[0].kind, d[0].Co, d[0].Ci, d[0].Ci_pad = kind, Co, Ci, Ci
+        call("crimac_pack_layers", ctypes.byref(d), 1, planes)
+    x4 = _round(torch.randn(B, Ci, H, W, generator=g), prec)
+    dy4 = _round(torch.randn(B, Co, H, W, generator=g), prec)
+    x, dy = to_nhwc(x4, prec), to_nhwc(dy4, prec)
+    bias = torch.randn(Co, generator=g).cuda()
+    yprev = to_nhwc(_round(torch.randn(B, Ci, H, W, generator=g) * 1.5 + 0.3, prec), prec)
+    vec = torch.stack([torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5,
+                       torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3]).contiguous().cuda()
+    M, P = B * H * W, hip.PREC_NAMES[prec]
+    res = {}
+    for tag, flag in (("row", 0), ("frag", hip.EPI_WFRAG | hip.EPI_WROWS)):
+        out = torch.empty(M, Co, dtype=_dt(prec), device="cuda")
+        st = torch.zeros(2, 3, Co, dtype=torch.float64, device="cuda")
+        call("crimac_conv3x3", P, ptr(x), Ci, B, H, W, Ci, Co, ptr(bufs[tag]["fwd_hi"]), None, ptr(bias), ptr(out), Co,
+             hip.EPI_RELU | flag, 1, ptr(st[0]), ptr(st[1]), 3, None, 0, None, 0)
+        da = torch.empty(M, Ci, dtype=_dt(prec), device="cuda")
+        acc = torch.zeros(2, 3, Ci, dtype=torch.float64, device="cuda")
+        call("crimac_conv3x3", P, ptr(dy), Co, B, H, W, Co, Ci, ptr(bufs[tag]["dg_hi"]), None, None, ptr(da), Ci, flag, 2,
+             ptr(acc[0]), ptr(acc[1]), 3, ptr(yprev), Ci, ptr(vec), Ci)
+        half = torch.zeros(M, Ci, dtype=_dt(prec), device="cuda")      # the second 64-channel range of the input gradient alone
+        if Ci >= 128:
+            call("crimac_conv3x3_cols", P, ptr(dy), Co, B, H, W, Co, Ci, ptr(bufs[tag]["dg_hi"]), None, None, ptr(half), Ci,
+                 flag, 0, None, None, 1, None, 0, None, 0, 64, 64)
+        torch.cuda.synchronize()
+        res[tag] = (out, st.sum(1), da, acc.sum(1), half)
+    ulp = 2.0 ** -7 if prec == "bf16" else 2.0 ** -10          # spacing of the storage type relative to a binade's lower end
+    for k in (0, 2):
+        a, b = res["frag"][k].double(), res["row"][k].double()
+        assert float(((a - b).abs() / b.abs().clamp_min(1e-2)).max()) <= 1.01 * ulp, k      # the storage type's last bit
+        assert float((a != b).double().mean()) < 0.02
+    assert relerr(res["frag"][1].cpu(), res["row"][1].cpu()) < 1e-4 and relerr(res["frag"][3].cpu(), res["row"][3].cpu()) < 2e-3
+    if Ci >= 128:
+        assert torch.equal(res["frag"][4][:, 64:128], res["frag"][2][:, 64:128]) and float(res["frag"][4][:, :64].float().abs().max()) == 0
+    if Ci > 128:
+        assert float(res["frag"][4][:, 128:].float().abs().max()) == 0
+    # float64 convolution of the rounded operands (weights as packed: the plane's rounding)
+    wq = _round(w.cpu(), prec).double()
+    ref = torch.relu(torch.nn.functional.conv2d(x4.double(), wq, bias.cpu().double(), padding=1))
+    got = res["frag"][0].double().cpu().reshape(B, H, W, Co).permute(0, 3, 1, 2)
+    assert relerr(got, ref) < 1.5 * ulp
+    refd = torch.nn.functional.conv_transpose2d(dy4.double(), wq, padding=1)
+    gotd = res["frag"][2].double().cpu().reshape(B, H, W, Ci).permute(0, 3, 1, 2)
+    assert relerr(gotd, refd) < 1.5 * ulp
+
+
+@pytest.mark.parametrize("prec", LOWP)
 @pytest.mark.parametrize("shape", [(2, 32, 48, 128, 128), (1, 24, 40, 128, 256), (3, 16, 16, 256, 128)])
 def test_fragment_major_weight_planes_pack_and_convolve_bit_for_bit(prec, shape):
     """CRIMAC_LAYER_FWD_FRAG / CRIMAC_LAYER_DG_FRAG + CRIMAC_EPI_WFRAG (round 5): crimac_pack_layers writes the planes the

@@ -90,8 +90,13 @@ def main():
                      "clock_ghz_p90": float(np.percentile(ghz, 90)), "workgroups_sampled": int(len(ghz)),
                      "loop_cycles_median": float(np.median(a[:, 0])), "launch_us": us,
                      "tflops": flops / us / 1e6, "launches_before_sample": n}
+        # 16-bit MFMAs: 1024 flop per cycle and SIMD (a 16x16x32 MFMA = 16384 flop in 16 cycles), 1024 SIMDs -- the share of
+        # the chip's MFMA issue slots the launch fills AT THE CLOCK IT RAN AT (launch overheads and tails included)
+        if not hp:
+            res[name]["mfma_slots_filled_at_that_clock"] = flops / us / 1e6 / (float(np.median(ghz)) * 1024 * 1024 / 1e3)
         print(f"{what:5s} {name:22s} clock {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz, 10):.3f}, p90 "
-              f"{np.percentile(ghz, 90):.3f}), {us:7.1f} us, {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+              f"{np.percentile(ghz, 90):.3f}), {us:7.1f} us, {flops / us / 1e6:7.1f} TFLOP/s"
+              + ("" if hp else f", MFMA slots filled at that clock {res[name]['mfma_slots_filled_at_that_clock']:.3f}"), flush=True)
     json.dump({"what": what, "method": "s_memtime / s_memrealtime x 100 MHz around the kernel's main loop, median over "
                "workgroups, after >= 2 s of back-to-back launches on random data (diagnostic build; stamps "
                "cost wave cycles, read the clock, not the run time)", "shapes": res}, open(out_path, "w"), indent=1)
