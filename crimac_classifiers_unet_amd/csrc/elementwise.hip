@@ -1,10 +1,12 @@
-#include <stdlib.h>
 // HBM-bound kernels of the U-Net hot path for CDNA4 (gfx950): BatchNorm statistics / apply /
 // backward, ReLU, 2x2 max-pool and its backward, layout conversion, weight packing, SGD.
 // All tensor accesses are 16-byte vectors over the contiguous NHWC channel axis; per-channel
 // reductions keep partial sums in registers, combine them in LDS and issue one global atomic per
 // channel per workgroup.
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <mutex>
 
 #include "common.h"
 
@@ -29,6 +31,40 @@ inline int grid_for(long work_items, int per_block) {
   if (b < 1) b = 1;
   if (b > kMaxBlocks) b = kMaxBlocks;
   return (int)b;
+}
+
+// WHOLE ROUNDS for the grid-stride streaming kernels.  A grid that is not a whole number of resident rounds ends with a partly
+// filled one in which the chip streams at a fraction of its rate: the 2048 workgroups of bn_bwd_apply at its three workgroups
+// per CU are 2.67 rounds -- 5.6 TB/s on the level-0 tensors; 768 (one round) or 1536: 6.4-6.5 TB/s, 1024: 5.4
+// (profiles/r05_elementwise_whole_rounds.txt).  So: never more workgroups than are resident at once
+// (CUs x hipOccupancyMaxActiveBlocksPerMultiprocessor of that kernel; fewer workgroups also means fewer prologues, which in the
+// replica-summing kernels are not free).  Looked up once per (kernel, device).
+struct ResidentEntry { const void* fn; int dev, blocks; };
+static ResidentEntry g_resident[96];
+static int g_resident_n = 0;
+static std::mutex g_resident_mu;
+template <typename K>
+inline int whole_rounds(K kernel, size_t lds, int grid, int block = 256) {
+  static const int off = getenv("CRIMAC_WHOLE_ROUNDS") ? atoi(getenv("CRIMAC_WHOLE_ROUNDS")) == 0 : 0;      // (A/B runs)
+  int dev = 0;
+  if (off || grid <= 256 || hipGetDevice(&dev) != hipSuccess) return grid;
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int blocks = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    for (int i = 0; i < g_resident_n; ++i)
+      if (g_resident[i].fn == fn && g_resident[i].dev == dev) blocks = g_resident[i].blocks;
+    if (blocks == 0) {
+      int per_cu = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) == hipSuccess &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+        blocks = per_cu * cus;
+      else
+        blocks = -1;
+      if (g_resident_n < 96) g_resident[g_resident_n++] = ResidentEntry{fn, dev, blocks};
+    }
+  }
+  return (blocks > 0 && grid > blocks) ? blocks : grid;
 }
 
 // pixel index -> (image, pixel in image); 32-bit divide when the operands fit (a 64-bit divide is ~4x the
@@ -788,7 +824,11 @@ void bn_bwd_apply_stream_kernel(
     }
   }
   const long stride = (long)gridDim.x * rpi;
+#ifdef CRIMAC_BNB_APPLY_U
+  constexpr int U = CRIMAC_BNB_APPLY_U;
+#else
   constexpr int U = CRIMAC_BNB_APPLY_WAVES >= 4 ? 2 : 4;      // rows in flight per thread (two fit the 128-register budget)
+#endif
   for (long m = (long)blockIdx.x * rpi + rl; m < M; m += U * stride) {
     float g[U][8], yv[U][8];
 #pragma unroll
@@ -1453,12 +1493,12 @@ static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, cons
   const size_t lds = FIN ? 512 * sizeof(double) + 4 * (size_t)C * sizeof(float) : 0;
   if (pool_out) {
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO, FIN>), dim3(grid_for(total, 256)), dim3(256), lds, st,
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO, FIN>), dim3(whole_rounds(bn_act_pool_kernel<T, TO, FIN>, lds, grid_for(total, 256))), dim3(256), lds, st,
                        (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, (TO*)pool_out, pool_ld, B,
                        H, W, C, fin);
   } else {
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL((bn_act_kernel<T, TO, FIN>), dim3(colreduce_grid(M, C)), dim3(256), lds, st,
+    hipLaunchKernelGGL((bn_act_kernel<T, TO, FIN>), dim3(whole_rounds(bn_act_kernel<T, TO, FIN>, lds, colreduce_grid(M, C))), dim3(256), lds, st,
                        (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, M, C, fin);
   }
   CRIMAC_LAUNCH_CHECK();
@@ -1539,7 +1579,7 @@ extern "C" int crimac_unpool_add(int prec, const void* dp, long dp_ld, const voi
   const int grid = grid_for(total, stat_sum ? 256 * 4 : 256);
   BnbArgs bnb{bnb_y, bnb_y_ld, bnb_vec, bnb_stride, stat_sum, stat_sumsq, stat_replicas};
 #define UA(T, TA, BNB, LDS)                                                                               \
-  hipLaunchKernelGGL((unpool_add_kernel<T, BNB, TA>), dim3(grid), dim3(256), LDS, ST, (const T*)dp, dp_ld, \
+  hipLaunchKernelGGL((unpool_add_kernel<T, BNB, TA>), dim3(whole_rounds(unpool_add_kernel<T, BNB, TA>, LDS, grid)), dim3(256), LDS, ST, (const T*)dp, dp_ld, \
                      (const TA*)a, a_ld, (const T*)ds, ds_ld, (T*)da, da_ld, B, H, W, C, bnb)
   const size_t lds = 2 * (size_t)C * sizeof(float);
   if (stat_sum) CRIMAC_FOR_STORAGE2(prec, T, TA, UA(T, TA, true, lds));
@@ -1584,7 +1624,7 @@ extern "C" int crimac_bn_bwd_apply(int prec, const void* da, long da_ld, const v
   const size_t lds = 2 * C * sizeof(float);
   static const int stream_form = getenv("CRIMAC_BNB_STREAM") ? atoi(getenv("CRIMAC_BNB_STREAM")) : 1;
   if (!dbias && stream_form && C <= 2048)
-    CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD>), dim3(grid), dim3(256), 0, ST,
+    CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD>), dim3(whole_rounds(bn_bwd_apply_stream_kernel<T, TD>, 0, grid)), dim3(256), 0, ST,
                                                    (const T*)da, da_ld, (const T*)y, y_ld, scale, shift, mean, invstd,
                                                    sum_dz, sum_dz_xhat, M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, 1));
   else
@@ -1610,7 +1650,7 @@ extern "C" int crimac_bn_bwd_apply_replicas(int prec, const void* da, long da_ld
                  "bn_bwd_apply_replicas: bad pixel strides");
   const int grid = colreduce_grid(M, C);
   const size_t lds = 512 * sizeof(double) + 2 * (size_t)C * sizeof(float);
-  CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD, true>), dim3(grid), dim3(256), lds,
+  CRIMAC_FOR_STORAGE2(prec, T, TD, hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, TD, true>), dim3(whole_rounds(bn_bwd_apply_stream_kernel<T, TD, true>, lds, grid)), dim3(256), lds,
                                                  ST, (const T*)da, da_ld, (const T*)y, y_ld, bn_vec + 2 * bn_stride,
                                                  bn_vec + 3 * bn_stride, bn_vec, bn_vec + bn_stride, sum_dz, sum_dz_xhat,
                                                  M, count, C, (TD*)dy, dy_ld, dgamma, dbeta, replicas));
@@ -1642,7 +1682,7 @@ extern "C" int crimac_unpool_bn_bwd_apply_replicas(int prec, const void* dp, lon
   const int grid = grid_for(total, 256 * 4);
   const size_t lds = 512 * sizeof(double) + 2 * (size_t)C * sizeof(float);
 #define UBA(T, TD, TA)                                                                                                  \
-  hipLaunchKernelGGL((unpool_bn_bwd_apply_kernel<T, TD, TA>), dim3(grid), dim3(256), lds, ST, (const T*)dp, dp_ld,      \
+  hipLaunchKernelGGL((unpool_bn_bwd_apply_kernel<T, TD, TA>), dim3(whole_rounds(unpool_bn_bwd_apply_kernel<T, TD, TA>, lds, grid)), dim3(256), lds, ST, (const T*)dp, dp_ld,      \
                      (const T*)ds, ds_ld, (const T*)y, y_ld, bn_vec + 2 * bn_stride, bn_vec + 3 * bn_stride, bn_vec,    \
                      bn_vec + bn_stride, sum_dz, sum_dz_xhat, replicas, count, (TD*)dy, dy_ld, B, H, W, C, dgamma, dbeta)
   if (prec == CRIMAC_PREC_H3F_BWD) UBA(float, half_t, hp_t);
@@ -1660,7 +1700,7 @@ static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, co
   if (Cin == 64) {
     const int grid64 = grid_for(npix, 256 * 4);
 #define HF64(NC)                                                                                              \
-  hipLaunchKernelGGL((head_fwd64_kernel<T, NC, TR>), dim3(grid64), dim3(256), 0, st, (const T*)x, x_ld, w, b, logits, \
+  hipLaunchKernelGGL((head_fwd64_kernel<T, NC, TR>), dim3(whole_rounds(head_fwd64_kernel<T, NC, TR>, 0, grid64)), dim3(256), 0, st, (const T*)x, x_ld, w, b, logits, \
                      npix, HW, softmax, bn_scale, bn_shift)
     if (ncls == 2) HF64(2); else if (ncls == 3) HF64(3); else HF64(4);
 #undef HF64
@@ -1669,7 +1709,7 @@ static int head_fwd_launch(const void* x, long x_ld, int Cin, const float* w, co
   }
   const int grid = grid_for(npix, (256 / lp) * 8);
 #define HF(NC)                                                                                      \
-  hipLaunchKernelGGL((head_fwd_kernel<T, NC, TR>), dim3(grid), dim3(256), 0, st, (const T*)x, x_ld, Cin, \
+  hipLaunchKernelGGL((head_fwd_kernel<T, NC, TR>), dim3(whole_rounds(head_fwd_kernel<T, NC, TR>, 0, grid)), dim3(256), 0, st, (const T*)x, x_ld, Cin, \
                      w, b, logits, npix, HW, softmax, bn_scale, bn_shift)
   if (ncls == 2) HF(2); else if (ncls == 3) HF(3); else HF(4);
 #undef HF
@@ -1711,7 +1751,7 @@ static int head_bwd_launch(const float* dl, const void* x, long x_ld, int Cin, c
   if (grid > 1024) grid = 1024;
   const size_t lds = (size_t)(ncls * Cin + ncls + (bnb.sum_dz ? 2 * Cin : 0)) * sizeof(float);
 #define HB(NC, BNB)                                                                                          \
-  hipLaunchKernelGGL((head_bwd_kernel<T, NC, BNB, TX>), dim3(grid), dim3(256), lds, st, dl, (const TX*)x, x_ld,   \
+  hipLaunchKernelGGL((head_bwd_kernel<T, NC, BNB, TX>), dim3(whole_rounds(head_bwd_kernel<T, NC, BNB, TX>, lds, grid)), dim3(256), lds, st, dl, (const TX*)x, x_ld,   \
                      Cin, w, (T*)dx, dx_ld, dw, db, npix, HW, bnb)
   if (bnb.sum_dz) {
     if (ncls == 2) HB(2, true); else if (ncls == 3) HB(3, true); else HB(4, true);
@@ -1769,7 +1809,7 @@ extern "C" int crimac_wce_bwd(const float* logits, const void* labels, int label
   const long HW = (long)H * W, npix = B * HW;
   const int grid = grid_for(npix, 256 * 4);
 #define WB(NC)                                                                                     \
-  hipLaunchKernelGGL(wce_bwd_kernel<NC>, dim3(grid), dim3(256), 0, ST, logits, labels, label_bytes, \
+  hipLaunchKernelGGL(wce_bwd_kernel<NC>, dim3(whole_rounds(wce_bwd_kernel<NC>, 0, grid)), dim3(256), 0, ST, logits, labels, label_bytes, \
                      class_w, ignore_index, npix, HW, sums, upstream, dlogits)
   if (ncls == 2) WB(2); else if (ncls == 3) WB(3); else WB(4);
 #undef WB
@@ -1782,7 +1822,7 @@ extern "C" int crimac_softmax_nchw(const float* logits, float* out, int B, int n
   CRIMAC_REQUIRE(ncls >= 2 && ncls <= 4, "softmax_nchw: ncls=%d unsupported (2..4)", ncls);
   const long HW = (long)H * W, npix = B * HW;
   const int grid = grid_for(npix, 256 * 4);
-#define SM(NC) hipLaunchKernelGGL(softmax_nchw_kernel<NC>, dim3(grid), dim3(256), 0, ST, logits, out, npix, HW)
+#define SM(NC) hipLaunchKernelGGL(softmax_nchw_kernel<NC>, dim3(whole_rounds(softmax_nchw_kernel<NC>, 0, grid)), dim3(256), 0, ST, logits, out, npix, HW)
   if (ncls == 2) SM(2); else if (ncls == 3) SM(3); else SM(4);
 #undef SM
   CRIMAC_LAUNCH_CHECK();
@@ -1796,7 +1836,7 @@ extern "C" int crimac_sgd_momentum(float* p, float* g, float* v, long n, float l
                  "sgd_momentum: buffers must be 16-byte aligned");
   const long n4 = n / 4;
   const int grid = grid_for(n4 > 0 ? n4 : 1, 256 * 4);
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
+  hipLaunchKernelGGL(sgd_kernel, dim3(whole_rounds(sgd_kernel, 0, grid)), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
                      zero_grad, (int*)nullptr);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
@@ -1817,7 +1857,7 @@ extern "C" int crimac_sgd_momentum_guarded(float* p, float* g, float* v, long n,
                  "sgd_momentum_guarded: buffers must be 16-byte aligned");
   const long n4 = n / 4;
   const int grid = grid_for(n4 > 0 ? n4 : 1, 256 * 4);
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
+  hipLaunchKernelGGL(sgd_kernel, dim3(whole_rounds(sgd_kernel, 0, grid)), dim3(256), 0, ST, p, g, v, n4, n, lr, momentum, grad_scale,
                      zero_grad, state);
   CRIMAC_LAUNCH_CHECK();
   return CRIMAC_OK;
