@@ -24,6 +24,14 @@ extern "C" int crimac_layer_desc_size(void) { return (int)sizeof(crimac_layer_de
 
 namespace {
 
+// (experiment builds, -DCRIMAC_EXP_REVERSE: the streaming passes walk their rows from the END of the tensor -- the rows their
+// producer wrote last, which the memory-side cache is most likely to hold)
+#ifdef CRIMAC_EXP_REVERSE
+#define CRIMAC_ROW(x, M) ((M) - 1 - (x))
+#else
+#define CRIMAC_ROW(x, M) (x)
+#endif
+
 constexpr int kMaxBlocks = 2048;
 
 inline int grid_for(long work_items, int per_block) {
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
     float v[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (m + u * stride < M) load8s(y + (m + u * stride) * y_ld + c0, v[u]);
+      if (m + u * stride < M) load8s(y + CRIMAC_ROW(m + u * stride, M) * y_ld + c0, v[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (m + u * stride >= M) continue;
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ y, lo
         v[u][j] = v[u][j] * sc[j] + sh[j];
         if (relu) v[u][j] = fmaxf(v[u][j], 0.f);
       }
-      store8(out + (m + u * stride) * out_ld + c0, v[u]);
+      store8(out + CRIMAC_ROW(m + u * stride, M) * out_ld + c0, v[u]);
     }
   }
 }
@@ -834,8 +842,8 @@ void bn_bwd_apply_stream_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (m + u * stride < M) {
-        load8s(da + (m + u * stride) * da_ld + c0, g[u]);
-        load8s(y + (m + u * stride) * y_ld + c0, yv[u]);
+        load8s(da + CRIMAC_ROW(m + u * stride, M) * da_ld + c0, g[u]);
+        load8s(y + CRIMAC_ROW(m + u * stride, M) * y_ld + c0, yv[u]);
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -843,7 +851,7 @@ void bn_bwd_apply_stream_kernel(
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = bn_bwd_dy(yv[u][j], g[u][j], sc[j], sh[j], mu[j], is[j], k1[j], k2[j]);
-      store8(dy + (m + u * stride) * dy_ld + c0, o);
+      store8(dy + CRIMAC_ROW(m + u * stride, M) * dy_ld + c0, o);
     }
   }
 }
