@@ -24,12 +24,16 @@ extern "C" int crimac_layer_desc_size(void) { return (int)sizeof(crimac_layer_de
 
 namespace {
 
-// (experiment builds, -DCRIMAC_EXP_REVERSE: the streaming passes walk their rows from the END of the tensor -- the rows their
-// producer wrote last, which the memory-side cache is most likely to hold)
-#ifdef CRIMAC_EXP_REVERSE
-#define CRIMAC_ROW(x, M) ((M) - 1 - (x))
-#else
+// The streaming BatchNorm passes (bn_act, bn_act_pool, bn_bwd_apply) walk their rows from the END of the tensor: their input
+// was written front to back by the convolution in front of them, so its last rows are what the memory-side cache still holds,
+// and the rows they write last are the first ones the next convolution asks for.  Serialized bf16 step: bn_bwd_apply 1041 ->
+// 1029 us, bn_act 505 -> 497, bn_act_pool 220 -> 213; timed step -0.03 to -0.06 ms in seven of seven alternating pairs on three
+// boxes (tools/runs/r5_31.sh, r5_32.sh).  Nothing for the pool-backward passes (their inputs are older), which walk forward.
+// -DCRIMAC_STREAM_FORWARD restores the forward walk for A/B builds.
+#ifdef CRIMAC_STREAM_FORWARD
 #define CRIMAC_ROW(x, M) (x)
+#else
+#define CRIMAC_ROW(x, M) ((M) - 1 - (x))
 #endif
 
 constexpr int kMaxBlocks = 2048;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int c0 = (int)(i % cpr) * 8;
-    long r = i / cpr;
+    long r = CRIMAC_ROW(i / cpr, total / cpr);
     const int xp = (int)(r % Wp);
     r /= Wp;
     const int yp = (int)(r % Hp);
