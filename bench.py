@@ -652,8 +652,9 @@ def measure_train_loop(args, precision, dev, log, resident_patches_per_s, pin_ba
                                      "collate + hand-over + H2D + step, one full pass of the DataLoader after one untimed pass",
                       "raw_f32": "random centre + crop gather from the in-memory survey in the workers (float32 crops), collate, "
                                  "hand-over, H2D, add_noise / flip / label refinement + indexing / remove_nan_inf / dB ON THE GPU, step",
-                      "raw_f64": "as raw_f32 with float64 crops (what the reference's zarr crop returns): twice the bytes through "
-                                 "collate, hand-over and H2D; the `.float()` runs on the device",
+                      "raw_f64": "as raw_f32 with float64 crops (what the reference's zarr crop returns); the `.float()` of "
+                                 "pipeline.py:163 is taken per crop in the workers' collate (staging.collate_float32, yaml key "
+                                 "collate_float32), so collate, hand-over and H2D move float32",
                       "host_chain": "random centre + crop gather + the reference's transform chain (add_noise, flip, label "
                                     "refinement + indexing, remove_nan_inf, dB) IN THE WORKERS, collate, hand-over, H2D, step"}[mode]}
 

@@ -52,7 +52,7 @@ class SegPipe:
                  save_model_params, meta_channels, late_meta_inject, eval_mode, experiment_name,
                  precision="bf16", infer_precision="h3p", loss_flush=50, gpu_augment=False, random_seed=0,
                  gpu_metrics=False, gpu_label_transform=False, sync_bn=False, pin_batches=True,
-                 release_batch_pages=True, **kwargs):
+                 release_batch_pages=True, collate_float32=True, **kwargs):
         assert not (save_model_params and (checkpoint_dir is None))
         self.model = None
         self.model_is_loaded = False
@@ -96,6 +96,10 @@ class SegPipe:
         # the batch's tensors read as zeros afterwards.  train_model never hands those batches out; set False if a
         # DataLoader wrapper of yours keeps references to the batches it yields
         self.release_batch_pages = bool(release_batch_pages)
+        # collate_float32: train_model swaps the training DataLoader's `default_collate` for one that casts the float64 crops
+        # of the zarr Dataset (batch/dataset.py:361) to float32 before stacking them -- the values of the reference's
+        # `.float()` (pipeline.py:163) at half the bytes through collate, hand-over and upload; other collate functions stay
+        self.collate_float32 = bool(collate_float32)
         self.loss_flush = max(int(loss_flush), 1)
         # gpu_augment: the train Dataset hands RAW linear-sv crops (augmentation_function=None,
         # data_transform_function=None) and add_noise / flip_x_axis / remove_nan_inf / db_with_limits
@@ -192,6 +196,9 @@ class SegPipe:
             """(i, data float32 on the device, labels on the device): the reference's in-step ``.float().to(device)``
             (pipeline.py:163-164), staged one batch ahead through pinned memory and a copy stream (staging.py) so that
             the upload of step i + 1 runs under step i; ``pin_batches: False`` keeps the in-line copy."""
+            if self.collate_float32:
+                from .staging import use_collate_float32
+                use_collate_float32(dataloader_train)
             if self.pin_batches and self.device.type == "cuda":
                 from .staging import BatchStager
                 for i, x, lab, _ in BatchStager(dataloader_train, self.device, yield_batch=False,

@@ -39,13 +39,43 @@ def _libc_madvise():
     return libc.madvise
 
 
+def collate_float32(samples):
+    """``default_collate`` with the float64 ``data`` arrays of the samples cast to float32 BEFORE they are stacked.  The
+    reference casts the collated batch (``batch['data'].float()``, pipeline.py:163,208): the same IEEE rounding of the same
+    values, taken while the 2 MB crop is still in the worker's cache -- its zarr Dataset returns float64 crops
+    (batch/dataset.py:361), i.e. 67 MB per batch of 32 through the stack, the shared-memory hand-over and the pinned copy
+    instead of 33.  Samples that are not dicts, and every other key, go through ``default_collate`` untouched."""
+    from torch.utils.data import default_collate
+    if samples and isinstance(samples[0], dict) and "data" in samples[0]:
+        def cast(v):
+            if isinstance(v, np.ndarray) and v.dtype == np.float64:
+                return v.astype(np.float32)
+            if torch.is_tensor(v) and v.dtype == torch.float64:
+                return v.float()
+            return v
+        samples = [{**s, "data": cast(s["data"])} for s in samples]
+    return default_collate(samples)
+
+
+def use_collate_float32(dataloader):
+    """Swap a DataLoader's ``default_collate`` for ``collate_float32`` (before its first iterator exists: worker processes
+    take the function when they start).  Returns True if swapped; any other collate function is left alone."""
+    from torch.utils.data import default_collate
+    if getattr(dataloader, "collate_fn", None) is not default_collate or getattr(dataloader, "batch_size", None) is None:
+        return False
+    if getattr(dataloader, "_iterator", None) is not None:          # (persistent workers already running the old function)
+        return False
+    dataloader.collate_fn = collate_float32
+    return True
+
+
 def collated_in_worker(dataloader):
     """True when every tensor the DataLoader yields is a FRESH shared-memory segment nobody else maps: worker processes
-    + automatic batching + ``default_collate`` (which stacks the samples into storage it allocates in shared memory,
+    + automatic batching + ``default_collate`` (or ``collate_float32`` above, which ends in it; it stacks the samples into storage it allocates in shared memory,
     torch/utils/data/_utils/collate.py) -- what the reference's four DataLoaders are (train.py:73,101, evaluate.py:69,107)."""
     from torch.utils.data import default_collate
     return (getattr(dataloader, "num_workers", 0) > 0 and getattr(dataloader, "batch_size", None) is not None
-            and getattr(dataloader, "collate_fn", None) is default_collate)
+            and getattr(dataloader, "collate_fn", None) in (default_collate, collate_float32))
 
 
 def release_shared_pages(batch, madvise=None, min_bytes=1 << 20):

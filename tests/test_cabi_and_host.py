@@ -240,3 +240,45 @@ def test_planes_argument_layout_matches_the_header():
     d = (hip.LayerDesc * 1)()
     assert lib.crimac_pack_layers(ctypes.byref(d), 1, 0, None) < 0
     assert lib.crimac_pack_layers(ctypes.byref(d), 1, 2 | 64, None) < 0
+
+
+class _F64Crops(torch.utils.data.Dataset):
+    """What the reference's zarr Dataset hands over (batch/dataset.py:361): float64 data, int16 labels, int64 centres."""
+
+    def __len__(self):
+        return 12
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng(i)
+        return {"data": np.power(10.0, rng.uniform(-9, -1, (4, 16, 16))), "labels": rng.integers(-1, 3, (16, 16)).astype(np.int16),
+                "center_coordinates": np.array([i, 2 * i], dtype=np.int64)}
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_collate_float32_gives_the_values_of_the_reference_cast(workers):
+    """`collate_float32` (yaml key of the same name; staging.py): the training DataLoader's float64 crops are cast per sample in
+    the collate -- the batch equals `default_collate(...)['data'].float()` (pipeline.py:163) bit for bit, the other keys are
+    untouched, a DataLoader with a collate function of its own is left alone, and the early page release still recognises
+    the batches as worker-collated."""
+    from torch.utils.data import DataLoader, default_collate
+    from crimac_classifiers_unet_amd import staging
+    ds = _F64Crops()
+    ref = list(DataLoader(ds, batch_size=4, shuffle=False, num_workers=0))
+    dl = DataLoader(ds, batch_size=4, shuffle=False, num_workers=workers)
+    assert staging.use_collate_float32(dl) and dl.collate_fn is staging.collate_float32
+    assert staging.collated_in_worker(dl) == (workers > 0)
+    got = list(dl)
+    assert len(got) == len(ref) == 3
+    for g, r in zip(got, ref):
+        assert r["data"].dtype == torch.float64 and g["data"].dtype == torch.float32
+        assert torch.equal(g["data"], r["data"].float())
+        assert g["labels"].dtype == torch.int16 and torch.equal(g["labels"], r["labels"])
+        assert torch.equal(g["center_coordinates"], r["center_coordinates"])
+    own = DataLoader(ds, batch_size=4, collate_fn=lambda s: default_collate(s))
+    assert not staging.use_collate_float32(own)
+    assert not staging.use_collate_float32(DataLoader(ds, batch_size=None))           # no automatic batching: nothing to collate
+    # samples that are not dicts, and float32 data, pass through default_collate unchanged
+    t = staging.collate_float32([np.ones(3), np.zeros(3)])
+    assert t.dtype == torch.float64 and t.shape == (2, 3)
+    f = staging.collate_float32([{"data": np.ones((2, 2), np.float32)}, {"data": np.zeros((2, 2), np.float32)}])
+    assert f["data"].dtype == torch.float32
