@@ -481,42 +481,60 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char bn_smem[];
   float* cst = reinterpret_cast<float*>(bn_smem + 512 * sizeof(double));
   if constexpr (FIN) bn_fin_block(fin, C, cst, reinterpret_cast<double*>(bn_smem));
+  // thread -> fixed 8-channel chunk (its scale / shift live in registers), pooled pixels strided over the grid, the eight
+  // vectors of TWO 2 x 2 windows in flight.  (The first form took one (window, chunk) item per thread and iteration: 64-bit
+  // divisions and sixteen constant loads per item, four loads in flight -- 4.4 TB/s on the level-0 tensors where bn_act
+  // reaches 6.3; tools/bench_stride.py.)
   const int cpr = C / 8;
+  const int rpi = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  if (rl >= rpi) return;
+  const int c0 = chunk * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if constexpr (FIN) {
+      sc[j] = cst[2 * C + c0 + j];
+      sh[j] = cst[3 * C + c0 + j];
+    } else {
+      sc[j] = scale ? scale[c0 + j] : 1.f;
+      sh[j] = scale ? shift[c0 + j] : 0.f;
+    }
+  }
   const int Hp = H / 2, Wp = W / 2;
-  const long total = (long)B * Hp * Wp * cpr;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cpr) * 8;
-    long r = CRIMAC_ROW(i / cpr, total / cpr);
-    const int xp = (int)(r % Wp);
-    r /= Wp;
-    const int yp = (int)(r % Hp);
-    const long b = r / Hp;
-    float sc[8], sh[8], mx[8];
+  const long HWp = (long)Hp * Wp, npool = (long)B * HWp;
+  const long stride = (long)gridDim.x * rpi;
+  constexpr int U = 2;
+  for (long m = (long)blockIdx.x * rpi + rl; m < npool; m += U * stride) {
+    float v[U][4][8];
+    long pix0[U], pp[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if constexpr (FIN) {
-        sc[j] = cst[2 * C + c0 + j];
-        sh[j] = cst[3 * C + c0 + j];
-      } else {
-        sc[j] = scale ? scale[c0 + j] : 1.f;
-        sh[j] = scale ? shift[c0 + j] : 0.f;
-      }
+    for (int u = 0; u < U; ++u) {
+      if (m + u * stride >= npool) continue;
+      long b, hw;
+      pix_split(CRIMAC_ROW(m + u * stride, npool), HWp, b, hw);
+      const int yp = (int)(hw / Wp), xp = (int)(hw - (long)yp * Wp);
+      pix0[u] = (b * H + 2 * yp) * (long)W + 2 * xp;
+      pp[u] = (b * Hp + yp) * (long)Wp + xp;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) load8s(y + (pix0[u] + (d >> 1) * (long)W + (d & 1)) * y_ld + c0, v[u][d]);
     }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const long pix = (b * H + 2 * yp + (d >> 1)) * (long)W + 2 * xp + (d & 1);
-      float v[8];
-      load8s(y + pix * y_ld + c0, v);
+    for (int u = 0; u < U; ++u) {
+      if (m + u * stride >= npool) continue;
+      float mx[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = v[j] * sc[j] + sh[j];
-        if (relu) v[j] = fmaxf(v[j], 0.f);
-        mx[j] = d == 0 ? v[j] : fmaxf(mx[j], v[j]);
+      for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[u][d][j] = v[u][d][j] * sc[j] + sh[j];
+          if (relu) v[u][d][j] = fmaxf(v[u][d][j], 0.f);
+          mx[j] = d == 0 ? v[u][d][j] : fmaxf(mx[j], v[u][d][j]);
+        }
+        if (out) store8(out + (pix0[u] + (d >> 1) * (long)W + (d & 1)) * out_ld + c0, v[u][d]);
       }
-      if (out) store8(out + pix * out_ld + c0, v);
+      store8(pool + pp[u] * pool_ld + c0, mx);
     }
-    store8(pool + ((b * Hp + yp) * (long)Wp + xp) * pool_ld + c0, mx);
   }
 }
 
@@ -1504,8 +1522,9 @@ static int bn_act_pool_launch(const void* y, long y_ld, const float* scale, cons
                               int H, int W, int C, hipStream_t st, BnFin fin = BnFin{}) {
   const size_t lds = FIN ? 512 * sizeof(double) + 4 * (size_t)C * sizeof(float) : 0;
   if (pool_out) {
-    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO, FIN>), dim3(whole_rounds(bn_act_pool_kernel<T, TO, FIN>, lds, grid_for(total, 256))), dim3(256), lds, st,
+    const long npool = (long)B * (H / 2) * (W / 2);
+    const int cpr = C / 8, rpi = 256 / cpr > 0 ? 256 / cpr : 1;      // (pooled pixels per workgroup and iteration, as in the kernel)
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, TO, FIN>), dim3(whole_rounds(bn_act_pool_kernel<T, TO, FIN>, lds, grid_for(npool, rpi * 2))), dim3(256), lds, st,
                        (const T*)y, y_ld, scale, shift, relu, (TO*)out, out_ld, (TO*)pool_out, pool_ld, B,
                        H, W, C, fin);
   } else {
