@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   // Two pixels per iteration, every load (x, y of the BatchNorm sums, dlogits) issued before the first use:
   // with one pixel and the y load behind the dx store the loop was two dependent memory round trips per
   // pixel.  (image, pixel-in-image) advance incrementally -- no 64-bit divide per pixel.
-  constexpr int UNR = 2;
+  constexpr int UNR = 2;      // (three: 228 registers, no faster; four: one wave per SIMD)
   const long step = (long)gridDim.x * ppb;
   const long step_b = (UNR * step) / HW, step_hw = (UNR * step) % HW;
   long p = (long)blockIdx.x * ppb + threadIdx.x / lp;
