@@ -1225,6 +1225,9 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#ifdef CRIMAC_EXP_P64_FEWEPI      // (ablation build, results garbage: one of the four staging iterations per accumulator tile)
+          if (r != 0) continue;
+#endif
           const int px = (lane >> 4) * 4 + r;
           float v = acc[i][j][r] + bv[j];
           if (e.relu) v = fmaxf(v, 0.f);
