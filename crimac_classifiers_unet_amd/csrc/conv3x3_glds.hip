@@ -822,12 +822,22 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned char* slab = smem + HALO_ROWS * CB + wave * SLAB;
   float* sstat = reinterpret_cast<float*>(smem + HALO_ROWS * CB + 4 * SLAB);      // [2][64]
-  unsigned char* wlds = smem + HALO_ROWS * CB + 4 * SLAB + 2 * BN * 4;
+  unsigned char* wlds = smem + HALO_ROWS * CB + 4 * SLAB + 2 * BN * 4 + BN * 4;      // (statistics [2][64], bias [64])
   const EpiParams& e = p.epi;
   const T16* inp = reinterpret_cast<const T16*>(p.in);
   TO* outp = reinterpret_cast<TO*>(e.out);
   const bool stats = e.stat_sum != nullptr && e.stat_mode == 1;
   if (tid < 2 * BN) sstat[tid] = 0.f;
+  // SW (16-bit outputs): the MFMAs take the WEIGHT fragment as the A operand, so that a lane holds four consecutive CHANNELS
+  // of one pixel -- the tile is staged with one packed 8-byte LDS write per accumulator tile instead of four conversions and
+  // four 2-byte writes (this kernel is its output stream: ~12 vector instructions per element of staging were most of a
+  // tile's cycles at four waves per SIMD).  The bias starts the accumulators (from LDS), the statistics are taken where the
+  // slab is read back (this lane's fixed 8-channel chunk).
+  constexpr bool SW = sizeof(TS) == 2 && !PP;
+  float* sbias = sstat + 2 * BN + 0;              // [64] (SW), behind the statistics; the weights start 256 B further
+  if constexpr (SW) {
+    if (tid < BN) sbias[tid] = e.bias ? e.bias[tid] : 0.f;
+  }
 
   // weights [tap][n][16] (18 KB) -> LDS once per workgroup; fragment (s, j) of a lane = row j*16 + fr of tap
   // 2s + (fq >> 1), channels (fq & 1)*8 .. +8 (same 32-byte pitch as the halo: conflict-free ds_read_b128)
@@ -853,10 +863,13 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
   float bv[4], cs1[4], cs2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    bv[j] = e.bias ? e.bias[j * 16 + fr] : 0.f;
+    bv[j] = (!SW && e.bias) ? e.bias[j * 16 + fr] : 0.f;
     cs1[j] = 0.f;
     cs2[j] = 0.f;
   }
+  float s1[8], s2[8];                              // (SW) statistics of channel chunk lane & 7
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
   // A fragment addresses per k-step (tap 2s + (fq >> 1), clamped where the weights are zero)
   int a_off[5];
 #pragma unroll
@@ -923,9 +936,12 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (SW) acc[i][j] = *reinterpret_cast<const f32x4*>(sbias + j * 16 + fq * 4);      // channels j*16 + fq*4 + r
+          else
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        }
       const unsigned char* hrow = halo + ih * (2 * HP * CB);
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
@@ -941,13 +957,27 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = E16<T16>::mfma16(af[i], bw[j], acc[i][j]);
+            acc[i][j] = SW ? E16<T16>::mfma16(bw[j], af[i], acc[i][j]) : E16<T16>::mfma16(af[i], bw[j], acc[i][j]);
       }
       // output: image row y0 + 4*wave + 2*ih + i = M tile i; accumulator element r of N tile j is pixel
       // (lane >> 4)*4 + r, channel j*16 + fr
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int y = y0 + wave * 4 + ih * 2 + i;
+        if constexpr (SW) {
+          // accumulator element r of N tile j: pixel fr, channel j*16 + fq*4 + r (bias already inside)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            TS q4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[i][j][r];
+              if (e.relu) v = fmaxf(v, 0.f);
+              q4[r] = (TS)v;
+            }
+            *reinterpret_cast<u32x2*>(slab + fr * SLAB_PITCH + (j * 16 + fq * 4) * 2) = *reinterpret_cast<const u32x2*>(q4);
+          }
+        } else
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -968,8 +998,15 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
           for (int k = 0; k < 2; ++k) {
             const int u = lane + k * 64, px = u >> 3, c8 = u & 7;
             const u32x4 v = *reinterpret_cast<const u32x4*>(slab + px * SLAB_PITCH + c8 * 16);
-            if (y < p.H && x0 + px < p.W)
+            if (y < p.H && x0 + px < p.W) {
               *reinterpret_cast<u32x4*>(outp + (((long)b * p.H + y) * p.W + x0 + px) * e.out_ld + c8 * 8) = v;
+              if (SW && stats) {                  // (statistics of the values as STORED; c8 = lane & 7 for both k)
+                float f8[8];
+                load8(reinterpret_cast<const TS*>(&v), f8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { s1[q] += f8[q]; s2[q] += f8[q] * f8[q]; }
+              }
+            }
           }
         } else {
           // 4-byte outputs: 16 lanes per pixel (256 bytes), one 16-byte store each: whole lines per wave-instruction; plane
@@ -995,6 +1032,18 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
     }
   }
   if (stats) {
+    if constexpr (SW) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float t1 = s1[q], t2 = s2[q];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+        if (lane < 8) {
+          atomicAdd(&sstat[lane * 8 + q], t1);
+          atomicAdd(&sstat[BN + lane * 8 + q], t2);
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float t1 = cs1[j], t2 = cs2[j];
@@ -1004,6 +1053,7 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
         atomicAdd(&sstat[j * 16 + lane], t1);
         atomicAdd(&sstat[BN + j * 16 + lane], t2);
       }
+    }
     }
     __syncthreads();
     const long rep = (long)(blockIdx.x % (unsigned)e.stat_replicas) * e.N;
@@ -1020,7 +1070,7 @@ int launch_c16(ConvParams p, hipStream_t st) {
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
   constexpr int OB = sizeof(TO) == 2 ? 2 : 4;               // bytes per staged output element
-  constexpr size_t lds = (size_t)HALO_ROWS * 32 + 4 * 16 * (64 * OB + 16) + 2 * 64 * 4 + 9 * 64 * 32;   // 38.6 KB (46.7 KB)
+  constexpr size_t lds = (size_t)HALO_ROWS * 32 + 4 * 16 * (64 * OB + 16) + 3 * 64 * 4 + 9 * 64 * 32;   // 38.9 KB (47 KB)
   const long cap = OB == 2 ? 1024 : 768;                    // 4 (3) workgroups per CU
   const long grid = ntiles < cap ? ntiles : cap;
   hipLaunchKernelGGL((conv3x3_c16_kernel<T16, TO, PP>), dim3((unsigned)grid), dim3(256), lds, st, p, (int)ntiles);
