@@ -965,7 +965,8 @@ void conv3x3_c16_kernel(ConvParams p, int ntiles) {
       for (int i = 0; i < 2; ++i) {
         const int y = y0 + wave * 4 + ih * 2 + i;
         if constexpr (SW) {
-          // accumulator element r of N tile j: pixel fr, channel j*16 + fq*4 + r (bias already inside)
+          // accumulator element r of N tile j: pixel fr, channel j*16 + fq*4 + r (bias already inside: this kernel has no
+          // other form its results would have to equal bit for bit, and reading the bias here costs 10 registers: 74 -> 90 us)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             TS q4[4];
@@ -1153,10 +1154,16 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   unsigned char* slab0 = halo + wave * NSL * SLAB;         // needs both rows of a window)
   static_assert(4 * NSL * SLAB <= H_BYTES, "the slabs live in the team's (dead) halo buffer");
   float* sstat = reinterpret_cast<float*>(smem + W_BYTES + 2 * H_BYTES);
+  // The MFMAs take the WEIGHT fragment as the A operand (round 5, as the first-layer kernel): a lane holds four consecutive
+  // CHANNELS of one pixel, the tile is staged with one packed 8-byte LDS write per accumulator tile instead of four conversions
+  // and four 2-byte writes (a quarter of the staging work made the plain launches 11-14 % faster in the ablation build).  The
+  // bias comes from LDS (four consecutive floats per accumulator tile) and the mode-1 statistics are taken where the slab is read back, like mode 2's sums.
+  float* sbias = sstat + 2 * BN + 8;                       // [64], behind the statistics and the team counters
   const T16* inp = reinterpret_cast<const T16*>(p.in);
   T16* outp = reinterpret_cast<T16*>(e.out);
   constexpr int mode = MODE;
   if (tid < 2 * BN) sstat[tid] = 0.f;
+  if (tid < BN) sbias[tid] = e.bias ? e.bias[p.n_first + tid] : 0.f;
 
   // weights: LDS unit c of row (t, n) holds source unit c ^ swizzle(n) (as the W4 weight slots)
   {
@@ -1178,13 +1185,6 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
   int asw[3];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) asw[kx] = halo_swz(fr + kx);
-  float bv[NT], cs1[NT], cs2[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    bv[j] = e.bias ? e.bias[p.n_first + j * 16 + fr] : 0.f;
-    cs1[j] = 0.f;
-    cs2[j] = 0.f;
-  }
   // mode 2: this lane always stores channel chunk c8 = lane & 7 -> its BatchNorm constants live in registers
   const int c8 = lane & 7;
   float sc[8], sh[8], mu[8], d1[8], d2[8];        // (d2 accumulates dz * (y - mean); invstd is applied at the flush)
@@ -1265,30 +1265,25 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         }
       }
     };
-    auto to_slab = [&](int i) {                  // bias / ReLU / rounding, one image row -> its slab (+ statistics)
-      const int y = y0 + wave * 4 + i;
+    auto to_slab = [&](int i) {                  // bias / ReLU / rounding, one image row -> its slab
       unsigned char* slab = slab0 + (i % NSL) * SLAB;
-      bool okm[4];
+      // accumulator element r of N tile j: pixel fr of the row, channel j*16 + fq*4 + r (bias: four consecutive floats in LDS,
+      // added to the finished sum like every other convolution kernel does -- 64-channel ranges equal the full convolution bit for bit)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) okm[r] = (y < Hl) & (x0 + (lane >> 4) * 4 + r < p.W);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + j * 16 + fq * 4);
+        T16 q4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #ifdef CRIMAC_EXP_P64_FEWEPI      // (ablation build, results garbage: one of the four staging iterations per accumulator tile)
           if (r != 0) continue;
 #endif
-          const int px = (lane >> 4) * 4 + r;
-          float v = acc[i][j][r] + bv[j];
+          float v = acc[i][j][r] + b4[r];
           if (e.relu) v = fmaxf(v, 0.f);
-          const T16 q = (T16)v;
-          *reinterpret_cast<T16*>(slab + px * SLAB_PITCH + (j * 16 + fr) * 2) = q;
-          if (mode == 1) {
-            const float vs = e.stat_raw ? v : (float)q;        // statistics of the value as STORED (pixels outside the image: 0)
-            cs1[j] += okm[r] ? vs : 0.f;
-            cs2[j] += okm[r] ? vs * vs : 0.f;
-          }
+          q4[r] = (T16)v;
         }
+        *reinterpret_cast<u32x2*>(slab + fr * SLAB_PITCH + (j * 16 + fq * 4) * 2) = *reinterpret_cast<const u32x2*>(q4);
+      }
     };
     auto from_slab = [&](int i) {                // (wave-private slab: the LDS operations of one wave execute in order)
       const int y = y0 + wave * 4 + i;
@@ -1300,6 +1295,15 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
         const bool ok = (y < Hl) & (x0 + px < p.W);
         const u32x4 val = *reinterpret_cast<const u32x4*>(sp);
         __builtin_amdgcn_raw_buffer_store_b128(val, ro, (int)(ok ? o_rel + (unsigned)(i * out_row + 8 * k * e.out_ld * 2) : OOB), 0, 0);
+        if constexpr (mode == 1) {               // statistics of the values as STORED, this lane's channel chunk c8
+          float g[8];
+          load8(sp, g);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            d1[kk] += ok ? g[kk] : 0.f;
+            d2[kk] += ok ? g[kk] * g[kk] : 0.f;
+          }
+        }
         if constexpr (mode == 2) {
           // This epilogue sits at the 256-register limit and hipcc's allocation around it is erratic (spill counts
           // between 3 and 220 for equivalent formulations).  Two forms, each kept for the storage type where it
@@ -1444,7 +1448,7 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = E16<T16>::mfma16(af[i], bfr[j], acc[i][j]);
+              acc[i][j] = E16<T16>::mfma16(bfr[j], af[i], acc[i][j]);      // (weights as A: rows = channels, lane column = pixel)
         }
       }
     };
@@ -1487,13 +1491,18 @@ void conv3x3_p64_kernel(ConvParams p, int ntiles) {
 #endif
   if (mode == 1) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float t1 = cs1[j], t2 = cs2[j];
-      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
-      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (lane < 16) {
-        atomicAdd(&sstat[j * 16 + lane], t1);
-        atomicAdd(&sstat[BN + j * 16 + lane], t2);
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        d1[k] += __shfl_xor(d1[k], o, 64);
+        d2[k] += __shfl_xor(d2[k], o, 64);
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        atomicAdd(&sstat[c8 * 8 + k], d1[k]);
+        atomicAdd(&sstat[BN + c8 * 8 + k], d2[k]);
       }
     }
   } else if (mode == 2) {
@@ -1528,7 +1537,7 @@ int launch_p64(ConvParams p, hipStream_t st) {
   p.tiles_y = cdiv(p.H, TR);
   p.tiles_x = cdiv(p.W, TC);
   const long ntiles = (long)p.B * p.tiles_y * p.tiles_x;
-  constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4 + 32;     // 157216 B
+  constexpr size_t lds = (size_t)9 * 64 * RB + 2 * (size_t)HALO_ROWS * RB + 2 * 64 * 4 + 32 + 64 * 4;     // 157472 B (statistics, team counters, bias)
   static unsigned long long attr_devs = 0;      // bit d: done on device d (the attribute is per device)
   if (crimac_first_use_on_device(&attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p64_kernel<0, false, T16>),
@@ -1607,7 +1616,8 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
     // a range of output channels (crimac_conv3x3_cols): 64 of them with the persistent 64-channel kernel,
     // multiples of 128 with the channel-split kernel
     const long nt = (long)B * cdiv(H, TR) * cdiv(W, TC);
-    if (n_count == 64 && Cin == 64 && nt >= 512 && H % TR == 0 && W % TC == 0) return launch_p64<T16>(p, st);
+    // (the persistent kernel takes its statistics from the STORED values: unrounded sums -- CRIMAC_EPI_STAT_RAW -- go to the tall form)
+    if (n_count == 64 && Cin == 64 && nt >= 512 && H % TR == 0 && W % TC == 0 && !p.epi.stat_raw) return launch_p64<T16>(p, st);
     const bool small_t = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);
     // other 64-channel ranges (small images, Cin != 64): the tall form of the channel-split kernel
     if ((n_first % 128 != 0 || n_count % 128 != 0) && n_first % 64 == 0 && n_count % 64 == 0 && small_t)
@@ -1629,7 +1639,7 @@ int glds_dispatch(ConvParams p, hipStream_t st) {
   if (N == 64 && small64 && (tall == 2 || (tall == 1 && Cin != 64))) return launch_wch<T16, T16, false, 2>(p, st);
   // 64 -> 64 with many tiles: persistent kernel with LDS-resident weights (CRIMAC_CONV_P64=0: W4 for A/B runs)
   static const int p64 = getenv("CRIMAC_CONV_P64") ? atoi(getenv("CRIMAC_CONV_P64")) : 1;
-  if (p64 && N == 64 && Cin == 64 && H % TR == 0 && W % TC == 0 && (long)B * (H / TR) * (W / TC) >= 512)
+  if (p64 && N == 64 && Cin == 64 && H % TR == 0 && W % TC == 0 && (long)B * (H / TR) * (W / TC) >= 512 && !p.epi.stat_raw)
     return launch_p64<T16>(p, st);
   if (N % 128 != 0) return launch_w4<64, T16>(p, st);
   const bool small = (((long)B * H * W - 1) * in_ld + Cin) * 2 < (1L << 31);     // 32-bit buffer offsets in wch
